@@ -1,0 +1,170 @@
+"""Parameter inventory of the mv-3ddet detector under the reference's state-dict names.
+
+One flat f32 buffer holds every parameter (and a second one every gradient), so that
+gradient all-reduce, grad-norm clipping and AdamW are each ONE pass over HBM
+(DESIGN.md "flat parameter arena").  Names / shapes follow:
+  * mmdet.ResNet(depth=50, base_channels=16)   configs/detection/mv-det3d_...py:24-34
+  * MinkResNet(depth=34, in_channels=3)        embodiedscan/models/backbones/mink_resnet.py:58-120
+  * FCAF3DHeadRotMat                           embodiedscan/models/dense_heads/fcaf3d_head.py:949-991
+Sparse conv kernels use the MinkowskiEngine layout [K^3, C_in, C_out] ([C_in, C_out] for k=1).
+"""
+import math
+from collections import OrderedDict
+import torch
+
+
+class Spec:
+    __slots__ = ('name', 'shape', 'init', 'trainable', 'buffer')
+
+    def __init__(self, name, shape, init, trainable=True, buffer=False):
+        self.name, self.shape, self.init, self.trainable, self.buffer = name, tuple(shape), init, trainable, buffer
+
+
+def _bn2d(specs, p, c):
+    specs += [Spec(p + '.weight', (c,), ('const', 1.), False), Spec(p + '.bias', (c,), ('const', 0.), False),
+              Spec(p + '.running_mean', (c,), ('const', 0.), False, True),
+              Spec(p + '.running_var', (c,), ('const', 1.), False, True)]
+
+
+def resnet50_specs(prefix='backbone.', base=16, frozen_stages=1):
+    s = []
+    s.append(Spec(prefix + 'conv1.weight', (base, 3, 7, 7), ('kaiming_out', base * 49), frozen_stages < 0))
+    _bn2d(s, prefix + 'bn1', base)
+    inpl = base
+    for li, nblk in enumerate((3, 4, 6, 3)):
+        planes = base * 2 ** li
+        train = (li + 1) > frozen_stages
+        for bi in range(nblk):
+            p = f'{prefix}layer{li + 1}.{bi}.'
+            s.append(Spec(p + 'conv1.weight', (planes, inpl, 1, 1), ('kaiming_out', planes), train))
+            _bn2d(s, p + 'bn1', planes)
+            s.append(Spec(p + 'conv2.weight', (planes, planes, 3, 3), ('kaiming_out', planes * 9), train))
+            _bn2d(s, p + 'bn2', planes)
+            s.append(Spec(p + 'conv3.weight', (planes * 4, planes, 1, 1), ('kaiming_out', planes * 4), train))
+            _bn2d(s, p + 'bn3', planes * 4)
+            if bi == 0:
+                s.append(Spec(p + 'downsample.0.weight', (planes * 4, inpl, 1, 1), ('kaiming_out', planes * 4), train))
+                _bn2d(s, p + 'downsample.1', planes * 4)
+            inpl = planes * 4
+    return s
+
+
+def _mbn(specs, p, c):
+    specs += [Spec(p + '.bn.weight', (c,), ('const', 1.)), Spec(p + '.bn.bias', (c,), ('const', 0.)),
+              Spec(p + '.bn.running_mean', (c,), ('const', 0.), False, True),
+              Spec(p + '.bn.running_var', (c,), ('const', 1.), False, True)]
+
+
+def mink_resnet34_specs(prefix='backbone_3d.', in_channels=3):
+    s = [Spec(prefix + 'conv1.kernel', (27, in_channels, 64), ('kaiming_out', 27 * 64)),
+         Spec(prefix + 'norm1.weight', (1, 64), ('const', 1.)), Spec(prefix + 'norm1.bias', (1, 64), ('const', 0.))]
+    inpl = 64
+    for li, nblk in enumerate((3, 4, 6, 3)):
+        planes = 64 * 2 ** li
+        for bi in range(nblk):
+            p = f'{prefix}layer{li + 1}.{bi}.'
+            s.append(Spec(p + 'conv1.kernel', (27, inpl, planes), ('kaiming_out', 27 * planes)))
+            _mbn(s, p + 'norm1', planes)
+            s.append(Spec(p + 'conv2.kernel', (27, planes, planes), ('kaiming_out', 27 * planes)))
+            _mbn(s, p + 'norm2', planes)
+            if bi == 0:
+                s.append(Spec(p + 'downsample.0.kernel', (inpl, planes), ('kaiming_out', planes)))
+                _mbn(s, p + 'downsample.1', planes)
+            inpl = planes
+    return s
+
+
+def fcaf3d_head_specs(prefix='bbox_head.', in_channels=(128, 256, 512, 1024), out_channels=128, n_reg=12,
+                      n_classes=284):
+    s = []
+    for i, c in enumerate(in_channels):
+        if i > 0:
+            p = f'{prefix}up_block_{i}'
+            co = in_channels[i - 1]
+            s.append(Spec(p + '.0.kernel', (8, c, co), ('uniform_fan', co * 8)))     # transpose: n = out*vol
+            _mbn(s, p + '.1', co)
+            s.append(Spec(p + '.3.kernel', (27, co, co), ('uniform_fan', co * 27)))
+            _mbn(s, p + '.4', co)
+        p = f'{prefix}out_block_{i}'
+        s.append(Spec(p + '.0.kernel', (27, c, out_channels), ('uniform_fan', c * 27)))
+        _mbn(s, p + '.1', out_channels)
+    s.append(Spec(prefix + 'conv_center.kernel', (out_channels, 1), ('normal', .01)))
+    s.append(Spec(prefix + 'conv_reg.kernel', (out_channels, n_reg), ('normal', .01)))
+    s.append(Spec(prefix + 'conv_cls.kernel', (out_channels, n_classes), ('normal', .01)))
+    s.append(Spec(prefix + 'conv_cls.bias', (1, n_classes), ('const', -math.log((1 - .01) / .01))))
+    for i in range(len(in_channels)):
+        s.append(Spec(f'{prefix}scales.{i}.scale', (), ('const', 1.)))
+    return s
+
+
+def detector_specs(n_classes=284):
+    return resnet50_specs() + mink_resnet34_specs() + fcaf3d_head_specs(n_classes=n_classes)
+
+
+def _fill(t, init, gen):
+    kind, a = init
+    if kind == 'const':
+        t.fill_(a)
+    elif kind == 'kaiming_out':
+        t.normal_(0, math.sqrt(2.0 / a), generator=gen)
+    elif kind == 'uniform_fan':
+        b = 1.0 / math.sqrt(a)
+        t.uniform_(-b, b, generator=gen)
+    elif kind == 'normal':
+        t.normal_(0, a, generator=gen)
+    else:
+        raise ValueError(kind)
+
+
+class ParamArena:
+    """Flat parameter / gradient storage with named views.
+
+    Trainable tensors are packed first (``data[:n_train]`` / ``grad``), frozen
+    parameters and buffers after them, every tensor 16-byte aligned."""
+
+    def __init__(self, specs, seed=0, device='cpu'):
+        self.specs = specs
+        order = [s for s in specs if s.trainable] + [s for s in specs if not s.trainable]
+        off, self.offsets = 0, {}
+        for s in order:
+            n = 1
+            for d in s.shape:
+                n *= d
+            self.offsets[s.name] = (off, n)
+            off += (n + 3) // 4 * 4
+            if s.trainable:
+                self.n_train = off
+        self.total = off
+        gen = torch.Generator().manual_seed(seed)
+        data = torch.zeros(self.total, dtype=torch.float32)
+        for s in specs:                     # init in spec order so the stream is layout independent
+            o, n = self.offsets[s.name]
+            _fill(data[o:o + n], s.init, gen)
+        self.data = data.to(device)
+        self.grad = torch.zeros(self.n_train, dtype=torch.float32, device=device)
+        self._views()
+
+    def _views(self):
+        self.p, self.g = OrderedDict(), OrderedDict()
+        for s in self.specs:
+            o, n = self.offsets[s.name]
+            self.p[s.name] = self.data[o:o + n].view(s.shape)
+            if s.trainable:
+                self.g[s.name] = self.grad[o:o + n].view(s.shape)
+
+    def to(self, device):
+        self.data = self.data.to(device)
+        self.grad = self.grad.to(device)
+        self._views()
+        return self
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.p.items())
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            if k in self.p:
+                self.p[k].copy_(v.reshape(self.p[k].shape))
+
+    def trainable_names(self):
+        return [s.name for s in self.specs if s.trainable]

@@ -1,0 +1,123 @@
+"""Seeded synthetic RGB-D scans of the shape the mv-3ddet pipeline consumes.
+
+There is no dataset in this environment, so bench.py, smoke() and the parity tests
+all draw from this generator: an axis-aligned room with rotated furniture boxes,
+V posed pinhole cameras, analytic ray-box z-depth, uint8 noise for RGB, the
+furniture as 9-DoF ground truth, and the host-side random decisions of the
+reference data pipeline (PointSample indices, RandomFlip3D, GlobalRotScaleTrans:
+configs/detection/mv-det3d_...py:134-160) drawn here so that the device path and
+the CPU oracle consume identical inputs.
+"""
+import math
+import numpy as np
+
+
+def _euler_zxy(a):
+    ca, sa, cb, sb, cc, sc = math.cos(a[0]), math.sin(a[0]), math.cos(a[1]), math.sin(a[1]), math.cos(a[2]), math.sin(a[2])
+    rz = np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1.]])
+    rx = np.array([[1., 0, 0], [0, cb, -sb], [0, sb, cb]])
+    ry = np.array([[cc, 0, sc], [0, 1., 0], [-sc, 0, cc]])
+    return rz @ rx @ ry
+
+
+def _mat_to_euler_zxy(m):
+    return np.array([math.atan2(-m[0, 1], m[1, 1]), math.asin(max(-1., min(1., m[2, 1]))), math.atan2(-m[2, 0], m[2, 2])])
+
+
+def _ray_box(o, d, c, half, R):
+    """z-free slab test. o (3,), d (P,3), box centre c, half sizes, rotation R -> t (P,) (inf = miss)."""
+    oo = (o - c) @ R                      # R^T (o-c)
+    dd = d @ R
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t1 = (-half - oo) / dd
+        t2 = (half - oo) / dd
+    tmin = np.nanmax(np.minimum(t1, t2), axis=1)
+    tmax = np.nanmin(np.maximum(t1, t2), axis=1)
+    hit = (tmax >= np.maximum(tmin, 0)) & (tmax > 0)
+    t = np.where(tmin > 0, tmin, tmax)    # inside the box -> exit distance
+    return np.where(hit, t, np.inf)
+
+
+def make_scan(seed, n_views=20, height=480, width=640, img_size=(480, 480), n_boxes=25, n_points=100000,
+              n_classes=284, augment=True, max_depth=6.0):
+    """One synthetic scan.  Returns a dict of numpy arrays + the meta dict the
+    reference attaches to a data sample (depth2img, scale_factor, img_shape, pcd_* ...)."""
+    rng = np.random.default_rng(seed)
+    room_c, room_h = np.array([0., 0., 1.4]), np.array([3., 2.5, 1.4])
+    sizes = rng.uniform(0.3, 1.6, (n_boxes, 3))
+    centers = np.stack([rng.uniform(-2.6, 2.6, n_boxes), rng.uniform(-2.1, 2.1, n_boxes), sizes[:, 2] / 2 + rng.uniform(0, 0.8, n_boxes)], 1)
+    eulers = np.stack([rng.uniform(-math.pi, math.pi, n_boxes), rng.uniform(-.1, .1, n_boxes), rng.uniform(-.1, .1, n_boxes)], 1)
+    labels = rng.integers(0, n_classes, n_boxes)
+    rots = [_euler_zxy(e) for e in eulers]
+
+    fx = fy = 577.87 * width / 640.0
+    cx, cy = (width - 1) / 2.0, (height - 1) / 2.0
+    K = np.array([[fx, 0, cx, 0], [0, fy, cy, 0], [0, 0, 1, 0], [0, 0, 0, 1.]])
+    us, vs = np.meshgrid(np.arange(width), np.arange(height))
+    dirs_cam = np.stack([(us.ravel() - cx) / fx, (vs.ravel() - cy) / fy, np.ones(width * height)], 1)
+
+    depth = np.zeros((n_views, height, width), np.float32)
+    extr, intr = [], []
+    for v in range(n_views):
+        pos = np.array([rng.uniform(-2.2, 2.2), rng.uniform(-1.8, 1.8), rng.uniform(1.0, 1.8)])
+        yaw, pitch = rng.uniform(0, 2 * math.pi), rng.uniform(-0.5, 0.1)
+        fwd = np.array([math.cos(yaw) * math.cos(pitch), math.sin(yaw) * math.cos(pitch), math.sin(pitch)])
+        right = np.cross(fwd, np.array([0, 0, 1.]))
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        c2w = np.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, pos
+        w2c = np.linalg.inv(c2w)
+        d = dirs_cam @ c2w[:3, :3].T
+        t = _ray_box(pos, d, room_c, room_h, np.eye(3))
+        for b in range(n_boxes):
+            t = np.minimum(t, _ray_box(pos, d, centers[b], sizes[b] / 2, rots[b]))
+        z = np.where(np.isfinite(t), t, 0.)          # camera-frame z == t because dirs_cam.z == 1
+        z = np.where(z > max_depth, 0., z)
+        depth[v] = z.reshape(height, width).astype(np.float32)
+        extr.append(w2c.astype(np.float32))
+        intr.append(K.astype(np.float32))
+
+    # PointSample(n_points // 10) per view on the non-zero pixels, then PointSample(n_points)
+    per_view = n_points // n_views * 2
+    sel_view, sel_pix = [], []
+    for v in range(n_views):
+        nz = np.nonzero(depth[v].reshape(-1))[0]
+        if len(nz) == 0:
+            nz = np.array([0])
+        pick = rng.choice(len(nz), per_view, replace=len(nz) < per_view)
+        sel_view.append(np.full(per_view, v, np.int32))
+        sel_pix.append(nz[pick].astype(np.int32))
+    sel_view, sel_pix = np.concatenate(sel_view), np.concatenate(sel_pix)
+    pick2 = rng.choice(len(sel_pix), n_points, replace=len(sel_pix) < n_points)
+    sel_view, sel_pix = sel_view[pick2], sel_pix[pick2]
+
+    meta = dict(depth2img=dict(extrinsic=extr, intrinsic=intr, origin=np.zeros(3, np.float32)),
+                img_shape=(img_size[0], img_size[1]), scale_factor=(img_size[1] / width, img_size[0] / height),
+                box_type_3d='euler-depth', transformation_3d_flow=[])
+    gt = np.concatenate([centers, sizes, eulers], 1)
+    aug = dict(hflip=False, vflip=False, rot=np.eye(3, dtype=np.float32), scale=1.0, trans=np.zeros(3, np.float32))
+    if augment:
+        # RandomFlip3D(flip_ratio 0.5/0.5) then GlobalRotScaleTrans (augmentation.py:87-139,322-348)
+        hf, vf = bool(rng.random() < .5), bool(rng.random() < .5)
+        ang = -rng.uniform(-0.087266, 0.087266)
+        scale = float(rng.uniform(.9, 1.1))
+        trans = rng.normal(scale=.1, size=3).astype(np.float32)
+        rz = _euler_zxy([ang, 0, 0])
+        rot_mat_T = rz.T.astype(np.float32)             # points @ rot_mat_T  (base_points.py:198-201)
+        M = np.diag([-1. if hf else 1., -1. if vf else 1., 1.])
+        A = rz @ M                                      # p_aug = scale * A p + trans
+        new = []
+        for b in range(n_boxes):
+            c = scale * (A @ centers[b]) + trans
+            Rb = A @ rots[b] @ M                        # keep a proper rotation (mirror the box frame too)
+            new.append(np.concatenate([c, sizes[b] * scale, _mat_to_euler_zxy(Rb)]))
+        gt = np.stack(new)
+        meta.update(pcd_horizontal_flip=hf, pcd_vertical_flip=vf, pcd_rotation=rot_mat_T, pcd_scale_factor=scale,
+                    pcd_trans=trans)
+        flow = (['HF'] if hf else []) + (['VF'] if vf else []) + ['R', 'S', 'T']
+        meta['transformation_3d_flow'] = flow
+        aug = dict(hflip=hf, vflip=vf, rot=rot_mat_T, scale=scale, trans=trans)
+    img = rng.integers(0, 256, (n_views, 3, img_size[0], img_size[1]), dtype=np.uint8)
+    return dict(depth=depth, img=img, extrinsic=np.stack(extr), intrinsic=np.stack(intr), sel_view=sel_view,
+                sel_pix=sel_pix, gt_boxes=gt.astype(np.float32), gt_labels=labels.astype(np.int64), meta=meta, aug=aug)
