@@ -1,0 +1,66 @@
+// Shared device/host helpers for the es_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ES_OFF (1 << 17)          // coordinate bias (matches oracle/coords.py)
+#define ES_FIELD 18
+#define ES_FMASK ((1ll << ES_FIELD) - 1)
+#define ES_EMPTY_KEY (-1ll)
+
+#define ES_CHECK_LAUNCH()                          \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+#define ES_TRY(x)                                  \
+  do {                                             \
+    hipError_t e__ = (x);                          \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+static inline int es_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+__host__ __device__ inline int64_t es_pack(int b, int x, int y, int z) {
+  return ((int64_t)b << (3 * ES_FIELD)) | ((int64_t)(x + ES_OFF) << (2 * ES_FIELD)) |
+         ((int64_t)(y + ES_OFF) << ES_FIELD) | (int64_t)(z + ES_OFF);
+}
+__host__ __device__ inline void es_unpack(int64_t k, int& b, int& x, int& y, int& z) {
+  b = (int)(k >> (3 * ES_FIELD));
+  x = (int)((k >> (2 * ES_FIELD)) & ES_FMASK) - ES_OFF;
+  y = (int)((k >> ES_FIELD) & ES_FMASK) - ES_OFF;
+  z = (int)(k & ES_FMASK) - ES_OFF;
+}
+
+// 64-bit mix (splitmix64 finaliser) -> slot
+__device__ inline uint32_t es_hash(int64_t k, uint32_t mask) {
+  uint64_t x = (uint64_t)k;
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return (uint32_t)x & mask;
+}
+
+// open-addressing lookup: returns value or -1
+__device__ inline int es_table_find(const int64_t* __restrict__ tkeys, const int* __restrict__ tvals,
+                                    uint32_t mask, int64_t key) {
+  uint32_t s = es_hash(key, mask);
+  for (uint32_t it = 0; it <= mask; ++it) {
+    int64_t k = tkeys[s];
+    if (k == key) return tvals[s];
+    if (k == ES_EMPTY_KEY) return -1;
+    s = (s + 1) & mask;
+  }
+  return -1;
+}
+
+__device__ inline float es_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double es_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,134 @@
+// Point <-> image projection fusion (row A8), one fused kernel per level:
+// voxel centre -> undo 3-D augmentation -> project into each of the V views -> nearest
+// feature fetch (channels-last, coalesced along C) -> unmasked sum / valid-view count.
+// Replaces batch_point_sample (+ apply_3d_transformation, batch_points_cam2img,
+// F.grid_sample) at embodiedscan/models/layers/fusion_layers/point_fusion.py:20-107,208-311
+// and embodiedscan/structures/bbox_3d/utils.py:289-332, called from
+// embodiedscan/models/detectors/sparse_featfusion_single_stage.py:142-207.
+#include "common.h"
+#include "../../include/es_hip.h"
+
+// per-sample meta block (floats), see es_hip.h: ES_FUSE_*
+__device__ inline void undo_aug(const float* m, float& x, float& y, float& z) {
+  int nops = (int)m[ES_FUSE_NOPS];
+  for (int o = 0; o < nops; ++o) {
+    int op = (int)m[ES_FUSE_OPS + o];
+    if (op == 1) {            // T (reverse): p += (-trans)
+      x = __fadd_rn(x, m[ES_FUSE_NTRANS + 0]);
+      y = __fadd_rn(y, m[ES_FUSE_NTRANS + 1]);
+      z = __fadd_rn(z, m[ES_FUSE_NTRANS + 2]);
+    } else if (op == 2) {     // S (reverse): p *= 1/scale
+      float s = m[ES_FUSE_ISCALE];
+      x = __fmul_rn(x, s); y = __fmul_rn(y, s); z = __fmul_rn(z, s);
+    } else if (op == 3) {     // R (reverse): p = p @ rot^-1
+      const float* r = m + ES_FUSE_ROTINV;
+      float nx = fmaf(z, r[6], fmaf(y, r[3], __fmul_rn(x, r[0])));
+      float ny = fmaf(z, r[7], fmaf(y, r[4], __fmul_rn(x, r[1])));
+      float nz = fmaf(z, r[8], fmaf(y, r[5], __fmul_rn(x, r[2])));
+      x = nx; y = ny; z = nz;
+    } else if (op == 4) {
+      x = -x;
+    } else if (op == 5) {
+      y = -y;
+    }
+  }
+}
+
+// returns pixel linear index (or -1 when grid_sample pads with zero) and the valid flag
+__device__ inline int project_view(const float* m, const float* P, float x, float y, float z, int Hf, int Wf,
+                                   bool& valid) {
+  float qx = fmaf(1.f, P[3], fmaf(z, P[2], fmaf(y, P[1], __fmul_rn(x, P[0]))));
+  float qy = fmaf(1.f, P[7], fmaf(z, P[6], fmaf(y, P[5], __fmul_rn(x, P[4]))));
+  float qz = fmaf(1.f, P[11], fmaf(z, P[10], fmaf(y, P[9], __fmul_rn(x, P[8]))));
+  float zc = fmaxf(qz, 1e-3f);                                    // clamp(min=1e-3)
+  float u = __fdiv_rn(qx, zc), v = __fdiv_rn(qy, zc);
+  u = __fsub_rn(__fmul_rn(u, m[ES_FUSE_SFX]), m[ES_FUSE_CROPX]);
+  v = __fsub_rn(__fmul_rn(v, m[ES_FUSE_SFY]), m[ES_FUSE_CROPY]);
+  if (m[ES_FUSE_FLIP] != 0.f) u = __fsub_rn(m[ES_FUSE_ORIW], u);
+  float w = m[ES_FUSE_PADW], h = m[ES_FUSE_PADH];
+  valid = (u < w) && (u > 0.f) && (v < h) && (v > 0.f) && (qz > 0.f);
+  float gx = __fsub_rn(__fmul_rn(__fdiv_rn(u, w), 2.f), 1.f);
+  float gy = __fsub_rn(__fmul_rn(__fdiv_rn(v, h), 2.f), 1.f);
+  // ATen CPU grid_sampler (vectorised): unnormalize = (g + 1) * ((size - 1) / 2); nearest = nearbyint
+  float ix = nearbyintf(__fmul_rn(__fadd_rn(gx, 1.f), __fdiv_rn((float)(Wf - 1), 2.f)));
+  float iy = nearbyintf(__fmul_rn(__fadd_rn(gy, 1.f), __fdiv_rn((float)(Hf - 1), 2.f)));
+  if (!(ix > -1.f && ix < (float)Wf && iy > -1.f && iy < (float)Hf)) return -1;
+  return (int)iy * Wf + (int)ix;
+}
+
+// one wave per point; lanes stride over channels
+__global__ __launch_bounds__(256) void k_point_sample_fwd(const int* __restrict__ coords, int n, float voxel_size,
+                                                          const float* __restrict__ meta, int meta_stride, int V,
+                                                          const float* __restrict__ feats, int Hf, int Wf, int C,
+                                                          float* __restrict__ out, int ldo, int* __restrict__ pix,
+                                                          int* __restrict__ cnt) {
+  int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  int4 c = ((const int4*)coords)[i];
+  const float* m = meta + (size_t)c.x * meta_stride;
+  float x = __fmul_rn((float)c.y, voxel_size), y = __fmul_rn((float)c.z, voxel_size),
+        z = __fmul_rn((float)c.w, voxel_size);
+  undo_aug(m, x, y, z);
+  int nvalid = 0;
+  const int MAXC = 8;                                   // supports C <= 512
+  float acc[MAXC];
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) acc[q] = 0.f;
+  for (int v = 0; v < V; ++v) {
+    bool valid;
+    int p = project_view(m, m + ES_FUSE_PROJ + v * 16, x, y, z, Hf, Wf, valid);
+    nvalid += valid ? 1 : 0;
+    if (lane == 0) pix[(size_t)i * V + v] = p;
+    if (p >= 0) {
+      const float* f = feats + (((size_t)c.x * V + v) * Hf * Wf + p) * C;
+#pragma unroll
+      for (int q = 0; q < MAXC; ++q) {
+        int ch = lane + q * 64;
+        if (ch < C) acc[q] += f[ch];                    // sum over ALL views, not masked
+      }
+    }
+  }
+  if (lane == 0) cnt[i] = nvalid;
+  float d = (float)max(nvalid, 1);
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    int ch = lane + q * 64;
+    if (ch < C) out[(size_t)i * ldo + ch] = nvalid > 0 ? __fdiv_rn(acc[q], d) : 0.f;
+  }
+}
+extern "C" int es_point_sample_fwd(const int* coords, int n, float voxel_size, const float* meta, int meta_stride,
+                                   int V, const float* feats, int Hf, int Wf, int C, float* out, int ldo, int* pix,
+                                   int* cnt, void* stream) {
+  if (n <= 0) return 0;
+  if (C > 512) return -4;
+  hipLaunchKernelGGL(k_point_sample_fwd, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords, n,
+                     voxel_size, meta, meta_stride, V, feats, Hf, Wf, C, out, ldo, pix, cnt);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_point_sample_bwd(const int* __restrict__ coords, int n, int V,
+                                                          const float* __restrict__ dout, int ldo,
+                                                          const int* __restrict__ pix, const int* __restrict__ cnt,
+                                                          int Hf, int Wf, int C, float* __restrict__ dfeats) {
+  int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  int nv = cnt[i];
+  if (nv <= 0) return;
+  int b = coords[(size_t)i * 4];
+  float inv = __fdiv_rn(1.f, (float)nv);
+  for (int v = 0; v < V; ++v) {
+    int p = pix[(size_t)i * V + v];
+    if (p < 0) continue;
+    float* f = dfeats + (((size_t)b * V + v) * Hf * Wf + p) * C;
+    for (int ch = lane; ch < C; ch += 64) atomicAdd(f + ch, dout[(size_t)i * ldo + ch] * inv);
+  }
+}
+extern "C" int es_point_sample_bwd(const int* coords, int n, int V, const float* dout, int ldo, const int* pix,
+                                   const int* cnt, int Hf, int Wf, int C, float* dfeats, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_point_sample_bwd, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords, n, V, dout,
+                     ldo, pix, cnt, Hf, Wf, C, dfeats);
+  ES_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,488 @@
+// Row-matrix operators on (N, C) f32 feature matrices: batch / instance norm (train mode)
+// with fused ReLU / ELU / residual, max pooling, row gather / scatter, strided 2-D copies.
+// All HBM-bound; channels are the fast axis so every access is coalesced along C.
+// Replaces MinkowskiBatchNorm / MinkowskiInstanceNorm / MinkowskiReLU / MinkowskiELU /
+// MinkowskiMaxPooling / MinkowskiPruning / ME.cat at
+//   embodiedscan/models/backbones/mink_resnet.py:64-69 (+ ME BasicBlock)
+//   embodiedscan/models/dense_heads/fcaf3d_head.py:919-947,1113
+//   embodiedscan/models/detectors/sparse_featfusion_single_stage.py:210-219
+#include "common.h"
+#include "../../include/es_hip.h"
+
+#define NCH 64   // rows per statistics chunk
+
+struct Segs { int n; int off[ES_MAX_SEG + 1]; };
+__device__ inline int seg_of(const Segs& s, int row) {
+  int g = 0;
+  for (int i = 1; i < s.n; ++i) g += (row >= s.off[i]);
+  return g;
+}
+static Segs make_segs(const int* seg_off, int nseg) {
+  Segs s;
+  s.n = nseg;
+  for (int i = 0; i <= nseg; ++i) s.off[i] = seg_off[i];
+  return s;
+}
+static int max_seg_rows(const Segs& s) {
+  int m = 0;
+  for (int i = 0; i < s.n; ++i) m = max(m, s.off[i + 1] - s.off[i]);
+  return m;
+}
+
+// partial[(seg*nchunk + chunk)*2*C + {0,1}*C + c]
+__global__ void k_norm_stats(const float* __restrict__ x, int ldx, int C, Segs segs, int nchunk,
+                             float* __restrict__ partial) {
+  int seg = blockIdx.y, chunk = blockIdx.x;
+  int r0 = segs.off[seg] + chunk * NCH, r1 = min(segs.off[seg + 1], r0 + NCH);
+  float* out = partial + ((size_t)(seg * nchunk + chunk) * 2) * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f, q = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      float v = x[(size_t)r * ldx + c];
+      s += v;
+      q += v * v;
+    }
+    out[c] = s;
+    out[C + c] = q;
+  }
+}
+__global__ void k_norm_finalize(const float* __restrict__ partial, int C, Segs segs, int nchunk, float eps,
+                                float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
+                                float* running_var, float momentum) {
+  int seg = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  int n = segs.off[seg + 1] - segs.off[seg];
+  int used = (n + NCH - 1) / NCH;
+  double s = 0, q = 0;
+  for (int ch = 0; ch < used; ++ch) {
+    const float* p = partial + ((size_t)(seg * nchunk + ch) * 2) * C;
+    s += p[c];
+    q += p[C + c];
+  }
+  double m = n > 0 ? s / n : 0.0;
+  double var = n > 0 ? q / n - m * m : 0.0;
+  if (var < 0) var = 0;
+  mean[seg * C + c] = (float)m;
+  invstd[seg * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean && n > 1) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1));
+  }
+}
+__device__ inline float act_fwd(float z, int act) {
+  if (act == 1) return z > 0.f ? z : 0.f;
+  if (act == 2) return z > 0.f ? z : (expf(z) - 1.f);
+  return z;
+}
+__global__ void k_norm_apply(const float* __restrict__ x, int ldx, int n, int C, Segs segs,
+                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                             const float* __restrict__ w, const float* __restrict__ b,
+                             const float* __restrict__ res, int ldr, int act, float* __restrict__ y, int ldy) {
+  size_t tot = (size_t)n * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / C), c = (int)(e - (size_t)r * C);
+    int sg = seg_of(segs, r);
+    float z = (x[(size_t)r * ldx + c] - mean[sg * C + c]) * invstd[sg * C + c] * w[c] + b[c];
+    if (res) z += res[(size_t)r * ldr + c];
+    y[(size_t)r * ldy + c] = act_fwd(z, act);
+  }
+}
+
+// workspace floats: nseg * cdiv(max_seg_rows, 64) * 2 * C
+extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg_off, int nseg, float eps,
+                           const float* weight, const float* bias, const float* res, int ldr, int act,
+                           float* running_mean, float* running_var, float momentum, float* mean, float* invstd,
+                           float* workspace, float* y, int ldy, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0 || nseg > ES_MAX_SEG) return nseg > ES_MAX_SEG ? -3 : 0;
+  Segs s = make_segs(seg_off, nseg);
+  int nchunk = es_cdiv(max_seg_rows(s), NCH);
+  if (nchunk < 1) nchunk = 1;
+  hipLaunchKernelGGL(k_norm_stats, dim3(nchunk, nseg), dim3(C >= 256 ? 256 : 64), 0, st, x, ldx, C, s, nchunk,
+                     workspace);
+  hipLaunchKernelGGL(k_norm_finalize, dim3(es_cdiv(C, 64), nseg), dim3(64), 0, st, workspace, C, s, nchunk, eps,
+                     mean, invstd, running_mean, running_var, momentum);
+  int g = es_cdiv((long long)n * C, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_norm_apply, dim3(g), dim3(256), 0, st, x, ldx, n, C, s, mean, invstd, weight, bias, res,
+                     ldr, act, y, ldy);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" size_t es_norm_workspace_floats(int n, int C, const int* seg_off, int nseg) {
+  int m = 0;
+  for (int i = 0; i < nseg; ++i) m = max(m, seg_off[i + 1] - seg_off[i]);
+  int nchunk = es_cdiv(m, NCH);
+  if (nchunk < 1) nchunk = 1;
+  return (size_t)nseg * nchunk * 2 * C;
+}
+
+// backward pass 1: dz = dy * act'(y) (written in place into dy), partial sums of dz and dz*xhat
+__global__ void k_norm_bwd_stats(float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
+                                 const float* __restrict__ x, int ldx, int C, Segs segs, int nchunk,
+                                 const float* __restrict__ mean, const float* __restrict__ invstd, int act,
+                                 float* __restrict__ partial) {
+  int seg = blockIdx.y, chunk = blockIdx.x;
+  int r0 = segs.off[seg] + chunk * NCH, r1 = min(segs.off[seg + 1], r0 + NCH);
+  float* out = partial + ((size_t)(seg * nchunk + chunk) * 2) * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f, q = 0.f, m = mean[seg * C + c], is = invstd[seg * C + c];
+    for (int r = r0; r < r1; ++r) {
+      float g = dy[(size_t)r * ldd + c];
+      if (act) {
+        float yv = y[(size_t)r * ldy + c];
+        g = (act == 1) ? (yv > 0.f ? g : 0.f) : (yv > 0.f ? g : g * (yv + 1.f));
+        dy[(size_t)r * ldd + c] = g;
+      }
+      s += g;
+      q += g * ((x[(size_t)r * ldx + c] - m) * is);
+    }
+    out[c] = s;
+    out[C + c] = q;
+  }
+}
+__global__ void k_norm_bwd_finalize(const float* __restrict__ partial, int C, Segs segs, int nchunk,
+                                    float* __restrict__ sum_dz, float* __restrict__ sum_dzx, float* dweight,
+                                    float* dbias) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double tw = 0, tb = 0;
+  for (int seg = 0; seg < segs.n; ++seg) {
+    int n = segs.off[seg + 1] - segs.off[seg];
+    int used = (n + NCH - 1) / NCH;
+    double s = 0, q = 0;
+    for (int ch = 0; ch < used; ++ch) {
+      const float* p = partial + ((size_t)(seg * nchunk + ch) * 2) * C;
+      s += p[c];
+      q += p[C + c];
+    }
+    sum_dz[seg * C + c] = (float)s;
+    sum_dzx[seg * C + c] = (float)q;
+    tb += s;
+    tw += q;
+  }
+  if (dweight) dweight[c] += (float)tw;
+  if (dbias) dbias[c] += (float)tb;
+}
+__global__ void k_norm_bwd_apply(const float* __restrict__ dz, int ldd, const float* __restrict__ x, int ldx, int n,
+                                 int C, Segs segs, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                 const float* __restrict__ w, const float* __restrict__ sum_dz,
+                                 const float* __restrict__ sum_dzx, float* __restrict__ dx, int ldo, int accumulate) {
+  size_t tot = (size_t)n * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / C), c = (int)(e - (size_t)r * C);
+    int sg = seg_of(segs, r);
+    float inv_n = 1.f / (float)(segs.off[sg + 1] - segs.off[sg]);
+    float is = invstd[sg * C + c];
+    float xh = (x[(size_t)r * ldx + c] - mean[sg * C + c]) * is;
+    float g = w[c] * is * (dz[(size_t)r * ldd + c] - sum_dz[sg * C + c] * inv_n - xh * sum_dzx[sg * C + c] * inv_n);
+    float* p = dx + (size_t)r * ldo + c;
+    *p = accumulate ? (*p + g) : g;
+  }
+}
+// dy is overwritten with dz (= gradient w.r.t. the pre-activation, which is also the
+// gradient of the residual input).  workspace as in es_norm_fwd plus 2*nseg*C floats.
+extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const float* x, int ldx, int n, int C,
+                           const int* seg_off, int nseg, const float* mean, const float* invstd,
+                           const float* weight, int act, float* dweight, float* dbias, float* workspace, float* dx,
+                           int ldo, int accumulate, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0 || nseg > ES_MAX_SEG) return nseg > ES_MAX_SEG ? -3 : 0;
+  Segs s = make_segs(seg_off, nseg);
+  int nchunk = es_cdiv(max_seg_rows(s), NCH);
+  if (nchunk < 1) nchunk = 1;
+  float* sums = workspace + (size_t)nseg * nchunk * 2 * C;
+  hipLaunchKernelGGL(k_norm_bwd_stats, dim3(nchunk, nseg), dim3(C >= 256 ? 256 : 64), 0, st, dy, ldd, y, ldy, x,
+                     ldx, C, s, nchunk, mean, invstd, act, workspace);
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(es_cdiv(C, 64)), dim3(64), 0, st, workspace, C, s, nchunk, sums,
+                     sums + (size_t)nseg * C, dweight, dbias);
+  int g = es_cdiv((long long)n * C, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_norm_bwd_apply, dim3(g), dim3(256), 0, st, dy, ldd, x, ldx, n, C, s, mean, invstd, weight,
+                     sums, sums + (size_t)nseg * C, dx, ldo, accumulate);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ max pooling (k=2,s=2)
+__global__ void k_maxpool_fwd(const float* __restrict__ x, int ldx, const int* __restrict__ nbr, int n_out, int K,
+                              int C, float* __restrict__ y, int* __restrict__ arg) {
+  size_t tot = (size_t)n_out * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int j = (int)(e / C), c = (int)(e - (size_t)j * C);
+    float best = -INFINITY;
+    int bi = -1;
+    for (int k = 0; k < K; ++k) {
+      int i = nbr[(size_t)j * K + k];
+      if (i < 0) continue;
+      float v = x[(size_t)i * ldx + c];
+      if (bi < 0 || v > best) { best = v; bi = i; }     // first tap wins ties
+    }
+    y[e] = best;
+    arg[e] = bi;
+  }
+}
+extern "C" int es_maxpool_fwd(const float* x, int ldx, const int* nbr, int n_out, int K, int C, float* y, int* arg,
+                              void* stream) {
+  if (n_out <= 0) return 0;
+  int g = es_cdiv((long long)n_out * C, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_maxpool_fwd, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, nbr, n_out, K, C, y, arg);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+__global__ void k_maxpool_bwd(const float* __restrict__ dy, const int* __restrict__ arg, int n_out, int C,
+                              float* __restrict__ dx, int ldo) {
+  size_t tot = (size_t)n_out * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(e % C);
+    int i = arg[e];
+    if (i >= 0) dx[(size_t)i * ldo + c] += dy[e];        // windows are disjoint: no race
+  }
+}
+extern "C" int es_maxpool_bwd(const float* dy, const int* arg, int n_out, int C, float* dx, int ldo, void* stream) {
+  if (n_out <= 0) return 0;
+  int g = es_cdiv((long long)n_out * C, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3(g), dim3(256), 0, (hipStream_t)stream, dy, arg, n_out, C, dx, ldo);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ gather / scatter / copies
+// mode 0: dst[i] = src[idx[i]]   mode 1: dst[idx[i]] += src[i] (idx unique)   mode 2: dst[idx[i]] = src[i]
+__global__ void k_row_move(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds,
+                           const int* __restrict__ idx, int n, int C, int mode) {
+  size_t tot = (size_t)n * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int i = (int)(e / C), c = (int)(e - (size_t)i * C);
+    int r = idx ? idx[i] : i;
+    if (r < 0) continue;
+    if (mode == 0) dst[(size_t)i * ldd + c] = src[(size_t)r * lds + c];
+    else if (mode == 1) dst[(size_t)r * ldd + c] += src[(size_t)i * lds + c];
+    else dst[(size_t)r * ldd + c] = src[(size_t)i * lds + c];
+  }
+}
+extern "C" int es_row_move(float* dst, int ldd, const float* src, int lds, const int* idx, int n, int C, int mode,
+                           void* stream) {
+  if (n <= 0 || C <= 0) return 0;
+  int g = es_cdiv((long long)n * C, 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_row_move, dim3(g), dim3(256), 0, (hipStream_t)stream, dst, ldd, src, lds, idx, n, C, mode);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+// dst (op)= alpha * src over a strided (n, C) block; op 0 assign, 1 add
+__global__ void k_axpy2d(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int n, int C,
+                         float alpha, int op) {
+  size_t tot = (size_t)n * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int i = (int)(e / C), c = (int)(e - (size_t)i * C);
+    float v = alpha * src[(size_t)i * lds + c];
+    float* p = dst + (size_t)i * ldd + c;
+    *p = op ? (*p + v) : v;
+  }
+}
+extern "C" int es_axpy2d(float* dst, int ldd, const float* src, int lds, int n, int C, float alpha, int op,
+                         void* stream) {
+  if (n <= 0 || C <= 0) return 0;
+  int g = es_cdiv((long long)n * C, 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_axpy2d, dim3(g), dim3(256), 0, (hipStream_t)stream, dst, ldd, src, lds, n, C, alpha, op);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ interpolated scores + top-k prune mask
+// s[i] = sum_k w[i,k] * score[idx[i,k]]  (fixed k order; absent corner contributes 0)
+__global__ void k_interp_scores(const float* __restrict__ score, const int* __restrict__ idx,
+                                const float* __restrict__ w, int n, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int r = idx[i * 8 + k];
+    float v = (r >= 0) ? score[r] : 0.f;
+    s = s + v * ((r >= 0) ? w[i * 8 + k] : 0.f);
+  }
+  out[i] = s;
+}
+extern "C" int es_interp_scores(const float* score, const int* idx, const float* w, int n, float* out,
+                                void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_interp_scores, dim3(es_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, score, idx, w, n,
+                     out);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+__device__ inline uint32_t f2ord(float f) {   // order preserving float -> uint
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// one workgroup per segment: mask[i] = 1 for the k largest values of v[off[s]:off[s+1]]
+// (ties at the threshold: lower row first).  Radix select, 4 passes of 8 bits.
+__global__ __launch_bounds__(1024) void k_topk_mask(const float* __restrict__ v, Segs segs, int kkeep,
+                                                    int* __restrict__ mask) {
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int s_prefix, s_remaining, s_carry;
+  __shared__ int wsum[16];
+  int seg = blockIdx.x;
+  int r0 = segs.off[seg], r1 = segs.off[seg + 1], n = r1 - r0;
+  if (kkeep >= n) {
+    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) mask[i] = 1;
+    return;
+  }
+  if (threadIdx.x == 0) { s_prefix = 0; s_remaining = kkeep; }
+  uint32_t pmask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    uint32_t prefix = s_prefix;
+    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+      uint32_t u = f2ord(v[i]);
+      if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned int rem = s_remaining, b = 255;
+      for (;; --b) {                      // walk buckets from the largest digit
+        if (hist[b] >= rem) break;
+        rem -= hist[b];
+        if (b == 0) break;
+      }
+      s_prefix = prefix | (b << shift);
+      s_remaining = rem;                  // how many to take from the bucket equal to the threshold
+    }
+    pmask |= (255u << shift);
+    __syncthreads();
+  }
+  uint32_t thr = s_prefix;
+  unsigned int take_eq = s_remaining;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int b0 = r0; b0 < r1; b0 += blockDim.x) {     // ordered pass: rank the ties by row
+    int i = b0 + threadIdx.x;
+    uint32_t u = (i < r1) ? f2ord(v[i]) : 0;
+    int eq = (i < r1) && (u == thr);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = eq;
+    for (int o = 1; o < 64; o <<= 1) {
+      int tt = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += tt;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int base = s_carry, tot = 0;
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) {
+      if (q < w) base += wsum[q];
+      tot += wsum[q];
+    }
+    if (i < r1) mask[i] = (u > thr) || (eq && (unsigned)(base + inc - 1) < take_eq);
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += tot;
+    __syncthreads();
+  }
+}
+extern "C" int es_topk_mask(const float* values, const int* seg_off, int nseg, int k, int* mask, void* stream) {
+  if (nseg <= 0 || nseg > ES_MAX_SEG) return nseg > ES_MAX_SEG ? -3 : 0;
+  Segs s = make_segs(seg_off, nseg);
+  hipLaunchKernelGGL(k_topk_mask, dim3(nseg), dim3(1024), 0, (hipStream_t)stream, values, s, k, mask);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+// row-wise max over channels (prune score = max class logit, fcaf3d_head.py:1131-1134)
+__global__ void k_row_max(const float* __restrict__ x, int ldx, int n, int C, float* __restrict__ out) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, x[(size_t)row * ldx + c]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) out[row] = m;
+}
+extern "C" int es_row_max(const float* x, int ldx, int n, int C, float* out, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_row_max, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, n, C, out);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ frozen-BN affine + residual + ReLU (2-D backbone)
+// y = act(x * scale[c] + shift[c] (+ res));  mmdet.ResNet with norm_eval=True, BN requires_grad=False
+// (configs/detection/mv-det3d_...py:24-34): scale = w / sqrt(var + eps), shift = b - mean * scale.
+__global__ void k_affine_act(const float* __restrict__ x, const float* __restrict__ scale,
+                             const float* __restrict__ shift, const float* __restrict__ res, size_t n, int C, int act,
+                             float* __restrict__ y) {
+  size_t tot = n * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(e % C);
+    float z = x[e] * scale[c] + shift[c];
+    if (res) z += res[e];
+    y[e] = act ? fmaxf(z, 0.f) : z;
+  }
+}
+extern "C" int es_affine_act_fwd(const float* x, const float* scale, const float* shift, const float* res, size_t n,
+                                 int C, int act, float* y, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_affine_act, dim3(8192), dim3(256), 0, (hipStream_t)stream, x, scale, shift, res, n, C, act, y);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+// dz = dy * relu'(y) ; dx (op)= dz * scale ; dres (op)= dz
+__global__ void k_affine_act_bwd(const float* __restrict__ dy, const float* __restrict__ y,
+                                 const float* __restrict__ scale, size_t n, int C, int act, float* __restrict__ dx,
+                                 int acc_x, float* __restrict__ dres, int acc_r) {
+  size_t tot = n * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(e % C);
+    float g = dy[e];
+    if (act && !(y[e] > 0.f)) g = 0.f;
+    if (dx) dx[e] = acc_x ? dx[e] + g * scale[c] : g * scale[c];
+    if (dres) dres[e] = acc_r ? dres[e] + g : g;
+  }
+}
+extern "C" int es_affine_act_bwd(const float* dy, const float* y, const float* scale, size_t n, int C, int act,
+                                 float* dx, int acc_x, float* dres, int acc_r, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_affine_act_bwd, dim3(8192), dim3(256), 0, (hipStream_t)stream, dy, y, scale, n, C, act, dx,
+                     acc_x, dres, acc_r);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+// scale/shift of a frozen BN from its four vectors
+__global__ void k_bn_fold(const float* w, const float* b, const float* rm, const float* rv, int C, float eps,
+                          float* scale, float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = w[c] / sqrtf(rv[c] + eps);
+  scale[c] = s;
+  shift[c] = b[c] - rm[c] * s;
+}
+extern "C" int es_bn_fold(const float* w, const float* b, const float* rm, const float* rv, int C, float eps,
+                          float* scale, float* shift, void* stream) {
+  hipLaunchKernelGGL(k_bn_fold, dim3(es_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, w, b, rm, rv, C, eps, scale,
+                     shift);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+// dense image-grid kernel map for a KHxKW conv (stride s, pad p) over NI images in channels-last row order
+__global__ void k_image_map(int NI, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                            int* __restrict__ nbr) {
+  long long tot = (long long)NI * Ho * Wo * KH * KW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long long)gridDim.x * blockDim.x) {
+    int k = (int)(e % (KH * KW));
+    long long j = e / (KH * KW);
+    int wo = (int)(j % Wo), ho = (int)((j / Wo) % Ho), im = (int)(j / ((long long)Wo * Ho));
+    int hi = ho * stride - pad + k / KW, wi = wo * stride - pad + k % KW;
+    nbr[e] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? (int)(((long long)im * H + hi) * W + wi) : -1;
+  }
+}
+extern "C" int es_image_map(int n_img, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int* nbr,
+                            void* stream) {
+  hipLaunchKernelGGL(k_image_map, dim3(4096), dim3(256), 0, (hipStream_t)stream, n_img, H, W, Ho, Wo, KH, KW, stride,
+                     pad, nbr);
+  ES_CHECK_LAUNCH();
+  return 0;
+}

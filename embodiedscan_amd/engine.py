@@ -1,0 +1,260 @@
+"""Operator layer of the MI355X path: thin Python drivers around the C-ABI kernels plus a
+minimal reverse-mode tape (HIP launches in, HIP launches out -- no torch.autograd, no CPU path).
+
+torch is used for device memory (caching allocator) and the current HIP stream only.
+Every forward function registers one closure on the tape; `TAPE.backward()` replays them in
+reverse.  Gradients w.r.t. parameters accumulate straight into the flat gradient arena.
+"""
+import torch
+from . import hip
+from .hip import P, call, iarr
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Var:
+    """A row matrix (N, C) f32 on the device with an optional gradient."""
+    __slots__ = ('d', 'g', 'rg')
+
+    def __init__(self, d, rg=True):
+        self.d, self.g, self.rg = d, None, rg
+
+    @property
+    def shape(self):
+        return self.d.shape
+
+
+class Param:
+    """View into the parameter / gradient arenas."""
+    __slots__ = ('d', 'g')
+
+    def __init__(self, d, g=None):
+        self.d, self.g = d, g
+
+
+class Tape:
+    def __init__(self):
+        self.fns = []
+        self.enabled = True
+
+    def add(self, fn):
+        if self.enabled:
+            self.fns.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.fns):
+            fn()
+        self.fns = []
+
+    def clear(self):
+        self.fns = []
+
+
+TAPE = Tape()
+
+
+def empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def zeros(shape, like, dtype=torch.float32):
+    return torch.zeros(shape, dtype=dtype, device=like.device)
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, 'row matrices must be contiguous along channels'
+    return t.stride(0)
+
+
+def _grad_target(v, shape_like):
+    """(tensor, accumulate flag) for writing the gradient of v."""
+    if v.g is None:
+        v.g = torch.empty_like(shape_like)
+        return v.g, 0
+    return v.g, 1
+
+
+# ------------------------------------------------------------------ convolution
+def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
+    """y[j] = sum_k x[nbr[j,k]] @ w[k] (+bias).  w.d: (K,Cin,Cout).  nbr None -> identity (K=1).
+    bias_from: first output column whose bias is trainable (earlier columns keep a zero bias)."""
+    K, cin, cout = w.d.shape
+    n_in = x.d.shape[0]
+    y = Var(empty((n_out, cout), x.d))
+    call('es_spconv_fwd', P(x.d), _ld(x.d), P(w.d), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0,
+         P(y.d), cout, 0, 0, _stream())
+
+    def bwd():
+        if y.g is None:
+            return
+        s = _stream()
+        if w.g is not None:
+            call('es_spconv_wgrad', P(x.d), _ld(x.d), P(y.g), _ld(y.g), P(nbr), n_out, n_in, K, cin, cout, P(w.g), s)
+        if bias is not None and bias.g is not None:
+            ones = torch.ones((n_out, 1), dtype=torch.float32, device=x.d.device)
+            call('es_spconv_wgrad', P(ones), 1, y.g.data_ptr() + 4 * bias_from, _ld(y.g), 0, n_out, n_out, 1, 1,
+                 cout - bias_from, bias.g.data_ptr() + 4 * bias_from, s)
+        if need_dx and x.rg:
+            g, acc = _grad_target(x, x.d)
+            call('es_spconv_fwd', P(y.g), _ld(y.g), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1,
+                 acc, s)
+    TAPE.add(bwd)
+    return y
+
+
+def gen_conv_transpose(x, w):
+    """MinkowskiGenerativeConvolutionTranspose(k=2,s=2): y[8i+k] = x[i] @ w[k]; 8 row GEMMs into the
+    (N, 8*Cout) view of the output."""
+    K, cin, cout = w.d.shape
+    n = x.d.shape[0]
+    y = Var(empty((n * 8, cout), x.d))
+    s = _stream()
+    for k in range(8):
+        call('es_spconv_fwd', P(x.d), _ld(x.d), w.d.data_ptr() + 4 * k * cin * cout, 0, n, n, 1, cin, cout, 0,
+             y.d.data_ptr() + 4 * k * cout, 8 * cout, 0, 0, s)
+
+    def bwd():
+        if y.g is None:
+            return
+        s = _stream()
+        g, acc = _grad_target(x, x.d) if x.rg else (None, 0)
+        for k in range(8):
+            gy = y.g.data_ptr() + 4 * k * cout
+            if w.g is not None:
+                call('es_spconv_wgrad', P(x.d), _ld(x.d), gy, 8 * cout, 0, n, n, 1, cin, cout,
+                     w.g.data_ptr() + 4 * k * cin * cout, s)
+            if g is not None:
+                call('es_spconv_fwd', gy, 8 * cout, w.d.data_ptr() + 4 * k * cin * cout, 0, n, n, 1, cout, cin, 0,
+                     P(g), _ld(g), 1, 1 if (acc or k > 0) else 0, s)
+    TAPE.add(bwd)
+    return y
+
+
+# ------------------------------------------------------------------ norms
+def norm(x, weight, bias, seg_off, eps, act=0, res=None, running=None, momentum=0.1):
+    """Train-mode batch norm (seg_off=[0,N]) / instance norm (seg_off=batch offsets) with fused
+    residual add and activation (0 none, 1 ReLU, 2 ELU)."""
+    n, C = x.d.shape
+    nseg = len(seg_off) - 1
+    so = iarr(seg_off)
+    ws_n = hip.raw('es_norm_workspace_floats')(n, C, so, nseg) + 2 * nseg * C
+    ws = empty((ws_n,), x.d)
+    mean, invstd = empty((nseg, C), x.d), empty((nseg, C), x.d)
+    y = Var(empty((n, C), x.d))
+    rm, rv = (running if running is not None else (None, None))
+    call('es_norm_fwd', P(x.d), _ld(x.d), n, C, so, nseg, float(eps), P(weight.d), P(bias.d),
+         P(res.d) if res is not None else 0, _ld(res.d) if res is not None else 0, act, P(rm), P(rv), float(momentum),
+         P(mean), P(invstd), P(ws), P(y.d), C, _stream())
+
+    def bwd():
+        if y.g is None:
+            return
+        s = _stream()
+        ws2 = empty((ws_n,), x.d)
+        g, acc = _grad_target(x, x.d)
+        call('es_norm_bwd', P(y.g), _ld(y.g), P(y.d), C, P(x.d), _ld(x.d), n, C, so, nseg, P(mean), P(invstd),
+             P(weight.d), act, P(weight.g), P(bias.g), P(ws2), P(g), _ld(g), acc, s)
+        if res is not None and res.rg:          # y.g now holds dz == gradient of the residual input
+            if res.g is None:
+                res.g = y.g
+            else:
+                call('es_axpy2d', P(res.g), _ld(res.g), P(y.g), _ld(y.g), n, C, 1.0, 1, s)
+    TAPE.add(bwd)
+    return y
+
+
+def affine_act(x, scale, shift, act=1, res=None, need_dx=True):
+    """frozen-BN affine (+residual) (+ReLU) for the 2-D backbone."""
+    n, C = x.d.shape
+    y = Var(empty((n, C), x.d))
+    call('es_affine_act_fwd', P(x.d), P(scale), P(shift), P(res.d) if res is not None else 0, n, C, act, P(y.d),
+         _stream())
+
+    def bwd():
+        if y.g is None:
+            return
+        gx = accx = gr = accr = 0
+        if need_dx and x.rg:
+            t, accx = _grad_target(x, x.d)
+            gx = P(t)
+        if res is not None and res.rg:
+            t, accr = _grad_target(res, res.d)
+            gr = P(t)
+        if gx or gr:
+            call('es_affine_act_bwd', P(y.g), P(y.d), P(scale), n, C, act, gx, accx, gr, accr, _stream())
+    TAPE.add(bwd)
+    return y
+
+
+# ------------------------------------------------------------------ pooling / row moves
+def maxpool(x, nbr, n_out, need_dx=True):
+    C = x.d.shape[1]
+    K = nbr.shape[1]
+    y = Var(empty((n_out, C), x.d))
+    arg = empty((n_out, C), x.d, torch.int32)
+    call('es_maxpool_fwd', P(x.d), _ld(x.d), P(nbr), n_out, K, C, P(y.d), P(arg), _stream())
+
+    def bwd():
+        if y.g is None or not (need_dx and x.rg):
+            return
+        if x.g is None:
+            x.g = torch.zeros_like(x.d)
+        call('es_maxpool_bwd', P(y.g), P(arg), n_out, C, P(x.g), _ld(x.g), _stream())
+    TAPE.add(bwd)
+    return y
+
+
+def gather_rows(x, idx):
+    """y = x[idx] (MinkowskiPruning with idx = kept rows)."""
+    n, C = idx.shape[0], x.d.shape[1]
+    y = Var(empty((n, C), x.d))
+    call('es_row_move', P(y.d), C, P(x.d), _ld(x.d), P(idx), n, C, 0, _stream())
+
+    def bwd():
+        if y.g is None or not x.rg:
+            return
+        if x.g is None:
+            x.g = torch.zeros_like(x.d)
+        call('es_row_move', P(x.g), _ld(x.g), P(y.g), _ld(y.g), P(idx), n, C, 1, _stream())
+    TAPE.add(bwd)
+    return y
+
+
+def union_add(a, b, pos_a, pos_b, n):
+    """sparse a + b on the coordinate union (rows pos_a / pos_b of the result)."""
+    C = a.d.shape[1]
+    y = Var(zeros((n, C), a.d))
+    s = _stream()
+    call('es_row_move', P(y.d), C, P(a.d), _ld(a.d), P(pos_a), a.d.shape[0], C, 2, s)
+    call('es_row_move', P(y.d), C, P(b.d), _ld(b.d), P(pos_b), b.d.shape[0], C, 1, s)
+
+    def bwd():
+        if y.g is None:
+            return
+        s = _stream()
+        for v, pos in ((a, pos_a), (b, pos_b)):
+            if not v.rg:
+                continue
+            m = v.d.shape[0]
+            if v.g is None:
+                v.g = empty((m, C), a.d)
+                call('es_row_move', P(v.g), C, P(y.g), _ld(y.g), P(pos), m, C, 0, s)
+            else:
+                t = empty((m, C), a.d)
+                call('es_row_move', P(t), C, P(y.g), _ld(y.g), P(pos), m, C, 0, s)
+                call('es_axpy2d', P(v.g), _ld(v.g), P(t), C, m, C, 1.0, 1, s)
+    TAPE.add(bwd)
+    return y
+
+
+def copy_cols(dst, col, src):
+    """dst[:, col:col+C] = src (raw tensors)."""
+    n, C = src.shape
+    call('es_axpy2d', dst.data_ptr() + 4 * col, dst.stride(0), P(src), src.stride(0), n, C, 1.0, 0, _stream())
+
+
+def add_into(dst, src):
+    n, C = src.shape
+    call('es_axpy2d', P(dst), dst.stride(0), P(src), src.stride(0), n, C, 1.0, 1, _stream())

@@ -1,0 +1,78 @@
+"""ctypes binding of libes_hip.so (the C-ABI drop-in boundary, include/es_hip.h).
+
+The prototypes are parsed from the header so the header stays the single source of truth.
+There is no fallback: if the shared library is missing or a symbol is absent this module
+raises at import, and every call checks the returned status.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libes_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'es_hip.h')
+
+_CT = {'int': ctypes.c_int, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes], [argnames])} for every prototype in es_hip.h."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(int|size_t)\s+(es_\w+)\s*\(([^)]*)\)\s*;', src):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        at, an = [], []
+        for a in args.split(','):
+            a = a.strip()
+            if not a or a == 'void':
+                continue
+            an.append(re.findall(r'(\w+)\s*$', a)[0])
+            if '*' in a:
+                at.append(ctypes.c_void_p)
+            else:
+                toks = [t for t in a.split() if t != 'const']
+                at.append(_CT[toks[0]])
+        out[name] = (_CT[ret], at, an)
+    return out
+
+
+PROTOS = parse_header()
+CONSTS = {k: int(v) for k, v in re.findall(r'#define\s+(ES_\w+)\s+(\d+)', open(HEADER_PATH).read())}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f'{LIB_PATH} is missing: build it with `make -C embodiedscan_amd/csrc` '
+                      '(or __graft_entry__.build()); there is no CPU fallback for the HIP path')
+_lib = ctypes.CDLL(LIB_PATH)
+_fn = {}
+for _name, (_ret, _at, _an) in PROTOS.items():
+    _f = getattr(_lib, _name)          # AttributeError if the .so does not export a declared symbol
+    _f.restype, _f.argtypes = _ret, _at
+    _fn[_name] = _f
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def call(name, *args):
+    rc = _fn[name](*args)
+    if rc != 0:
+        raise HipError(f'{name} failed with status {rc}')
+
+
+def raw(name):
+    return _fn[name]
+
+
+def P(t):
+    """device/host pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def iarr(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def farr(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])

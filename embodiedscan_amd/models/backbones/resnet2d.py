@@ -1,0 +1,138 @@
+"""mmdet.ResNet (depth 50, torchvision-style bottlenecks, frozen eval-mode BN) on the es_hip row-matrix
+convolution engine: images are channels-last row matrices (N*H*W, C); a 3x3 / strided conv is the sparse
+conv kernel driven by a static image-grid kernel map, a 1x1 conv is a plain row GEMM.
+Stand-in for the `backbone=dict(type='mmdet.ResNet', depth=50, base_channels=16, frozen_stages=1,
+norm_eval=True, ...)` entry of configs/detection/mv-det3d_8xb4_embodiedscan-3d-284class-9dof.py:24-34,
+called at embodiedscan/models/detectors/sparse_featfusion_single_stage.py:130-136.
+"""
+import torch
+from ... import engine as E
+from ...hip import P, call
+from ...registry import MODELS
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Grid:
+    """static kernel maps of one (n_img, H, W) image grid."""
+
+    def __init__(self, n_img, H, W, dev):
+        self.n_img, self.H, self.W, self.dev = n_img, H, W, dev
+        self.maps = {}
+
+    def conv_map(self, kh, stride, pad, want_inv=True):
+        key = (kh, stride, pad)
+        if key not in self.maps:
+            Ho, Wo = (self.H + 2 * pad - kh) // stride + 1, (self.W + 2 * pad - kh) // stride + 1
+            n_out, K = self.n_img * Ho * Wo, kh * kh
+            nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.dev)
+            call('es_image_map', self.n_img, self.H, self.W, Ho, Wo, kh, kh, stride, pad, P(nbr), _stream())
+            inv = None
+            if want_inv:
+                n_in = self.n_img * self.H * self.W
+                inv = torch.empty((n_in, K), dtype=torch.int32, device=self.dev)
+                call('es_inverse_map', P(nbr), n_out, K, n_in, P(inv), _stream())
+            self.maps[key] = (nbr, inv, n_out, Ho, Wo)
+        return self.maps[key]
+
+
+@MODELS.register_module(name='mmdet.ResNet')
+class ResNet:
+    arch = {50: (3, 4, 6, 3)}
+
+    def __init__(self, depth=50, in_channels=3, stem_channels=None, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), out_indices=(0, 1, 2, 3), style='pytorch', frozen_stages=-1, norm_cfg=None,
+                 norm_eval=True, init_cfg=None, **kw):
+        assert depth == 50 and style == 'pytorch' and num_stages == 4 and tuple(strides) == (1, 2, 2, 2)
+        assert norm_eval and norm_cfg is not None and not norm_cfg.get('requires_grad', True), \
+            'only the frozen / eval-mode BN of the shipped config is implemented'
+        self.base = base_channels
+        self.out_indices, self.frozen_stages = tuple(out_indices), frozen_stages
+        self.grids = {}
+
+    def bind(self, arena, prefix='backbone.'):
+        self.arena, self.prefix = arena, prefix
+        self.refresh()
+        return self
+
+    def _par(self, n):
+        return E.Param(self.arena.p[self.prefix + n], self.arena.g.get(self.prefix + n))
+
+    def refresh(self):
+        """fold every frozen BatchNorm2d into (scale, shift) -- call again after load_state_dict."""
+        a, pre = self.arena, self.prefix
+        self.fold = {}
+        for name in [k[len(pre):-len('.running_var')] for k in a.p if k.startswith(pre) and k.endswith('.running_var')]:
+            C = a.p[pre + name + '.weight'].numel()
+            sc = torch.empty(C, dtype=torch.float32, device=a.data.device)
+            sh = torch.empty(C, dtype=torch.float32, device=a.data.device)
+            call('es_bn_fold', P(a.p[pre + name + '.weight']), P(a.p[pre + name + '.bias']),
+                 P(a.p[pre + name + '.running_mean']), P(a.p[pre + name + '.running_var']), C, 1e-5, P(sc), P(sh),
+                 _stream())
+            self.fold[name] = (sc, sh)
+
+    def forward(self, x):
+        """x: (n_img, H, W, 3) f32 channels-last.  Returns [(Var (n_img*h*w, C), h, w)] for the out_indices."""
+        n_img, H, W, _ = x.shape
+        dev = x.device
+        key = (n_img, H, W)
+        if key not in self.grids:
+            g0 = _Grid(n_img, H, W, dev)
+            stem = g0.conv_map(7, 2, 3, want_inv=False)
+            nbr_a, nbr_b = stem[0][:, :27].contiguous(), stem[0][:, 27:].contiguous()
+            g1 = _Grid(n_img, stem[3], stem[4], dev)
+            pool = g1.conv_map(3, 2, 1, want_inv=False)
+            grids = [_Grid(n_img, pool[3], pool[4], dev)]
+            for li in range(1, 4):
+                h, w = grids[-1].H, grids[-1].W
+                grids.append(_Grid(n_img, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, dev))
+            self.grids[key] = (stem, nbr_a, nbr_b, pool, grids)
+        stem, nbr_a, nbr_b, pool, grids = self.grids[key]
+        s = _stream()
+        prev = E.TAPE.enabled
+        E.TAPE.enabled = prev and self.frozen_stages < 0
+        # ---- stem: 7x7 s2 conv (49 taps as 27 + 22) + BN + ReLU + 3x3 s2 max pool
+        w1 = self.arena.p[self.prefix + 'conv1.weight']
+        xin = x.reshape(n_img * H * W, 3)
+        y = torch.empty((stem[2], self.base), dtype=torch.float32, device=dev)
+        call('es_spconv_fwd', P(xin), 3, P(w1), P(nbr_a), stem[2], xin.shape[0], 27, 3, self.base, 0, P(y), self.base,
+             0, 0, s)
+        call('es_spconv_fwd', P(xin), 3, w1.data_ptr() + 4 * 27 * 3 * self.base, P(nbr_b), stem[2], xin.shape[0], 22, 3,
+             self.base, 0, P(y), self.base, 0, 1, s)
+        cur = E.affine_act(E.Var(y, rg=False), *self.fold['bn1'], act=1)
+        cur = E.maxpool(cur, pool[0], pool[2], need_dx=False)
+        cur.rg = self.frozen_stages < 0
+        outs = []
+        for li, nblk in enumerate(self.arch[50]):
+            E.TAPE.enabled = prev and (li + 1) > self.frozen_stages
+            gin = grids[li - 1] if li > 0 else grids[0]
+            for bi in range(nblk):
+                p = f'layer{li + 1}.{bi}.'
+                stride = 2 if (bi == 0 and li > 0) else 1
+                g_in = gin if bi == 0 else grids[li]
+                o = E.conv(cur, self._par(p + 'conv1.weight'), None, None, cur.d.shape[0])
+                o = E.affine_act(o, *self.fold[p + 'bn1'], act=1)
+                nbr, inv, n_out, _, _ = g_in.conv_map(3, stride, 1)
+                o = E.conv(o, self._par(p + 'conv2.weight'), nbr, inv, n_out)
+                o = E.affine_act(o, *self.fold[p + 'bn2'], act=1)
+                o = E.conv(o, self._par(p + 'conv3.weight'), None, None, n_out)
+                if bi == 0:
+                    if stride == 1:
+                        idt = E.conv(cur, self._par(p + 'downsample.0.weight'), None, None, n_out)
+                    else:
+                        dn, di, _, _, _ = g_in.conv_map(1, stride, 0)
+                        idt = E.conv(cur, self._par(p + 'downsample.0.weight'), dn, di, n_out)
+                    idt = E.affine_act(idt, *self.fold[p + 'downsample.1'], act=0)
+                else:
+                    idt = cur
+                cur = E.affine_act(o, *self.fold[p + 'bn3'], act=1, res=idt)
+                if not E.TAPE.enabled:
+                    cur.rg = False
+            if li in self.out_indices:
+                outs.append((cur, grids[li].H, grids[li].W))
+        E.TAPE.enabled = prev
+        return outs
+
+    __call__ = forward

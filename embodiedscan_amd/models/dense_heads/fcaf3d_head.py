@@ -1,0 +1,266 @@
+"""FCAF3DHeadRotMat on the MI355X kernels.
+
+Same constructor arguments, loss keys and call protocol as the reference class
+(embodiedscan/models/dense_heads/fcaf3d_head.py:827-1725); the sparse FPN + head run on the
+es_hip convolution engine, target assignment / focal / box-coder + corner-Chamfer losses are
+single fused kernels that also emit the gradients of the head outputs (no autograd graph, no
+per-sample host sync inside the loss).
+"""
+import torch
+from ... import engine as E
+from ... import sparse
+from ...geometry import euler_to_matrix_zxy
+from ...hip import P, call, iarr, farr
+from ...registry import MODELS
+from ...sparse import SparseTensor
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def get_targets_device(points_per_level, gt_boxes, gt_labels, assign_thr, center_thr):
+    """A12 for one sample.  points_per_level: device (n_l,3) f32 tensors (or one concatenated tensor +
+    level offsets as a tuple).  gt_boxes (G,9) / gt_labels (G,) may live on the host.
+    Returns center_t (N,), bbox_t (N,9), cls_t (N,) int32, box_idx (N,) int32, n_pos (1,) int32 (device)."""
+    if isinstance(points_per_level, tuple):
+        points, level_off = points_per_level
+    else:
+        points = torch.cat(points_per_level)
+        level_off = [0]
+        for p in points_per_level:
+            level_off.append(level_off[-1] + int(p.shape[0]))
+    dev = points.device
+    N, G = int(points.shape[0]), int(gt_boxes.shape[0])
+    boxes_h = gt_boxes.detach().float().cpu()
+    rot_neg = euler_to_matrix_zxy(-boxes_h[:, 6:9]).reshape(G, 9) if G else torch.zeros((0, 9))
+    boxes = boxes_h.to(dev).contiguous()
+    rot = rot_neg.to(dev).contiguous()
+    labels = gt_labels.detach().to(torch.int32).to(dev).contiguous()
+    n_lvl = len(level_off) - 1
+    scratch = torch.empty(max(G, 1) * max(N, 1) + (n_lvl + 2) * max(G, 1) + 8, dtype=torch.float32, device=dev)
+    center_t = torch.empty(N, dtype=torch.float32, device=dev)
+    bbox_t = torch.empty((N, 9), dtype=torch.float32, device=dev)
+    cls_t = torch.empty(N, dtype=torch.int32, device=dev)
+    box_idx = torch.empty(N, dtype=torch.int32, device=dev)
+    n_pos = torch.empty(1, dtype=torch.int32, device=dev)
+    call('es_get_targets', P(points), N, iarr(level_off), n_lvl, P(boxes), P(rot), P(labels), G, int(assign_thr),
+         int(center_thr), P(scratch), P(center_t), P(bbox_t), P(cls_t), P(box_idx), P(n_pos), _stream())
+    return center_t, bbox_t, cls_t, box_idx, n_pos
+
+
+class _BN:
+    def __init__(self, arena, prefix):
+        g = arena.g
+        self.w = E.Param(arena.p[prefix + '.bn.weight'], g.get(prefix + '.bn.weight'))
+        self.b = E.Param(arena.p[prefix + '.bn.bias'], g.get(prefix + '.bn.bias'))
+        self.running = (arena.p[prefix + '.bn.running_mean'], arena.p[prefix + '.bn.running_var'])
+
+    def __call__(self, x, act=0, res=None, training=True):
+        n = x.d.shape[0]
+        return E.norm(x, self.w, self.b, [0, n], 1e-5, act=act, res=res, running=self.running if training else None)
+
+
+def conv3(st, w, out_set=None):
+    """3^3 MinkowskiConvolution on the same coordinate set."""
+    cs = st.cs
+    nbr, inv = cs.kernel_map(cs, 3), cs.inverse_map(cs, 3)
+    return SparseTensor(cs, E.conv(st.F, w, nbr, inv, cs.n))
+
+
+@MODELS.register_module()
+class FCAF3DHeadRotMat:
+    def __init__(self, num_classes, in_channels, out_channels, num_reg_outs, voxel_size, pts_prune_threshold,
+                 pts_assign_threshold, pts_center_threshold, center_loss=None, bbox_loss=None, cls_loss=None,
+                 decouple_bbox_loss=False, decouple_groups=3, decouple_weights=None, norm_decouple_loss=False,
+                 train_cfg=None, test_cfg=None, init_cfg=None):
+        self.num_classes, self.in_channels, self.out_channels = num_classes, tuple(in_channels), out_channels
+        self.num_reg_outs = num_reg_outs
+        self.voxel_size = voxel_size
+        self.pts_prune_threshold = pts_prune_threshold
+        self.pts_assign_threshold = pts_assign_threshold
+        self.pts_center_threshold = pts_center_threshold
+        center_loss = center_loss or dict(type='mmdet.CrossEntropyLoss', use_sigmoid=True)
+        bbox_loss = bbox_loss or dict(type='BBoxCDLoss', mode='l1', loss_weight=1.0, group='g8')
+        cls_loss = cls_loss or dict(type='mmdet.FocalLoss')
+        # the fused loss kernels implement exactly the shipped configuration
+        assert center_loss.get('type') == 'mmdet.CrossEntropyLoss' and center_loss.get('use_sigmoid', False)
+        assert bbox_loss.get('type') == 'BBoxCDLoss' and bbox_loss.get('mode', 'l2') == 'l1' and \
+            bbox_loss.get('group', 'g8') == 'g8'
+        assert cls_loss.get('type') == 'mmdet.FocalLoss'
+        assert num_reg_outs == 12, 'only the 6D-rotation (12 output) coder is implemented'
+        self.bbox_loss_weight = float(bbox_loss.get('loss_weight', 1.0))
+        self.focal_gamma, self.focal_alpha = float(cls_loss.get('gamma', 2.0)), float(cls_loss.get('alpha', 0.25))
+        self.decouple_bbox_loss = decouple_bbox_loss
+        self.decouple_groups = decouple_groups
+        assert not norm_decouple_loss, 'norm_decouple_loss is not used by the shipped configs'
+        if decouple_weights is None:
+            decouple_weights = [1.0 / decouple_groups] * decouple_groups
+        self.decouple_weights = list(decouple_weights)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.training = True
+
+    # ------------------------------------------------------------------ parameters
+    def bind(self, arena, prefix='bbox_head.'):
+        g = arena.g
+        self.arena, self.prefix = arena, prefix
+        par = lambda n: E.Param(arena.p[prefix + n], g.get(prefix + n))
+        n_lvl = len(self.in_channels)
+        self.up, self.out = {}, {}
+        for i in range(n_lvl):
+            if i > 0:
+                p = f'up_block_{i}'
+                self.up[i] = (par(p + '.0.kernel'), _BN(arena, prefix + p + '.1'), par(p + '.3.kernel'),
+                              _BN(arena, prefix + p + '.4'))
+            p = f'out_block_{i}'
+            self.out[i] = (par(p + '.0.kernel'), _BN(arena, prefix + p + '.1'))
+        self.head_w = par('head_out.kernel')             # (1, out_channels, 1 + 12 + num_classes)
+        self.head_b = par('head_out.bias')               # (1 + 12 + num_classes,), only the class part is live
+        self.scales = [par(f'scales.{i}.scale') for i in range(n_lvl)]
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def _prune(self, x, score_set, score):
+        """fcaf3d_head.py:1091-1114.  Fast path: every sample already has <= threshold rows."""
+        off = x.cs.offsets()
+        thr = self.pts_prune_threshold
+        if all(off[b + 1] - off[b] <= thr for b in range(x.cs.n_batch)):
+            return x
+        idx, w = sparse.interp_map(x.cs, score_set)
+        s = torch.empty(x.cs.n, dtype=torch.float32, device=x.cs.device)
+        call('es_interp_scores', P(score), P(idx), P(w), x.cs.n, P(s), _stream())
+        mask = torch.empty(x.cs.n, dtype=torch.int32, device=x.cs.device)
+        call('es_topk_mask', P(s), iarr(off), x.cs.n_batch, int(thr), P(mask), _stream())
+        new_set, src = sparse.compact(x.cs, mask)
+        return SparseTensor(new_set, E.gather_rows(x.F, src))
+
+    def _levels(self, inputs):
+        """Runs the sparse FPN + head.  Returns per level (fine->coarse) a dict with the
+        coordinate set, the raw head GEMM output Var (n, 1+12+C) and the decoded boxes (n,12)."""
+        n_lvl = len(inputs)
+        levels = [None] * n_lvl
+        x = inputs[-1]
+        score_set = score = None
+        tr = self.training
+        for i in range(n_lvl - 1, -1, -1):
+            if i < n_lvl - 1:
+                wt, bn1, wc, bn2 = self.up[i + 1]
+                y = SparseTensor(x.cs.children(), bn1(E.gen_conv_transpose(x.F, wt), act=2, training=tr))
+                y = conv3(y, wc)
+                y = SparseTensor(y.cs, bn2(y.F, act=2, training=tr))
+                u, pa, pb = sparse.union(inputs[i].cs, y.cs)
+                x = SparseTensor(u, E.union_add(inputs[i].F, y.F, pa, pb, u.n))
+                x = self._prune(x, score_set, score)
+            wo, bno = self.out[i]
+            out = conv3(x, wo)
+            out = SparseTensor(out.cs, bno(out.F, act=2, training=tr))
+            n = out.cs.n
+            ho = E.conv(out.F, self.head_w, None, None, n, bias=self.head_b, bias_from=13)
+            ncol = ho.d.shape[1]
+            bbox = torch.empty((n, 12), dtype=torch.float32, device=ho.d.device)
+            call('es_reg_decode_fwd', ho.d.data_ptr() + 4, ncol, n, P(self.scales[i].d), P(bbox), _stream())
+            score = torch.empty(n, dtype=torch.float32, device=ho.d.device)
+            call('es_row_max', ho.d.data_ptr() + 4 * 13, ncol, n, self.num_classes, P(score), _stream())
+            score_set = out.cs
+            levels[i] = dict(cs=out.cs, ho=ho, bbox=bbox, scale=self.scales[i])
+        return levels
+
+    def forward(self, x):
+        """Reference return format (fcaf3d_head.py:993-1020): four lists over levels (fine->coarse) of lists
+        over samples: center (n,1), bbox (n,12), cls (n,C), points (n,3)."""
+        levels = self._levels(x)
+        cp, bp, kp, pts = [], [], [], []
+        for lv in levels:
+            off = lv['cs'].offsets()
+            ho, bbox = lv['ho'].d, lv['bbox']
+            points = torch.empty((lv['cs'].n, 3), dtype=torch.float32, device=ho.device)
+            call('es_coords_to_points', P(lv['cs'].coords), lv['cs'].n, float(self.voxel_size), P(points), _stream())
+            sl = [slice(off[b], off[b + 1]) for b in range(lv['cs'].n_batch)]
+            cp.append([ho[s, 0:1] for s in sl])
+            bp.append([bbox[s] for s in sl])
+            kp.append([ho[s, 13:] for s in sl])
+            pts.append([points[s] for s in sl])
+        return cp, bp, kp, pts
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ loss
+    def loss(self, x, batch_data_samples, **kwargs):
+        """fcaf3d_head.py:1022-1050.  Returns dict(loss_center, loss_bbox, loss_cls) (device scalars) and
+        seeds the gradients of the head outputs on the tape (call engine.TAPE.backward())."""
+        gts = [(ds.gt_instances_3d.bboxes_3d, ds.gt_instances_3d.labels_3d) for ds in batch_data_samples]
+        levels = self._levels(x)
+        return self.loss_by_levels(levels, [(getattr(b, 'tensor', b), l) for b, l in gts])
+
+    def loss_by_levels(self, levels, gts):
+        dev = levels[0]['ho'].d.device
+        B = len(gts)
+        n_lvl = len(levels)
+        s = _stream()
+        offs = [lv['cs'].offsets() for lv in levels]
+        # locations in metres, per level
+        for lv in levels:
+            pts = torch.empty((lv['cs'].n, 3), dtype=torch.float32, device=dev)
+            call('es_coords_to_points', P(lv['cs'].coords), lv['cs'].n, float(self.voxel_size), P(pts), s)
+            lv['points'] = pts
+            lv['dho'] = torch.zeros_like(lv['ho'].d)
+            lv['dbbox'] = torch.zeros_like(lv['bbox'])
+        # phase 1: targets per sample (points of a sample concatenated fine->coarse, fcaf3d_head.py:1595-1600)
+        per = []
+        n_pos_all = torch.empty(B, dtype=torch.int32, device=dev)
+        for b in range(B):
+            lo = [0]
+            for l in range(n_lvl):
+                lo.append(lo[-1] + offs[l][b + 1] - offs[l][b])
+            pts = torch.cat([levels[l]['points'][offs[l][b]:offs[l][b + 1]] for l in range(n_lvl)])
+            ct, bt, kt, bi, npos = get_targets_device((pts, lo), gts[b][0], gts[b][1], self.pts_assign_threshold,
+                                                      self.pts_center_threshold)
+            n_pos_all[b:b + 1] = npos
+            per.append((pts, lo, ct, bt, kt, npos))
+        # phase 2: avg_factor = max(reduce_mean(n_pos), 1) for all samples in ONE collective
+        avg = n_pos_all.float()
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            avg = avg / torch.distributed.get_world_size()
+            torch.distributed.all_reduce(avg)
+        avg = avg.clamp(min=1.0).contiguous()
+        # phase 3: losses + gradients, per (sample, level) slice, no host sync
+        loss_cls = torch.zeros(B, dtype=torch.float32, device=dev)
+        loss_acc = torch.zeros((B, 2), dtype=torch.float32, device=dev)
+        partial = torch.empty(2048, dtype=torch.float64, device=dev)
+        gw = [w * self.bbox_loss_weight for w in self.decouple_weights]
+        if not self.decouple_bbox_loss:
+            gw = [0., 0., 0., self.bbox_loss_weight]
+        elif self.decouple_groups == 3:
+            gw = gw[:3] + [0.]
+        gwa = farr(gw)
+        gscale = 1.0 / B
+        for b in range(B):
+            pts, lo, ct, bt, kt, npos = per[b]
+            for l in range(n_lvl):
+                n = lo[l + 1] - lo[l]
+                if n == 0:
+                    continue
+                lv = levels[l]
+                r0 = offs[l][b]
+                ho, dho = lv['ho'].d, lv['dho']
+                ncol = ho.shape[1]
+                hp, dp = ho.data_ptr() + 4 * r0 * ncol, dho.data_ptr() + 4 * r0 * ncol
+                call('es_focal_loss', hp + 4 * 13, ncol, kt.data_ptr() + 4 * lo[l], n, self.num_classes,
+                     self.focal_gamma, self.focal_alpha, avg.data_ptr() + 4 * b, gscale, dp + 4 * 13, ncol,
+                     P(partial), loss_cls.data_ptr() + 4 * b, s)
+                call('es_pos_losses', kt.data_ptr() + 4 * lo[l], n, P(npos), pts.data_ptr() + 12 * lo[l], hp, ncol,
+                     lv['bbox'].data_ptr() + 48 * r0, ct.data_ptr() + 4 * lo[l], bt.data_ptr() + 36 * lo[l],
+                     avg.data_ptr() + 4 * b, gscale, gwa, dp, ncol, lv['dbbox'].data_ptr() + 48 * r0,
+                     loss_acc.data_ptr() + 8 * b, s)
+        # chain through exp/Scale/clamp and seed the head GEMM gradients
+        for lv in levels:
+            n = lv['cs'].n
+            ncol = lv['ho'].d.shape[1]
+            call('es_reg_decode_bwd', lv['ho'].d.data_ptr() + 4, ncol, P(lv['bbox']), P(lv['dbbox']), n,
+                 P(lv['scale'].d), lv['dho'].data_ptr() + 4, ncol, P(lv['scale'].g), s)
+            lv['ho'].g = lv['dho']
+        eps = float(torch.finfo(torch.float32).eps)
+        losses = dict(loss_center=(loss_acc[:, 0] / (avg + eps)).mean(), loss_bbox=loss_acc[:, 1].mean(),
+                      loss_cls=loss_cls.mean())
+        self.last_targets = [(p[2], p[3], p[4]) for p in per]
+        return losses

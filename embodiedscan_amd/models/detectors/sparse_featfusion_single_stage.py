@@ -1,0 +1,148 @@
+"""SparseFeatureFusionSingleStage3DDetector on the MI355X kernels.
+
+Same registry name, constructor arguments, `forward(inputs, data_samples, mode)` protocol and loss keys as
+embodiedscan/models/detectors/sparse_featfusion_single_stage.py:28-330; `train_step` follows mmengine's
+BaseModel.train_step (preprocess -> forward(mode='loss') -> parse_losses -> optimiser update).
+"""
+import torch
+from ... import engine as E
+from ... import sparse
+from ...hip import P, call
+from ...params import ParamArena, detector_specs
+from ...registry import MODELS
+from ...sparse import SparseTensor
+from ..layers.fusion_layers.point_fusion import (batch_point_sample_level, batch_point_sample_level_bwd,
+                                                 build_fusion_meta)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@MODELS.register_module()
+class SparseFeatureFusionSingleStage3DDetector:
+    _version = 2
+
+    def __init__(self, backbone, backbone_3d, bbox_head, neck=None, neck_3d=None, coord_type='CAMERA',
+                 train_cfg=None, test_cfg=None, data_preprocessor=None, use_xyz_feat=False, init_cfg=None, seed=0,
+                 device='cuda:0'):
+        assert neck is None and neck_3d is None, 'the shipped mv-3ddet config has no necks'
+        self.device = torch.device(device)
+        self.backbone = MODELS.build(backbone)
+        self.backbone_3d = MODELS.build(backbone_3d)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = MODELS.build(bbox_head)
+        self.data_preprocessor = MODELS.build(data_preprocessor) if data_preprocessor else None
+        self.voxel_size = self.bbox_head.voxel_size
+        self.use_xyz_feat = use_xyz_feat
+        self.coord_type = coord_type
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.arena = ParamArena(detector_specs(self.bbox_head.num_classes), seed=seed)
+        self.training = True
+        self._bound = False
+
+    # ------------------------------------------------------------------ parameters
+    def to(self, device):
+        self.device = torch.device(device)
+        self.arena.to(self.device)
+        self._bound = False
+        return self
+
+    def _bind(self):
+        if not self._bound:
+            if self.arena.data.device != self.device:
+                self.arena.to(self.device)
+            self.backbone.bind(self.arena, 'backbone.')
+            self.backbone_3d.bind(self.arena, 'backbone_3d.')
+            self.bbox_head.bind(self.arena, 'bbox_head.')
+            self._bound = True
+
+    def state_dict(self):
+        return self.arena.state_dict()
+
+    def load_state_dict(self, sd):
+        self.arena.load_state_dict(sd)
+        if self._bound:
+            self.backbone.refresh()
+
+    def train(self, mode=True):
+        self.training = mode
+        self.backbone_3d.training = mode
+        self.bbox_head.training = mode
+        return self
+
+    # ------------------------------------------------------------------ features
+    def extract_feat(self, batch_inputs_dict, batch_data_samples):
+        """sparse_featfusion_single_stage.py:86-221.  Returns 4 SparseTensors with [3-D | image] channels."""
+        self._bind()
+        points = batch_inputs_dict['points']
+        assert self.use_xyz_feat, 'shipped configs use use_xyz_feat=True'
+        pts = [p if (p.dtype == torch.float32 and p.stride(-1) == 1) else p.float().contiguous() for p in points]
+        cs, src = sparse.voxelize(pts, self.voxel_size)
+        allp = torch.cat([p[:, :3] for p in pts]) if len(pts) > 1 else pts[0][:, :3].contiguous()
+        feats = torch.empty((cs.n, 3), dtype=torch.float32, device=allp.device)
+        call('es_row_move', P(feats), 3, P(allp), allp.stride(0), P(src), cs.n, 3, 0, _stream())
+        x = self.backbone_3d(SparseTensor(cs, E.Var(feats, rg=False)))
+        # image features: views folded into the batch dimension (:130-136), channels-last row matrices
+        img = batch_inputs_dict['imgs']
+        B, V = img.shape[:2]
+        H, W = img.shape[-2:]
+        if img.stride(2) != 1:       # (B,V,3,H,W) given NCHW-contiguous: convert once to channels-last
+            img = img.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+        nhwc = img.permute(0, 1, 3, 4, 2).reshape(B * V, H, W, 3)
+        img_feats = self.backbone(nhwc)
+        metas = [ds.metainfo for ds in batch_data_samples]
+        meta_dev = build_fusion_meta(metas, self.coord_type, (H, W), V).to(self.device, non_blocking=True)
+        outs = []
+        for lvl, xl in enumerate(x):
+            f2d, Hf, Wf = img_feats[lvl]
+            C3, C2 = xl.F.d.shape[1], f2d.d.shape[1]
+            cat = torch.empty((xl.cs.n, C3 + C2), dtype=torch.float32, device=self.device)
+            E.copy_cols(cat, 0, xl.F.d)
+            pix, cnt = batch_point_sample_level(xl.cs, self.voxel_size, meta_dev, V, f2d, Hf, Wf, cat, C3)
+            y = E.Var(cat)
+
+            def bwd(y=y, xl=xl, f2d=f2d, Hf=Hf, Wf=Wf, pix=pix, cnt=cnt, C3=C3):
+                if y.g is None:
+                    return
+                g3 = y.g[:, :C3]
+                if xl.F.g is None:
+                    xl.F.g = torch.empty_like(xl.F.d)
+                    E.copy_cols(xl.F.g, 0, g3)
+                else:
+                    E.add_into(xl.F.g, g3)
+                batch_point_sample_level_bwd(xl.cs, V, y.g, C3, pix, cnt, f2d, Hf, Wf)
+            E.TAPE.add(bwd)
+            outs.append(SparseTensor(xl.cs, y))
+        return outs
+
+    # ------------------------------------------------------------------ reference protocol
+    def loss(self, batch_inputs_dict, batch_data_samples, **kwargs):
+        x = self.extract_feat(batch_inputs_dict, batch_data_samples)
+        return self.bbox_head.loss(x, batch_data_samples, **kwargs)
+
+    def predict(self, batch_inputs_dict, batch_data_samples, **kwargs):
+        raise NotImplementedError("mode='predict' (per-class rotated NMS, SURVEY section 8f N1) is the next row; "
+                                  'this round implements the train step')
+
+    def forward(self, inputs, data_samples=None, mode='tensor', **kwargs):
+        if mode == 'loss':
+            return self.loss(inputs, data_samples, **kwargs)
+        elif mode == 'predict':
+            return self.predict(inputs, data_samples, **kwargs)
+        raise RuntimeError(f'Invalid mode "{mode}". Only supports loss, predict and tensor mode')
+
+    __call__ = forward
+
+    def train_step(self, data, optim_wrapper):
+        """mmengine BaseModel.train_step: preprocess, loss forward, sum of the 'loss' entries, backward, update."""
+        E.TAPE.clear()
+        if self.data_preprocessor is not None:
+            data = self.data_preprocessor(data, True)
+        self._bind()
+        self.arena.grad.zero_()
+        losses = self.forward(data['inputs'], data['data_samples'], mode='loss')
+        E.TAPE.backward()
+        optim_wrapper.update_params(self.arena)
+        return losses

@@ -1,0 +1,36 @@
+"""Optimiser wrapper over the flat parameter arena (mmengine OptimWrapper + torch AdamW + clip_grad as
+configured at configs/detection/mv-det3d_8xb4_embodiedscan-3d-284class-9dof.py:219-223), with the
+data-parallel gradient exchange folded in: ONE RCCL all-reduce of the flat gradient buffer per step."""
+import torch
+import torch.distributed as dist
+from .hip import P, call
+
+
+class OptimWrapper:
+    def __init__(self, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=10.0):
+        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.step = 0
+        self.m = self.v = None
+        self.last_norm = None
+
+    def state_init(self, arena):
+        n = arena.n_train
+        self.m = torch.zeros(n, dtype=torch.float32, device=arena.data.device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=arena.data.device)
+        self.partial = torch.empty(2048, dtype=torch.float64, device=arena.data.device)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=arena.data.device)
+
+    def update_params(self, arena):
+        if self.m is None:
+            self.state_init(arena)
+        s = torch.cuda.current_stream().cuda_stream
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(arena.grad)                       # RCCL over xGMI, one flat 346 MB buffer
+            arena.grad.mul_(1.0 / dist.get_world_size())
+        n = arena.n_train
+        self.step += 1
+        call('es_grad_norm', P(arena.grad), n, P(self.partial), P(self.norm), s)
+        call('es_adamw_step', P(arena.data), P(arena.grad), P(self.m), P(self.v), n, float(self.lr),
+             float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step,
+             float(self.max_norm if self.max_norm else 0.0), P(self.norm), s)
+        self.last_norm = self.norm

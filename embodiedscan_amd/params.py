@@ -14,10 +14,18 @@ import torch
 
 
 class Spec:
-    __slots__ = ('name', 'shape', 'init', 'trainable', 'buffer')
+    """One arena tensor.  `ref` describes how it appears in the reference state dict:
+    None = same name / shape; ('oihw', (O,I,KH,KW)) = a conv2d weight kept as [KH*KW, I, O] for the
+    row-matrix conv engine; ('head_out',) = the fused 1x1 head kernels (see fcaf3d_head_specs)."""
+    __slots__ = ('name', 'shape', 'init', 'trainable', 'buffer', 'ref')
 
-    def __init__(self, name, shape, init, trainable=True, buffer=False):
+    def __init__(self, name, shape, init, trainable=True, buffer=False, ref=None):
         self.name, self.shape, self.init, self.trainable, self.buffer = name, tuple(shape), init, trainable, buffer
+        self.ref = ref
+
+
+def _conv2d(name, o, i, kh, kw, fan, trainable):
+    return Spec(name, (kh * kw, i, o), ('kaiming_out', fan), trainable, ref=('oihw', (o, i, kh, kw)))
 
 
 def _bn2d(specs, p, c):
@@ -28,7 +36,7 @@ def _bn2d(specs, p, c):
 
 def resnet50_specs(prefix='backbone.', base=16, frozen_stages=1):
     s = []
-    s.append(Spec(prefix + 'conv1.weight', (base, 3, 7, 7), ('kaiming_out', base * 49), frozen_stages < 0))
+    s.append(_conv2d(prefix + 'conv1.weight', base, 3, 7, 7, base * 49, frozen_stages < 0))
     _bn2d(s, prefix + 'bn1', base)
     inpl = base
     for li, nblk in enumerate((3, 4, 6, 3)):
@@ -36,14 +44,14 @@ def resnet50_specs(prefix='backbone.', base=16, frozen_stages=1):
         train = (li + 1) > frozen_stages
         for bi in range(nblk):
             p = f'{prefix}layer{li + 1}.{bi}.'
-            s.append(Spec(p + 'conv1.weight', (planes, inpl, 1, 1), ('kaiming_out', planes), train))
+            s.append(_conv2d(p + 'conv1.weight', planes, inpl, 1, 1, planes, train))
             _bn2d(s, p + 'bn1', planes)
-            s.append(Spec(p + 'conv2.weight', (planes, planes, 3, 3), ('kaiming_out', planes * 9), train))
+            s.append(_conv2d(p + 'conv2.weight', planes, planes, 3, 3, planes * 9, train))
             _bn2d(s, p + 'bn2', planes)
-            s.append(Spec(p + 'conv3.weight', (planes * 4, planes, 1, 1), ('kaiming_out', planes * 4), train))
+            s.append(_conv2d(p + 'conv3.weight', planes * 4, planes, 1, 1, planes * 4, train))
             _bn2d(s, p + 'bn3', planes * 4)
             if bi == 0:
-                s.append(Spec(p + 'downsample.0.weight', (planes * 4, inpl, 1, 1), ('kaiming_out', planes * 4), train))
+                s.append(_conv2d(p + 'downsample.0.weight', planes * 4, inpl, 1, 1, planes * 4, train))
                 _bn2d(s, p + 'downsample.1', planes * 4)
             inpl = planes * 4
     return s
@@ -68,7 +76,7 @@ def mink_resnet34_specs(prefix='backbone_3d.', in_channels=3):
             s.append(Spec(p + 'conv2.kernel', (27, planes, planes), ('kaiming_out', 27 * planes)))
             _mbn(s, p + 'norm2', planes)
             if bi == 0:
-                s.append(Spec(p + 'downsample.0.kernel', (inpl, planes), ('kaiming_out', planes)))
+                s.append(Spec(p + 'downsample.0.kernel', (1, inpl, planes), ('kaiming_out', planes), ref=('squeeze0',)))
                 _mbn(s, p + 'downsample.1', planes)
             inpl = planes
     return s
@@ -88,10 +96,12 @@ def fcaf3d_head_specs(prefix='bbox_head.', in_channels=(128, 256, 512, 1024), ou
         p = f'{prefix}out_block_{i}'
         s.append(Spec(p + '.0.kernel', (27, c, out_channels), ('uniform_fan', c * 27)))
         _mbn(s, p + '.1', out_channels)
-    s.append(Spec(prefix + 'conv_center.kernel', (out_channels, 1), ('normal', .01)))
-    s.append(Spec(prefix + 'conv_reg.kernel', (out_channels, n_reg), ('normal', .01)))
-    s.append(Spec(prefix + 'conv_cls.kernel', (out_channels, n_classes), ('normal', .01)))
-    s.append(Spec(prefix + 'conv_cls.bias', (1, n_classes), ('const', -math.log((1 - .01) / .01))))
+    # conv_center (C,1) | conv_reg (C,n_reg) | conv_cls (C,n_classes) fused into ONE row GEMM; exported to the
+    # reference names conv_center.kernel / conv_reg.kernel / conv_cls.kernel / conv_cls.bias
+    nh = 1 + n_reg + n_classes
+    s.append(Spec(prefix + 'head_out.kernel', (1, out_channels, nh), ('normal', .01), ref=('head_out', n_reg, n_classes)))
+    s.append(Spec(prefix + 'head_out.bias', (nh,), ('head_bias', (1 + n_reg, -math.log((1 - .01) / .01))),
+                  ref=('head_bias', n_reg, n_classes)))
     for i in range(len(in_channels)):
         s.append(Spec(f'{prefix}scales.{i}.scale', (), ('const', 1.)))
     return s
@@ -112,6 +122,9 @@ def _fill(t, init, gen):
         t.uniform_(-b, b, generator=gen)
     elif kind == 'normal':
         t.normal_(0, a, generator=gen)
+    elif kind == 'head_bias':
+        t.zero_()
+        t[a[0]:] = a[1]
     else:
         raise ValueError(kind)
 
@@ -159,12 +172,82 @@ class ParamArena:
         return self
 
     def state_dict(self):
-        return OrderedDict((k, v.detach().clone()) for k, v in self.p.items())
+        """Reference-named, reference-shaped copy (what `model.state_dict()` gives in the reference)."""
+        out = OrderedDict()
+        for s in self.specs:
+            t = self.p[s.name].detach()
+            if s.ref is None:
+                out[s.name] = t.clone()
+            elif s.ref[0] == 'oihw':
+                o, i, kh, kw = s.ref[1]
+                out[s.name] = t.reshape(kh, kw, i, o).permute(3, 2, 0, 1).contiguous()
+            elif s.ref[0] == 'squeeze0':
+                out[s.name] = t[0].clone()
+            elif s.ref[0] == 'head_out':
+                pre = s.name[:-len('head_out.kernel')]
+                nr = s.ref[1]
+                out[pre + 'conv_center.kernel'] = t[0, :, 0:1].clone()
+                out[pre + 'conv_reg.kernel'] = t[0, :, 1:1 + nr].clone()
+                out[pre + 'conv_cls.kernel'] = t[0, :, 1 + nr:].clone()
+            elif s.ref[0] == 'head_bias':
+                pre = s.name[:-len('head_out.bias')]
+                out[pre + 'conv_cls.bias'] = t[1 + s.ref[1]:].reshape(1, -1).clone()
+        return out
+
+    def _to_ref(self, which):
+        """reference-named view of the gradient (which='g') arena, same conversions as state_dict()."""
+        src = self.g if which == 'g' else self.p
+        out = OrderedDict()
+        for s in self.specs:
+            if s.name not in src:
+                continue
+            t = src[s.name].detach()
+            if s.ref is None:
+                out[s.name] = t.clone()
+            elif s.ref[0] == 'oihw':
+                o, i, kh, kw = s.ref[1]
+                out[s.name] = t.reshape(kh, kw, i, o).permute(3, 2, 0, 1).contiguous()
+            elif s.ref[0] == 'squeeze0':
+                out[s.name] = t[0].clone()
+            elif s.ref[0] == 'head_out':
+                pre = s.name[:-len('head_out.kernel')]
+                nr = s.ref[1]
+                out[pre + 'conv_center.kernel'] = t[0, :, 0:1].clone()
+                out[pre + 'conv_reg.kernel'] = t[0, :, 1:1 + nr].clone()
+                out[pre + 'conv_cls.kernel'] = t[0, :, 1 + nr:].clone()
+            elif s.ref[0] == 'head_bias':
+                pre = s.name[:-len('head_out.bias')]
+                out[pre + 'conv_cls.bias'] = t[1 + s.ref[1]:].reshape(1, -1).clone()
+        return out
+
+    def grad_dict(self):
+        return self._to_ref('g')
 
     def load_state_dict(self, sd):
-        for k, v in sd.items():
-            if k in self.p:
-                self.p[k].copy_(v.reshape(self.p[k].shape))
+        """Accepts a reference-named state dict (the inverse of state_dict())."""
+        for s in self.specs:
+            dst = self.p[s.name]
+            if s.ref is None:
+                if s.name in sd:
+                    dst.copy_(sd[s.name].reshape(dst.shape))
+            elif s.ref[0] == 'oihw':
+                if s.name in sd:
+                    o, i, kh, kw = s.ref[1]
+                    dst.copy_(sd[s.name].permute(2, 3, 1, 0).reshape(kh * kw, i, o))
+            elif s.ref[0] == 'squeeze0':
+                if s.name in sd:
+                    dst.copy_(sd[s.name].reshape(dst.shape))
+            elif s.ref[0] == 'head_out':
+                pre = s.name[:-len('head_out.kernel')]
+                nr = s.ref[1]
+                if pre + 'conv_center.kernel' in sd:
+                    dst[0, :, 0:1].copy_(sd[pre + 'conv_center.kernel'])
+                    dst[0, :, 1:1 + nr].copy_(sd[pre + 'conv_reg.kernel'])
+                    dst[0, :, 1 + nr:].copy_(sd[pre + 'conv_cls.kernel'])
+            elif s.ref[0] == 'head_bias':
+                pre = s.name[:-len('head_out.bias')]
+                if pre + 'conv_cls.bias' in sd:
+                    dst[1 + s.ref[1]:].copy_(sd[pre + 'conv_cls.bias'].reshape(-1))
 
     def trainable_names(self):
         return [s.name for s in self.specs if s.trainable]

@@ -1,0 +1,200 @@
+"""Host side of the coordinate manager: coordinate sets, hash tables and cached kernel maps
+living in HBM, built by the es_hip kernels (csrc/coords.hip).
+
+Mirrors what the reference obtains implicitly from MinkowskiEngine's CoordinateManager
+(`coordinate_map_key` / `coordinate_manager` at
+embodiedscan/models/detectors/sparse_featfusion_single_stage.py:215-218): every sparse tensor
+derived from one input shares the maps cached here.
+"""
+import ctypes
+import torch
+from . import hip
+from .hip import P, call
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pow2_cap(n):
+    c = 1024
+    while c < 2 * n + 2:
+        c *= 2
+    return c
+
+
+class CoordSet:
+    """A unique, batch-major set of voxel coordinates at tensor stride `ts`."""
+
+    def __init__(self, keys, n, ts, n_batch, tkeys=None, tvals=None):
+        self.keys, self.n, self.ts, self.n_batch = keys, int(n), int(ts), int(n_batch)
+        self.tkeys, self.tvals = tkeys, tvals
+        self._coords = None
+        self._off_dev = None
+        self._off_host = None
+        self.cache = {}
+
+    @property
+    def device(self):
+        return self.keys.device
+
+    def table(self):
+        if self.tkeys is None:
+            cap = _pow2_cap(self.n)
+            self.tkeys = torch.empty(cap, dtype=torch.int64, device=self.device)
+            self.tvals = torch.empty(cap, dtype=torch.int32, device=self.device)
+            call('es_build_table', P(self.keys), self.n, P(self.tkeys), P(self.tvals), cap, _stream())
+        return self.tkeys, self.tvals, self.tkeys.numel()
+
+    @property
+    def coords(self):
+        """(n,4) int32 (b,x,y,z) on the device."""
+        if self._coords is None:
+            self._coords = torch.empty((self.n, 4), dtype=torch.int32, device=self.device)
+            call('es_keys_to_coords', P(self.keys), self.n, P(self._coords), _stream())
+        return self._coords
+
+    def offsets_dev(self):
+        if self._off_dev is None:
+            self._off_dev = torch.empty(self.n_batch + 1, dtype=torch.int32, device=self.device)
+            call('es_batch_offsets', P(self.keys), self.n, self.n_batch, P(self._off_dev), _stream())
+        return self._off_dev
+
+    def offsets(self):
+        """host list of n_batch+1 row offsets (one small D2H copy, cached)."""
+        if self._off_host is None:
+            self._off_host = [int(v) for v in self.offsets_dev().cpu().tolist()]
+        return self._off_host
+
+    # ------------------------------------------------------------------ derived sets / maps
+    def strided(self, stride):
+        key = ('stride', stride)
+        if key not in self.cache:
+            out_ts = self.ts * stride
+            tmp = torch.empty(self.n, dtype=torch.int64, device=self.device)
+            call('es_stride_keys', P(self.keys), self.n, out_ts, P(tmp), _stream())
+            self.cache[key] = unique_first(tmp, self.n, out_ts, self.n_batch)[0]
+        return self.cache[key]
+
+    def kernel_map(self, out, ksize):
+        """nbr (out.n, ksize^3) int32: rows of self around each row of `out`."""
+        key = ('kmap', id(out), ksize)
+        if key not in self.cache:
+            tk, tv, cap = self.table()
+            K = ksize ** 3
+            nbr = torch.empty((out.n, K), dtype=torch.int32, device=self.device)
+            call('es_kernel_map', P(out.keys), out.n, P(tk), P(tv), cap, ksize, self.ts, P(nbr), _stream())
+            self.cache[key] = (nbr, out)
+        return self.cache[key][0]
+
+    def inverse_map(self, out, ksize):
+        key = ('imap', id(out), ksize)
+        if key not in self.cache:
+            nbr = self.kernel_map(out, ksize)
+            K = ksize ** 3
+            inv = torch.empty((self.n, K), dtype=torch.int32, device=self.device)
+            call('es_inverse_map', P(nbr), out.n, K, self.n, P(inv), _stream())
+            self.cache[key] = (inv, out)
+        return self.cache[key][0]
+
+    def children(self):
+        """MinkowskiGenerativeConvolutionTranspose(k=2,s=2) output set: row 8*i+k."""
+        if 'gen' not in self.cache:
+            keys = torch.empty(self.n * 8, dtype=torch.int64, device=self.device)
+            call('es_gen_children_keys', P(self.keys), self.n, self.ts // 2, P(keys), _stream())
+            self.cache['gen'] = CoordSet(keys, self.n * 8, self.ts // 2, self.n_batch)
+        return self.cache['gen']
+
+
+def unique_first(keys, n, ts, n_batch, want_src=True):
+    """hash-unique in first-occurrence order.  Returns (CoordSet, src_rows int32)."""
+    dev = keys.device
+    cap = _pow2_cap(n)
+    tkeys = torch.empty(cap, dtype=torch.int64, device=dev)
+    tvals = torch.empty(cap, dtype=torch.int32, device=dev)
+    scratch = torch.empty(2 * n + n // 2048 + 8, dtype=torch.int32, device=dev)
+    out_keys = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    out_src = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = ctypes.c_int(0)
+    call('es_unique_first', P(keys), n, P(tkeys), P(tvals), cap, P(scratch), P(out_keys), P(out_src),
+         ctypes.byref(cnt), _stream())
+    m = cnt.value
+    return CoordSet(out_keys[:m], m, ts, n_batch, tkeys, tvals), out_src[:m]
+
+
+def voxelize(points, voxel_size):
+    """A4.  list of (N_i, >=3) f32 device tensors -> (CoordSet at stride 1, src rows into cat(points))."""
+    dev = points[0].device
+    n = sum(int(p.shape[0]) for p in points)
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    o = 0
+    for b, p in enumerate(points):
+        assert p.dtype == torch.float32 and p.stride(1) == 1
+        call('es_voxel_keys', P(p), p.shape[0], p.stride(0), b, float(voxel_size), keys.data_ptr() + 8 * o, _stream())
+        o += int(p.shape[0])
+    return unique_first(keys, n, 1, len(points))
+
+
+def union(a, b):
+    """coordinate union for sparse a + b.  Returns (CoordSet, pos_a, pos_b) (int32 rows)."""
+    dev = a.device
+    tk, tv, cap = a.table()
+    scratch = torch.empty(3 * b.n + b.n // 2048 + 8, dtype=torch.int32, device=dev)
+    pos_a = torch.empty(max(a.n, 1), dtype=torch.int32, device=dev)
+    pos_b = torch.empty(max(b.n, 1), dtype=torch.int32, device=dev)
+    out_keys = torch.empty(a.n + b.n, dtype=torch.int64, device=dev)
+    cnt = ctypes.c_int(0)
+    call('es_union_plan', P(a.keys), a.n, P(tk), P(tv), cap, P(b.keys), b.n, P(a.offsets_dev()), P(b.offsets_dev()),
+         a.n_batch, P(scratch), P(pos_a), P(pos_b), P(out_keys), ctypes.byref(cnt), _stream())
+    m = cnt.value
+    return CoordSet(out_keys[:m], m, a.ts, a.n_batch), pos_a[:a.n], pos_b[:b.n]
+
+
+def compact(cs, mask):
+    """rows of `cs` where mask (int32 0/1) is set.  Returns (CoordSet, src rows)."""
+    dev = cs.device
+    scratch = torch.empty(cs.n + cs.n // 2048 + 8, dtype=torch.int32, device=dev)
+    out_keys = torch.empty(max(cs.n, 1), dtype=torch.int64, device=dev)
+    out_src = torch.empty(max(cs.n, 1), dtype=torch.int32, device=dev)
+    cnt = ctypes.c_int(0)
+    call('es_compact_mask', P(cs.keys), cs.n, P(mask), P(scratch), P(out_keys), P(out_src), ctypes.byref(cnt),
+         _stream())
+    m = cnt.value
+    return CoordSet(out_keys[:m], m, cs.ts, cs.n_batch), out_src[:m]
+
+
+def interp_map(query, table_set):
+    tk, tv, cap = table_set.table()
+    idx = torch.empty((query.n, 8), dtype=torch.int32, device=query.device)
+    w = torch.empty((query.n, 8), dtype=torch.float32, device=query.device)
+    call('es_interp_map', P(query.keys), query.n, P(tk), P(tv), cap, table_set.ts, P(idx), P(w), _stream())
+    return idx, w
+
+
+class SparseTensor:
+    """Feature matrix `F` (engine.Var, (n,C)) on a CoordSet -- the ME.SparseTensor stand-in."""
+
+    def __init__(self, cs, F):
+        self.cs, self.F = cs, F
+
+    @property
+    def C(self):                       # ME: x.C -> (n,4) int coordinates
+        return self.cs.coords
+
+    @property
+    def features(self):
+        return self.F.d
+
+    @property
+    def tensor_stride(self):
+        return self.cs.ts
+
+    @property
+    def decomposition_permutations(self):
+        off = self.cs.offsets()
+        return [torch.arange(off[b], off[b + 1], device=self.cs.device) for b in range(self.cs.n_batch)]
+
+    @property
+    def decomposed_coordinates(self):
+        off = self.cs.offsets()
+        return [self.cs.coords[off[b]:off[b + 1], 1:] for b in range(self.cs.n_batch)]

@@ -1,0 +1,163 @@
+/* es_hip.h -- C ABI of libes_hip.so: the MI355X (gfx950) kernels of the EmbodiedScan
+ * mv-3ddet train-step hot path.
+ *
+ * The reference (OpenRobotLab/EmbodiedScan) has NO FFI for this path: its native code lives in
+ * un-vendored Python packages (MinkowskiEngine, mmcv._ext, pytorch3d._C, cuDNN via torch).  Each
+ * entry point below therefore names the reference CALL SITE (file:line under /root/reference)
+ * whose native dependency it replaces.  INTEGRATION.md shows the ctypes binding a maintainer
+ * would add on the reference side.
+ *
+ * Conventions: plain pointers + sizes, no torch types.  All pointers are DEVICE pointers unless
+ * the name ends in _host (or the comment says "host").  Row matrices are f32, row-major, with an
+ * explicit leading dimension (ld*, in floats) so column slices of wider buffers can be passed.
+ * `stream` is a hipStream_t.  Return value: 0 on success, a hipError_t (>0) or a negative
+ * argument error otherwise; nothing is printed, nothing is allocated, inputs are only read.
+ * Functions that must report a data-dependent size write it to *count_host after synchronising
+ * `stream` (documented per function); every other function is purely stream-ordered.
+ */
+#ifndef ES_HIP_H
+#define ES_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ES_MAX_SEG 8 /* max samples per batch for segmented (per-sample) operators */
+
+/* ---- coordinate manager (replaces ME.SparseTensor / CoordinateManager) ------------------- */
+/* A4: keys[i] = pack(batch, trunc(p_i / voxel_size)).  sparse_featfusion_single_stage.py:109-116 */
+int es_voxel_keys(const float* points, int n, int ld, int batch, float voxel_size, int64_t* keys, void* stream);
+/* A4: de-duplicate keeping the first occurrence; builds the key->row hash table (cap = power of two >= 2n).
+ * scratch: 2n + n/2048 + 4 ints.  Synchronises; *count_host = number of unique keys.
+ * sparse_featfusion_single_stage.py:118 (ME.SparseTensor) */
+int es_unique_first(const int64_t* keys, int n, int64_t* tkeys, int* tvals, int cap, int* scratch,
+                    int64_t* out_keys, int* out_src, int* count_host, void* stream);
+int es_build_table(const int64_t* keys, int n, int64_t* tkeys, int* tvals, int cap, void* stream);
+/* strided output coordinates floor(c / ts) * ts.  mink_resnet.py:58-69,104-108 (stride-2 conv / pool) */
+int es_stride_keys(const int64_t* in_keys, int n, int out_ts, int64_t* out_keys, void* stream);
+int es_keys_to_coords(const int64_t* keys, int n, int* coords /* (n,4) b,x,y,z */, void* stream);
+/* points = float(coords[:, 1:]) * voxel_size  (sparse_featfusion_single_stage.py:167-168, fcaf3d_head.py:1145-1147) */
+int es_coords_to_points(const int* coords, int n, float voxel_size, float* points /* (n,3) */, void* stream);
+int es_batch_offsets(const int64_t* keys, int n, int n_batch, int* offsets_dev /* n_batch+1 */, void* stream);
+/* MinkowskiGenerativeConvolutionTranspose(k=2,s=2) output coordinates.  fcaf3d_head.py:937-941 */
+int es_gen_children_keys(const int64_t* in_keys, int n, int half_ts, int64_t* out_keys /* 8n */, void* stream);
+/* A6: nbr[j*K + k] = input row at out_j + offset_k * in_ts, or -1 (K = ksize^3, x fastest). */
+int es_kernel_map(const int64_t* out_keys, int n_out, const int64_t* tkeys, const int* tvals, int cap, int ksize,
+                  int in_ts, int* nbr, void* stream);
+int es_inverse_map(const int* nbr, int n_out, int K, int n_in, int* inv /* (n_in,K) */, void* stream);
+/* sparse `a + b` coordinate union, batch-major.  fcaf3d_head.py:1009.  scratch: 3nb + nb/2048 + 4 ints.
+ * Synchronises; *count_host = rows of the union. */
+int es_union_plan(const int64_t* keys_a, int na, const int64_t* tkeys_a, const int* tvals_a, int cap_a,
+                  const int64_t* keys_b, int nb, const int* a_off_dev, const int* b_off_dev, int n_batch,
+                  int* scratch, int* pos_a, int* pos_b, int64_t* out_keys, int* count_host, void* stream);
+/* features_at_coordinates corner indices + trilinear weights.  fcaf3d_head.py:1102-1103 */
+int es_interp_map(const int64_t* query_keys, int n, const int64_t* tkeys, const int* tvals, int cap, int table_ts,
+                  int* idx /* (n,8) */, float* w /* (n,8) */, void* stream);
+/* MinkowskiPruning row selection.  fcaf3d_head.py:1113.  scratch: n + n/2048 + 4 ints.  Synchronises. */
+int es_compact_mask(const int64_t* keys, int n, const int* mask, int* scratch, int64_t* out_keys, int* out_src,
+                    int* count_host, void* stream);
+
+/* ---- convolution engine (replaces MinkowskiConvolution*, and conv2d through image-grid maps) ------ */
+/* Y[j] (+)= sum_k X[nbr[j,k]] . W[k] (+ bias).  W is [K][Cin][Cout]; trans_w: W is [K][Cout][Cin] (dgrad).
+ * nbr == NULL means the identity map with K == 1 (plain row GEMM).  mink_resnet.py:58-62,88-120;
+ * fcaf3d_head.py:907-984,1116-1136 */
+int es_spconv_fwd(const float* X, int ldx, const float* W, const int* nbr, int n_out, int n_in, int K, int Cin,
+                  int Cout, const float* bias, float* Y, int ldy, int trans_w, int accumulate, void* stream);
+/* dW[k] += X[nbr[:,k]]^T . dY */
+int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
+                    int Cin, int Cout, float* dW, void* stream);
+int es_image_map(int n_img, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int* nbr, void* stream);
+
+/* ---- row operators ----------------------------------------------------------------------------- */
+/* MinkowskiBatchNorm (nseg = 1) / MinkowskiInstanceNorm (one segment per sample), train mode, fused
+ * residual + activation (act: 0 none, 1 ReLU, 2 ELU).  seg_off is a HOST array of nseg+1 row offsets.
+ * mink_resnet.py:64,109 ; fcaf3d_head.py:923,942,947 */
+size_t es_norm_workspace_floats(int n, int C, const int* seg_off_host, int nseg);
+int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg_off_host, int nseg, float eps,
+                const float* weight, const float* bias, const float* res, int ldr, int act, float* running_mean,
+                float* running_var, float momentum, float* mean, float* invstd, float* workspace, float* y, int ldy,
+                void* stream);
+/* dy is overwritten with the pre-activation gradient (== gradient of the residual input). */
+int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const float* x, int ldx, int n, int C,
+                const int* seg_off_host, int nseg, const float* mean, const float* invstd, const float* weight,
+                int act, float* dweight, float* dbias, float* workspace, float* dx, int ldo, int accumulate,
+                void* stream);
+/* MinkowskiMaxPooling(k=2,s=2) and the 2-D stem max-pool.  mink_resnet.py:66-69 */
+int es_maxpool_fwd(const float* x, int ldx, const int* nbr, int n_out, int K, int C, float* y, int* arg, void* stream);
+int es_maxpool_bwd(const float* dy, const int* arg, int n_out, int C, float* dx, int ldo, void* stream);
+/* mode 0: dst[i]=src[idx[i]]  1: dst[idx[i]]+=src[i]  2: dst[idx[i]]=src[i]  (idx NULL = identity) */
+int es_row_move(float* dst, int ldd, const float* src, int lds, const int* idx, int n, int C, int mode, void* stream);
+int es_axpy2d(float* dst, int ldd, const float* src, int lds, int n, int C, float alpha, int op, void* stream);
+int es_interp_scores(const float* score, const int* idx, const float* w, int n, float* out, void* stream);
+/* per-sample top-k keep mask (ties: lower row first).  fcaf3d_head.py:1105-1112 */
+int es_topk_mask(const float* values, const int* seg_off_host, int nseg, int k, int* mask, void* stream);
+int es_row_max(const float* x, int ldx, int n, int C, float* out, void* stream);
+/* frozen BatchNorm2d folded to scale/shift + residual + ReLU (mmdet.ResNet, norm_eval=True) */
+int es_bn_fold(const float* w, const float* b, const float* rm, const float* rv, int C, float eps, float* scale,
+               float* shift, void* stream);
+int es_affine_act_fwd(const float* x, const float* scale, const float* shift, const float* res, size_t n, int C,
+                      int act, float* y, void* stream);
+int es_affine_act_bwd(const float* dy, const float* y, const float* scale, size_t n, int C, int act, float* dx,
+                      int acc_x, float* dres, int acc_r, void* stream);
+
+/* ---- A8 projection fusion.  point_fusion.py:208-311 ----------------------------------------------- */
+/* per-sample meta block layout (floats) */
+#define ES_FUSE_NOPS 0    /* number of reverse-augmentation ops */
+#define ES_FUSE_OPS 1     /* 8 op codes: 1 T, 2 S, 3 R, 4 HF, 5 VF (already reversed) */
+#define ES_FUSE_ROTINV 9  /* 3x3 inverse of pcd_rotation, row-major */
+#define ES_FUSE_ISCALE 18 /* 1 / pcd_scale_factor */
+#define ES_FUSE_NTRANS 19 /* -pcd_trans (3) */
+#define ES_FUSE_SFX 22
+#define ES_FUSE_SFY 23
+#define ES_FUSE_CROPX 24
+#define ES_FUSE_CROPY 25
+#define ES_FUSE_FLIP 26
+#define ES_FUSE_ORIW 27
+#define ES_FUSE_PADW 28
+#define ES_FUSE_PADH 29
+#define ES_FUSE_PROJ 32   /* V row-major 4x4 matrices intrinsic @ extrinsic */
+int es_point_sample_fwd(const int* coords, int n, float voxel_size, const float* meta, int meta_stride, int V,
+                        const float* feats /* (B,V,Hf,Wf,C) */, int Hf, int Wf, int C, float* out, int ldo,
+                        int* pix /* (n,V) */, int* cnt /* (n) */, void* stream);
+int es_point_sample_bwd(const int* coords, int n, int V, const float* dout, int ldo, const int* pix, const int* cnt,
+                        int Hf, int Wf, int C, float* dfeats, void* stream);
+
+/* ---- A12 target assignment.  fcaf3d_head.py:1578-1664 --------------------------------------------- */
+/* level_off: HOST array n_levels+1.  rot_neg: (G,9) row-major R(-euler) (ZXY) computed on the host.
+ * scratch: G*N floats + (n_levels*G + G) ints + G floats. */
+int es_get_targets(const float* points, int N, const int* level_off_host, int n_levels, const float* boxes,
+                   const float* rot_neg, const int* labels, int G, int assign_thr, int center_thr, float* scratch,
+                   float* center_t, float* bbox_t, int* cls_t, int* box_idx, int* n_pos_dev, void* stream);
+
+/* ---- A13-A15 losses (value + gradient).  fcaf3d_head.py:1151-1294 ---------------------------------- */
+int es_focal_loss(const float* logits, int ldl, const int* labels, int N, int C, float gamma, float alpha,
+                  const float* avg_factor_dev, float grad_scale, float* grad, int ldg, double* partial /* 2048 */,
+                  float* loss_out /* accumulated */, void* stream);
+/* bbox[:, :6] = clamp(exp(scale * reg[:, :6]), 1e-3), bbox[:, 6:] = reg[:, 6:]  (fcaf3d_head.py:1135-1137) */
+int es_reg_decode_fwd(const float* reg, int ldr, int n, const float* scale, float* bbox /* (n,12) */, void* stream);
+int es_reg_decode_bwd(const float* reg, int ldr, const float* bbox, const float* dbbox, int n, const float* scale,
+                      float* dreg, int ldg, float* dscale, void* stream);
+/* All n locations are visited, rows with cls_t < 0 are skipped (no host-side nonzero()).  group_w: HOST array of
+ * the 4 decouple weights.  loss_acc[0] += sum BCE, loss_acc[1] += weighted corner loss (mean over n_pos*8). */
+int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, const float* points, const float* center_pred,
+                  int ldc, const float* bbox_pred /* (n,12) */, const float* center_t, const float* bbox_t,
+                  const float* avg_factor_dev, float grad_scale, const float* group_w_host, float* dcenter, int ldg,
+                  float* dbbox /* (n,12) */, float* loss_acc, void* stream);
+
+/* ---- optimiser.  configs/detection/mv-det3d_...py:219-223 ------------------------------------------ */
+int es_grad_norm(const float* grad, size_t n, double* partial /* 2048 */, float* norm_out, void* stream);
+int es_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float max_norm, const float* grad_norm_dev,
+                  void* stream);
+
+/* ---- A1-A3, A18 data side ---------------------------------------------------------------------------- */
+int es_depth_to_points(const float* depth, int H, int W, const int* sel_view, const int* sel_pix, int n,
+                       const float* mats /* (V,32) */, const float* aug /* 15 */, float* out, void* stream);
+int es_preprocess_img(const unsigned char* img, int n_img, int H, int W, const float* mean_host,
+                      const float* std_host, float* out /* (n_img,H,W,3) */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

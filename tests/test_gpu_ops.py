@@ -1,0 +1,246 @@
+"""GPU parity of every es_hip operator against the CPU oracle (same seeded inputs).
+Integer outputs (coordinates, maps, labels) must be bit-exact; float tolerances are stated inline."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def _pts(seed, n, lo=-2.0, hi=2.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(n, 3, generator=g) * (hi - lo) + lo).float()
+
+
+def _err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max()), float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def test_voxelize_and_maps_bit_exact(dev):
+    from embodiedscan_amd import sparse
+    from oracle import coords as C
+    pts = [_pts(1, 30000), _pts(2, 20000, -1.5, 2.5)]
+    # include exact voxel-boundary and negative values (trunc-toward-zero quirk)
+    pts[0][:7] = torch.tensor([[0.005, -0.005, 0.0], [-0.0099, 0.0099, 1.0], [0.29, 0.57, -0.29], [1.13, 0.07, 0.35],
+                               [-1.13, -0.07, -0.35], [0.01, 0.02, 0.03], [0.0100001, 0.9999999, 1.49]])
+    oc, osrc = C.voxelize([p.numpy() for p in pts], 0.01)
+    cs, src = sparse.voxelize([p.to(dev) for p in pts], 0.01)
+    torch.cuda.synchronize()
+    assert cs.n == oc.shape[0]
+    np.testing.assert_array_equal(cs.coords.cpu().numpy(), oc)
+    np.testing.assert_array_equal(src.cpu().numpy().astype(np.int64), osrc)
+    assert cs.offsets() == [0] + list(np.cumsum(C.batch_counts(oc, 2)))
+    # strided sets and kernel maps down the pyramid
+    cur, ocur, ts = cs, oc, 1
+    for stride, ks in ((2, 3), (2, 2), (2, 3), (2, 3)):
+        out = cur.strided(stride)
+        oout = C.stride_coords(ocur, ts * stride)
+        np.testing.assert_array_equal(out.coords.cpu().numpy(), oout)
+        nbr = cur.kernel_map(out, ks)
+        onbr = C.kernel_map(ocur, oout, ks, ts)
+        np.testing.assert_array_equal(nbr.cpu().numpy(), onbr)
+        inv = cur.inverse_map(out, ks)
+        np.testing.assert_array_equal(inv.cpu().numpy(), C.inverse_map(onbr, ocur.shape[0]))
+        # same-set 3^3 map
+        nb3 = out.kernel_map(out, 3)
+        np.testing.assert_array_equal(nb3.cpu().numpy(), C.kernel_map(oout, oout, 3, ts * stride))
+        cur, ocur, ts = out, oout, ts * stride
+    # generative children + union + interpolation map
+    ch = cur.children()
+    och = C.gen_transpose_coords(ocur, ts)
+    np.testing.assert_array_equal(ch.coords.cpu().numpy(), och)
+    fine = cs.strided(2).strided(2).strided(2)
+    ofine = C.stride_coords(C.stride_coords(C.stride_coords(oc, 2), 4), 8)
+    u, pa, pb = sparse.union(fine, ch)
+    ou, opa, opb = C.union_coords(ofine, och, 2)
+    np.testing.assert_array_equal(u.coords.cpu().numpy(), ou)
+    np.testing.assert_array_equal(pa.cpu().numpy(), opa)
+    np.testing.assert_array_equal(pb.cpu().numpy(), opb)
+    idx, w = sparse.interp_map(u, cur)
+    oidx, ow = C.interp_weights(ou, ocur, ts)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oidx)
+    np.testing.assert_array_equal(w.cpu().numpy(), ow)
+    # prune compaction
+    m = (torch.arange(u.n) % 3 != 0).to(torch.int32).to(dev)
+    pr, psrc = sparse.compact(u, m)
+    np.testing.assert_array_equal(pr.coords.cpu().numpy(), ou[m.cpu().numpy().astype(bool)])
+
+
+def _sparse_case(dev, n=20000, seed=3):
+    from embodiedscan_amd import sparse
+    from oracle import coords as C
+    pts = [_pts(seed, n), _pts(seed + 1, n // 2)]
+    cs, _ = sparse.voxelize([p.to(dev) for p in pts], 0.02)
+    oc, _ = C.voxelize([p.numpy() for p in pts], 0.02)
+    return cs, oc
+
+
+@pytest.mark.parametrize('cin,cout,ks,stride', [(3, 64, 3, 2), (64, 64, 3, 1), (64, 128, 3, 2), (96, 40, 3, 1),
+                                                (64, 128, 1, 2), (128, 297, 1, 1)])
+def test_spconv_fwd_bwd(dev, cin, cout, ks, stride):
+    from embodiedscan_amd import engine as E
+    from oracle import coords as C, sparse as S
+    cs, oc = _sparse_case(dev)
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    K = ks ** 3
+    x = torch.randn(cs.n, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) / (K * cin) ** 0.5
+    out = cs.strided(stride) if stride > 1 else cs
+    if ks == 1 and stride == 1:
+        nbr = inv = None
+    else:
+        nbr, inv = cs.kernel_map(out, ks), cs.inverse_map(out, ks)
+    xv = E.Var(x.to(dev))
+    wp = E.Param(w.to(dev), torch.zeros_like(w).to(dev))
+    E.TAPE.clear()
+    y = E.conv(xv, wp, nbr, inv, out.n)
+    dy = torch.randn(out.n, cout, generator=g)
+    y.g = dy.to(dev)
+    E.TAPE.backward()
+    torch.cuda.synchronize()
+    # oracle
+    xo = x.clone().requires_grad_(True)
+    wo = w.clone().requires_grad_(True)
+    st = S.SpT(oc, xo, 1, 2, {})
+    yo = S.conv(st, wo if ks > 1 else wo[0], ks, stride)
+    (yo.feats * dy).sum().backward()
+    tol = 2e-5
+    for name, a, b in (('y', y.d.cpu(), yo.feats.detach()), ('dx', xv.g.cpu(), xo.grad), ('dw', wp.g.cpu(), wo.grad)):
+        ea, er = _err(a, b)
+        print(f'spconv {cin}->{cout} k{ks} s{stride} {name}: max abs err {ea:.3e} rel-to-max {er:.3e} (tol {tol})')
+        assert er < tol, (name, ea, er)
+
+
+def test_gen_transpose_norm_pool(dev):
+    from embodiedscan_amd import engine as E
+    from oracle import coords as C, sparse as S
+    cs0, oc0 = _sparse_case(dev, 6000, 9)
+    cs, oc = cs0.strided(2), C.stride_coords(oc0, 2)            # tensor stride 2
+    g = torch.Generator().manual_seed(5)
+    cin, cout = 64, 32
+    x = torch.randn(cs.n, cin, generator=g)
+    w = torch.randn(8, cin, cout, generator=g) * 0.1
+    bw, bb = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    E.TAPE.clear()
+    xv = E.Var(x.to(dev))
+    wp = E.Param(w.to(dev), torch.zeros_like(w).to(dev))
+    bwp, bbp = E.Param(bw.to(dev), torch.zeros(cout, device=dev)), E.Param(bb.to(dev), torch.zeros(cout, device=dev))
+    rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    y = E.gen_conv_transpose(xv, wp)
+    ch = cs.children()                                           # stride 1
+    z = E.norm(y, bwp, bbp, [0, ch.n], 1e-5, act=2, running=(rm, rv))
+    pooled_set = ch.strided(2)
+    pn = ch.kernel_map(pooled_set, 2)
+    p = E.maxpool(z, pn, pooled_set.n)
+    iw = E.Param(torch.ones(1, cout, device=dev), torch.zeros(1, cout, device=dev))
+    ib = E.Param(torch.zeros(1, cout, device=dev), torch.zeros(1, cout, device=dev))
+    q = E.norm(p, iw, ib, pooled_set.offsets(), 1e-8, act=1)
+    dq = torch.randn(pooled_set.n, cout, generator=g)
+    q.g = dq.to(dev)
+    E.TAPE.backward()
+    torch.cuda.synchronize()
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bwo, bbo = bw.clone().requires_grad_(True), bb.clone().requires_grad_(True)
+    orm, orv = torch.zeros(cout), torch.ones(cout)
+    st = S.SpT(oc, xo, 2, 2, {})
+    yo = S.gen_conv_transpose(st, wo)
+    np.testing.assert_array_equal(ch.coords.cpu().numpy(), yo.coords)
+    zo = S.batch_norm(yo, bwo, bbo, orm, orv, True)
+    zo = zo.new(torch.nn.functional.elu(zo.feats))
+    po = S.max_pool(zo)
+    np.testing.assert_array_equal(pooled_set.coords.cpu().numpy(), po.coords)
+    qo = S.instance_norm(po, torch.ones(1, cout), torch.zeros(1, cout))
+    qo = qo.new(torch.relu(qo.feats))
+    (qo.feats * dq).sum().backward()
+    for name, a, b, tol in (('gen', y.d.cpu(), yo.feats.detach(), 1e-5), ('bn+elu', z.d.cpu(), zo.feats.detach(), 1e-4),
+                            ('pool', p.d.cpu(), po.feats.detach(), 1e-4), ('in+relu', q.d.cpu(), qo.feats.detach(), 2e-4),
+                            ('dx', xv.g.cpu(), xo.grad, 2e-3), ('dw', wp.g.cpu(), wo.grad, 2e-3),
+                            ('dbn_w', bwp.g.cpu(), bwo.grad, 2e-3), ('dbn_b', bbp.g.cpu(), bbo.grad, 2e-3),
+                            ('run_mean', rm.cpu(), orm, 1e-5), ('run_var', rv.cpu(), orv, 1e-4)):
+        ea, er = _err(a, b)
+        print(f'{name}: max abs err {ea:.3e} rel-to-max {er:.3e} (tol {tol})')
+        assert er < tol, (name, ea, er)
+
+
+def test_union_add_and_gather(dev):
+    from embodiedscan_amd import engine as E, sparse
+    from oracle import coords as C
+    cs, oc = _sparse_case(dev, 5000, 21)
+    a_set = cs.strided(2)
+    b_set = cs.strided(4).children()
+    u, pa, pb = sparse.union(a_set, b_set)
+    g = torch.Generator().manual_seed(2)
+    a, b = torch.randn(a_set.n, 16, generator=g), torch.randn(b_set.n, 16, generator=g)
+    E.TAPE.clear()
+    av, bv = E.Var(a.to(dev)), E.Var(b.to(dev))
+    y = E.union_add(av, bv, pa, pb, u.n)
+    idx = torch.arange(0, u.n, 2, dtype=torch.int32, device=dev)
+    z = E.gather_rows(y, idx)
+    dz = torch.randn(idx.numel(), 16, generator=g)
+    z.g = dz.to(dev)
+    E.TAPE.backward()
+    torch.cuda.synchronize()
+    ao, bo = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = torch.zeros(u.n, 16).index_add(0, pa.cpu().long(), ao).index_add(0, pb.cpu().long(), bo)
+    zo = yo[idx.cpu().long()]
+    (zo * dz).sum().backward()
+    np.testing.assert_allclose(z.d.cpu().numpy(), zo.detach().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(av.g.cpu().numpy(), ao.grad.numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(bv.g.cpu().numpy(), bo.grad.numpy(), rtol=0, atol=1e-6)
+
+
+def test_topk_mask(dev):
+    from embodiedscan_amd.hip import call, P, iarr
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(5000, generator=g)
+    v[100:140] = v[7]                      # ties, some straddling the threshold
+    seg = [0, 3000, 5000]
+    k = 1200
+    mask = torch.zeros(5000, dtype=torch.int32, device=dev)
+    call('es_topk_mask', P(v.to(dev)), iarr(seg), 2, k, P(mask), torch.cuda.current_stream().cuda_stream)
+    m = mask.cpu().numpy().astype(bool)
+    for s in range(2):
+        sl = slice(seg[s], seg[s + 1])
+        order = torch.argsort(v[sl], descending=True, stable=True)[:k].numpy()
+        exp = np.zeros(seg[s + 1] - seg[s], bool)
+        exp[order] = True
+        np.testing.assert_array_equal(m[sl], exp)
+
+
+def test_get_targets_golden_and_random(dev, golden_dir):
+    import os
+    from embodiedscan_amd.models.dense_heads import fcaf3d_head as H
+    from oracle import geometry as G
+    for name in ('get_targets', 'get_targets_empty'):
+        d = np.load(os.path.join(golden_dir, name + '.npz'))
+        pts = [torch.from_numpy(d[f'points{i}']) for i in range(4)]
+        ct, bt, kt, _, npos = H.get_targets_device([p.to(dev) for p in pts], torch.from_numpy(d['gt_boxes']),
+                                                   torch.from_numpy(d['gt_labels']), 27, 18)
+        np.testing.assert_array_equal(kt.cpu().numpy(), d['cls_targets'])      # vs the REFERENCE's own output
+        np.testing.assert_array_equal(bt.cpu().numpy(), d['bbox_targets'])
+        pos = d['cls_targets'] >= 0
+        assert int(npos) == int(pos.sum())
+        oct_, _, _ = G.get_targets(pts, torch.from_numpy(d['gt_boxes']), torch.from_numpy(d['gt_labels']))
+        np.testing.assert_array_equal(ct.cpu().numpy(), oct_.numpy())           # bit-exact vs the oracle
+    # random dense case
+    g = torch.Generator().manual_seed(4)
+    pts = [(torch.rand(n, 3, generator=g) * torch.tensor([6., 5., 2.8]) - torch.tensor([3., 2.5, 0.])) for n in
+           (40000, 6000, 900, 150)]
+    nb = 30
+    gtb = torch.cat([torch.rand(nb, 2, generator=g) * 5 - 2.5, torch.rand(nb, 1, generator=g) * 1.5 + .3,
+                     torch.rand(nb, 3, generator=g) * 1.5 + .3, torch.rand(nb, 1, generator=g) * 6.2 - 3.1,
+                     torch.rand(nb, 2, generator=g) * .2 - .1], 1)
+    gtl = torch.randint(0, 284, (nb,), generator=g)
+    ct, bt, kt, _, npos = H.get_targets_device([p.to(dev) for p in pts], gtb, gtl, 27, 18)
+    oc_, ob_, ok_ = G.get_targets(pts, gtb, gtl)
+    np.testing.assert_array_equal(kt.cpu().numpy(), ok_.numpy())
+    np.testing.assert_array_equal(bt.cpu().numpy(), ob_.numpy())
+    np.testing.assert_array_equal(ct.cpu().numpy(), oc_.numpy())
+    assert (ok_ >= 0).sum() > 100
