@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py -- mv-3ddet train-step throughput on MI355X (BASELINE.json metric: scans/sec).
+
+One "step" = one full train step of SparseFeatureFusionSingleStage3DDetector on a batch of synthetic
+20 x (480x640) RGB-D scans already resident in HBM: depth->points (A1-A3), image normalisation (A18), 2-D and
+3-D backbones, projection fusion, FCAF3D head, target assignment, losses, backward, gradient all-reduce
+(N > 1), clip + AdamW.  Prints ONE JSON line (rank 0).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=4, help='scans per GPU per step (reference config: 8xb4)')
+    ap.add_argument('--views', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-views', type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)          # "nccl" == RCCL on ROCm
+
+    from embodiedscan_amd import engine as E, hip, pipeline
+    from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
+    from embodiedscan_amd.synth import make_scan
+
+    cfg = load_config(os.path.join(ROOT, 'configs', 'mv_3ddet.py'))
+    det = build_detector(cfg, device=dev, seed=0).to(dev)          # same initial weights on every rank
+    optim = build_optim_wrapper(cfg)
+
+    # per-rank synthetic scans: seed = 1234 + rank*10007 + i ; rendered on the GPU, untimed
+    scans = [make_scan(1234 + rank * 10007 + i, n_views=args.views, render_device=str(dev)) for i in range(args.batch)]
+    dscans = [pipeline.upload_scan(s, dev) for s in scans]        # inputs resident in HBM before timing
+
+    def step():
+        batch = pipeline.make_batch(dscans)                       # A1-A3 on device
+        return det.train_step(batch, optim)
+
+    for _ in range(args.warmup):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    # time EXACTLY `steps` steps; the convolution engine launches are bracketed by HIP events on the same stream
+    prof = {'names': {'es_spconv_fwd', 'es_spconv_wgrad'}, 'records': [],
+            'event': lambda: torch.cuda.Event(enable_timing=True)}
+    hip.PROFILE = prof
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(args.steps):
+        losses = step()
+        recs = prof['records']
+        for i in range(done, len(recs)):        # resolve map pointer -> pair counter while the maps are still alive
+            name, e0, e1, a = recs[i]
+            recs[i] = (name, e0, e1, a, hip.PAIRS.get(a[3] if name == 'es_spconv_fwd' else a[4]))
+        done = len(recs)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hip.PROFILE = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (the MFMA convolution engine), from the live HIP-event timings
+    K_PEAK_F32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+    tot_ms, tot_flop, n_launch = 0.0, 0.0, 0
+    for name, e0, e1, a, pairs_dev in prof['records']:
+        tot_ms += e0.elapsed_time(e1)
+        n_launch += 1
+        if name == 'es_spconv_fwd':
+            nbr, n_out, n_in, K, cin, cout = a[3], a[4], a[5], a[6], a[7], a[8]
+        else:
+            nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
+        pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
+        tot_flop += 2.0 * pairs * cin * cout
+    achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    roofline = dict(bound='mfma', achieved=round(achieved, 3), peak=K_PEAK_F32_MFMA, unit='TFLOP/s',
+                    frac=round(achieved / K_PEAK_F32_MFMA, 4), traffic=None, kernel='k_spconv / k_spconv_wgrad (f32 MFMA)',
+                    launches_per_step=n_launch // max(args.steps, 1),
+                    kernel_ms_per_step=round(tot_ms / max(args.steps, 1), 3),
+                    note='algorithmic flops = 2 * valid (output,tap) pairs * Cin * Cout per launch')
+
+    out = dict(metric='scans/sec (train step) mv-3ddet, 20x(480x640) RGB-D views', value=round(world * args.batch * args.steps / dt, 4),
+               unit='scans/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
+               dtype='f32', data='synthetic',
+               config=dict(workload='mv-3ddet ResNet-50(w16) + MinkResNet34 + FCAF3DHeadRotMat, 20 views 480x640, '
+                                    '100k points/scan, f32 (exact-f32 MFMA), full train step incl. AdamW',
+                           scans_per_gpu_per_step=args.batch, views=args.views, parallelism=f'dp{world}'),
+               losses={k: round(float(v), 6) for k, v in losses.items()}, roofline=roofline)
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(scans[0], det, args)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scan, det, args):
+    """The CPU oracle (a restatement, kind='port') timed on this box's host cores on ONE scan of the same workload:
+    forward + backward of the detector loss (no optimiser).  Bounded sample, reported next to the GPU number."""
+    import torch
+    from oracle import model as OM, pipeline as OP
+    sd = {k: v.cpu() for k, v in det.state_dict().items()}
+    names = set(det.arena.grad_dict().keys())
+    sd = {k: v.requires_grad_(k in names) for k, v in sd.items()}
+    t0 = time.perf_counter()
+    pts = [OP.scan_to_points(scan)]
+    imgs = OM.preprocess_img(torch.from_numpy(scan['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])[None]
+    losses = OM.detector_loss(sd, pts, imgs, [scan['meta']], [torch.from_numpy(scan['gt_boxes'])],
+                              [torch.from_numpy(scan['gt_labels'])])
+    sum(losses.values()).backward()
+    dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 5), unit='scans/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'1 scan x {scan["depth"].shape[0]} views 480x640, 100k points, one forward+backward of the '
+                       f'PyTorch-f32 CPU oracle (no optimiser step), {dt:.1f} s; os.cpu_count()={os.cpu_count()}')
+
+
+if __name__ == '__main__':
+    main()

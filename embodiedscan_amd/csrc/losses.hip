@@ -123,18 +123,22 @@ extern "C" int es_reg_decode_bwd(const float* reg, int ldr, const float* bbox, c
 }
 
 // ------------------------------------------------------------------ dual numbers (12 partials)
+// Evaluated in f64: only a few hundred positive locations exist per scan, so the cost is nil, and the
+// atan2/asin/normalise chain of the 6D-rotation coder is ill-conditioned enough that f32 partials were the
+// largest noise source of the whole backward pass (measured: 3e-5 vs 7e-6 for the f32 autograd oracle).
 #define ND 12
+typedef double real;
 struct Dual {
-  float v;
-  float d[ND];
+  real v;
+  real d[ND];
 };
-__device__ inline Dual dconst(float v) {
+__device__ inline Dual dconst(real v) {
   Dual r; r.v = v;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = 0.f;
+  for (int i = 0; i < ND; ++i) r.d[i] = 0;
   return r;
 }
-__device__ inline Dual dvar(float v, int i) { Dual r = dconst(v); r.d[i] = 1.f; return r; }
+__device__ inline Dual dvar(real v, int i) { Dual r = dconst(v); r.d[i] = 1; return r; }
 __device__ inline Dual operator+(const Dual& a, const Dual& b) {
   Dual r; r.v = a.v + b.v;
 #pragma unroll
@@ -159,7 +163,7 @@ __device__ inline Dual operator*(const Dual& a, const Dual& b) {
   for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
   return r;
 }
-__device__ inline Dual operator*(const Dual& a, float s) {
+__device__ inline Dual operator*(const Dual& a, real s) {
   Dual r; r.v = a.v * s;
 #pragma unroll
   for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * s;
@@ -167,30 +171,30 @@ __device__ inline Dual operator*(const Dual& a, float s) {
 }
 __device__ inline Dual operator/(const Dual& a, const Dual& b) {
   Dual r; r.v = a.v / b.v;
-  float ib = 1.f / b.v;
+  real ib = 1.0 / b.v;
 #pragma unroll
   for (int i = 0; i < ND; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
   return r;
 }
-__device__ inline Dual dchain(const Dual& a, float v, float dv) {   // f(a) with f' = dv
+__device__ inline Dual dchain(const Dual& a, real v, real dv) {   // f(a) with f' = dv
   Dual r; r.v = v;
 #pragma unroll
   for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * dv;
   return r;
 }
-__device__ inline Dual dsqrt(const Dual& a) { float s = sqrtf(a.v); return dchain(a, s, s > 0.f ? 0.5f / s : 0.f); }
-__device__ inline Dual dsin(const Dual& a) { return dchain(a, sinf(a.v), cosf(a.v)); }
-__device__ inline Dual dcos(const Dual& a) { return dchain(a, cosf(a.v), -sinf(a.v)); }
-__device__ inline Dual dasin(const Dual& a) { return dchain(a, asinf(a.v), 1.f / sqrtf(fmaxf(1.f - a.v * a.v, 1e-20f))); }
+__device__ inline Dual dsqrt(const Dual& a) { real s = sqrt(a.v); return dchain(a, s, s > 0 ? 0.5 / s : 0.0); }
+__device__ inline Dual dsin(const Dual& a) { return dchain(a, sin(a.v), cos(a.v)); }
+__device__ inline Dual dcos(const Dual& a) { return dchain(a, cos(a.v), -sin(a.v)); }
+__device__ inline Dual dasin(const Dual& a) { return dchain(a, asin(a.v), 1.0 / sqrt(fmax(1.0 - a.v * a.v, 1e-30))); }
 __device__ inline Dual datan2(const Dual& y, const Dual& x) {
-  Dual r; r.v = atan2f(y.v, x.v);
-  float den = x.v * x.v + y.v * y.v;
-  float gy = den > 0.f ? x.v / den : 0.f, gx = den > 0.f ? -y.v / den : 0.f;
+  Dual r; r.v = atan2(y.v, x.v);
+  real den = x.v * x.v + y.v * y.v;
+  real gy = den > 0 ? x.v / den : 0.0, gx = den > 0 ? -y.v / den : 0.0;
 #pragma unroll
   for (int i = 0; i < ND; ++i) r.d[i] = y.d[i] * gy + x.d[i] * gx;
   return r;
 }
-__device__ inline Dual dabs(const Dual& a) { return a.v < 0.f ? -a : (a.v > 0.f ? a : dconst(0.f)); }
+__device__ inline Dual dabs(const Dual& a) { return a.v < 0 ? -a : (a.v > 0 ? a : dconst(0)); }
 
 struct D3 { Dual x, y, z; };
 __device__ inline D3 dcross(const D3& a, const D3& b) {
@@ -201,7 +205,7 @@ __device__ inline D3 dcross(const D3& a, const D3& b) {
   return r;
 }
 __device__ inline D3 dnormalize(const D3& a) {
-  Dual n = dsqrt(a.x * a.x + a.y * a.y + a.z * a.z) + dconst(1e-8f);
+  Dual n = dsqrt(a.x * a.x + a.y * a.y + a.z * a.z) + dconst(1e-8);
   D3 r; r.x = a.x / n; r.y = a.y / n; r.z = a.z / n;
   return r;
 }
@@ -213,20 +217,20 @@ __device__ inline void deuler_to_mat(const Dual* e, Dual* R) {
   R[6] = -(cb * sc);             R[7] = sb;         R[8] = cb * cc;
 }
 // sum over the 8 source corners of min over target corners of the L1 distance
-__device__ inline Dual corner_cd(const Dual* box, const float* tc) {
+__device__ inline Dual corner_cd(const Dual* box, const real* tc) {
   Dual R[9];
   deuler_to_mat(box + 6, R);
-  Dual total = dconst(0.f);
-  const float SX[8] = {1, 1, 1, 1, -1, -1, -1, -1}, SY[8] = {1, 1, -1, -1, 1, 1, -1, -1},
-              SZ[8] = {1, -1, 1, -1, 1, -1, 1, -1};
-  Dual hx = box[3] * 0.5f, hy = box[4] * 0.5f, hz = box[5] * 0.5f;
+  Dual total = dconst(0);
+  const real SX[8] = {1, 1, 1, 1, -1, -1, -1, -1}, SY[8] = {1, 1, -1, -1, 1, 1, -1, -1},
+             SZ[8] = {1, -1, 1, -1, 1, -1, 1, -1};
+  Dual hx = box[3] * 0.5, hy = box[4] * 0.5, hz = box[5] * 0.5;
   for (int a = 0; a < 8; ++a) {
     Dual ex = hx * SX[a], ey = hy * SY[a], ez = hz * SZ[a];
     Dual cx = box[0] + (ex * R[0] + ey * R[1] + ez * R[2]);
     Dual cy = box[1] + (ex * R[3] + ey * R[4] + ez * R[5]);
     Dual cz = box[2] + (ex * R[6] + ey * R[7] + ez * R[8]);
-    Dual best = dconst(0.f);
-    float bv = INFINITY;
+    Dual best = dconst(0);
+    real bv = INFINITY;
     for (int b = 0; b < 8; ++b) {
       Dual dist = dabs(cx - dconst(tc[b * 3])) + dabs(cy - dconst(tc[b * 3 + 1])) + dabs(cz - dconst(tc[b * 3 + 2]));
       if (dist.v < bv) { bv = dist.v; best = dist; }
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
     eul[2] = datan2(-xo.z, z.z);         // atan2(-M20, M22)
     Dual R[9];
     deuler_to_mat(eul, R);
-    Dual s0 = (bp[1] - bp[0]) * 0.5f, s1 = (bp[3] - bp[2]) * 0.5f, s2 = (bp[5] - bp[4]) * 0.5f;
+    Dual s0 = (bp[1] - bp[0]) * 0.5, s1 = (bp[3] - bp[2]) * 0.5, s2 = (bp[5] - bp[4]) * 0.5;
     Dual dec[9];
     dec[0] = dconst(points[(size_t)i * 3 + 0]) + (s0 * R[0] + s1 * R[1] + s2 * R[2]);
     dec[1] = dconst(points[(size_t)i * 3 + 1]) + (s0 * R[3] + s1 * R[4] + s2 * R[5]);
@@ -283,23 +287,23 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
     dec[6] = eul[0]; dec[7] = eul[1]; dec[8] = eul[2];
     // ---- target corners (constants)
     Dual tb[9];
-    float tc[24];
+    real tc[24];
 #pragma unroll
     for (int c = 0; c < 9; ++c) tb[c] = dconst(bbox_t[(size_t)i * 9 + c]);
     {
       Dual Rt[9];
       deuler_to_mat(tb + 6, Rt);
-      const float SX[8] = {1, 1, 1, 1, -1, -1, -1, -1}, SY[8] = {1, 1, -1, -1, 1, 1, -1, -1},
-                  SZ[8] = {1, -1, 1, -1, 1, -1, 1, -1};
+      const real SX[8] = {1, 1, 1, 1, -1, -1, -1, -1}, SY[8] = {1, 1, -1, -1, 1, 1, -1, -1},
+                 SZ[8] = {1, -1, 1, -1, 1, -1, 1, -1};
       for (int a = 0; a < 8; ++a) {
-        float ex = tb[3].v * 0.5f * SX[a], ey = tb[4].v * 0.5f * SY[a], ez = tb[5].v * 0.5f * SZ[a];
+        real ex = tb[3].v * 0.5 * SX[a], ey = tb[4].v * 0.5 * SY[a], ez = tb[5].v * 0.5 * SZ[a];
         tc[a * 3 + 0] = tb[0].v + (ex * Rt[0].v + ey * Rt[1].v + ez * Rt[2].v);
         tc[a * 3 + 1] = tb[1].v + (ex * Rt[3].v + ey * Rt[4].v + ez * Rt[5].v);
         tc[a * 3 + 2] = tb[2].v + (ex * Rt[6].v + ey * Rt[7].v + ez * Rt[8].v);
       }
     }
     Dual v[9];
-    Dual tot = dconst(0.f);
+    Dual tot = dconst(0);
     // group 0: predicted centre, target size + euler
     for (int c = 0; c < 9; ++c) v[c] = c < 3 ? dec[c] : tb[c];
     tot = tot + corner_cd(v, tc) * w0;
@@ -308,10 +312,10 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
     for (int c = 0; c < 9; ++c) v[c] = c >= 6 ? dec[c] : tb[c];
     tot = tot + corner_cd(v, tc) * w2;
     tot = tot + corner_cd(dec, tc) * w3;
-    float inv_mean = 1.f / ((float)P * 8.f);
-    lb = tot.v * inv_mean;
+    real inv_mean = 1.0 / ((real)P * 8.0);
+    lb = (float)(tot.v * inv_mean);
 #pragma unroll
-    for (int c = 0; c < 12; ++c) dbbox[(size_t)i * 12 + c] = tot.d[c] * inv_mean * grad_scale;
+    for (int c = 0; c < 12; ++c) dbbox[(size_t)i * 12 + c] = (float)(tot.d[c] * inv_mean * (real)grad_scale);
   }
   lc = es_wave_sum(lc);
   lb = es_wave_sum(lb);

@@ -42,7 +42,7 @@ __device__ inline float centerness(const float* fd) {
   v = __fdiv_rn(v, fmaxf(fd[2], fd[3]));
   v = __fmul_rn(v, fminf(fd[4], fd[5]));
   v = __fdiv_rn(v, fmaxf(fd[4], fd[5]));
-  return __fsqrt_rn(v);
+  return sqrtf(v);   // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the 1-ulp native op
 }
 
 // cen[g*N + i] = inside ? centerness : -1 ; npos[l*G + g] += inside

@@ -53,6 +53,7 @@ class Tape:
 
 
 TAPE = Tape()
+DEBUG_GRADS = None      # tools/debug_grads.py sets a dict: id(Var) -> snapshot of its gradient when consumed
 
 
 def empty(shape, like, dtype=torch.float32):
@@ -90,6 +91,8 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
         if y.g is None:
             return
         s = _stream()
+        if DEBUG_GRADS is not None:
+            DEBUG_GRADS[id(y)] = y.g.clone()
         if w.g is not None:
             call('es_spconv_wgrad', P(x.d), _ld(x.d), P(y.g), _ld(y.g), P(nbr), n_out, n_in, K, cin, cout, P(w.g), s)
         if bias is not None and bias.g is not None:
@@ -152,10 +155,15 @@ def norm(x, weight, bias, seg_off, eps, act=0, res=None, running=None, momentum=
         if y.g is None:
             return
         s = _stream()
+        if DEBUG_GRADS is not None:
+            DEBUG_GRADS[id(y)] = y.g.clone()
         ws2 = empty((ws_n,), x.d)
         g, acc = _grad_target(x, x.d)
         call('es_norm_bwd', P(y.g), _ld(y.g), P(y.d), C, P(x.d), _ld(x.d), n, C, so, nseg, P(mean), P(invstd),
              P(weight.d), act, P(weight.g), P(bias.g), P(ws2), P(g), _ld(g), acc, s)
+        if DEBUG_GRADS is not None:
+            DEBUG_GRADS[('norm', id(y))] = dict(dx=g.clone(), dz=y.g.clone(), mean=mean.clone(), invstd=invstd.clone(),
+                                                x=x.d.clone(), yd=y.d.clone(), acc=acc, n=n, C=C, act=act)
         if res is not None and res.rg:          # y.g now holds dz == gradient of the residual input
             if res.g is None:
                 res.g = y.g

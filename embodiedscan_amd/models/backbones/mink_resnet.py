@@ -18,6 +18,7 @@ class MinkResNet:
         self.depth, self.in_channels, self.num_stages, self.pool = depth, in_channels, num_stages, pool
         self.stage_blocks = self.arch_settings[depth][:num_stages]
         self.training = True
+        self.trace = None          # debugging aid: list collecting every block output Var
 
     def bind(self, arena, prefix='backbone_3d.'):
         self.arena, self.prefix = arena, prefix
@@ -62,9 +63,13 @@ class MinkResNet:
                 else:
                     o = E.conv(f, blk['conv1'], cs.kernel_map(cs, 3), cs.inverse_map(cs, 3), cs.n)
                     idt = f
+                c1 = o
                 o = blk['norm1'](o, act=1, training=tr)
+                n1 = o
                 o = E.conv(o, blk['conv2'], cs.kernel_map(cs, 3), cs.inverse_map(cs, 3), cs.n)
                 f = blk['norm2'](o, act=1, res=idt, training=tr)       # relu(bn(conv2) + identity)
+                if self.trace is not None:
+                    self.trace += [c1, n1, o, f]
             outs.append(SparseTensor(cs, f))
         return outs
 

@@ -7,6 +7,7 @@ called at embodiedscan/models/detectors/sparse_featfusion_single_stage.py:130-13
 """
 import torch
 from ... import engine as E
+from ... import hip
 from ...hip import P, call
 from ...registry import MODELS
 
@@ -35,7 +36,11 @@ class _Grid:
                 inv = torch.empty((n_in, K), dtype=torch.int32, device=self.dev)
                 call('es_inverse_map', P(nbr), n_out, K, n_in, P(inv), _stream())
             self.maps[key] = (nbr, inv, n_out, Ho, Wo)
-        return self.maps[key]
+        m = self.maps[key]
+        if hip.PROFILE is not None and m[0].data_ptr() not in hip.PAIRS:     # static maps: count pairs once
+            hip.register_map(m[0])
+            hip.register_map(m[1])
+        return m
 
 
 @MODELS.register_module(name='mmdet.ResNet')

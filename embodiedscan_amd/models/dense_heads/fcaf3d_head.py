@@ -162,7 +162,7 @@ class FCAF3DHeadRotMat:
             score = torch.empty(n, dtype=torch.float32, device=ho.d.device)
             call('es_row_max', ho.d.data_ptr() + 4 * 13, ncol, n, self.num_classes, P(score), _stream())
             score_set = out.cs
-            levels[i] = dict(cs=out.cs, ho=ho, bbox=bbox, scale=self.scales[i])
+            levels[i] = dict(cs=out.cs, ho=ho, bbox=bbox, scale=self.scales[i], out=out.F, x=x.F)
         return levels
 
     def forward(self, x):
@@ -263,4 +263,5 @@ class FCAF3DHeadRotMat:
         losses = dict(loss_center=(loss_acc[:, 0] / (avg + eps)).mean(), loss_bbox=loss_acc[:, 1].mean(),
                       loss_cls=loss_cls.mean())
         self.last_targets = [(p[2], p[3], p[4]) for p in per]
+        self.last_levels = levels
         return losses

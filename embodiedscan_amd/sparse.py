@@ -84,7 +84,7 @@ class CoordSet:
             K = ksize ** 3
             nbr = torch.empty((out.n, K), dtype=torch.int32, device=self.device)
             call('es_kernel_map', P(out.keys), out.n, P(tk), P(tv), cap, ksize, self.ts, P(nbr), _stream())
-            self.cache[key] = (nbr, out)
+            self.cache[key] = (hip.register_map(nbr), out)
         return self.cache[key][0]
 
     def inverse_map(self, out, ksize):
@@ -94,7 +94,7 @@ class CoordSet:
             K = ksize ** 3
             inv = torch.empty((self.n, K), dtype=torch.int32, device=self.device)
             call('es_inverse_map', P(nbr), out.n, K, self.n, P(inv), _stream())
-            self.cache[key] = (inv, out)
+            self.cache[key] = (hip.register_map(inv), out)
         return self.cache[key][0]
 
     def children(self):

@@ -24,22 +24,25 @@ def _mat_to_euler_zxy(m):
     return np.array([math.atan2(-m[0, 1], m[1, 1]), math.asin(max(-1., min(1., m[2, 1]))), math.atan2(-m[2, 0], m[2, 2])])
 
 
-def _ray_box(o, d, c, half, R):
-    """z-free slab test. o (3,), d (P,3), box centre c, half sizes, rotation R -> t (P,) (inf = miss)."""
-    oo = (o - c) @ R                      # R^T (o-c)
-    dd = d @ R
-    with np.errstate(divide='ignore', invalid='ignore'):
-        t1 = (-half - oo) / dd
-        t2 = (half - oo) / dd
-    tmin = np.nanmax(np.minimum(t1, t2), axis=1)
-    tmax = np.nanmin(np.maximum(t1, t2), axis=1)
-    hit = (tmax >= np.maximum(tmin, 0)) & (tmax > 0)
-    t = np.where(tmin > 0, tmin, tmax)    # inside the box -> exit distance
-    return np.where(hit, t, np.inf)
+def _ray_boxes(o, d, c, half, R):
+    """Slab test of P rays against nb oriented boxes at once (torch, any device).
+    o (3,), d (P,3), c (nb,3), half (nb,3), R (nb,3,3) -> nearest hit distance t (P,) (inf = miss)."""
+    import torch
+    oo = torch.einsum('bj,bjk->bk', o[None] - c, R)            # R^T (o - c)            (nb,3)
+    dd = torch.einsum('pj,bjk->pbk', d, R)                       # (P,nb,3)
+    dd = torch.where(dd.abs() < 1e-12, torch.full_like(dd, 1e-12), dd)
+    t1 = (-half[None] - oo[None]) / dd
+    t2 = (half[None] - oo[None]) / dd
+    tmin = torch.minimum(t1, t2).amax(-1)
+    tmax = torch.maximum(t1, t2).amin(-1)
+    hit = (tmax >= tmin.clamp(min=0)) & (tmax > 0)
+    t = torch.where(tmin > 0, tmin, tmax)                        # inside the box -> exit distance
+    t = torch.where(hit, t, torch.full_like(t, float('inf')))
+    return t.amin(1)
 
 
 def make_scan(seed, n_views=20, height=480, width=640, img_size=(480, 480), n_boxes=25, n_points=100000,
-              n_classes=284, augment=True, max_depth=6.0):
+              n_classes=284, augment=True, max_depth=6.0, render_device='cpu'):
     """One synthetic scan.  Returns a dict of numpy arrays + the meta dict the
     reference attaches to a data sample (depth2img, scale_factor, img_shape, pcd_* ...)."""
     rng = np.random.default_rng(seed)
@@ -56,8 +59,14 @@ def make_scan(seed, n_views=20, height=480, width=640, img_size=(480, 480), n_bo
     us, vs = np.meshgrid(np.arange(width), np.arange(height))
     dirs_cam = np.stack([(us.ravel() - cx) / fx, (vs.ravel() - cy) / fy, np.ones(width * height)], 1)
 
+    import torch
     depth = np.zeros((n_views, height, width), np.float32)
     extr, intr = [], []
+    rd = torch.device(render_device)
+    all_c = torch.tensor(np.concatenate([room_c[None], centers]), dtype=torch.float64, device=rd)
+    all_h = torch.tensor(np.concatenate([room_h[None], sizes / 2]), dtype=torch.float64, device=rd)
+    all_R = torch.tensor(np.stack([np.eye(3)] + rots), dtype=torch.float64, device=rd)
+    dirs_t = torch.tensor(dirs_cam, dtype=torch.float64, device=rd)
     for v in range(n_views):
         pos = np.array([rng.uniform(-2.2, 2.2), rng.uniform(-1.8, 1.8), rng.uniform(1.0, 1.8)])
         yaw, pitch = rng.uniform(0, 2 * math.pi), rng.uniform(-0.5, 0.1)
@@ -68,10 +77,13 @@ def make_scan(seed, n_views=20, height=480, width=640, img_size=(480, 480), n_bo
         c2w = np.eye(4)
         c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, pos
         w2c = np.linalg.inv(c2w)
-        d = dirs_cam @ c2w[:3, :3].T
-        t = _ray_box(pos, d, room_c, room_h, np.eye(3))
-        for b in range(n_boxes):
-            t = np.minimum(t, _ray_box(pos, d, centers[b], sizes[b] / 2, rots[b]))
+        d = dirs_t @ torch.tensor(c2w[:3, :3].T, dtype=torch.float64, device=rd)
+        pos_t = torch.tensor(pos, dtype=torch.float64, device=rd)
+        chunks = []
+        step = 65536 if rd.type == 'cpu' else d.shape[0]
+        for c0 in range(0, d.shape[0], step):
+            chunks.append(_ray_boxes(pos_t, d[c0:c0 + step], all_c, all_h, all_R))
+        t = torch.cat(chunks).cpu().numpy()
         z = np.where(np.isfinite(t), t, 0.)          # camera-frame z == t because dirs_cam.z == 1
         z = np.where(z > max_depth, 0., z)
         depth[v] = z.reshape(height, width).astype(np.float32)

@@ -134,6 +134,11 @@ def centerness_from_faces(fd):
     """fcaf3d_head.py:1559-1576 (left-to-right product, then sqrt)."""
     x, y, z = fd[..., 0:2], fd[..., 2:4], fd[..., 4:6]
     c = x.min(-1)[0] / x.max(-1)[0] * y.min(-1)[0] / y.max(-1)[0] * z.min(-1)[0] / z.max(-1)[0]
+    # IEEE correctly-rounded f32 sqrt (sqrt in f64, then one rounding).  torch's CPU sqrt on large f32 tensors
+    # goes through MKL VML and is off by 1 ulp in ~0.6% of the elements (and exact on short tensors), so it
+    # cannot serve as a reproducible spec; the HIP kernel uses the correctly rounded sqrtf.
+    if c.dtype == torch.float32:
+        return torch.sqrt(c.double()).float()
     return torch.sqrt(c)
 
 

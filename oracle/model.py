@@ -86,7 +86,7 @@ def _bn(x, sd, p, training=True):
                         sd[p + '.bn.running_var'], training)
 
 
-def mink_resnet34(x, sd, prefix='backbone_3d.', training=True):
+def mink_resnet34(x, sd, prefix='backbone_3d.', training=True, trace=None):
     """mink_resnet.py:122-140 with ME BasicBlock (conv3-BN-ReLU-conv3-BN (+down) ReLU)."""
     x = S.conv(x, sd[prefix + 'conv1.kernel'], 3, 2)
     x = S.instance_norm(x, sd[prefix + 'norm1.weight'], sd[prefix + 'norm1.bias'])
@@ -98,9 +98,12 @@ def mink_resnet34(x, sd, prefix='backbone_3d.', training=True):
             p = f'{prefix}layer{li + 1}.{bi}.'
             stride = 2 if bi == 0 else 1
             o = S.conv(x, sd[p + 'conv1.kernel'], 3, stride)
+            tr_c1 = o.feats
             o = _bn(o, sd, p + 'norm1', training)
             o = o.new(F.relu(o.feats))
+            tr_n1 = o.feats
             o = S.conv(o, sd[p + 'conv2.kernel'], 3, 1)
+            tr_c2 = o.feats
             o = _bn(o, sd, p + 'norm2', training)
             if bi == 0:
                 idt = S.conv(x, sd[p + 'downsample.0.kernel'], 1, stride)
@@ -108,6 +111,10 @@ def mink_resnet34(x, sd, prefix='backbone_3d.', training=True):
             else:
                 idt = x
             x = o.new(F.relu(o.feats + idt.feats))
+            if trace is not None:
+                for nm, t in (('conv1', tr_c1), ('norm1', tr_n1), ('conv2', tr_c2), ('out', x.feats)):
+                    t.retain_grad()
+                    trace.append((f'layer{li + 1}.{bi}.{nm}', t))
         outs.append(x)
     return outs
 
@@ -144,6 +151,7 @@ def batch_point_sample(meta, img_features, points, proj_mat, img_scale_factor, i
     """point_fusion.py:208-311 with aligned=False, padding 'zeros', align_corners=True,
     valid_flag=True.  img_features (V,C,H,W); points (N,3); proj_mat (V,4,4)."""
     points = apply_3d_transformation_reverse(points, meta)
+    proj_mat = proj_mat.to(points.dtype)
     points = points.repeat(proj_mat.shape[0], 1, 1)
     p4 = torch.cat([points, points.new_ones(points.shape[:-1] + (1,))], dim=-1)
     p2 = torch.bmm(p4, proj_mat.permute(0, 2, 1))
@@ -177,13 +185,13 @@ def projection_matrices(meta):
 
 
 # ----------------------------------------------------------------------------- detector
-def extract_feat(sd, points, imgs, metas, voxel_size=0.01, training=True):
+def extract_feat(sd, points, imgs, metas, voxel_size=0.01, training=True, trace=None):
     """sparse_featfusion_single_stage.py:86-221 (use_xyz_feat=True)."""
     n_batch = len(points)
     coords, src = C.voxelize([p.detach().numpy() for p in points], voxel_size)
     feats = torch.cat([p[:, :3] for p in points])[torch.from_numpy(src)]
     x = S.SpT(coords, feats, 1, n_batch, {})
-    xs = mink_resnet34(x, sd, training=training)
+    xs = mink_resnet34(x, sd, training=training, trace=trace)
     B, V = imgs.shape[:2]
     img_feats = resnet50_w16(imgs.reshape((-1,) + imgs.shape[2:]), sd)
     img_feats = [f.reshape((B, V) + f.shape[1:]) for f in img_feats]
@@ -193,7 +201,7 @@ def extract_feat(sd, points, imgs, metas, voxel_size=0.01, training=True):
         for b in range(n_batch):
             meta = metas[b]
             rows = xl.batch_rows(b)
-            pts = torch.from_numpy(xl.coords[rows, 1:]).float() * voxel_size
+            pts = (torch.from_numpy(xl.coords[rows, 1:]).float() * voxel_size).to(xl.feats.dtype)
             sf = torch.tensor(meta['scale_factor'][:2], dtype=torch.float32) if 'scale_factor' in meta else 1
             off = torch.tensor(meta['img_crop_offset'], dtype=torch.float32) if 'img_crop_offset' in meta else 0
             per_sample.append(batch_point_sample(meta, img_feats[lvl][b], pts, projection_matrices(meta), sf, off,
@@ -235,7 +243,7 @@ def prune_mask(x, scores, thr):
     return mask
 
 
-def head_forward(xs, sd, prefix='bbox_head.', voxel_size=0.01, thr=100000, training=True):
+def head_forward(xs, sd, prefix='bbox_head.', voxel_size=0.01, thr=100000, training=True, trace=None):
     """fcaf3d_head.py:993-1020,1116-1149.  Returns per-level lists (fine->coarse) of
     per-sample tensors: center (N,1), bbox (N,12), cls (N,C), points (N,3)."""
     n_lvl = len(xs)
@@ -253,6 +261,11 @@ def head_forward(xs, sd, prefix='bbox_head.', voxel_size=0.01, thr=100000, train
         reg = out.feats @ sd[prefix + 'conv_reg.kernel']
         dist = torch.exp(reg[:, :6] * sd[f'{prefix}scales.{i}.scale']).clamp(min=1e-3)
         bbox = torch.cat((dist, reg[:, 6:]), 1)
+        if trace is not None:
+            for nm, t in (('out', out.feats), ('center', center), ('reg', reg), ('cls', cls), ('x', x.feats)):
+                if t.requires_grad:
+                    t.retain_grad()
+                trace.append((f'head.L{i}.{nm}', t))
         score = out.new(cls.detach().max(dim=1, keepdim=True).values)
         per = []
         for b in range(out.n_batch):
@@ -263,11 +276,15 @@ def head_forward(xs, sd, prefix='bbox_head.', voxel_size=0.01, thr=100000, train
 
 
 def loss_single(level_preds, gt_boxes, gt_labels, world_size_mean=lambda t: t,
-                decouple_weights=(0.2, 0.2, 0.2, 0.4)):
+                decouple_weights=(0.2, 0.2, 0.2, 0.4), targets_override=None):
     """fcaf3d_head.py:1151-1294 for one sample.  level_preds: list over levels of
     (center, bbox, cls, points)."""
     points_l = [p[3] for p in level_preds]
-    center_t, bbox_t, cls_t = G.get_targets(points_l, gt_boxes, gt_labels)
+    if targets_override is None:
+        center_t, bbox_t, cls_t = G.get_targets(points_l, gt_boxes, gt_labels)
+    else:   # f64 "truth" runs reuse the f32 integer decisions
+        center_t, bbox_t, cls_t = (targets_override[0].to(level_preds[0][0].dtype),
+                                   targets_override[1].to(level_preds[0][0].dtype), targets_override[2])
     center_p = torch.cat([p[0] for p in level_preds])
     bbox_p = torch.cat([p[1] for p in level_preds])
     cls_p = torch.cat([p[2] for p in level_preds])
@@ -292,14 +309,15 @@ def loss_single(level_preds, gt_boxes, gt_labels, world_size_mean=lambda t: t,
 
 
 def detector_loss(sd, points, imgs, metas, gt_boxes, gt_labels, voxel_size=0.01, thr=100000, training=True,
-                  return_aux=False):
+                  return_aux=False, targets_override=None, trace=None):
     """SparseFeatureFusionSingleStage3DDetector.loss -> dict(loss_center, loss_bbox, loss_cls)."""
-    xs = extract_feat(sd, points, imgs, metas, voxel_size, training)
-    outs = head_forward(xs, sd, voxel_size=voxel_size, thr=thr, training=training)
+    xs = extract_feat(sd, points, imgs, metas, voxel_size, training, trace)
+    outs = head_forward(xs, sd, voxel_size=voxel_size, thr=thr, training=training, trace=trace)
     n_batch = len(points)
     cl, bl, kl, aux = [], [], [], []
     for b in range(n_batch):
-        c, bb, k, tg = loss_single([outs[l][b] for l in range(len(outs))], gt_boxes[b], gt_labels[b])
+        c, bb, k, tg = loss_single([outs[l][b] for l in range(len(outs))], gt_boxes[b], gt_labels[b],
+                                   targets_override=None if targets_override is None else targets_override[b])
         cl.append(c), bl.append(bb), kl.append(k), aux.append(tg)
     losses = dict(loss_center=torch.stack(cl).mean(), loss_bbox=torch.stack(bl).mean(), loss_cls=torch.stack(kl).mean())
     if return_aux:

@@ -45,7 +45,8 @@ def test_point_sample_vs_reference_golden(golden_dir):
         out = torch.zeros((len(ci), C), device=dev)
         pix = torch.empty((len(ci), V), dtype=torch.int32, device=dev)
         cnt = torch.empty(len(ci), dtype=torch.int32, device=dev)
-        call('es_point_sample_fwd', P(torch.from_numpy(coords).to(dev)), len(ci), vs, P(md), md.shape[1], V, P(nhwc), H, W,
+        cd = torch.from_numpy(coords).to(dev)
+        call('es_point_sample_fwd', P(cd), len(ci), vs, P(md), md.shape[1], V, P(nhwc), H, W,
              C, P(out), C, P(pix), P(cnt), torch.cuda.current_stream().cuda_stream)
         diff = (out.cpu() - ref).abs().max(1).values
         bad = int((diff > 1e-5).sum())
@@ -81,10 +82,13 @@ def test_losses_vs_oracle(golden_dir):
     dcen = torch.zeros(n, device=dev)
     dbb = torch.zeros((n, 12), device=dev)
     acc = torch.zeros(2, device=dev)
-    call('es_pos_losses', P(cls_t.to(dev)), n, P(torch.tensor([npos], dtype=torch.int32, device=dev)), P(pts.to(dev)),
-         P(center_p.to(dev)), 1, P(pred.to(dev)), P(center_t.to(dev)), P(tgt.to(dev)), P(avg.to(dev)), 1.0, farr(w),
+    # keep every device tensor alive in a variable: P() only takes the pointer
+    d_cls, d_np, d_pts, d_cp = cls_t.to(dev), torch.tensor([npos], dtype=torch.int32, device=dev), pts.to(dev), center_p.to(dev)
+    d_pred, d_ct, d_tgt, d_avg = pred.to(dev), center_t.to(dev), tgt.to(dev), avg.to(dev)
+    call('es_pos_losses', P(d_cls), n, P(d_np), P(d_pts), P(d_cp), 1, P(d_pred), P(d_ct), P(d_tgt), P(d_avg), 1.0, farr(w),
          P(dcen), 1, P(dbb), P(acc), torch.cuda.current_stream().cuda_stream)
     acc = acc.cpu()
+    lb, lc = lb.detach(), lc.detach()
     print(f'bbox loss hip {float(acc[1]):.6f} oracle {float(lb):.6f}; center sum hip {float(acc[0]):.6f}')
     assert abs(float(acc[1]) - float(lb)) / float(lb) < 1e-5
     assert abs(float(acc[0]) / (float(avg[0]) + 1.1920929e-07) - float(lc)) / float(lc) < 1e-5
@@ -102,7 +106,8 @@ def test_losses_vs_oracle(golden_dir):
     grad = torch.zeros((N, C), device=dev)
     partial = torch.empty(2048, dtype=torch.float64, device=dev)
     out = torch.zeros(1, device=dev)
-    call('es_focal_loss', P(logits.to(dev)), C, P(labels.int().to(dev)), N, C, 2.0, 0.25, P(avg.to(dev)), 1.0, P(grad), C,
+    d_log, d_lab = logits.to(dev), labels.int().to(dev)
+    call('es_focal_loss', P(d_log), C, P(d_lab), N, C, 2.0, 0.25, P(d_avg), 1.0, P(grad), C,
          P(partial), P(out), torch.cuda.current_stream().cuda_stream)
     e = abs(float(out.cpu()) - float(fl)) / float(fl)
     eg = float((grad.cpu() - lo.grad).abs().max() / lo.grad.abs().max())

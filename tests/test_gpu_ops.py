@@ -146,27 +146,34 @@ def test_gen_transpose_norm_pool(dev):
     q.g = dq.to(dev)
     E.TAPE.backward()
     torch.cuda.synchronize()
-    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    bwo, bbo = bw.clone().requires_grad_(True), bb.clone().requires_grad_(True)
-    orm, orv = torch.zeros(cout), torch.ones(cout)
-    st = S.SpT(oc, xo, 2, 2, {})
-    yo = S.gen_conv_transpose(st, wo)
-    np.testing.assert_array_equal(ch.coords.cpu().numpy(), yo.coords)
-    zo = S.batch_norm(yo, bwo, bbo, orm, orv, True)
-    zo = zo.new(torch.nn.functional.elu(zo.feats))
-    po = S.max_pool(zo)
-    np.testing.assert_array_equal(pooled_set.coords.cpu().numpy(), po.coords)
-    qo = S.instance_norm(po, torch.ones(1, cout), torch.zeros(1, cout))
-    qo = qo.new(torch.relu(qo.feats))
-    (qo.feats * dq).sum().backward()
-    for name, a, b, tol in (('gen', y.d.cpu(), yo.feats.detach(), 1e-5), ('bn+elu', z.d.cpu(), zo.feats.detach(), 1e-4),
-                            ('pool', p.d.cpu(), po.feats.detach(), 1e-4), ('in+relu', q.d.cpu(), qo.feats.detach(), 2e-4),
-                            ('dx', xv.g.cpu(), xo.grad, 2e-3), ('dw', wp.g.cpu(), wo.grad, 2e-3),
-                            ('dbn_w', bwp.g.cpu(), bwo.grad, 2e-3), ('dbn_b', bbp.g.cpu(), bbo.grad, 2e-3),
-                            ('run_mean', rm.cpu(), orm, 1e-5), ('run_var', rv.cpu(), orv, 1e-4)):
-        ea, er = _err(a, b)
-        print(f'{name}: max abs err {ea:.3e} rel-to-max {er:.3e} (tol {tol})')
-        assert er < tol, (name, ea, er)
+    def run_oracle(dt):
+        xo, wo = x.detach().clone().to(dt).requires_grad_(True), w.detach().clone().to(dt).requires_grad_(True)
+        bwo, bbo = bw.detach().clone().to(dt).requires_grad_(True), bb.detach().clone().to(dt).requires_grad_(True)
+        orm, orv = torch.zeros(cout, dtype=dt), torch.ones(cout, dtype=dt)
+        st = S.SpT(oc, xo, 2, 2, {})
+        yo = S.gen_conv_transpose(st, wo)
+        zo = S.batch_norm(yo, bwo, bbo, orm, orv, True)
+        zo = zo.new(torch.nn.functional.elu(zo.feats))
+        po = S.max_pool(zo)
+        qo = S.instance_norm(po, torch.ones(1, cout, dtype=dt), torch.zeros(1, cout, dtype=dt))
+        qo = qo.new(torch.relu(qo.feats))
+        (qo.feats * dq.to(dt)).sum().backward()
+        return dict(coords_gen=yo.coords, coords_pool=po.coords, gen=yo.feats.detach(), bn_elu=zo.feats.detach(),
+                    pool=po.feats.detach(), in_relu=qo.feats.detach(), dx=xo.grad, dw=wo.grad, dbn_w=bwo.grad,
+                    dbn_b=bbo.grad, run_mean=orm, run_var=orv)
+    o32, o64 = run_oracle(torch.float32), run_oracle(torch.float64)
+    np.testing.assert_array_equal(ch.coords.cpu().numpy(), o32['coords_gen'])
+    np.testing.assert_array_equal(pooled_set.coords.cpu().numpy(), o32['coords_pool'])
+    got = dict(gen=y.d, bn_elu=z.d, pool=p.d, in_relu=q.d, dx=xv.g, dw=wp.g, dbn_w=bwp.g, dbn_b=bbp.g, run_mean=rm,
+               run_var=rv)
+    for name, a in got.items():
+        # truth = the oracle evaluated in f64; the f32 oracle's own distance to it calibrates the tolerance
+        # (per-channel BN gradients are sums of ~50k signed terms: cancellation noise, not a kernel defect)
+        _, e_hip = _err(a.cpu(), o64[name])
+        _, e_o32 = _err(o32[name], o64[name])
+        tol = max(2e-5, 4 * e_o32)
+        print(f'{name}: hip rel-to-max err vs f64 truth {e_hip:.3e}; f32 oracle vs f64 truth {e_o32:.3e}; tol {tol:.1e}')
+        assert e_hip < tol, (name, e_hip, tol)
 
 
 def test_union_add_and_gather(dev):
@@ -204,7 +211,8 @@ def test_topk_mask(dev):
     seg = [0, 3000, 5000]
     k = 1200
     mask = torch.zeros(5000, dtype=torch.int32, device=dev)
-    call('es_topk_mask', P(v.to(dev)), iarr(seg), 2, k, P(mask), torch.cuda.current_stream().cuda_stream)
+    vd = v.to(dev)
+    call('es_topk_mask', P(vd), iarr(seg), 2, k, P(mask), torch.cuda.current_stream().cuda_stream)
     m = mask.cpu().numpy().astype(bool)
     for s in range(2):
         sl = slice(seg[s], seg[s + 1])
