@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='scans per GPU per step (reference config: 8xb4)')
     ap.add_argument('--views', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'],
+                    help='conv fwd/dgrad matrix-core type: bf16 MFMA with f32 accumulate (BASELINE config) or exact-f32 MFMA')
     ap.add_argument('--cpu-views', type=int, default=20)
     args = ap.parse_args()
 
@@ -46,6 +48,7 @@ def main():
     from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
     from embodiedscan_amd.synth import make_scan
 
+    E.PRECISION[0] = args.precision
     cfg = load_config(os.path.join(ROOT, 'configs', 'mv_3ddet.py'))
     det = build_detector(cfg, device=dev, seed=0).to(dev)          # same initial weights on every rank
     optim = build_optim_wrapper(cfg)
@@ -65,7 +68,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     # time EXACTLY `steps` steps; the convolution engine launches are bracketed by HIP events on the same stream
-    prof = {'names': {'es_spconv_fwd', 'es_spconv_wgrad'}, 'records': [],
+    prof = {'names': {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_wgrad', 'es_spconv_wgrad_bf16'}, 'records': [],
             'event': lambda: torch.cuda.Event(enable_timing=True)}
     hip.PROFILE = prof
     t0 = time.perf_counter()
@@ -75,7 +78,7 @@ def main():
         recs = prof['records']
         for i in range(done, len(recs)):        # resolve map pointer -> pair counter while the maps are still alive
             name, e0, e1, a = recs[i]
-            recs[i] = (name, e0, e1, a, hip.PAIRS.get(a[3] if name == 'es_spconv_fwd' else a[4]))
+            recs[i] = (name, e0, e1, a, hip.PAIRS.get(a[4] if name.startswith('es_spconv_wgrad') else a[3]))
         done = len(recs)
     torch.cuda.synchronize()
     if world > 1:
@@ -94,12 +97,14 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (the MFMA convolution engine), from the live HIP-event timings
-    K_PEAK_F32_MFMA = 157.3          # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+    # TFLOP/s dense peaks from MI355X_MICROARCH.md: f32-input MFMA 157.3, bf16 MFMA ~2500.  In bf16 mode the engine is a
+    # mix (fwd/dgrad bf16, wgrad f32): the fraction is quoted against the peak of the type that does most of the flops.
+    K_PEAK_F32_MFMA = 157.3 if args.precision == 'f32' else 2500.0
     tot_ms, tot_flop, n_launch = 0.0, 0.0, 0
     for name, e0, e1, a, pairs_dev in prof['records']:
         tot_ms += e0.elapsed_time(e1)
         n_launch += 1
-        if name == 'es_spconv_fwd':
+        if not name.startswith('es_spconv_wgrad'):
             nbr, n_out, n_in, K, cin, cout = a[3], a[4], a[5], a[6], a[7], a[8]
         else:
             nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
@@ -107,7 +112,8 @@ def main():
         tot_flop += 2.0 * pairs * cin * cout
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     roofline = dict(bound='mfma', achieved=round(achieved, 3), peak=K_PEAK_F32_MFMA, unit='TFLOP/s',
-                    frac=round(achieved / K_PEAK_F32_MFMA, 4), traffic=None, kernel='k_spconv / k_spconv_wgrad (f32 MFMA)',
+                    frac=round(achieved / K_PEAK_F32_MFMA, 4), traffic=None,
+                    kernel='k_spconv_bf16 (fwd/dgrad) + k_spconv_wgrad_bf16' if args.precision == 'bf16' else 'k_spconv / k_spconv_wgrad (f32 MFMA)',
                     launches_per_step=n_launch // max(args.steps, 1),
                     kernel_ms_per_step=round(tot_ms / max(args.steps, 1), 3),
                     note='algorithmic flops = 2 * valid (output,tap) pairs * Cin * Cout per launch')
@@ -115,9 +121,9 @@ def main():
     out = dict(metric='scans/sec (train step) mv-3ddet, 20x(480x640) RGB-D views', value=round(world * args.batch * args.steps / dt, 4),
                unit='scans/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
-               dtype='f32', data='synthetic',
+               dtype=args.precision, data='synthetic',
                config=dict(workload='mv-3ddet ResNet-50(w16) + MinkResNet34 + FCAF3DHeadRotMat, 20 views 480x640, '
-                                    '100k points/scan, f32 (exact-f32 MFMA), full train step incl. AdamW',
+                                    f'100k points/scan, {args.precision} matrix cores with f32 accumulate / f32 master weights, full train step incl. AdamW',
                            scans_per_gpu_per_step=args.batch, views=args.views, parallelism=f'dp{world}'),
                losses={k: round(float(v), 6) for k, v in losses.items()}, roofline=roofline)
     if world == 1 and not args.no_cpu_baseline:

@@ -9,7 +9,8 @@
 #include "common.h"
 #include "../../include/es_hip.h"
 
-#define NCH 64   // rows per statistics chunk
+#define NCH 128  // rows per statistics chunk
+#define FST 16   // chunk stripes per channel in the finalize kernels (block = 64 channels x FST)
 
 struct Segs { int n; int off[ES_MAX_SEG + 1]; };
 __device__ inline int seg_of(const Segs& s, int row) {
@@ -29,44 +30,67 @@ static int max_seg_rows(const Segs& s) {
   return m;
 }
 
-// partial[(seg*nchunk + chunk)*2*C + {0,1}*C + c]
+// partial[(seg*nchunk + chunk)*2*C + {0,1}*C + c] = {sum, M2 about the chunk mean}  (Chan et al. merge in the
+// finalize kernel: robust against |mean| >> std, unlike E[x^2] - E[x]^2)
 __global__ void k_norm_stats(const float* __restrict__ x, int ldx, int C, Segs segs, int nchunk,
                              float* __restrict__ partial) {
   int seg = blockIdx.y, chunk = blockIdx.x;
   int r0 = segs.off[seg] + chunk * NCH, r1 = min(segs.off[seg + 1], r0 + NCH);
+  if (r0 >= r1) return;
   float* out = partial + ((size_t)(seg * nchunk + chunk) * 2) * C;
+  float inv = 1.f / (float)(r1 - r0);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f, q = 0.f;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + c];
+    float m = s * inv, q = 0.f;
     for (int r = r0; r < r1; ++r) {
-      float v = x[(size_t)r * ldx + c];
-      s += v;
-      q += v * v;
+      float d = x[(size_t)r * ldx + c] - m;
+      q += d * d;
     }
     out[c] = s;
     out[C + c] = q;
   }
 }
-__global__ void k_norm_finalize(const float* __restrict__ partial, int C, Segs segs, int nchunk, float eps,
-                                float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
-                                float* running_var, float momentum) {
-  int seg = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  int n = segs.off[seg + 1] - segs.off[seg];
+__global__ __launch_bounds__(64 * FST) void k_norm_finalize(const float* __restrict__ partial, int C, Segs segs,
+                                                            int nchunk, float eps, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* running_mean,
+                                                            float* running_var, float momentum) {
+  __shared__ double red[FST][64];
+  int seg = blockIdx.y, cl = threadIdx.x & 63, st = threadIdx.x >> 6;
+  int c = blockIdx.x * 64 + cl;
+  int r0 = segs.off[seg], n = segs.off[seg + 1] - r0;
   int used = (n + NCH - 1) / NCH;
-  double s = 0, q = 0;
-  for (int ch = 0; ch < used; ++ch) {
-    const float* p = partial + ((size_t)(seg * nchunk + ch) * 2) * C;
-    s += p[c];
-    q += p[C + c];
-  }
-  double m = n > 0 ? s / n : 0.0;
-  double var = n > 0 ? q / n - m * m : 0.0;
-  if (var < 0) var = 0;
-  mean[seg * C + c] = (float)m;
-  invstd[seg * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean && n > 1) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1));
+  // pass 1: total sum -> mean
+  double s = 0;
+  if (c < C)
+    for (int ch = st; ch < used; ch += FST) s += partial[((size_t)(seg * nchunk + ch) * 2) * C + c];
+  red[st][cl] = s;
+  __syncthreads();
+  double tot = 0;
+  for (int i = 0; i < FST; ++i) tot += red[i][cl];
+  double m = n > 0 ? tot / n : 0.0;
+  __syncthreads();
+  // pass 2: M2 = sum_c [ M2_c + n_c (m_c - m)^2 ]
+  double q = 0;
+  if (c < C)
+    for (int ch = st; ch < used; ch += FST) {
+      const float* p = partial + ((size_t)(seg * nchunk + ch) * 2) * C;
+      int nc = min(NCH, n - ch * NCH);
+      double d = (double)p[c] / nc - m;
+      q += (double)p[C + c] + nc * d * d;
+    }
+  red[st][cl] = q;
+  __syncthreads();
+  if (st == 0 && c < C) {
+    double m2 = 0;
+    for (int i = 0; i < FST; ++i) m2 += red[i][cl];
+    double var = n > 0 ? m2 / n : 0.0;
+    mean[seg * C + c] = (float)m;
+    invstd[seg * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean && n > 1) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1));
+    }
   }
 }
 __device__ inline float act_fwd(float z, int act) {
@@ -100,7 +124,7 @@ extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg
   if (nchunk < 1) nchunk = 1;
   hipLaunchKernelGGL(k_norm_stats, dim3(nchunk, nseg), dim3(C >= 256 ? 256 : 64), 0, st, x, ldx, C, s, nchunk,
                      workspace);
-  hipLaunchKernelGGL(k_norm_finalize, dim3(es_cdiv(C, 64), nseg), dim3(64), 0, st, workspace, C, s, nchunk, eps,
+  hipLaunchKernelGGL(k_norm_finalize, dim3(es_cdiv(C, 64), nseg), dim3(64 * FST), 0, st, workspace, C, s, nchunk, eps,
                      mean, invstd, running_mean, running_var, momentum);
   int g = es_cdiv((long long)n * C, 256);
   if (g > 4096) g = 4096;
@@ -141,28 +165,41 @@ __global__ void k_norm_bwd_stats(float* __restrict__ dy, int ldd, const float* _
     out[C + c] = q;
   }
 }
-__global__ void k_norm_bwd_finalize(const float* __restrict__ partial, int C, Segs segs, int nchunk,
-                                    float* __restrict__ sum_dz, float* __restrict__ sum_dzx, float* dweight,
-                                    float* dbias) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64 * FST) void k_norm_bwd_finalize(const float* __restrict__ partial, int C, Segs segs,
+                                                                int nchunk, float* __restrict__ sum_dz,
+                                                                float* __restrict__ sum_dzx, float* dweight,
+                                                                float* dbias) {
+  __shared__ double red[2][FST][64];
+  int cl = threadIdx.x & 63, st = threadIdx.x >> 6;
+  int c = blockIdx.x * 64 + cl;
   double tw = 0, tb = 0;
   for (int seg = 0; seg < segs.n; ++seg) {
     int n = segs.off[seg + 1] - segs.off[seg];
     int used = (n + NCH - 1) / NCH;
     double s = 0, q = 0;
-    for (int ch = 0; ch < used; ++ch) {
-      const float* p = partial + ((size_t)(seg * nchunk + ch) * 2) * C;
-      s += p[c];
-      q += p[C + c];
+    if (c < C)
+      for (int ch = st; ch < used; ch += FST) {
+        const float* p = partial + ((size_t)(seg * nchunk + ch) * 2) * C;
+        s += p[c];
+        q += p[C + c];
+      }
+    red[0][st][cl] = s;
+    red[1][st][cl] = q;
+    __syncthreads();
+    if (st == 0 && c < C) {
+      double ts = 0, tq = 0;
+      for (int i = 0; i < FST; ++i) { ts += red[0][i][cl]; tq += red[1][i][cl]; }
+      sum_dz[seg * C + c] = (float)ts;
+      sum_dzx[seg * C + c] = (float)tq;
+      tb += ts;
+      tw += tq;
     }
-    sum_dz[seg * C + c] = (float)s;
-    sum_dzx[seg * C + c] = (float)q;
-    tb += s;
-    tw += q;
+    __syncthreads();
   }
-  if (dweight) dweight[c] += (float)tw;
-  if (dbias) dbias[c] += (float)tb;
+  if (st == 0 && c < C) {
+    if (dweight) dweight[c] += (float)tw;
+    if (dbias) dbias[c] += (float)tb;
+  }
 }
 __global__ void k_norm_bwd_apply(const float* __restrict__ dz, int ldd, const float* __restrict__ x, int ldx, int n,
                                  int C, Segs segs, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -194,7 +231,7 @@ extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const fl
   float* sums = workspace + (size_t)nseg * nchunk * 2 * C;
   hipLaunchKernelGGL(k_norm_bwd_stats, dim3(nchunk, nseg), dim3(C >= 256 ? 256 : 64), 0, st, dy, ldd, y, ldy, x,
                      ldx, C, s, nchunk, mean, invstd, act, workspace);
-  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(es_cdiv(C, 64)), dim3(64), 0, st, workspace, C, s, nchunk, sums,
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(es_cdiv(C, 64)), dim3(64 * FST), 0, st, workspace, C, s, nchunk, sums,
                      sums + (size_t)nseg * C, dweight, dbias);
   int g = es_cdiv((long long)n * C, 256);
   if (g > 4096) g = 4096;

@@ -27,11 +27,29 @@ class Var:
 
 
 class Param:
-    """View into the parameter / gradient arenas."""
-    __slots__ = ('d', 'g')
+    """View into the parameter / gradient arenas (+ lazily refreshed bf16 copies for the bf16 MFMA path)."""
+    __slots__ = ('d', 'g', 'bf_n', 'bf_t', 'bf_step')
 
     def __init__(self, d, g=None):
         self.d, self.g = d, g
+        self.bf_n = self.bf_t = None
+        self.bf_step = -1
+
+    def bf16(self):
+        """(natural [K][Cin][Cout], transposed [K][Cout][Cin]) bf16 copies, re-made when the weights changed."""
+        if self.bf_step != WEIGHT_VERSION[0]:
+            K, a, b = self.d.shape
+            if self.bf_n is None:
+                self.bf_n = torch.empty((K, a, b), dtype=torch.bfloat16, device=self.d.device)
+                self.bf_t = torch.empty((K, b, a), dtype=torch.bfloat16, device=self.d.device)
+            call('es_cast_weight_bf16', P(self.d), K, a, b, P(self.bf_n), P(self.bf_t), _stream())
+            self.bf_step = WEIGHT_VERSION[0]
+        return self.bf_n, self.bf_t
+
+
+PRECISION = ['f32']       # 'f32': exact-f32 MFMA everywhere; 'bf16': bf16 MFMA (f32 accumulate) for conv fwd / dgrad
+WGRAD_BF16 = [True]       # in bf16 mode also run the weight-gradient GEMMs on the bf16 matrix cores
+WEIGHT_VERSION = [0]      # bumped by the optimiser: invalidates the bf16 weight copies
 
 
 class Tape:
@@ -84,8 +102,13 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
     K, cin, cout = w.d.shape
     n_in = x.d.shape[0]
     y = Var(empty((n_out, cout), x.d))
-    call('es_spconv_fwd', P(x.d), _ld(x.d), P(w.d), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0,
-         P(y.d), cout, 0, 0, _stream())
+    bf = PRECISION[0] == 'bf16' and cin >= 16
+    if bf:
+        call('es_spconv_fwd_bf16', P(x.d), _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout,
+             P(bias.d) if bias else 0, P(y.d), cout, 0, _stream())
+    else:
+        call('es_spconv_fwd', P(x.d), _ld(x.d), P(w.d), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0,
+             P(y.d), cout, 0, 0, _stream())
 
     def bwd():
         if y.g is None:
@@ -94,15 +117,20 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
         if DEBUG_GRADS is not None:
             DEBUG_GRADS[id(y)] = y.g.clone()
         if w.g is not None:
-            call('es_spconv_wgrad', P(x.d), _ld(x.d), P(y.g), _ld(y.g), P(nbr), n_out, n_in, K, cin, cout, P(w.g), s)
+            call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), P(y.g),
+                 _ld(y.g), P(nbr), n_out, n_in, K, cin, cout, P(w.g), s)
         if bias is not None and bias.g is not None:
             ones = torch.ones((n_out, 1), dtype=torch.float32, device=x.d.device)
             call('es_spconv_wgrad', P(ones), 1, y.g.data_ptr() + 4 * bias_from, _ld(y.g), 0, n_out, n_out, 1, 1,
                  cout - bias_from, bias.g.data_ptr() + 4 * bias_from, s)
         if need_dx and x.rg:
             g, acc = _grad_target(x, x.d)
-            call('es_spconv_fwd', P(y.g), _ld(y.g), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1,
-                 acc, s)
+            if bf and cout >= 16:
+                call('es_spconv_fwd_bf16', P(y.g), _ld(y.g), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0,
+                     P(g), _ld(g), acc, s)
+            else:
+                call('es_spconv_fwd', P(y.g), _ld(y.g), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1,
+                     acc, s)
     TAPE.add(bwd)
     return y
 
@@ -114,9 +142,14 @@ def gen_conv_transpose(x, w):
     n = x.d.shape[0]
     y = Var(empty((n * 8, cout), x.d))
     s = _stream()
+    bf = PRECISION[0] == 'bf16'
     for k in range(8):
-        call('es_spconv_fwd', P(x.d), _ld(x.d), w.d.data_ptr() + 4 * k * cin * cout, 0, n, n, 1, cin, cout, 0,
-             y.d.data_ptr() + 4 * k * cout, 8 * cout, 0, 0, s)
+        if bf:
+            call('es_spconv_fwd_bf16', P(x.d), _ld(x.d), w.bf16()[1].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cin,
+                 cout, 0, y.d.data_ptr() + 4 * k * cout, 8 * cout, 0, s)
+        else:
+            call('es_spconv_fwd', P(x.d), _ld(x.d), w.d.data_ptr() + 4 * k * cin * cout, 0, n, n, 1, cin, cout, 0,
+                 y.d.data_ptr() + 4 * k * cout, 8 * cout, 0, 0, s)
 
     def bwd():
         if y.g is None:
@@ -126,9 +159,12 @@ def gen_conv_transpose(x, w):
         for k in range(8):
             gy = y.g.data_ptr() + 4 * k * cout
             if w.g is not None:
-                call('es_spconv_wgrad', P(x.d), _ld(x.d), gy, 8 * cout, 0, n, n, 1, cin, cout,
-                     w.g.data_ptr() + 4 * k * cin * cout, s)
-            if g is not None:
+                call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), gy,
+                     8 * cout, 0, n, n, 1, cin, cout, w.g.data_ptr() + 4 * k * cin * cout, s)
+            if g is not None and bf:
+                call('es_spconv_fwd_bf16', gy, 8 * cout, w.bf16()[0].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cout,
+                     cin, 0, P(g), _ld(g), 1 if (acc or k > 0) else 0, s)
+            elif g is not None:
                 call('es_spconv_fwd', gy, 8 * cout, w.d.data_ptr() + 4 * k * cin * cout, 0, n, n, 1, cout, cin, 0,
                      P(g), _ld(g), 1, 1 if (acc or k > 0) else 0, s)
     TAPE.add(bwd)

@@ -59,11 +59,14 @@ class ResNet:
 
     def bind(self, arena, prefix='backbone.'):
         self.arena, self.prefix = arena, prefix
+        self._params = {}
         self.refresh()
         return self
 
     def _par(self, n):
-        return E.Param(self.arena.p[self.prefix + n], self.arena.g.get(self.prefix + n))
+        if n not in self._params:
+            self._params[n] = E.Param(self.arena.p[self.prefix + n], self.arena.g.get(self.prefix + n))
+        return self._params[n]
 
     def refresh(self):
         """fold every frozen BatchNorm2d into (scale, shift) -- call again after load_state_dict."""

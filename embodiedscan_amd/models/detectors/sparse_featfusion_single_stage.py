@@ -63,6 +63,7 @@ class SparseFeatureFusionSingleStage3DDetector:
 
     def load_state_dict(self, sd):
         self.arena.load_state_dict(sd)
+        E.WEIGHT_VERSION[0] += 1
         if self._bound:
             self.backbone.refresh()
 

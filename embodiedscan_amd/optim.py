@@ -34,3 +34,5 @@ class OptimWrapper:
              float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step,
              float(self.max_norm if self.max_norm else 0.0), P(self.norm), s)
         self.last_norm = self.norm
+        from . import engine
+        engine.WEIGHT_VERSION[0] += 1          # bf16 weight copies are stale now

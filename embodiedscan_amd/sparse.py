@@ -132,7 +132,22 @@ def voxelize(points, voxel_size):
         assert p.dtype == torch.float32 and p.stride(1) == 1
         call('es_voxel_keys', P(p), p.shape[0], p.stride(0), b, float(voxel_size), keys.data_ptr() + 8 * o, _stream())
         o += int(p.shape[0])
-    return unique_first(keys, n, 1, len(points))
+    cs, src = unique_first(keys, n, 1, len(points))
+    return morton_sorted(cs, src)
+
+
+def morton_sorted(cs, src):
+    """re-order a unique set (and its source rows) along a Z-curve; see csrc/sort.hip."""
+    m = cs.n
+    if m == 0:
+        return cs, src
+    dev = cs.device
+    nbytes = hip.raw('es_sort_scratch_bytes')(m)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out_keys = torch.empty(m, dtype=torch.int64, device=dev)
+    out_src = torch.empty(m, dtype=torch.int32, device=dev)
+    call('es_morton_sort', P(cs.keys), P(src), m, P(scratch), nbytes, P(out_keys), P(out_src), _stream())
+    return CoordSet(out_keys, m, cs.ts, cs.n_batch), out_src
 
 
 def union(a, b):

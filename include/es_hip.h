@@ -33,6 +33,10 @@ int es_voxel_keys(const float* points, int n, int ld, int batch, float voxel_siz
  * sparse_featfusion_single_stage.py:118 (ME.SparseTensor) */
 int es_unique_first(const int64_t* keys, int n, int64_t* tkeys, int* tvals, int cap, int* scratch,
                     int64_t* out_keys, int* out_src, int* count_host, void* stream);
+/* Z-curve (Morton) ordering of a unique key list (row order of the root voxel set) */
+size_t es_sort_scratch_bytes(int n);
+int es_morton_sort(const int64_t* keys, const int* src, int n, void* scratch, size_t scratch_bytes, int64_t* out_keys,
+                   int* out_src, void* stream);
 int es_build_table(const int64_t* keys, int n, int64_t* tkeys, int* tvals, int cap, void* stream);
 /* strided output coordinates floor(c / ts) * ts.  mink_resnet.py:58-69,104-108 (stride-2 conv / pool) */
 int es_stride_keys(const int64_t* in_keys, int n, int out_ts, int64_t* out_keys, void* stream);
@@ -64,9 +68,18 @@ int es_compact_mask(const int64_t* keys, int n, const int* mask, int* scratch, i
  * fcaf3d_head.py:907-984,1116-1136 */
 int es_spconv_fwd(const float* X, int ldx, const float* W, const int* nbr, int n_out, int n_in, int K, int Cin,
                   int Cout, const float* bias, float* Y, int ldy, int trans_w, int accumulate, void* stream);
+/* bf16-MFMA variant (f32 features rounded to bf16 while staged, f32 accumulate).  W_bf16 is [K][Cout][Cin]
+ * (reduction index contiguous): the transposed copy for the forward pass, the natural copy for dgrad. */
+int es_spconv_fwd_bf16(const float* X, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in, int K,
+                       int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, void* stream);
+/* per-step bf16 copies of an f32 [K][A][B] kernel: natural [K][A][B] and/or transposed [K][B][A] (either may be NULL) */
+int es_cast_weight_bf16(const float* w, int K, int A, int B, void* natural, void* transposed, void* stream);
 /* dW[k] += X[nbr[:,k]]^T . dY */
 int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
                     int Cin, int Cout, float* dW, void* stream);
+/* bf16-MFMA variant of es_spconv_wgrad (operands rounded to bf16 while staged, f32 accumulate / atomics) */
+int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
+                         int Cin, int Cout, float* dW, void* stream);
 int es_image_map(int n_img, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int* nbr, void* stream);
 
 /* ---- row operators ----------------------------------------------------------------------------- */

@@ -11,8 +11,8 @@ coordinate-manager semantics used by the reference at:
 
 Conventions fixed here (the spec both this oracle and the HIP kernels implement):
   * a coordinate row is int32 (b, x, y, z) in units of the ORIGINAL voxel grid;
-  * rows of every coordinate set are kept batch-major, and inside a batch in
-    "first occurrence" order of the operation that created them;
+  * rows of every coordinate set are kept batch-major; the root voxel set is ordered along a Z-curve
+    (Morton key of x,y,z), every derived set in "first occurrence" order of the operation that created it;
   * tap enumeration for a k^3 kernel: x fastest, i.e. k = ix + K*iy + K*K*iz with
     offset (ix,iy,iz) - (K//2 if K odd else 0).
 """
@@ -70,6 +70,21 @@ def lookup(table_keys, query_keys):
     return out
 
 
+def _spread3(v):
+    v = v.astype(np.uint64) & np.uint64(0x1fffff)
+    for sh, m in ((32, 0x1f00000000ffff), (16, 0x1f0000ff0000ff), (8, 0x100f00f00f00f00f), (4, 0x10c30c30c30c30c3),
+                  (2, 0x1249249249249249)):
+        v = (v | (v << np.uint64(sh))) & np.uint64(m)
+    return v
+
+
+def morton_key(c):
+    """Z-curve key of (N,4) int coords: batch major, then bit-interleaved (x,y,z) (x most significant)."""
+    c = np.asarray(c).astype(np.int64)
+    m = _spread3(c[:, 3] + OFF) | (_spread3(c[:, 2] + OFF) << np.uint64(1)) | (_spread3(c[:, 1] + OFF) << np.uint64(2))
+    return (c[:, 0].astype(np.uint64) << np.uint64(54)) | m
+
+
 def voxelize(points_list, voxel_size):
     """A4.  sparse_featfusion_single_stage.py:109-118 + ME sparse_collate.
 
@@ -85,6 +100,10 @@ def voxelize(points_list, voxel_size):
         cs.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
     c = np.concatenate(cs, 0) if cs else np.zeros((0, 4), np.int32)
     uk, first, _ = unique_first(pack(c))
+    # rows of the root voxel set are laid out along a Z-curve (a free choice: ME's order is hash-map order); every
+    # derived set keeps "first occurrence" order and therefore inherits the spatial locality
+    order = np.argsort(morton_key(c[first]), kind='stable')
+    first = first[order]
     return c[first], first
 
 

@@ -123,3 +123,39 @@ def test_train_step_parity(setup):
     print(f'{n_ok}/{len(rows)} tensors within max(1e-3, 5x f32-oracle error)')
     assert n_ok >= 0.9 * len(rows)
     assert med_h < max(1e-4, 3 * med_o)
+
+
+def test_train_step_bf16_mode(setup):
+    """BASELINE config dtype: bf16 matrix cores (f32 accumulate, f32 master weights).  Integer outputs (targets) stay
+    bit exact; stated tolerance on the three losses: 2e-2 relative to the f32 oracle."""
+    from embodiedscan_amd import engine as E, pipeline
+    from oracle import model as OM
+    det, scans, dscans, sd = setup
+    batch = pipeline.make_batch(dscans)
+    points_host = [p.cpu() for p in batch['inputs']['points']]
+    E.PRECISION[0] = 'bf16'
+    try:
+        E.TAPE.clear()
+        E.WEIGHT_VERSION[0] += 1
+        data = det.data_preprocessor(batch, True)
+        det._bind()
+        det.arena.grad.zero_()
+        losses = det.forward(data['inputs'], data['data_samples'], mode='loss')
+        E.TAPE.backward()
+        torch.cuda.synchronize()
+    finally:
+        E.PRECISION[0] = 'f32'
+    imgs = torch.stack([OM.preprocess_img(torch.from_numpy(s['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])
+                        for s in scans])
+    with torch.no_grad():
+        olosses, aux = OM.detector_loss(sd, points_host, imgs, [s['meta'] for s in scans],
+                                        [torch.from_numpy(s['gt_boxes']) for s in scans],
+                                        [torch.from_numpy(s['gt_labels']) for s in scans], return_aux=True, training=True)
+    tg = det.bbox_head.last_targets
+    for b in range(len(scans)):
+        np.testing.assert_array_equal(tg[b][2].cpu().numpy(), aux['targets'][b][2].numpy())
+    for k in olosses:
+        e = abs(float(losses[k]) - float(olosses[k])) / abs(float(olosses[k]))
+        print(f'bf16 mode {k}: hip {float(losses[k]):.6f} oracle(f32) {float(olosses[k]):.6f} rel err {e:.2e} (tol 2e-2)')
+        assert e < 2e-2
+    assert torch.isfinite(det.arena.grad).all()

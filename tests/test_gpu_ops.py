@@ -118,6 +118,38 @@ def test_spconv_fwd_bwd(dev, cin, cout, ks, stride):
         assert er < tol, (name, ea, er)
 
 
+def test_spconv_bf16_mode(dev):
+    """bf16-MFMA forward / dgrad against the f32 oracle: stated tolerance 1e-2 relative L2 (bf16 has 8 mantissa bits,
+    accumulation is f32)."""
+    from embodiedscan_amd import engine as E
+    from oracle import sparse as S
+    cs, oc = _sparse_case(dev)
+    g = torch.Generator().manual_seed(77)
+    for cin, cout, ks in ((64, 128, 3), (128, 297, 1), (96, 40, 3)):
+        K = ks ** 3
+        x = torch.randn(cs.n, cin, generator=g)
+        w = torch.randn(K, cin, cout, generator=g) / (K * cin) ** 0.5
+        nbr, inv = (cs.kernel_map(cs, 3), cs.inverse_map(cs, 3)) if ks == 3 else (None, None)
+        E.PRECISION[0] = 'bf16'
+        try:
+            E.TAPE.clear()
+            xv, wp = E.Var(x.to(dev)), E.Param(w.to(dev), torch.zeros_like(w).to(dev))
+            y = E.conv(xv, wp, nbr, inv, cs.n)
+            dy = torch.randn(cs.n, cout, generator=g)
+            y.g = dy.to(dev)
+            E.TAPE.backward()
+            torch.cuda.synchronize()
+        finally:
+            E.PRECISION[0] = 'f32'
+        xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yo = S.conv(S.SpT(oc, xo, 1, 2, {}), wo if ks > 1 else wo[0], ks, 1)
+        (yo.feats * dy).sum().backward()
+        for name, a, b in (('y', y.d.cpu(), yo.feats.detach()), ('dx', xv.g.cpu(), xo.grad), ('dw', wp.g.cpu(), wo.grad)):
+            e = float((a.double() - b.double()).norm() / b.double().norm())
+            print(f'bf16 spconv {cin}->{cout} k{ks} {name}: relative L2 err {e:.3e} (tol 1e-2)')
+            assert e < 1e-2
+
+
 def test_gen_transpose_norm_pool(dev):
     from embodiedscan_amd import engine as E
     from oracle import coords as C, sparse as S
