@@ -11,6 +11,7 @@ from ... import engine as E
 from ... import sparse
 from ...geometry import euler_to_matrix_zxy
 from ...hip import P, call, iarr, farr
+from ...parallel import reduce_mean
 from ...registry import MODELS
 from ...sparse import SparseTensor
 
@@ -218,11 +219,7 @@ class FCAF3DHeadRotMat:
             n_pos_all[b:b + 1] = npos
             per.append((pts, lo, ct, bt, kt, npos))
         # phase 2: avg_factor = max(reduce_mean(n_pos), 1) for all samples in ONE collective
-        avg = n_pos_all.float()
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            avg = avg / torch.distributed.get_world_size()
-            torch.distributed.all_reduce(avg)
-        avg = avg.clamp(min=1.0).contiguous()
+        avg = reduce_mean(n_pos_all.float()).clamp(min=1.0).contiguous()
         # phase 3: losses + gradients, per (sample, level) slice, no host sync
         loss_cls = torch.zeros(B, dtype=torch.float32, device=dev)
         loss_acc = torch.zeros((B, 2), dtype=torch.float32, device=dev)

@@ -1,0 +1,144 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header declares, the host-side
+packing / parameter / config logic, and the data-parallel exchange on 2 gloo ranks."""
+import os
+import subprocess
+import sys
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from embodiedscan_amd import hip
+    import ctypes
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    assert len(hip.PROTOS) >= 40
+    for name, (ret, argtypes, argnames) in hip.PROTOS.items():
+        assert hasattr(lib, name), name
+        assert len(argtypes) == len(argnames)
+    # the header is the single source of truth for the per-sample fusion meta block
+    assert hip.CONSTS['ES_FUSE_PROJ'] == 32 and hip.CONSTS['ES_MAX_SEG'] == 8
+
+
+def test_param_arena_reference_names_and_roundtrip():
+    from embodiedscan_amd.params import ParamArena, detector_specs
+    a = ParamArena(detector_specs(), seed=3)
+    sd = a.state_dict()
+    # reference state-dict names / shapes (mmdet.ResNet, MinkResNet, FCAF3DHeadRotMat)
+    assert sd['backbone.conv1.weight'].shape == (16, 3, 7, 7)
+    assert sd['backbone.layer4.2.conv3.weight'].shape == (512, 128, 1, 1)
+    assert sd['backbone_3d.conv1.kernel'].shape == (27, 3, 64)
+    assert sd['backbone_3d.layer4.0.downsample.0.kernel'].shape == (256, 512)
+    assert sd['bbox_head.up_block_3.0.kernel'].shape == (8, 1024, 512)
+    assert sd['bbox_head.conv_cls.kernel'].shape == (128, 284) and sd['bbox_head.conv_cls.bias'].shape == (1, 284)
+    assert sd['bbox_head.conv_center.kernel'].shape == (128, 1) and sd['bbox_head.conv_reg.kernel'].shape == (128, 12)
+    assert abs(float(sd['bbox_head.conv_cls.bias'][0, 0]) + 4.59512) < 1e-4
+    n3d = sum(v.numel() for k, v in sd.items() if k.startswith('backbone_3d.') and 'running' not in k)
+    assert n3d == 63457088                      # MinkResNet34 parameter count (63.46 M)
+    b = ParamArena(detector_specs(), seed=9)
+    b.load_state_dict(sd)
+    assert all(torch.equal(a.p[k], b.p[k]) for k in a.p)
+    train = set(a.trainable_names())
+    assert 'backbone.layer1.0.conv1.weight' not in train and 'backbone.layer2.0.conv1.weight' in train
+    assert not any(k.endswith('bn1.weight') for k in train if k.startswith('backbone.'))   # frozen 2-D BN
+
+
+def test_config_loader_and_registry():
+    from embodiedscan_amd.config import load_config
+    from embodiedscan_amd.registry import MODELS
+    import embodiedscan_amd.models  # noqa: F401
+    cfg = load_config(os.path.join(ROOT, 'configs', 'mv_3ddet.py'))
+    assert cfg['model']['type'] == 'SparseFeatureFusionSingleStage3DDetector'
+    for t in ('mmdet.ResNet', 'MinkResNet', 'FCAF3DHeadRotMat', 'Det3DDataPreprocessor', cfg['model']['type']):
+        assert MODELS.get(t) is not None
+    head = MODELS.build(dict(cfg['model']['bbox_head'], train_cfg=None, test_cfg=None))
+    assert head.decouple_weights == [0.2, 0.2, 0.2, 0.4] and head.pts_center_threshold == 18
+
+
+def test_fusion_meta_matches_reference_order_of_ops():
+    """the reverse 3-D augmentation op list and projection matrices are packed as the reference applies them
+    (point_fusion.py:79-105, sparse_featfusion_single_stage.py:160-164)."""
+    from embodiedscan_amd.hip import CONSTS
+    from embodiedscan_amd.models.layers.fusion_layers.point_fusion import build_fusion_meta
+    from embodiedscan_amd.synth import make_scan
+    from oracle import model as OM
+    s = make_scan(5, n_views=2, height=60, width=80, img_size=(64, 64), n_points=500, n_boxes=3)
+    m = build_fusion_meta([s['meta']], 'DEPTH', (64, 64), 2)[0]
+    flow = s['meta']['transformation_3d_flow'][::-1]
+    codes = [{'T': 1, 'S': 2, 'R': 3, 'HF': 4, 'VF': 5}[o] for o in flow]
+    assert int(m[CONSTS['ES_FUSE_NOPS']]) == len(codes)
+    assert [int(v) for v in m[CONSTS['ES_FUSE_OPS']:CONSTS['ES_FUSE_OPS'] + len(codes)]] == codes
+    proj = OM.projection_matrices(s['meta'])
+    np.testing.assert_array_equal(m[CONSTS['ES_FUSE_PROJ']:CONSTS['ES_FUSE_PROJ'] + 32].reshape(2, 4, 4).numpy(), proj.numpy())
+    assert float(m[CONSTS['ES_FUSE_SFX']]) == float(np.float32(64 / 80)) and float(m[CONSTS['ES_FUSE_PADW']]) == 64
+
+
+def test_synthetic_scan_is_seeded_and_shaped():
+    from embodiedscan_amd.synth import make_scan
+    a = make_scan(42, n_views=2, height=60, width=80, img_size=(64, 64), n_points=1000, n_boxes=4)
+    b = make_scan(42, n_views=2, height=60, width=80, img_size=(64, 64), n_points=1000, n_boxes=4)
+    c = make_scan(43, n_views=2, height=60, width=80, img_size=(64, 64), n_points=1000, n_boxes=4)
+    assert np.array_equal(a['depth'], b['depth']) and np.array_equal(a['sel_pix'], b['sel_pix'])
+    assert not np.array_equal(a['depth'], c['depth'])
+    assert a['depth'].shape == (2, 60, 80) and a['img'].shape == (2, 3, 64, 64) and a['gt_boxes'].shape == (4, 9)
+    assert (a['depth'].reshape(2, -1)[a['sel_view'], a['sel_pix']] > 0).all()      # PointSample draws non-zero depth
+
+
+def test_oracle_coordinate_rules():
+    """edge cases of the voxel rules the kernels are held to: truncation toward zero, first point wins,
+    empty input, strided floor for negatives, generative children, union order."""
+    from oracle import coords as C
+    p = np.array([[0.005, -0.005, 0.0], [-0.0149, 0.0149, 0.02], [0.0051, -0.0001, 0.0099], [0.031, 0.0, -0.031]], np.float32)
+    c, src = C.voxelize([p], 0.01)
+    assert sorted(map(tuple, c.tolist())) == sorted([(0, 0, 0, 0), (0, -1, 1, 2), (0, 3, 0, -3)])
+    assert src[[tuple(r) for r in c.tolist()].index((0, 0, 0, 0))] == 0          # first occurrence survives
+    e, es = C.voxelize([np.zeros((0, 3), np.float32)], 0.01)
+    assert e.shape == (0, 4) and es.shape == (0,)
+    s = C.stride_coords(np.array([[0, -1, 1, 2], [0, -2, 0, 3], [0, 3, 0, -3]], np.int32), 2)
+    assert s.tolist() == [[0, -2, 0, 2], [0, 2, 0, -4]]
+    g = C.gen_transpose_coords(np.array([[0, 4, 0, -4]], np.int32), 4)
+    assert g.shape == (8, 4) and g[7].tolist() == [0, 6, 2, -2]
+    a = np.array([[0, 0, 0, 0], [1, 0, 0, 0]], np.int32)
+    b = np.array([[0, 2, 0, 0], [0, 0, 0, 0], [1, 2, 0, 0]], np.int32)
+    u, pa, pb = C.union_coords(a, b, 2)
+    assert u.tolist() == [[0, 0, 0, 0], [0, 2, 0, 0], [1, 0, 0, 0], [1, 2, 0, 0]] and pb.tolist() == [1, 0, 3]
+
+
+def _dp_worker():
+    import torch.distributed as dist
+    from embodiedscan_amd.parallel import allreduce_mean_, reduce_mean
+    from embodiedscan_amd.params import ParamArena, fcaf3d_head_specs
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    arena = ParamArena(fcaf3d_head_specs(in_channels=(8, 16), out_channels=8, n_classes=5), seed=0)   # same seed: replicas
+    chk = arena.data.clone()
+    dist.broadcast(chk, 0)
+    assert torch.equal(chk, arena.data), 'replicas must start identical'
+    g = torch.Generator().manual_seed(100 + rank)
+    arena.grad.copy_(torch.randn(arena.n_train, generator=g))
+    mine = arena.grad.clone()
+    allreduce_mean_(arena.grad)
+    others = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(others, mine)
+    assert torch.allclose(arena.grad, torch.stack(others).mean(0), atol=1e-7)
+    n_pos = torch.tensor([10.0 + rank, 0.0, 3.0 * rank])            # per-sample positive counts of this rank
+    avg = reduce_mean(n_pos).clamp(min=1.0)
+    assert torch.allclose(avg, torch.tensor([10.5, 1.0, 1.5]))
+    assert torch.equal(n_pos, torch.tensor([10.0 + rank, 0.0, 3.0 * rank]))   # not modified in place
+    dist.destroy_process_group()
+    print(f'rank {rank} ok')
+
+
+def test_data_parallel_exchange_two_gloo_ranks():
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', PYTHONPATH=ROOT)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29611', os.path.abspath(__file__), '--dp-worker']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count('ok') == 2
+
+
+if __name__ == '__main__' and '--dp-worker' in sys.argv:
+    sys.path.insert(0, ROOT)
+    _dp_worker()
