@@ -96,11 +96,12 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (the MFMA convolution engine), from the live HIP-event timings
-    # TFLOP/s dense peaks from MI355X_MICROARCH.md: f32-input MFMA 157.3, bf16 MFMA ~2500.  In bf16 mode the engine is a
-    # mix (fwd/dgrad bf16, wgrad f32): the fraction is quoted against the peak of the type that does most of the flops.
-    K_PEAK_F32_MFMA = 157.3 if args.precision == 'f32' else 2500.0
-    tot_ms, tot_flop, n_launch = 0.0, 0.0, 0
+    # ---- roofline of the dominant kernel family (the convolution engine), from the live HIP-event timings.
+    # The PMC passes (profiles/r1_conv_pmc*.txt) show the engine moving ~9 TB/s between L2 and the CUs at 16 % MFMA
+    # utilisation: it is bandwidth bound, so the roofline is quoted against HBM bandwidth with the ALGORITHMIC bytes of
+    # sum over launches of P*(Cin + Cout)*4 + weights, P = valid (output, tap) pairs of the kernel map.
+    K_PEAK_HBM = 8000.0               # GB/s, MI355X_MICROARCH.md
+    tot_ms, tot_flop, tot_bytes, n_launch = 0.0, 0.0, 0.0, 0
     for name, e0, e1, a, pairs_dev in prof['records']:
         tot_ms += e0.elapsed_time(e1)
         n_launch += 1
@@ -110,13 +111,18 @@ def main():
             nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
         pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
         tot_flop += 2.0 * pairs * cin * cout
-    achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-    roofline = dict(bound='mfma', achieved=round(achieved, 3), peak=K_PEAK_F32_MFMA, unit='TFLOP/s',
-                    frac=round(achieved / K_PEAK_F32_MFMA, 4), traffic=None,
-                    kernel='k_spconv_bf16 (fwd/dgrad) + k_spconv_wgrad_bf16' if args.precision == 'bf16' else 'k_spconv / k_spconv_wgrad (f32 MFMA)',
+        wbytes = 2 if name.endswith('bf16') and not name.startswith('es_spconv_wgrad') else 4
+        tot_bytes += pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wbytes
+    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=K_PEAK_HBM, unit='GB/s',
+                    frac=round(achieved / K_PEAK_HBM, 4), traffic=None,
+                    kernel='convolution engine: k_spconv_bf16* (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
+                    else 'convolution engine: k_spconv / k_spconv_wgrad (exact-f32 MFMA)',
                     launches_per_step=n_launch // max(args.steps, 1),
                     kernel_ms_per_step=round(tot_ms / max(args.steps, 1), 3),
-                    note='algorithmic flops = 2 * valid (output,tap) pairs * Cin * Cout per launch')
+                    algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
+                    note='algorithmic bytes = sum over launches of P*(Cin+Cout)*4 + K*Cin*Cout*sizeof(w), P = valid '
+                         '(output,tap) pairs; algorithmic flops = 2*P*Cin*Cout; traffic: see profiles/ (PMC), null here')
 
     out = dict(metric='scans/sec (train step) mv-3ddet, 20x(480x640) RGB-D views', value=round(world * args.batch * args.steps / dt, 4),
                unit='scans/s', n_gpus=world, steps=args.steps, warmup=args.warmup,

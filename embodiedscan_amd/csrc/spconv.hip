@@ -326,17 +326,24 @@ __device__ inline uint32_t pack_bf16(float a, float b) {
   return *(uint32_t*)&y;
 }
 
+// BNT = output channels per workgroup (64, or 128 when Cout >= 128: the gathered A tile is then re-used for twice as
+// many output channels).  The (tap, C_in-chunk) stream is software-pipelined TWO chunks deep in registers (raw f32 loads
+// are only converted to bf16 when they are written to LDS), because the PMC profile of the first version showed the
+// waves parked on memory 72 % of their cycles with one chunk in flight.
+template <int BNT>
 __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X, int ldx,
                                                      const unsigned short* __restrict__ W /* [K][N][Kr] bf16 */,
                                                      const int* __restrict__ nbr, int n_out, int n_in, int K, int Cin,
                                                      int Cout, const float* __restrict__ bias, float* __restrict__ Y,
                                                      int ldy, int accumulate) {
+  constexpr int NF = BNT / 16;      // 16-wide output fragments per wave
+  constexpr int NB = BNT / 64;      // 16-byte weight pieces per thread and chunk
   __shared__ __attribute__((aligned(16))) unsigned short As[BM * HLD];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[BN * HLD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[BNT * HLD];
   __shared__ int nbrS[BM * MAXK];
   __shared__ int tapAny[32];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int row0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int row0 = blockIdx.x * BM, n0 = blockIdx.y * BNT;
   const bool vecA = ((ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
   const bool vecB = ((Cin & 7) == 0) && ((((uintptr_t)W) & 15) == 0);
 
@@ -351,101 +358,271 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
   }
   __syncthreads();
 
-  f32x4 acc[2][4];
+  f32x4 acc[2][NF];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nC = (Cin + HBK - 1) / HBK;
-  // A staging: thread t owns row t>>1 and 16 consecutive channels (one nbr lookup, four 16-byte loads, two 16-byte
-  // LDS stores).  (A variant where 8 lanes share one 128-byte line per load instruction measured 20 % slower: four
-  // map lookups and four 8-byte LDS stores per thread outweigh the better line utilisation.)
-  const int a_r = t >> 1, a_kk = (t & 1) * 16;
-  const int b_n = t >> 2, b_kk = (t & 3) * 8;           // B: one output channel, 8 consecutive reduction elements
-  uint32_t ra[8];
-  uint4 rb;
-  auto load_chunk = [&](int k, int c0) {
-    int idx = nbrS[a_r * K + k];
+  const int a_r = t >> 1, a_kk = (t & 1) * 16;          // A: one row, 16 consecutive channels
+  const int b_n = t >> 2, b_kk = (t & 3) * 8;           // B: output channel b_n (+64), 8 consecutive reduction elements
+  struct Regs { float4 a[4]; uint4 b[NB]; };
+  struct It { int k, ci; };
+
+  auto load_chunk = [&](Regs& R, It it) {
+    int c0 = it.ci * HBK;
+    int idx = nbrS[a_r * K + it.k];
     int c = c0 + a_kk;
     if (idx >= 0 && c < Cin) {
       const float* p = X + (size_t)idx * ldx + c;
       if (vecA && c + 15 < Cin) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float4 v = ((const float4*)p)[q];
-          ra[2 * q] = pack_bf16(v.x, v.y);
-          ra[2 * q + 1] = pack_bf16(v.z, v.w);
-        }
+        for (int q = 0; q < 4; ++q) R.a[q] = ((const float4*)p)[q];
       } else {
+        float v[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          float v0 = (c + 2 * q < Cin) ? p[2 * q] : 0.f, v1 = (c + 2 * q + 1 < Cin) ? p[2 * q + 1] : 0.f;
-          ra[q] = pack_bf16(v0, v1);
-        }
+        for (int q = 0; q < 16; ++q) v[q] = (c + q < Cin) ? p[q] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R.a[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) ra[q] = 0u;
+      for (int q = 0; q < 4; ++q) R.a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    int n = n0 + b_n, cb = c0 + b_kk;
-    if (n < Cout && cb < Cin) {
-      const unsigned short* p = W + ((size_t)k * Cout + n) * Cin + cb;
-      if (vecB && cb + 7 < Cin) {
-        rb = *(const uint4*)p;
-      } else {
-        unsigned short h[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) h[q] = (cb + q < Cin) ? p[q] : (unsigned short)0;
-        rb.x = h[0] | ((uint32_t)h[1] << 16); rb.y = h[2] | ((uint32_t)h[3] << 16);
-        rb.z = h[4] | ((uint32_t)h[5] << 16); rb.w = h[6] | ((uint32_t)h[7] << 16);
+    for (int h = 0; h < NB; ++h) {
+      int n = n0 + b_n + h * 64, cb = c0 + b_kk;
+      if (n < Cout && cb < Cin) {
+        const unsigned short* p = W + ((size_t)it.k * Cout + n) * Cin + cb;
+        if (vecB && cb + 7 < Cin) {
+          R.b[h] = *(const uint4*)p;
+        } else {
+          unsigned short hh[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) hh[q] = (cb + q < Cin) ? p[q] : (unsigned short)0;
+          R.b[h].x = hh[0] | ((uint32_t)hh[1] << 16); R.b[h].y = hh[2] | ((uint32_t)hh[3] << 16);
+          R.b[h].z = hh[4] | ((uint32_t)hh[5] << 16); R.b[h].w = hh[6] | ((uint32_t)hh[7] << 16);
+        }
+      } else {
+        R.b[h] = make_uint4(0u, 0u, 0u, 0u);
       }
-    } else {
-      rb = make_uint4(0u, 0u, 0u, 0u);
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](const Regs& R) {
     uint4* pa = (uint4*)&As[a_r * HLD + a_kk];
-    pa[0] = make_uint4(ra[0], ra[1], ra[2], ra[3]);
-    pa[1] = make_uint4(ra[4], ra[5], ra[6], ra[7]);
-    *(uint4*)&Bs[b_n * HLD + b_kk] = rb;
+    pa[0] = make_uint4(pack_bf16(R.a[0].x, R.a[0].y), pack_bf16(R.a[0].z, R.a[0].w), pack_bf16(R.a[1].x, R.a[1].y),
+                       pack_bf16(R.a[1].z, R.a[1].w));
+    pa[1] = make_uint4(pack_bf16(R.a[2].x, R.a[2].y), pack_bf16(R.a[2].z, R.a[2].w), pack_bf16(R.a[3].x, R.a[3].y),
+                       pack_bf16(R.a[3].z, R.a[3].w));
+#pragma unroll
+    for (int h = 0; h < NB; ++h) *(uint4*)&Bs[(b_n + h * 64) * HLD + b_kk] = R.b[h];
   };
-
-  int k = 0, ci = 0;
-  while (k < K && !tapAny[k]) ++k;
-  bool have = k < K;
-  if (have) load_chunk(k, 0);
-  const int li = lane & 15, kq = lane >> 4;
-  while (have) {
-    store_chunk();
-    __syncthreads();
-    int nk = k, nci = ci + 1;
-    if (nci >= nC) {
-      nci = 0;
-      ++nk;
-      while (nk < K && !tapAny[nk]) ++nk;
+  auto advance = [&](It it) {
+    It n = it;
+    if (n.k >= K) return n;
+    if (++n.ci >= nC) {
+      n.ci = 0;
+      ++n.k;
+      while (n.k < K && !tapAny[n.k]) ++n.k;
     }
-    bool nhave = nk < K;
-    if (nhave) load_chunk(nk, nci * HBK);
-    bf16x8_t a[2], b[4];
+    return n;
+  };
+  const int li = lane & 15, kq = lane >> 4;
+  auto compute = [&]() {
+    bf16x8_t a[2], b[NF];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) a[mf] = *(const bf16x8_t*)&As[(wv * 32 + mf * 16 + li) * HLD + kq * 8];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) b[nf] = *(const bf16x8_t*)&Bs[(nf * 16 + li) * HLD + kq * 8];
+    for (int nf = 0; nf < NF; ++nf) b[nf] = *(const bf16x8_t*)&Bs[(nf * 16 + li) * HLD + kq * 8];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
+      for (int nf = 0; nf < NF; ++nf)
         acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+  };
+
+  It i0 = {0, 0};
+  while (i0.k < K && !tapAny[i0.k]) ++i0.k;
+  It i1 = advance(i0);
+  Regs r0, r1;
+  if (i0.k < K) load_chunk(r0, i0);
+  if (i1.k < K) load_chunk(r1, i1);
+  while (i0.k < K) {
+    store_chunk(r0);
     __syncthreads();
-    k = nk; ci = nci; have = nhave;
+    It i2 = advance(i1);
+    if (i2.k < K) load_chunk(r0, i2);
+    compute();
+    __syncthreads();
+    if (i1.k >= K) break;
+    store_chunk(r1);
+    __syncthreads();
+    It i3 = advance(i2);
+    if (i3.k < K) load_chunk(r1, i3);
+    compute();
+    __syncthreads();
+    i0 = i2;
+    i1 = i3;
   }
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
+    for (int nf = 0; nf < NF; ++nf) {
       int col = n0 + nf * 16 + li;
       if (col >= Cout) continue;
+      float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + wv * 32 + mf * 16 + kq * 4 + r;
+        if (row < n_out) {
+          float* p = Y + (size_t)row * ldy + col;
+          float v = acc[mf][nf][r] + bv;
+          *p = accumulate ? (*p + v) : v;
+        }
+      }
+    }
+}
+
+// Fast path of k_spconv_bf16: shapes where no bounds checks are needed (Cin % 32 == 0, Cout % BNT == 0, 16-byte
+// aligned rows, 32-bit element offsets).  The PMC profile of the generic kernel showed 5.5 VALU + 3 SALU instructions
+// per MFMA (64-bit address multiplies, per-element bounds tests, iterator bookkeeping): it was VALU-issue bound at 16 %
+// MFMA utilisation.  Here the per-tap offsets are computed once per tap, the per-chunk work is add + load + cvt + store.
+template <int BNT>
+__global__ __launch_bounds__(256) void k_spconv_bf16_fast(const float* __restrict__ X, int ldx,
+                                                          const unsigned short* __restrict__ W,
+                                                          const int* __restrict__ nbr, int n_out, int n_in, int K,
+                                                          int Cin, int Cout, const float* __restrict__ bias,
+                                                          float* __restrict__ Y, int ldy, int accumulate) {
+  constexpr int NF = BNT / 16;
+  constexpr int NB = BNT / 64;
+  __shared__ __attribute__((aligned(16))) unsigned short As[BM * HLD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[BNT * HLD];
+  __shared__ int nbrS[BM * MAXK];
+  __shared__ int taps[32];
+  __shared__ int nTaps;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int row0 = blockIdx.x * BM, n0 = blockIdx.y * BNT;
+
+  if (t < 32) taps[t] = 0;
+  __syncthreads();
+  for (int e = t; e < BM * K; e += 256) {
+    int r = e / K, k = e - r * K;
+    int j = row0 + r, v = -1;
+    if (j < n_out) v = nbr ? nbr[(size_t)j * K + k] : (j < n_in ? j : -1);
+    nbrS[e] = v;
+    if (v >= 0) taps[k] = 1;
+  }
+  __syncthreads();
+  if (t == 0) {                       // compact the list of taps that have at least one neighbour in this tile
+    int m = 0;
+    for (int k = 0; k < K; ++k)
+      if (taps[k]) taps[m++] = k;
+    nTaps = m;
+  }
+  __syncthreads();
+  const int nT = nTaps;
+
+  f32x4 acc[2][NF];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nC = Cin / HBK;
+  const int a_r = t >> 1, a_kk = (t & 1) * 16;
+  const int b_n = t >> 2, b_kk = (t & 3) * 8;
+  const int b_row = (n0 + b_n) * Cin + b_kk;              // element offset of this thread's weight piece inside a tap
+  const int w_tap = Cout * Cin;
+  struct Regs { float4 a[4]; uint4 b[NB]; int valid; };
+  struct It { int ti, ci, a_off, b_off, valid; };
+  // Loads are UNCONDITIONAL (an absent neighbour reads row 0 and is zeroed when written to LDS, a chunk past the end
+  // re-reads the last tap) so that the compiler can keep the second prefetched chunk in flight with a counted
+  // s_waitcnt instead of vmcnt(0); the chunk stream is processed in pairs without a mid-loop exit so that the 64
+  // accumulator registers stay in place (the first version of this loop moved them through v_accvgpr_mov).
+  auto set_tap = [&](It& it) {
+    int ti = it.ti < nT ? it.ti : (nT - 1);
+    int k = taps[ti];
+    int idx = nbrS[a_r * K + k];
+    it.valid = (idx >= 0) && (it.ti < nT);
+    it.a_off = (idx >= 0 ? idx : 0) * ldx + a_kk;
+    it.b_off = k * w_tap + b_row;
+  };
+  auto advance = [&](It& it) {
+    if (++it.ci >= nC) {
+      it.ci = 0;
+      ++it.ti;
+      set_tap(it);
+    }
+  };
+  auto load_chunk = [&](Regs& R, const It& it) {
+    int c0 = it.ci * HBK;
+    const float4* p = (const float4*)(X + it.a_off + c0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) R.a[q] = p[q];
+#pragma unroll
+    for (int h = 0; h < NB; ++h) R.b[h] = *(const uint4*)(W + it.b_off + h * 64 * Cin + c0);
+    R.valid = it.valid;
+  };
+  auto store_chunk = [&](const Regs& R) {
+    uint4* pa = (uint4*)&As[a_r * HLD + a_kk];
+    uint4 v0 = make_uint4(pack_bf16(R.a[0].x, R.a[0].y), pack_bf16(R.a[0].z, R.a[0].w), pack_bf16(R.a[1].x, R.a[1].y),
+                          pack_bf16(R.a[1].z, R.a[1].w));
+    uint4 v1 = make_uint4(pack_bf16(R.a[2].x, R.a[2].y), pack_bf16(R.a[2].z, R.a[2].w), pack_bf16(R.a[3].x, R.a[3].y),
+                          pack_bf16(R.a[3].z, R.a[3].w));
+    if (!R.valid) v0 = v1 = make_uint4(0u, 0u, 0u, 0u);
+    pa[0] = v0;
+    pa[1] = v1;
+#pragma unroll
+    for (int h = 0; h < NB; ++h) *(uint4*)&Bs[(b_n + h * 64) * HLD + b_kk] = R.b[h];
+  };
+  const int li = lane & 15, kq = lane >> 4;
+  const unsigned short* a_base = &As[(wv * 32 + li) * HLD + kq * 8];
+  const unsigned short* b_base = &Bs[li * HLD + kq * 8];
+  auto compute = [&]() {
+    bf16x8_t a[2], b[NF];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) a[mf] = *(const bf16x8_t*)(a_base + mf * 16 * HLD);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) b[nf] = *(const bf16x8_t*)(b_base + nf * 16 * HLD);
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+  };
+
+  if (nT > 0) {
+    It i0 = {0, 0, 0, 0, 0};
+    set_tap(i0);
+    It i1 = i0;
+    advance(i1);
+    Regs r0, r1;
+    load_chunk(r0, i0);
+    load_chunk(r1, i1);
+    const int npairs = (nT * nC + 1) >> 1;
+    for (int pr = 0; pr < npairs; ++pr) {
+      store_chunk(r0);
+      __syncthreads();
+      i0 = i1;
+      advance(i0);                    // chunk 2*pr + 2
+      load_chunk(r0, i0);
+      compute();
+      __syncthreads();
+      store_chunk(r1);                // (a zeroed A tile when the chunk count is odd)
+      __syncthreads();
+      i1 = i0;
+      advance(i1);                    // chunk 2*pr + 3
+      load_chunk(r1, i1);
+      compute();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      int col = n0 + nf * 16 + li;
       float bv = bias ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -464,9 +641,23 @@ extern "C" int es_spconv_fwd_bf16(const float* X, int ldx, const void* W_bf16, c
                                   void* stream) {
   if (n_out <= 0 || Cout <= 0) return 0;
   if (K > MAXK) return -2;
-  dim3 grid(es_cdiv(n_out, BM), es_cdiv(Cout, BN));
-  hipLaunchKernelGGL(k_spconv_bf16, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, (const unsigned short*)W_bf16,
-                     nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short* Wh = (const unsigned short*)W_bf16;
+  bool fast = (Cin % HBK == 0) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)Wh) & 15) == 0) &&
+              ((long long)n_in * ldx < (1ll << 31)) && ((long long)K * Cout * Cin < (1ll << 31));
+  if (fast && Cout % 128 == 0) {
+    hipLaunchKernelGGL(k_spconv_bf16_fast<128>, dim3(es_cdiv(n_out, BM), Cout / 128), dim3(256), 0, st, X, ldx, Wh, nbr,
+                       n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
+  } else if (fast && Cout % 64 == 0) {
+    hipLaunchKernelGGL(k_spconv_bf16_fast<64>, dim3(es_cdiv(n_out, BM), Cout / 64), dim3(256), 0, st, X, ldx, Wh, nbr,
+                       n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
+  } else if (Cout >= 128) {
+    hipLaunchKernelGGL(k_spconv_bf16<128>, dim3(es_cdiv(n_out, BM), es_cdiv(Cout, 128)), dim3(256), 0, st, X, ldx, Wh,
+                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
+  } else {
+    hipLaunchKernelGGL(k_spconv_bf16<64>, dim3(es_cdiv(n_out, BM), es_cdiv(Cout, 64)), dim3(256), 0, st, X, ldx, Wh,
+                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
+  }
   ES_CHECK_LAUNCH();
   return 0;
 }
@@ -595,9 +786,110 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restri
   }
 }
 
+// Large-tile bf16 wgrad: one workgroup owns a 128 (C_in) x 128 (C_out) block of dW[k]; each wave a 32 x 128 slab
+// (16 MFMAs per 32-row chunk instead of 4).  For C = 128 layers X[nbr] and dY are then each read exactly once per tap.
+// Fast path only (Cin % 128 == 0, Cout % 128 == 0, aligned, 32-bit offsets); other shapes use k_spconv_wgrad_bf16.
+__global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __restrict__ X, int ldx,
+                                                               const float* __restrict__ dY, int ldy,
+                                                               const int* __restrict__ nbr, int n_out, int n_in, int K,
+                                                               int Cin, int Cout, int rows_per_split,
+                                                               float* __restrict__ dW) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[128 * GLD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[128 * GLD];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int nCt = Cin / 128;
+  const int k = blockIdx.x / nCt, c0 = (blockIdx.x % nCt) * 128;
+  const int n0 = blockIdx.y * 128;
+  const int rbeg = blockIdx.z * rows_per_split;
+  const int rend = min(n_out, rbeg + rows_per_split);
+  // staging: thread = (row pair rp 0..15, channel group cg 0..15); it converts channels cg*8 .. cg*8+7 of rows
+  // 2rp, 2rp+1 into 8 packed bf16x2 words (same channel, two consecutive rows) -> As[c][2rp..2rp+1]
+  const int rp = t & 15, c8 = (t >> 4) * 8;
+  const int li = lane & 15, kq = lane >> 4;
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 xa[2][2], xb[2][2];
+  int va[2];
+  auto load_rows = [&](int r0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int j = r0 + 2 * rp + h;
+      int jj = j < rend ? j : rbeg;                       // unconditional loads, masked when packed
+      int idx = nbr ? nbr[(size_t)jj * K + k] : jj;
+      va[h] = (j < rend) && (idx >= 0);
+      const float4* px = (const float4*)(X + (idx >= 0 ? idx : 0) * ldx + c0 + c8);
+      const float4* py = (const float4*)(dY + jj * ldy + n0 + c8);
+      xa[h][0] = px[0]; xa[h][1] = px[1];
+      xb[h][0] = py[0]; xb[h][1] = py[1];
+    }
+  };
+  auto store_rows = [&]() {
+    float a0[8] = {xa[0][0].x, xa[0][0].y, xa[0][0].z, xa[0][0].w, xa[0][1].x, xa[0][1].y, xa[0][1].z, xa[0][1].w};
+    float a1[8] = {xa[1][0].x, xa[1][0].y, xa[1][0].z, xa[1][0].w, xa[1][1].x, xa[1][1].y, xa[1][1].z, xa[1][1].w};
+    float b0[8] = {xb[0][0].x, xb[0][0].y, xb[0][0].z, xb[0][0].w, xb[0][1].x, xb[0][1].y, xb[0][1].z, xb[0][1].w};
+    float b1[8] = {xb[1][0].x, xb[1][0].y, xb[1][0].z, xb[1][0].w, xb[1][1].x, xb[1][1].y, xb[1][1].z, xb[1][1].w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float p0 = va[0] ? a0[e] : 0.f, p1 = va[1] ? a1[e] : 0.f;
+      *(uint32_t*)&As[(c8 + e) * GLD + 2 * rp] = pack_bf16(p0, p1);
+      float q0 = va[0] ? b0[e] : 0.f, q1 = va[1] ? b1[e] : 0.f;
+      *(uint32_t*)&Bs[(c8 + e) * GLD + 2 * rp] = pack_bf16(q0, q1);
+    }
+  };
+  if (rbeg < rend) load_rows(rbeg);
+  for (int r0 = rbeg; r0 < rend; r0 += GR) {
+    store_rows();
+    __syncthreads();
+    load_rows(r0 + GR);                                   // rows past the slice are masked (and clamped) inside
+    bf16x8_t a[2], b[8];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) a[mf] = *(const bf16x8_t*)&As[(wv * 32 + mf * 16 + li) * GLD + kq * 8];
+#pragma unroll
+    for (int nf = 0; nf < 8; ++nf) b[nf] = *(const bf16x8_t*)&Bs[(nf * 16 + li) * GLD + kq * 8];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 8; ++nf)
+        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < 8; ++nf) {
+      int col = n0 + nf * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int c = c0 + wv * 32 + mf * 16 + kq * 4 + r;
+        atomicAdd(dW + ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r]);
+      }
+    }
+}
+
 extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out,
                                     int n_in, int K, int Cin, int Cout, float* dW, void* stream) {
   if (n_out <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  bool big = (Cin % 128 == 0) && (Cout % 128 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+             ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)dY) & 15) == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
+             ((long long)n_out * ldy < (1ll << 31)) && n_out >= 512;
+  if (big) {
+    int base = K * (Cin / 128) * (Cout / 128);
+    int splits = es_cdiv(2048, base);
+    int max_splits = es_cdiv(n_out, 512);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
+    splits = es_cdiv(n_out, rows_per_split);
+    dim3 grid(K * (Cin / 128), Cout / 128, splits);
+    hipLaunchKernelGGL(k_spconv_wgrad_bf16_big, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out,
+                       n_in, K, Cin, Cout, rows_per_split, dW);
+    ES_CHECK_LAUNCH();
+    return 0;
+  }
   int base = K * es_cdiv(Cin, WM) * es_cdiv(Cout, WN);
   int splits = es_cdiv(4096, base);
   int max_splits = es_cdiv(n_out, 256);
