@@ -69,3 +69,60 @@ extern "C" int es_preprocess_img(const unsigned char* img, int n_img, int H, int
   ES_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------ ResNet stem: 7x7 s2 p3 conv (3 -> Cout<=32) + frozen-BN
+// affine + ReLU in one direct kernel.  The stem is frozen (frozen_stages=1, configs/detection/mv-det3d_...py:29) so only the
+// forward pass exists.  A workgroup computes a 16x16 output tile from a 37x37x3 input patch staged in LDS together with
+// the [49][3][Cout] weights; this replaces two generic-engine launches that padded C_in = 3 to a 16-wide K chunk.
+#define ST_T 16
+#define ST_P (ST_T * 2 + 5)
+template <int CO>
+__global__ __launch_bounds__(256) void k_stem_conv(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   int H, int W, int Ho, int Wo, float* __restrict__ y) {
+  __shared__ float patch[ST_P * ST_P * 3];
+  __shared__ float ws[49 * 3 * CO];
+  const int t = threadIdx.x;
+  const int im = blockIdx.z, ty0 = blockIdx.y * ST_T, tx0 = blockIdx.x * ST_T;
+  for (int e = t; e < 49 * 3 * CO; e += 256) ws[e] = w[e];
+  const int hi0 = ty0 * 2 - 3, wi0 = tx0 * 2 - 3;
+  const float* xi = x + (size_t)im * H * W * 3;
+  for (int e = t; e < ST_P * ST_P * 3; e += 256) {
+    int c = e % 3, p = e / 3;
+    int pw = p % ST_P, ph = p / ST_P;
+    int hi = hi0 + ph, wi = wi0 + pw;
+    patch[e] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? xi[((size_t)hi * W + wi) * 3 + c] : 0.f;
+  }
+  __syncthreads();
+  const int oy = t / ST_T, ox = t % ST_T;
+  const int ho = ty0 + oy, wo = tx0 + ox;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  for (int ky = 0; ky < 7; ++ky)
+    for (int kx = 0; kx < 7; ++kx) {
+      const float* pp = &patch[((oy * 2 + ky) * ST_P + ox * 2 + kx) * 3];
+      const float* wp = &ws[(ky * 7 + kx) * 3 * CO];
+      float v0 = pp[0], v1 = pp[1], v2 = pp[2];
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] = fmaf(v2, wp[2 * CO + c], fmaf(v1, wp[CO + c], fmaf(v0, wp[c], acc[c])));
+    }
+  if (ho < Ho && wo < Wo) {
+    float* yo = y + (((size_t)im * Ho + ho) * Wo + wo) * CO;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) yo[c] = fmaxf(acc[c] * scale[c] + shift[c], 0.f);
+  }
+}
+extern "C" int es_stem_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, int n_img, int H,
+                                int W, int Cout, float* y, void* stream) {
+  int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  dim3 grid(es_cdiv(Wo, ST_T), es_cdiv(Ho, ST_T), n_img);
+  if (Cout == 16)
+    hipLaunchKernelGGL(k_stem_conv<16>, grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, H, W, Ho, Wo, y);
+  else if (Cout == 32)
+    hipLaunchKernelGGL(k_stem_conv<32>, grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, H, W, Ho, Wo, y);
+  else
+    return -6;
+  ES_CHECK_LAUNCH();
+  return 0;
+}

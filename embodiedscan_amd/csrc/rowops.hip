@@ -31,24 +31,61 @@ static int max_seg_rows(const Segs& s) {
 }
 
 // partial[(seg*nchunk + chunk)*2*C + {0,1}*C + c] = {sum, M2 about the chunk mean}  (Chan et al. merge in the
-// finalize kernel: robust against |mean| >> std, unlike E[x^2] - E[x]^2)
-__global__ void k_norm_stats(const float* __restrict__ x, int ldx, int C, Segs segs, int nchunk,
-                             float* __restrict__ partial) {
+// finalize kernel: robust against |mean| >> std, unlike E[x^2] - E[x]^2).  One pass: sums are taken about the chunk's
+// first row (a shift that is itself a sample), M2 = q - s^2/n.  256 threads = (C/4 column lanes) x (row lanes), float4
+// loads, LDS reduction over the row lanes.
+__global__ __launch_bounds__(256) void k_norm_stats(const float* __restrict__ x, int ldx, int C, Segs segs, int nchunk,
+                                                    float* __restrict__ partial) {
+  __shared__ float4 red[2][256];
   int seg = blockIdx.y, chunk = blockIdx.x;
   int r0 = segs.off[seg] + chunk * NCH, r1 = min(segs.off[seg + 1], r0 + NCH);
   if (r0 >= r1) return;
   float* out = partial + ((size_t)(seg * nchunk + chunk) * 2) * C;
-  float inv = 1.f / (float)(r1 - r0);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + c];
-    float m = s * inv, q = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      float d = x[(size_t)r * ldx + c] - m;
-      q += d * d;
+  const bool vec = ((C & 3) == 0) && ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
+  if (!vec) {                                              // generic scalar path (C = 3 image rows never get here)
+    float inv = 1.f / (float)(r1 - r0);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float s = 0.f;
+      for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + c];
+      float m = s * inv, q = 0.f;
+      for (int r = r0; r < r1; ++r) { float d = x[(size_t)r * ldx + c] - m; q += d * d; }
+      out[c] = s;
+      out[C + c] = q;
     }
-    out[c] = s;
-    out[C + c] = q;
+    return;
+  }
+  int C4 = C >> 2;
+  int TX = C4 < 64 ? C4 : 64, TY = 256 / TX;
+  int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  float nrows = (float)(r1 - r0);
+  for (int cb = 0; cb < C4; cb += TX) {
+    int c4 = cb + tx;
+    float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0), kk = make_float4(0, 0, 0, 0);
+    if (c4 < C4 && ty < TY) {
+      kk = *(const float4*)(x + (size_t)r0 * ldx + c4 * 4);
+      for (int r = r0 + ty; r < r1; r += TY) {
+        float4 v = *(const float4*)(x + (size_t)r * ldx + c4 * 4);
+        float dx = v.x - kk.x, dy = v.y - kk.y, dz = v.z - kk.z, dw = v.w - kk.w;
+        s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+        q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+      }
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (ty == 0 && c4 < C4) {
+      for (int j = 1; j < TY; ++j) {
+        float4 a = red[0][j * TX + tx], b = red[1][j * TX + tx];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+      }
+      float4 so = make_float4(s.x + nrows * kk.x, s.y + nrows * kk.y, s.z + nrows * kk.z, s.w + nrows * kk.w);
+      float4 qo = make_float4(q.x - s.x * s.x / nrows, q.y - s.y * s.y / nrows, q.z - s.z * s.z / nrows,
+                              q.w - s.w * s.w / nrows);
+      *(float4*)(out + c4 * 4) = so;
+      *(float4*)(out + C + c4 * 4) = make_float4(fmaxf(qo.x, 0.f), fmaxf(qo.y, 0.f), fmaxf(qo.z, 0.f), fmaxf(qo.w, 0.f));
+    }
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(64 * FST) void k_norm_finalize(const float* __restrict__ partial, int C, Segs segs,
@@ -122,7 +159,7 @@ extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg
   Segs s = make_segs(seg_off, nseg);
   int nchunk = es_cdiv(max_seg_rows(s), NCH);
   if (nchunk < 1) nchunk = 1;
-  hipLaunchKernelGGL(k_norm_stats, dim3(nchunk, nseg), dim3(C >= 256 ? 256 : 64), 0, st, x, ldx, C, s, nchunk,
+  hipLaunchKernelGGL(k_norm_stats, dim3(nchunk, nseg), dim3(256), 0, st, x, ldx, C, s, nchunk,
                      workspace);
   hipLaunchKernelGGL(k_norm_finalize, dim3(es_cdiv(C, 64), nseg), dim3(64 * FST), 0, st, workspace, C, s, nchunk, eps,
                      mean, invstd, running_mean, running_var, momentum);
@@ -142,27 +179,76 @@ extern "C" size_t es_norm_workspace_floats(int n, int C, const int* seg_off, int
 }
 
 // backward pass 1: dz = dy * act'(y) (written in place into dy), partial sums of dz and dz*xhat
-__global__ void k_norm_bwd_stats(float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
-                                 const float* __restrict__ x, int ldx, int C, Segs segs, int nchunk,
-                                 const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-                                 float* __restrict__ partial) {
+// (same 2-D thread layout / float4 accesses as k_norm_stats)
+__global__ __launch_bounds__(256) void k_norm_bwd_stats(float* __restrict__ dy, int ldd, const float* __restrict__ y,
+                                                        int ldy, const float* __restrict__ x, int ldx, int C, Segs segs,
+                                                        int nchunk, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, int act,
+                                                        float* __restrict__ partial) {
+  __shared__ float4 red[2][256];
   int seg = blockIdx.y, chunk = blockIdx.x;
   int r0 = segs.off[seg] + chunk * NCH, r1 = min(segs.off[seg + 1], r0 + NCH);
   float* out = partial + ((size_t)(seg * nchunk + chunk) * 2) * C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f, q = 0.f, m = mean[seg * C + c], is = invstd[seg * C + c];
-    for (int r = r0; r < r1; ++r) {
-      float g = dy[(size_t)r * ldd + c];
-      if (act) {
-        float yv = y[(size_t)r * ldy + c];
-        g = (act == 1) ? (yv > 0.f ? g : 0.f) : (yv > 0.f ? g : g * (yv + 1.f));
-        dy[(size_t)r * ldd + c] = g;
+  const bool vec = ((C & 3) == 0) && ((ldx & 3) == 0) && ((ldd & 3) == 0) && ((ldy & 3) == 0) &&
+                   ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) && ((((uintptr_t)y) & 15) == 0);
+  if (!vec) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float s = 0.f, q = 0.f, m = mean[seg * C + c], is = invstd[seg * C + c];
+      for (int r = r0; r < r1; ++r) {
+        float g = dy[(size_t)r * ldd + c];
+        if (act) {
+          float yv = y[(size_t)r * ldy + c];
+          g = (act == 1) ? (yv > 0.f ? g : 0.f) : (yv > 0.f ? g : g * (yv + 1.f));
+          dy[(size_t)r * ldd + c] = g;
+        }
+        s += g;
+        q += g * ((x[(size_t)r * ldx + c] - m) * is);
       }
-      s += g;
-      q += g * ((x[(size_t)r * ldx + c] - m) * is);
+      out[c] = s;
+      out[C + c] = q;
     }
-    out[c] = s;
-    out[C + c] = q;
+    return;
+  }
+  int C4 = C >> 2;
+  int TX = C4 < 64 ? C4 : 64, TY = 256 / TX;
+  int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  for (int cb = 0; cb < C4; cb += TX) {
+    int c4 = cb + tx;
+    float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+    if (c4 < C4 && ty < TY) {
+      float4 m = *(const float4*)(mean + seg * C + c4 * 4), is = *(const float4*)(invstd + seg * C + c4 * 4);
+      for (int r = r0 + ty; r < r1; r += TY) {
+        float4 g = *(const float4*)(dy + (size_t)r * ldd + c4 * 4);
+        if (act) {
+          float4 yv = *(const float4*)(y + (size_t)r * ldy + c4 * 4);
+          if (act == 1) {
+            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+            g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+          } else {
+            g.x = yv.x > 0.f ? g.x : g.x * (yv.x + 1.f); g.y = yv.y > 0.f ? g.y : g.y * (yv.y + 1.f);
+            g.z = yv.z > 0.f ? g.z : g.z * (yv.z + 1.f); g.w = yv.w > 0.f ? g.w : g.w * (yv.w + 1.f);
+          }
+          *(float4*)(dy + (size_t)r * ldd + c4 * 4) = g;
+        }
+        float4 xv = *(const float4*)(x + (size_t)r * ldx + c4 * 4);
+        s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+        q.x += g.x * ((xv.x - m.x) * is.x); q.y += g.y * ((xv.y - m.y) * is.y);
+        q.z += g.z * ((xv.z - m.z) * is.z); q.w += g.w * ((xv.w - m.w) * is.w);
+      }
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (ty == 0 && c4 < C4) {
+      for (int j = 1; j < TY; ++j) {
+        float4 a = red[0][j * TX + tx], b = red[1][j * TX + tx];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+      }
+      *(float4*)(out + c4 * 4) = s;
+      *(float4*)(out + C + c4 * 4) = q;
+    }
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(64 * FST) void k_norm_bwd_finalize(const float* __restrict__ partial, int C, Segs segs,
@@ -229,7 +315,7 @@ extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const fl
   int nchunk = es_cdiv(max_seg_rows(s), NCH);
   if (nchunk < 1) nchunk = 1;
   float* sums = workspace + (size_t)nseg * nchunk * 2 * C;
-  hipLaunchKernelGGL(k_norm_bwd_stats, dim3(nchunk, nseg), dim3(C >= 256 ? 256 : 64), 0, st, dy, ldd, y, ldy, x,
+  hipLaunchKernelGGL(k_norm_bwd_stats, dim3(nchunk, nseg), dim3(256), 0, st, dy, ldd, y, ldy, x,
                      ldx, C, s, nchunk, mean, invstd, act, workspace);
   hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(es_cdiv(C, 64)), dim3(64 * FST), 0, st, workspace, C, s, nchunk, sums,
                      sums + (size_t)nseg * C, dweight, dbias);

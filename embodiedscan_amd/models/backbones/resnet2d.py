@@ -87,9 +87,13 @@ class ResNet:
         dev = x.device
         key = (n_img, H, W)
         if key not in self.grids:
-            g0 = _Grid(n_img, H, W, dev)
-            stem = g0.conv_map(7, 2, 3, want_inv=False)
-            nbr_a, nbr_b = stem[0][:, :27].contiguous(), stem[0][:, 27:].contiguous()
+            direct = self.base in (16, 32) and self.frozen_stages >= 0
+            if direct:                          # fused stem kernel: no 49-tap image map needed
+                Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+                stem, nbr_a, nbr_b = (None, None, n_img * Ho * Wo, Ho, Wo), None, None
+            else:
+                stem = _Grid(n_img, H, W, dev).conv_map(7, 2, 3, want_inv=False)
+                nbr_a, nbr_b = stem[0][:, :27].contiguous(), stem[0][:, 27:].contiguous()
             g1 = _Grid(n_img, stem[3], stem[4], dev)
             pool = g1.conv_map(3, 2, 1, want_inv=False)
             grids = [_Grid(n_img, pool[3], pool[4], dev)]
@@ -101,15 +105,21 @@ class ResNet:
         s = _stream()
         prev = E.TAPE.enabled
         E.TAPE.enabled = prev and self.frozen_stages < 0
-        # ---- stem: 7x7 s2 conv (49 taps as 27 + 22) + BN + ReLU + 3x3 s2 max pool
+        # ---- stem: direct 7x7 s2 conv + frozen BN + ReLU (one fused kernel), then 3x3 s2 max pool
         w1 = self.arena.p[self.prefix + 'conv1.weight']
         xin = x.reshape(n_img * H * W, 3)
-        y = torch.empty((stem[2], self.base), dtype=torch.float32, device=dev)
-        call('es_spconv_fwd', P(xin), 3, P(w1), P(nbr_a), stem[2], xin.shape[0], 27, 3, self.base, 0, P(y), self.base,
-             0, 0, s)
-        call('es_spconv_fwd', P(xin), 3, w1.data_ptr() + 4 * 27 * 3 * self.base, P(nbr_b), stem[2], xin.shape[0], 22, 3,
-             self.base, 0, P(y), self.base, 0, 1, s)
-        cur = E.affine_act(E.Var(y, rg=False), *self.fold['bn1'], act=1)
+        if self.base in (16, 32) and self.frozen_stages >= 0:
+            y = torch.empty((stem[2], self.base), dtype=torch.float32, device=dev)
+            call('es_stem_conv_fwd', P(xin), P(w1), P(self.fold['bn1'][0]), P(self.fold['bn1'][1]), n_img, H, W,
+                 self.base, P(y), s)
+            cur = E.Var(y, rg=False)
+        else:                                   # generic engine: 49 taps as 27 + 22
+            y = torch.empty((stem[2], self.base), dtype=torch.float32, device=dev)
+            call('es_spconv_fwd', P(xin), 3, P(w1), P(nbr_a), stem[2], xin.shape[0], 27, 3, self.base, 0, P(y),
+                 self.base, 0, 0, s)
+            call('es_spconv_fwd', P(xin), 3, w1.data_ptr() + 4 * 27 * 3 * self.base, P(nbr_b), stem[2], xin.shape[0], 22,
+                 3, self.base, 0, P(y), self.base, 0, 1, s)
+            cur = E.affine_act(E.Var(y, rg=False), *self.fold['bn1'], act=1)
         cur = E.maxpool(cur, pool[0], pool[2], need_dx=False)
         cur.rg = self.frozen_stages < 0
         outs = []
