@@ -78,7 +78,7 @@ def main():
         recs = prof['records']
         for i in range(done, len(recs)):        # resolve map pointer -> pair counter while the maps are still alive
             name, e0, e1, a = recs[i]
-            recs[i] = (name, e0, e1, a, hip.PAIRS.get(a[4] if name.startswith('es_spconv_wgrad') else a[3]))
+            recs[i] = (name, e0, e1, a, hip.PAIRS.get(a[4] if (name.startswith('es_spconv_wgrad') or name == 'es_spconv_fwd_bf16') else a[3]))
         done = len(recs)
     torch.cuda.synchronize()
     if world > 1:
@@ -105,7 +105,9 @@ def main():
     for name, e0, e1, a, pairs_dev in prof['records']:
         tot_ms += e0.elapsed_time(e1)
         n_launch += 1
-        if not name.startswith('es_spconv_wgrad'):
+        if name == 'es_spconv_fwd_bf16':
+            nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
+        elif not name.startswith('es_spconv_wgrad'):
             nbr, n_out, n_in, K, cin, cout = a[3], a[4], a[5], a[6], a[7], a[8]
         else:
             nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]

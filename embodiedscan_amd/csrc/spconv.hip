@@ -488,8 +488,10 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
 // aligned rows, 32-bit element offsets).  The PMC profile of the generic kernel showed 5.5 VALU + 3 SALU instructions
 // per MFMA (64-bit address multiplies, per-element bounds tests, iterator bookkeeping): it was VALU-issue bound at 16 %
 // MFMA utilisation.  Here the per-tap offsets are computed once per tap, the per-chunk work is add + load + cvt + store.
-template <int BNT>
-__global__ __launch_bounds__(256) void k_spconv_bf16_fast(const float* __restrict__ X, int ldx,
+// XH = true: X is a bf16 row matrix (the "shadow" copy made by es_cast_rows_bf16) -> half the gather bytes and no
+// conversion instructions; XH = false: f32 rows converted while staged.
+template <int BNT, bool XH>
+__global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restrict__ Xv, int ldx,
                                                           const unsigned short* __restrict__ W,
                                                           const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                           int Cin, int Cout, const float* __restrict__ bias,
@@ -504,21 +506,26 @@ __global__ __launch_bounds__(256) void k_spconv_bf16_fast(const float* __restric
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int row0 = blockIdx.x * BM, n0 = blockIdx.y * BNT;
 
-  if (t < 32) taps[t] = 0;
+  __shared__ int tapFlag[32];
+  if (t < 32) tapFlag[t] = 0;
   __syncthreads();
-  for (int e = t; e < BM * K; e += 256) {
-    int r = e / K, k = e - r * K;
-    int j = row0 + r, v = -1;
-    if (j < n_out) v = nbr ? nbr[(size_t)j * K + k] : (j < n_in ? j : -1);
-    nbrS[e] = v;
-    if (v >= 0) taps[k] = 1;
+  {                                   // kernel-map tile -> LDS: two threads per row, each walks half of the taps
+    int r = t >> 1, kh = (K + 1) >> 1, k0 = (t & 1) * kh, k1 = min(K, k0 + kh);
+    int j = row0 + r;
+    const int* src = nbr ? nbr + (size_t)j * K : nullptr;
+    for (int k = k0; k < k1; ++k) {
+      int v = -1;
+      if (j < n_out) v = src ? src[k] : (j < n_in ? j : -1);
+      nbrS[r * K + k] = v;
+      if (v >= 0) tapFlag[k] = 1;
+    }
   }
   __syncthreads();
-  if (t == 0) {                       // compact the list of taps that have at least one neighbour in this tile
-    int m = 0;
-    for (int k = 0; k < K; ++k)
-      if (taps[k]) taps[m++] = k;
-    nTaps = m;
+  if (t < 64) {                       // compact the taps that have at least one neighbour in this tile (one wave)
+    int f = (t < K) ? tapFlag[t] : 0;
+    unsigned long long m = __ballot(f);
+    if (f) taps[__popcll(m & ((1ull << t) - 1ull))] = t;
+    if (t == 0) nTaps = __popcll(m);
   }
   __syncthreads();
   const int nT = nTaps;
@@ -534,7 +541,9 @@ __global__ __launch_bounds__(256) void k_spconv_bf16_fast(const float* __restric
   const int b_n = t >> 2, b_kk = (t & 3) * 8;
   const int b_row = (n0 + b_n) * Cin + b_kk;              // element offset of this thread's weight piece inside a tap
   const int w_tap = Cout * Cin;
-  struct Regs { float4 a[4]; uint4 b[NB]; int valid; };
+  const float* X = (const float*)Xv;
+  const unsigned short* Xh = (const unsigned short*)Xv;
+  struct Regs { float4 a[4]; uint4 b[NB]; int valid; };      // XH: only a[0], a[1] are used (2 x 8 bf16)
   struct It { int ti, ci, a_off, b_off, valid; };
   // Loads are UNCONDITIONAL (an absent neighbour reads row 0 and is zeroed when written to LDS, a chunk past the end
   // re-reads the last tap) so that the compiler can keep the second prefetched chunk in flight with a counted
@@ -557,19 +566,31 @@ __global__ __launch_bounds__(256) void k_spconv_bf16_fast(const float* __restric
   };
   auto load_chunk = [&](Regs& R, const It& it) {
     int c0 = it.ci * HBK;
-    const float4* p = (const float4*)(X + it.a_off + c0);
+    if (XH) {
+      const float4* p = (const float4*)(Xh + it.a_off + c0);
+      R.a[0] = p[0];
+      R.a[1] = p[1];
+    } else {
+      const float4* p = (const float4*)(X + it.a_off + c0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) R.a[q] = p[q];
+      for (int q = 0; q < 4; ++q) R.a[q] = p[q];
+    }
 #pragma unroll
     for (int h = 0; h < NB; ++h) R.b[h] = *(const uint4*)(W + it.b_off + h * 64 * Cin + c0);
     R.valid = it.valid;
   };
   auto store_chunk = [&](const Regs& R) {
     uint4* pa = (uint4*)&As[a_r * HLD + a_kk];
-    uint4 v0 = make_uint4(pack_bf16(R.a[0].x, R.a[0].y), pack_bf16(R.a[0].z, R.a[0].w), pack_bf16(R.a[1].x, R.a[1].y),
-                          pack_bf16(R.a[1].z, R.a[1].w));
-    uint4 v1 = make_uint4(pack_bf16(R.a[2].x, R.a[2].y), pack_bf16(R.a[2].z, R.a[2].w), pack_bf16(R.a[3].x, R.a[3].y),
-                          pack_bf16(R.a[3].z, R.a[3].w));
+    uint4 v0, v1;
+    if (XH) {
+      v0 = *(const uint4*)&R.a[0];
+      v1 = *(const uint4*)&R.a[1];
+    } else {
+      v0 = make_uint4(pack_bf16(R.a[0].x, R.a[0].y), pack_bf16(R.a[0].z, R.a[0].w), pack_bf16(R.a[1].x, R.a[1].y),
+                      pack_bf16(R.a[1].z, R.a[1].w));
+      v1 = make_uint4(pack_bf16(R.a[2].x, R.a[2].y), pack_bf16(R.a[2].z, R.a[2].w), pack_bf16(R.a[3].x, R.a[3].y),
+                      pack_bf16(R.a[3].z, R.a[3].w));
+    }
     if (!R.valid) v0 = v1 = make_uint4(0u, 0u, 0u, 0u);
     pa[0] = v0;
     pa[1] = v1;
@@ -636,21 +657,37 @@ __global__ __launch_bounds__(256) void k_spconv_bf16_fast(const float* __restric
     }
 }
 
-extern "C" int es_spconv_fwd_bf16(const float* X, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in,
-                                  int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate,
-                                  void* stream) {
+// 1 if (shape, alignment) is served by the fast kernels -- the host uses it to decide whether a bf16 shadow of X pays
+extern "C" int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout) {
+  return (Cin % HBK == 0) && (ldx % 8 == 0) && (Cout % 64 == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
+         ((long long)K * Cout * Cin < (1ll << 31));
+}
+
+extern "C" int es_spconv_fwd_bf16(const void* Xv, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out,
+                                  int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy,
+                                  int accumulate, void* stream) {
   if (n_out <= 0 || Cout <= 0) return 0;
   if (K > MAXK) return -2;
   hipStream_t st = (hipStream_t)stream;
   const unsigned short* Wh = (const unsigned short*)W_bf16;
-  bool fast = (Cin % HBK == 0) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)Wh) & 15) == 0) &&
-              ((long long)n_in * ldx < (1ll << 31)) && ((long long)K * Cout * Cin < (1ll << 31));
-  if (fast && Cout % 128 == 0) {
-    hipLaunchKernelGGL(k_spconv_bf16_fast<128>, dim3(es_cdiv(n_out, BM), Cout / 128), dim3(256), 0, st, X, ldx, Wh, nbr,
-                       n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
-  } else if (fast && Cout % 64 == 0) {
-    hipLaunchKernelGGL(k_spconv_bf16_fast<64>, dim3(es_cdiv(n_out, BM), Cout / 64), dim3(256), 0, st, X, ldx, Wh, nbr,
-                       n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
+  const float* X = (const float*)Xv;
+  bool fast = (Cin % HBK == 0) && (ldx % (x_is_bf16 ? 8 : 4) == 0) && ((((uintptr_t)Xv) & 15) == 0) &&
+              ((((uintptr_t)Wh) & 15) == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
+              ((long long)K * Cout * Cin < (1ll << 31)) && (Cout % 64 == 0);
+  if (x_is_bf16 && !fast) return -7;            // bf16 input rows are only supported by the fast kernels
+  dim3 g128(es_cdiv(n_out, BM), Cout / 128), g64(es_cdiv(n_out, BM), Cout / 64);
+  if (fast && x_is_bf16 && Cout % 128 == 0) {
+    hipLaunchKernelGGL((k_spconv_bf16_fast<128, true>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+                       Cout, bias, Y, ldy, accumulate);
+  } else if (fast && x_is_bf16) {
+    hipLaunchKernelGGL((k_spconv_bf16_fast<64, true>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+                       Cout, bias, Y, ldy, accumulate);
+  } else if (fast && Cout % 128 == 0) {
+    hipLaunchKernelGGL((k_spconv_bf16_fast<128, false>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+                       Cout, bias, Y, ldy, accumulate);
+  } else if (fast) {
+    hipLaunchKernelGGL((k_spconv_bf16_fast<64, false>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+                       Cout, bias, Y, ldy, accumulate);
   } else if (Cout >= 128) {
     hipLaunchKernelGGL(k_spconv_bf16<128>, dim3(es_cdiv(n_out, BM), es_cdiv(Cout, 128)), dim3(256), 0, st, X, ldx, Wh,
                        nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
@@ -900,6 +937,27 @@ extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, in
   dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), splits);
   hipLaunchKernelGGL(k_spconv_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out, n_in,
                      K, Cin, Cout, rows_per_split, dW);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+// f32 row matrix -> contiguous bf16 "shadow" (n, C) used as the gather source of the bf16 kernels
+__global__ void k_cast_rows(const float* __restrict__ x, int ldx, size_t n, int C, unsigned short* __restrict__ h) {
+  size_t tot = n * (size_t)(C >> 1);
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    size_t r = e / (C >> 1);
+    int c2 = (int)(e - r * (C >> 1)) * 2;
+    const float* p = x + r * ldx + c2;
+    ((uint32_t*)h)[e] = pack_bf16(p[0], p[1]);
+  }
+}
+extern "C" int es_cast_rows_bf16(const float* x, int ldx, int n, int C, void* h, void* stream) {
+  if (n <= 0 || C <= 0) return 0;
+  if (C & 1) return -8;
+  long long tot = (long long)n * (C >> 1);
+  int g = es_cdiv(tot, 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_cast_rows, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, (size_t)n, C, (unsigned short*)h);
   ES_CHECK_LAUNCH();
   return 0;
 }

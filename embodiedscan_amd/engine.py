@@ -15,11 +15,23 @@ def _stream():
 
 
 class Var:
-    """A row matrix (N, C) f32 on the device with an optional gradient."""
-    __slots__ = ('d', 'g', 'rg')
+    """A row matrix (N, C) f32 on the device with an optional gradient (and lazily made bf16 shadows of both, the
+    gather sources of the bf16 convolution kernels)."""
+    __slots__ = ('d', 'g', 'rg', 'dh', 'gh')
 
     def __init__(self, d, rg=True):
         self.d, self.g, self.rg = d, None, rg
+        self.dh = self.gh = None
+
+    def shadow(self):
+        if self.dh is None:
+            self.dh = _cast_rows(self.d)
+        return self.dh
+
+    def grad_shadow(self):
+        if self.gh is None:
+            self.gh = _cast_rows(self.g)
+        return self.gh
 
     @property
     def shape(self):
@@ -48,6 +60,7 @@ class Param:
 
 
 PRECISION = ['f32']       # 'f32': exact-f32 MFMA everywhere; 'bf16': bf16 MFMA (f32 accumulate) for conv fwd / dgrad
+SHADOW = [True]           # gather from bf16 shadow copies of activations / gradients in the bf16 kernels
 WGRAD_BF16 = [True]       # in bf16 mode also run the weight-gradient GEMMs on the bf16 matrix cores
 WEIGHT_VERSION = [0]      # bumped by the optimiser: invalidates the bf16 weight copies
 
@@ -72,6 +85,18 @@ class Tape:
 
 TAPE = Tape()
 DEBUG_GRADS = None      # tools/debug_grads.py sets a dict: id(Var) -> snapshot of its gradient when consumed
+
+
+def _cast_rows(t):
+    n, C = t.shape
+    h = torch.empty((n, C), dtype=torch.bfloat16, device=t.device)
+    call('es_cast_rows_bf16', P(t), t.stride(0), n, C, P(h), _stream())
+    return h
+
+
+def _use_shadow(n_rows, C, K, cin, cout):
+    """bf16 shadow pays when the rows are gathered several times (K > 1) and the fast kernel takes the shape"""
+    return K > 1 and hip.raw('es_spconv_bf16_is_fast')(n_rows, C, K, cin, cout) == 1
 
 
 def empty(shape, like, dtype=torch.float32):
@@ -103,8 +128,11 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
     n_in = x.d.shape[0]
     y = Var(empty((n_out, cout), x.d))
     bf = PRECISION[0] == 'bf16' and cin >= 16
-    if bf:
-        call('es_spconv_fwd_bf16', P(x.d), _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout,
+    if bf and SHADOW[0] and _ld(x.d) == cin and _use_shadow(n_in, cin, K, cin, cout):
+        call('es_spconv_fwd_bf16', P(x.shadow()), 1, cin, P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout,
+             P(bias.d) if bias else 0, P(y.d), cout, 0, _stream())
+    elif bf:
+        call('es_spconv_fwd_bf16', P(x.d), 0, _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout,
              P(bias.d) if bias else 0, P(y.d), cout, 0, _stream())
     else:
         call('es_spconv_fwd', P(x.d), _ld(x.d), P(w.d), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0,
@@ -125,8 +153,11 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
                  cout - bias_from, bias.g.data_ptr() + 4 * bias_from, s)
         if need_dx and x.rg:
             g, acc = _grad_target(x, x.d)
-            if bf and cout >= 16:
-                call('es_spconv_fwd_bf16', P(y.g), _ld(y.g), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0,
+            if bf and cout >= 16 and SHADOW[0] and _ld(y.g) == cout and _use_shadow(n_out, cout, K, cout, cin):
+                call('es_spconv_fwd_bf16', P(y.grad_shadow()), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout,
+                     cin, 0, P(g), _ld(g), acc, s)
+            elif bf and cout >= 16:
+                call('es_spconv_fwd_bf16', P(y.g), 0, _ld(y.g), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0,
                      P(g), _ld(g), acc, s)
             else:
                 call('es_spconv_fwd', P(y.g), _ld(y.g), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1,
@@ -145,7 +176,7 @@ def gen_conv_transpose(x, w):
     bf = PRECISION[0] == 'bf16'
     for k in range(8):
         if bf:
-            call('es_spconv_fwd_bf16', P(x.d), _ld(x.d), w.bf16()[1].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cin,
+            call('es_spconv_fwd_bf16', P(x.d), 0, _ld(x.d), w.bf16()[1].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cin,
                  cout, 0, y.d.data_ptr() + 4 * k * cout, 8 * cout, 0, s)
         else:
             call('es_spconv_fwd', P(x.d), _ld(x.d), w.d.data_ptr() + 4 * k * cin * cout, 0, n, n, 1, cin, cout, 0,
@@ -162,7 +193,7 @@ def gen_conv_transpose(x, w):
                 call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), gy,
                      8 * cout, 0, n, n, 1, cin, cout, w.g.data_ptr() + 4 * k * cin * cout, s)
             if g is not None and bf:
-                call('es_spconv_fwd_bf16', gy, 8 * cout, w.bf16()[0].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cout,
+                call('es_spconv_fwd_bf16', gy, 0, 8 * cout, w.bf16()[0].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cout,
                      cin, 0, P(g), _ld(g), 1 if (acc or k > 0) else 0, s)
             elif g is not None:
                 call('es_spconv_fwd', gy, 8 * cout, w.d.data_ptr() + 4 * k * cin * cout, 0, n, n, 1, cout, cin, 0,

@@ -70,8 +70,12 @@ int es_spconv_fwd(const float* X, int ldx, const float* W, const int* nbr, int n
                   int Cout, const float* bias, float* Y, int ldy, int trans_w, int accumulate, void* stream);
 /* bf16-MFMA variant (f32 features rounded to bf16 while staged, f32 accumulate).  W_bf16 is [K][Cout][Cin]
  * (reduction index contiguous): the transposed copy for the forward pass, the natural copy for dgrad. */
-int es_spconv_fwd_bf16(const float* X, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in, int K,
-                       int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, void* stream);
+int es_spconv_fwd_bf16(const void* X, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in,
+                       int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, void* stream);
+/* X may also be a bf16 row matrix (x_is_bf16 = 1, ldx in bf16 elements): the shadow made by es_cast_rows_bf16; only for
+ * shapes where es_spconv_bf16_is_fast() returns 1 */
+int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout);
+int es_cast_rows_bf16(const float* x, int ldx, int n, int C, void* h /* (n,C) bf16 */, void* stream);
 /* per-step bf16 copies of an f32 [K][A][B] kernel: natural [K][A][B] and/or transposed [K][B][A] (either may be NULL) */
 int es_cast_weight_bf16(const float* w, int K, int A, int B, void* natural, void* transposed, void* stream);
 /* dW[k] += X[nbr[:,k]]^T . dY */

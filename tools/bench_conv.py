@@ -48,13 +48,30 @@ for (S, cin, cout) in cases:
     for tag, m, p_ in (('map', nbr, pairs), ('identity-map(all 27 taps same row)', ident, n * 27)):
         t = timeit(lambda: call('es_spconv_fwd', P(x), cin, P(w), P(m), n, n, 27, cin, cout, 0, P(y), cout, 0, 0, st))
         print(f'  f32 fwd  [{tag}]: {t:.3f} ms  {2 * p_ * cin * cout / t / 1e9:.1f} TF/s alg  gather {p_ * cin * 4 / t / 1e6:.0f} GB/s')
-        t = timeit(lambda: call('es_spconv_fwd_bf16', P(x), cin, P(wb_t), P(m), n, n, 27, cin, cout, 0, P(y), cout, 0, st))
+        t = timeit(lambda: call('es_spconv_fwd_bf16', P(x), 0, cin, P(wb_t), P(m), n, n, 27, cin, cout, 0, P(y), cout, 0, st))
+        print(f'  bf16 fwd [{tag}]: {t:.3f} ms  {2 * p_ * cin * cout / t / 1e9:.1f} TF/s alg  gather {p_ * cin * 4 / t / 1e6:.0f} GB/s')
+        xh = x.to(torch.bfloat16)
+        t = timeit(lambda: call('es_spconv_fwd_bf16', P(xh), 1, cin, P(wb_t), P(m), n, n, 27, cin, cout, 0, P(y), cout, 0, st))
+        tag = tag + ', bf16 rows'
         print(f'  bf16 fwd [{tag}]: {t:.3f} ms  {2 * p_ * cin * cout / t / 1e9:.1f} TF/s alg  gather {p_ * cin * 4 / t / 1e6:.0f} GB/s')
         t = timeit(lambda: call('es_spconv_wgrad', P(x), cin, P(y), cout, P(m), n, n, 27, cin, cout, P(dw), st))
         print(f'  f32 wgrad[{tag}]: {t:.3f} ms  {2 * p_ * cin * cout / t / 1e9:.1f} TF/s alg')
         t = timeit(lambda: call('es_spconv_wgrad_bf16', P(x), cin, P(y), cout, P(m), n, n, 27, cin, cout, P(dw), st))
         print(f'  bf16 wgrad[{tag}]: {t:.3f} ms  {2 * p_ * cin * cout / t / 1e9:.1f} TF/s alg')
-    t = timeit(lambda: call('es_spconv_fwd_bf16', P(x), cin, P(wb_t), 0, n, n, 1, cin, cout, 0, P(y), cout, 0, st))
+    t = timeit(lambda: call('es_spconv_fwd_bf16', P(x), 0, cin, P(wb_t), 0, n, n, 1, cin, cout, 0, P(y), cout, 0, st))
     print(f'  bf16 k1 GEMM: {t:.3f} ms  {2 * n * cin * cout / t / 1e9:.1f} TF/s  read {n * cin * 4 / t / 1e6:.0f} GB/s')
     t = timeit(lambda: y.copy_(x[:, :cout]) if cin >= cout else None)
     print(f'  torch copy n x {cout}: {t:.3f} ms  {2 * n * cout * 4 / t / 1e6:.0f} GB/s')
+
+if os.environ.get('ABLATE'):
+    S, cin, cout = cases[0]
+    n = S.n
+    nbr = S.kernel_map(S, 3)
+    x = torch.randn(n, cin, device=dev); y = torch.empty(n, cout, device=dev)
+    w = torch.randn(27, cin, cout, device=dev) * 0.05
+    wb_n, wb_t = torch.empty((27, cin, cout), dtype=torch.bfloat16, device=dev), torch.empty((27, cout, cin), dtype=torch.bfloat16, device=dev)
+    call('es_cast_weight_bf16', P(w), 27, cin, cout, P(wb_n), P(wb_t), st)
+    for abl, tag in ((0, 'full'), (1, 'no compute (no LDS reads / MFMA)'), (2, 'no global loads'), (4, 'no LDS stores'), (8, 'no barriers'),
+                     (3, 'no compute, no loads'), (6, 'no loads, no stores (compute only)'), (7, 'only barriers+iterator'), (15, 'iterator only'), (9, 'no compute no barriers')):
+        t = timeit(lambda: call('es_spconv_fwd_bf16', P(x), 0, cin, P(wb_t), P(nbr), n, n, 27, cin, cout, 0, P(y), cout, abl << 8, st))
+        print(f'  ablation {abl:2d} {tag}: {t:.3f} ms')
