@@ -60,7 +60,8 @@ class Param:
 
 
 PRECISION = ['f32']       # 'f32': exact-f32 MFMA everywhere; 'bf16': bf16 MFMA (f32 accumulate) for conv fwd / dgrad
-SHADOW = [True]           # gather from bf16 shadow copies of activations / gradients in the bf16 kernels
+SHADOW = [False]          # gather from bf16 shadow copies of activations / gradients (measured: no gain -- the
+                          # kernel is not gather-bandwidth bound -- so off by default)
 WGRAD_BF16 = [True]       # in bf16 mode also run the weight-gradient GEMMs on the bf16 matrix cores
 WEIGHT_VERSION = [0]      # bumped by the optimiser: invalidates the bf16 weight copies
 
