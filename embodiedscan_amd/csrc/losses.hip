@@ -240,33 +240,45 @@ __device__ inline Dual corner_cd(const Dual* box, const real* tc) {
   return total;
 }
 
-// one thread per positive location
+// one thread per location of ONE sample (all levels, fine -> coarse); rows with cls_t < 0 exit immediately.
+// The head outputs live in per-level buffers, the targets in per-sample arrays: the level table maps between them.
+struct PosLevels {
+  int n;
+  int off[ES_MAX_LEVELS + 1];          // row offsets of the levels inside the per-sample arrays
+  const float* ho[ES_MAX_LEVELS];      // this sample's rows of the level's head output (column 0 = centerness), ld = ldh
+  const float* bbox[ES_MAX_LEVELS];    // decoded (n,12) boxes
+  float* dho[ES_MAX_LEVELS];
+  float* dbbox[ES_MAX_LEVELS];
+};
 __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t, int n,
                                                    const int* __restrict__ n_pos_dev,
-                                                   const float* __restrict__ points,
-                                                   const float* __restrict__ center_pred, int ldc,
-                                                   const float* __restrict__ bbox_pred,
+                                                   const float* __restrict__ points, PosLevels LV, int ldc,
                                                    const float* __restrict__ center_t,
                                                    const float* __restrict__ bbox_t,
                                                    const float* __restrict__ avg_factor, float grad_scale,
                                                    float w0, float w1, float w2, float w3,
-                                                   float* __restrict__ dcenter, int ldg,
-                                                   float* __restrict__ dbbox,
                                                    float* __restrict__ loss_acc /* [0]=center sum, [1]=bbox sum */) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   float lc = 0.f, lb = 0.f;
   if (i < n && cls_t[i] >= 0) {
     const int P = n_pos_dev[0];
+    int lv = 0;
+    for (int l = 1; l < LV.n; ++l) lv += (i >= LV.off[l]);
+    const int li_ = i - LV.off[lv];                       // row inside this sample's slice of the level
+    const float* center_pred = LV.ho[lv] + (size_t)li_ * ldc;
+    const float* bbox_pred = LV.bbox[lv] + (size_t)li_ * 12;
+    float* dcenter = LV.dho[lv] + (size_t)li_ * ldc;
+    float* dbbox = LV.dbbox[lv] + (size_t)li_ * 12;
     // ---- centerness BCE with logits, sum / (avg_factor + eps)
-    float x = center_pred[(size_t)i * ldc], t = center_t[i];
+    float x = center_pred[0], t = center_t[i];
     float inv_avg = 1.f / (avg_factor[0] + 1.1920929e-07f);
     lc = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
     float sg = 1.f / (1.f + expf(-x));
-    dcenter[(size_t)i * ldg] = (sg - t) * inv_avg * grad_scale;
+    dcenter[0] = (sg - t) * inv_avg * grad_scale;
     // ---- box coder on dual numbers (the 12 head outputs are the independent variables)
     Dual bp[12];
 #pragma unroll
-    for (int c = 0; c < 12; ++c) bp[c] = dvar(bbox_pred[(size_t)i * 12 + c], c);
+    for (int c = 0; c < 12; ++c) bp[c] = dvar(bbox_pred[c], c);
     D3 xr = {bp[6], bp[7], bp[8]}, yr = {bp[9], bp[10], bp[11]};
     D3 y = dnormalize(yr);
     D3 z = dnormalize(dcross(xr, y));
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
     real inv_mean = 1.0 / ((real)P * 8.0);
     lb = (float)(tot.v * inv_mean);
 #pragma unroll
-    for (int c = 0; c < 12; ++c) dbbox[(size_t)i * 12 + c] = (float)(tot.d[c] * inv_mean * (real)grad_scale);
+    for (int c = 0; c < 12; ++c) dbbox[c] = (float)(tot.d[c] * inv_mean * (real)grad_scale);
   }
   lc = es_wave_sum(lc);
   lb = es_wave_sum(lb);
@@ -324,14 +336,25 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
     atomicAdd(loss_acc + 1, lb);
   }
 }
-extern "C" int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, const float* points,
-                             const float* center_pred, int ldc, const float* bbox_pred, const float* center_t,
+extern "C" int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, const float* points, int n_levels,
+                             const int* level_off_host, const void* const* ho_host, const void* const* bbox_host,
+                             void* const* dho_host, void* const* dbbox_host, int ldh, const float* center_t,
                              const float* bbox_t, const float* avg_factor_dev, float grad_scale, const float* group_w,
-                             float* dcenter, int ldg, float* dbbox, float* loss_acc, void* stream) {
+                             float* loss_acc, void* stream) {
   if (n <= 0) return 0;
+  if (n_levels > ES_MAX_LEVELS) return -3;
+  PosLevels LV;
+  LV.n = n_levels;
+  for (int l = 0; l <= n_levels; ++l) LV.off[l] = level_off_host[l];
+  for (int l = 0; l < n_levels; ++l) {
+    LV.ho[l] = (const float*)ho_host[l];
+    LV.bbox[l] = (const float*)bbox_host[l];
+    LV.dho[l] = (float*)dho_host[l];
+    LV.dbbox[l] = (float*)dbbox_host[l];
+  }
   hipLaunchKernelGGL(k_pos_losses, dim3(es_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, cls_t, n, n_pos_dev, points,
-                     center_pred, ldc, bbox_pred, center_t, bbox_t, avg_factor_dev, grad_scale, group_w[0],
-                     group_w[1], group_w[2], group_w[3], dcenter, ldg, dbbox, loss_acc);
+                     LV, ldh, center_t, bbox_t, avg_factor_dev, grad_scale, group_w[0], group_w[1], group_w[2],
+                     group_w[3], loss_acc);
   ES_CHECK_LAUNCH();
   return 0;
 }

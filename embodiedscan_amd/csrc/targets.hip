@@ -93,14 +93,19 @@ __global__ __launch_bounds__(1024) void k_tg_select(const float* __restrict__ ce
   __syncthreads();
   int lb = L.off[s_best], le = L.off[s_best + 1];
   const float* cg = cen + (size_t)g * N;
+  // Every location outside the best level carries the masked value -1, so the k-th largest of all N values is the
+  // k-th largest inside [lb, le) when that range holds at least k values, and -1 otherwise: only the range is scanned.
+  if (le - lb < (int)s_remaining) {
+    if (threadIdx.x == 0) thr_out[g] = -1.f;
+    return;
+  }
   uint32_t pmask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t prefix = s_prefix;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-      float v = (i >= lb && i < le) ? cg[i] : -1.f;
-      uint32_t u = f2ord_t(v);
+    for (int i = lb + threadIdx.x; i < le; i += blockDim.x) {
+      uint32_t u = f2ord_t(cg[i]);
       if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
     }
     __syncthreads();

@@ -93,5 +93,10 @@ def iarr(vals):
     return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
 
 
+def parr(ptrs):
+    """host array of device pointers"""
+    return (ctypes.c_void_p * len(ptrs))(*[int(v) for v in ptrs])
+
+
 def farr(vals):
     return (ctypes.c_float * len(vals))(*[float(v) for v in vals])

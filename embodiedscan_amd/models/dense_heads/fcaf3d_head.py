@@ -10,7 +10,7 @@ import torch
 from ... import engine as E
 from ... import sparse
 from ...geometry import euler_to_matrix_zxy
-from ...hip import P, call, iarr, farr
+from ...hip import P, call, iarr, farr, parr
 from ...parallel import reduce_mean
 from ...registry import MODELS
 from ...sparse import SparseTensor
@@ -233,22 +233,22 @@ class FCAF3DHeadRotMat:
         gscale = 1.0 / B
         for b in range(B):
             pts, lo, ct, bt, kt, npos = per[b]
+            ncol = levels[0]['ho'].d.shape[1]
+            hos, bbs, dhos, dbbs = [], [], [], []
             for l in range(n_lvl):
-                n = lo[l + 1] - lo[l]
-                if n == 0:
-                    continue
                 lv = levels[l]
                 r0 = offs[l][b]
-                ho, dho = lv['ho'].d, lv['dho']
-                ncol = ho.shape[1]
-                hp, dp = ho.data_ptr() + 4 * r0 * ncol, dho.data_ptr() + 4 * r0 * ncol
-                call('es_focal_loss', hp + 4 * 13, ncol, kt.data_ptr() + 4 * lo[l], n, self.num_classes,
-                     self.focal_gamma, self.focal_alpha, avg.data_ptr() + 4 * b, gscale, dp + 4 * 13, ncol,
-                     P(partial), loss_cls.data_ptr() + 4 * b, s)
-                call('es_pos_losses', kt.data_ptr() + 4 * lo[l], n, P(npos), pts.data_ptr() + 12 * lo[l], hp, ncol,
-                     lv['bbox'].data_ptr() + 48 * r0, ct.data_ptr() + 4 * lo[l], bt.data_ptr() + 36 * lo[l],
-                     avg.data_ptr() + 4 * b, gscale, gwa, dp, ncol, lv['dbbox'].data_ptr() + 48 * r0,
-                     loss_acc.data_ptr() + 8 * b, s)
+                hos.append(lv['ho'].d.data_ptr() + 4 * r0 * ncol)
+                dhos.append(lv['dho'].data_ptr() + 4 * r0 * ncol)
+                bbs.append(lv['bbox'].data_ptr() + 48 * r0)
+                dbbs.append(lv['dbbox'].data_ptr() + 48 * r0)
+                n = lo[l + 1] - lo[l]
+                if n:
+                    call('es_focal_loss', hos[l] + 4 * 13, ncol, kt.data_ptr() + 4 * lo[l], n, self.num_classes,
+                         self.focal_gamma, self.focal_alpha, avg.data_ptr() + 4 * b, gscale, dhos[l] + 4 * 13, ncol,
+                         P(partial), loss_cls.data_ptr() + 4 * b, s)
+            call('es_pos_losses', P(kt), lo[-1], P(npos), P(pts), n_lvl, iarr(lo), parr(hos), parr(bbs), parr(dhos),
+                 parr(dbbs), ncol, P(ct), P(bt), avg.data_ptr() + 4 * b, gscale, gwa, loss_acc.data_ptr() + 8 * b, s)
         # chain through exp/Scale/clamp and seed the head GEMM gradients
         for lv in levels:
             n = lv['cs'].n

@@ -155,12 +155,17 @@ int es_focal_loss(const float* logits, int ldl, const int* labels, int N, int C,
 int es_reg_decode_fwd(const float* reg, int ldr, int n, const float* scale, float* bbox /* (n,12) */, void* stream);
 int es_reg_decode_bwd(const float* reg, int ldr, const float* bbox, const float* dbbox, int n, const float* scale,
                       float* dreg, int ldg, float* dscale, void* stream);
-/* All n locations are visited, rows with cls_t < 0 are skipped (no host-side nonzero()).  group_w: HOST array of
- * the 4 decouple weights.  loss_acc[0] += sum BCE, loss_acc[1] += weighted corner loss (mean over n_pos*8). */
-int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, const float* points, const float* center_pred,
-                  int ldc, const float* bbox_pred /* (n,12) */, const float* center_t, const float* bbox_t,
-                  const float* avg_factor_dev, float grad_scale, const float* group_w_host, float* dcenter, int ldg,
-                  float* dbbox /* (n,12) */, float* loss_acc, void* stream);
+/* One launch per SAMPLE over its n locations of all levels (fine -> coarse, level_off_host = n_levels+1 row offsets inside
+ * the per-sample arrays cls_t / points / center_t / bbox_t).  Rows with cls_t < 0 are skipped (no host-side nonzero()).
+ * ho_host[l] / dho_host[l]: this sample's first row of level l in the head output / its gradient (leading dim ldh,
+ * column 0 = centerness logit); bbox_host[l] / dbbox_host[l]: decoded (.,12) boxes / their gradient.  All four are HOST
+ * arrays of device pointers.  group_w: HOST array of the 4 decouple weights.
+ * loss_acc[0] += sum BCE, loss_acc[1] += weighted corner loss (mean over n_pos*8). */
+#define ES_MAX_LEVELS 8
+int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, const float* points, int n_levels,
+                  const int* level_off_host, const void* const* ho_host, const void* const* bbox_host,
+                  void* const* dho_host, void* const* dbbox_host, int ldh, const float* center_t, const float* bbox_t,
+                  const float* avg_factor_dev, float grad_scale, const float* group_w_host, float* loss_acc, void* stream);
 
 /* ---- optimiser.  configs/detection/mv-det3d_...py:219-223 ------------------------------------------ */
 int es_grad_norm(const float* grad, size_t n, double* partial /* 2048 */, float* norm_out, void* stream);

@@ -56,7 +56,7 @@ def test_point_sample_vs_reference_golden(golden_dir):
 
 
 def test_losses_vs_oracle(golden_dir):
-    from embodiedscan_amd.hip import P, call, farr
+    from embodiedscan_amd.hip import P, call, farr, iarr, parr
     from oracle import geometry as G
     dev = torch.device('cuda:0')
     d = np.load(os.path.join(golden_dir, 'box_coder_cdloss.npz'))
@@ -85,8 +85,12 @@ def test_losses_vs_oracle(golden_dir):
     # keep every device tensor alive in a variable: P() only takes the pointer
     d_cls, d_np, d_pts, d_cp = cls_t.to(dev), torch.tensor([npos], dtype=torch.int32, device=dev), pts.to(dev), center_p.to(dev)
     d_pred, d_ct, d_tgt, d_avg = pred.to(dev), center_t.to(dev), tgt.to(dev), avg.to(dev)
-    call('es_pos_losses', P(d_cls), n, P(d_np), P(d_pts), P(d_cp), 1, P(d_pred), P(d_ct), P(d_tgt), P(d_avg), 1.0, farr(w),
-         P(dcen), 1, P(dbb), P(acc), torch.cuda.current_stream().cuda_stream)
+    # two "levels" (rows 0..39 and 40..n) to exercise the level table
+    n0 = 40
+    call('es_pos_losses', P(d_cls), n, P(d_np), P(d_pts), 2, iarr([0, n0, n]), parr([d_cp.data_ptr(), d_cp.data_ptr() + 4 * n0]),
+         parr([d_pred.data_ptr(), d_pred.data_ptr() + 48 * n0]), parr([dcen.data_ptr(), dcen.data_ptr() + 4 * n0]),
+         parr([dbb.data_ptr(), dbb.data_ptr() + 48 * n0]), 1, P(d_ct), P(d_tgt), P(d_avg), 1.0, farr(w), P(acc),
+         torch.cuda.current_stream().cuda_stream)
     acc = acc.cpu()
     lb, lc = lb.detach(), lc.detach()
     print(f'bbox loss hip {float(acc[1]):.6f} oracle {float(lb):.6f}; center sum hip {float(acc[0]):.6f}')
