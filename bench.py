@@ -23,8 +23,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=4, help='scans per GPU per step (reference config: 8xb4)')
     ap.add_argument('--views', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
