@@ -159,3 +159,53 @@ def test_train_step_bf16_mode(setup):
         print(f'bf16 mode {k}: hip {float(losses[k]):.6f} oracle(f32) {float(olosses[k]):.6f} rel err {e:.2e} (tol 2e-2)')
         assert e < 2e-2
     assert torch.isfinite(det.arena.grad).all()
+
+
+def test_prune_path_and_ragged_batch(setup):
+    """Edge cases of the train step: the FCAF3D prune path active (threshold far below the level sizes, so the
+    interpolated-score top-k, compaction and row gather all run), a ragged batch (different point counts per sample)
+    and one sample WITHOUT ground-truth boxes (fcaf3d_head.py:1603-1607,1283-1285).  Exact-f32 mode, losses and target
+    labels against the oracle run with the same threshold."""
+    import copy
+    from embodiedscan_amd import engine as E, pipeline
+    from embodiedscan_amd.structures import Det3DDataSample, EulerDepthInstance3DBoxes, InstanceData
+    from oracle import model as OM
+    det, scans, dscans, sd = setup
+    batch = pipeline.make_batch(dscans)
+    pts = batch['inputs']['points']
+    pts[1] = pts[1][:13001].contiguous()                       # ragged
+    empty_boxes, empty_labels = torch.zeros((0, 9)), torch.zeros((0,), dtype=torch.int64)
+    batch['data_samples'][1] = Det3DDataSample(dscans[1]['meta'], InstanceData(bboxes_3d=EulerDepthInstance3DBoxes(empty_boxes),
+                                                                               labels_3d=empty_labels))
+    points_host = [p.cpu() for p in pts]
+    old_thr = det.bbox_head.pts_prune_threshold
+    det.bbox_head.pts_prune_threshold = 1500
+    try:
+        E.TAPE.clear()
+        data = det.data_preprocessor(batch, True)
+        det._bind()
+        det.arena.grad.zero_()
+        losses = det.forward(data['inputs'], data['data_samples'], mode='loss')
+        E.TAPE.backward()
+        torch.cuda.synchronize()
+    finally:
+        det.bbox_head.pts_prune_threshold = old_thr
+    sizes = [lv['cs'].offsets() for lv in det.bbox_head.last_levels]
+    assert max(o[1] - o[0] for o in sizes) <= 1500 and max(o[2] - o[1] for o in sizes) <= 1500
+    imgs = torch.stack([OM.preprocess_img(torch.from_numpy(s['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])
+                        for s in scans])
+    with torch.no_grad():
+        olosses, aux = OM.detector_loss(sd, points_host, imgs, [s['meta'] for s in scans],
+                                        [torch.from_numpy(scans[0]['gt_boxes']), empty_boxes],
+                                        [torch.from_numpy(scans[0]['gt_labels']), empty_labels], thr=1500, return_aux=True)
+    osz = [[len(p[0]) for p in lvl] for lvl in aux['outs']]
+    assert [[o[1] - o[0], o[2] - o[1]] for o in sizes] == osz, (sizes, osz)       # same voxels survive the pruning
+    tg = det.bbox_head.last_targets
+    for b in range(2):
+        np.testing.assert_array_equal(tg[b][2].cpu().numpy(), aux['targets'][b][2].numpy())
+    assert int((tg[1][2] >= 0).sum()) == 0
+    for k in olosses:
+        a, o = float(losses[k]), float(olosses[k])
+        print(f'prune/ragged/empty-GT {k}: hip {a:.6f} oracle {o:.6f}')
+        assert abs(a - o) <= 1e-4 * max(abs(o), 1e-3)
+    assert torch.isfinite(det.arena.grad).all()
