@@ -70,16 +70,16 @@ def main():
     # time EXACTLY `steps` steps; the convolution engine launches are bracketed by HIP events on the same stream
     prof = {'names': {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_wgrad', 'es_spconv_wgrad_bf16'}, 'records': [],
             'event': lambda: torch.cuda.Event(enable_timing=True)}
-    hip.PROFILE = prof
     t0 = time.perf_counter()
-    done = 0
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        # the engine launches of the LAST timed step are bracketed by HIP events (2 events per launch and one pair
+        # counter per kernel map cost ~3 ms of host time per step, so they are not recorded on every step)
+        hip.PROFILE = prof if it == args.steps - 1 else None
         losses = step()
-        recs = prof['records']
-        for i in range(done, len(recs)):        # resolve map pointer -> pair counter while the maps are still alive
-            name, e0, e1, a = recs[i]
-            recs[i] = (name, e0, e1, a, hip.PAIRS.get(a[4] if (name.startswith('es_spconv_wgrad') or name == 'es_spconv_fwd_bf16') else a[3]))
-        done = len(recs)
+    recs = prof['records']
+    for i in range(len(recs)):              # resolve map pointer -> pair counter while the maps are still alive
+        name, e0, e1, a = recs[i]
+        recs[i] = (name, e0, e1, a, hip.PAIRS.get(a[4] if (name.startswith('es_spconv_wgrad') or name == 'es_spconv_fwd_bf16') else a[3]))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -120,8 +120,7 @@ def main():
                     frac=round(achieved / K_PEAK_HBM, 4), traffic=None,
                     kernel='convolution engine: k_spconv_bf16* (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
                     else 'convolution engine: k_spconv / k_spconv_wgrad (exact-f32 MFMA)',
-                    launches_per_step=n_launch // max(args.steps, 1),
-                    kernel_ms_per_step=round(tot_ms / max(args.steps, 1), 3),
+                    launches_per_step=n_launch, kernel_ms_per_step=round(tot_ms, 3),
                     algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                     note='algorithmic bytes = sum over launches of P*(Cin+Cout)*4 + K*Cin*Cout*sizeof(w), P = valid '
                          '(output,tap) pairs; algorithmic flops = 2*P*Cin*Cout; traffic: see profiles/ (PMC), null here')

@@ -258,9 +258,13 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
                                                    const float* __restrict__ avg_factor, float grad_scale,
                                                    float w0, float w1, float w2, float w3,
                                                    float* __restrict__ loss_acc /* [0]=center sum, [1]=bbox sum */) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // four consecutive lanes share one location: lane q evaluates decouple group q (its corner-Chamfer term carries the
+  // f64 dual numbers), the 13 partial results are then summed over the quad with shuffles
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = tid >> 2, grp = tid & 3;
   float lc = 0.f, lb = 0.f;
-  if (i < n && cls_t[i] >= 0) {
+  const bool active = (i < n) && (cls_t[i] >= 0);
+  if (active) {
     const int P = n_pos_dev[0];
     int lv = 0;
     for (int l = 1; l < LV.n; ++l) lv += (i >= LV.off[l]);
@@ -272,9 +276,11 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
     // ---- centerness BCE with logits, sum / (avg_factor + eps)
     float x = center_pred[0], t = center_t[i];
     float inv_avg = 1.f / (avg_factor[0] + 1.1920929e-07f);
-    lc = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-    float sg = 1.f / (1.f + expf(-x));
-    dcenter[0] = (sg - t) * inv_avg * grad_scale;
+    if (grp == 0) {
+      lc = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+      float sg = 1.f / (1.f + expf(-x));
+      dcenter[0] = (sg - t) * inv_avg * grad_scale;
+    }
     // ---- box coder on dual numbers (the 12 head outputs are the independent variables)
     Dual bp[12];
 #pragma unroll
@@ -315,19 +321,31 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
       }
     }
     Dual v[9];
-    Dual tot = dconst(0);
-    // group 0: predicted centre, target size + euler
-    for (int c = 0; c < 9; ++c) v[c] = c < 3 ? dec[c] : tb[c];
-    tot = tot + corner_cd(v, tc) * w0;
-    for (int c = 0; c < 9; ++c) v[c] = (c >= 3 && c < 6) ? dec[c] : tb[c];
-    tot = tot + corner_cd(v, tc) * w1;
-    for (int c = 0; c < 9; ++c) v[c] = c >= 6 ? dec[c] : tb[c];
-    tot = tot + corner_cd(v, tc) * w2;
-    tot = tot + corner_cd(dec, tc) * w3;
+    Dual tot;
+    const real wg = grp == 0 ? (real)w0 : (grp == 1 ? (real)w1 : (grp == 2 ? (real)w2 : (real)w3));
+    if (grp == 3) {
+      tot = corner_cd(dec, tc) * wg;
+    } else {
+      // group 0: predicted centre, 1: predicted size, 2: predicted euler; the other components from the target
+      for (int c = 0; c < 9; ++c) v[c] = (c / 3 == grp) ? dec[c] : tb[c];
+      tot = corner_cd(v, tc) * wg;
+    }
     real inv_mean = 1.0 / ((real)P * 8.0);
-    lb = (float)(tot.v * inv_mean);
+    // quad reduction of value + 12 partials (lanes 4j .. 4j+3 are always in the same wave)
+    real red[13];
+    red[0] = tot.v;
 #pragma unroll
-    for (int c = 0; c < 12; ++c) dbbox[c] = (float)(tot.d[c] * inv_mean * (real)grad_scale);
+    for (int c = 0; c < 12; ++c) red[c + 1] = tot.d[c];
+#pragma unroll
+    for (int c = 0; c < 13; ++c) {
+      red[c] += __shfl_xor(red[c], 1, 64);
+      red[c] += __shfl_xor(red[c], 2, 64);
+    }
+    if (grp == 0) {
+      lb = (float)(red[0] * inv_mean);
+#pragma unroll
+      for (int c = 0; c < 12; ++c) dbbox[c] = (float)(red[c + 1] * inv_mean * (real)grad_scale);
+    }
   }
   lc = es_wave_sum(lc);
   lb = es_wave_sum(lb);
@@ -352,8 +370,8 @@ extern "C" int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, cons
     LV.dho[l] = (float*)dho_host[l];
     LV.dbbox[l] = (float*)dbbox_host[l];
   }
-  hipLaunchKernelGGL(k_pos_losses, dim3(es_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, cls_t, n, n_pos_dev, points,
-                     LV, ldh, center_t, bbox_t, avg_factor_dev, grad_scale, group_w[0], group_w[1], group_w[2],
+  hipLaunchKernelGGL(k_pos_losses, dim3(es_cdiv(n * 4, 64)), dim3(64), 0, (hipStream_t)stream, cls_t, n, n_pos_dev,
+                     points, LV, ldh, center_t, bbox_t, avg_factor_dev, grad_scale, group_w[0], group_w[1], group_w[2],
                      group_w[3], loss_acc);
   ES_CHECK_LAUNCH();
   return 0;

@@ -495,7 +495,10 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
                                                           const unsigned short* __restrict__ W,
                                                           const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                           int Cin, int Cout, const float* __restrict__ bias,
-                                                          float* __restrict__ Y, int ldy, int accumulate) {
+                                                          float* __restrict__ Y, int ldy, int accumulate,
+                                                          const float* __restrict__ ep_scale,
+                                                          const float* __restrict__ ep_shift,
+                                                          const float* __restrict__ ep_res, int ep_ldr, int ep_act) {
   constexpr int NF = BNT / 16;
   constexpr int NB = BNT / 64;
   __shared__ __attribute__((aligned(16))) unsigned short As[BM * HLD];
@@ -639,18 +642,23 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
       __syncthreads();
     }
   }
+  // epilogue: optional fused frozen-BN affine (+ residual) (+ ReLU) of the 2-D backbone
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       int col = n0 + nf * 16 + li;
       float bv = bias ? bias[col] : 0.f;
+      float sc = ep_scale ? ep_scale[col] : 1.f, sh = ep_scale ? ep_shift[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = row0 + wv * 32 + mf * 16 + kq * 4 + r;
         if (row < n_out) {
           float* p = Y + (size_t)row * ldy + col;
           float v = acc[mf][nf][r] + bv;
+          if (ep_scale) v = v * sc + sh;
+          if (ep_res) v += ep_res[(size_t)row * ep_ldr + col];
+          if (ep_act) v = fmaxf(v, 0.f);
           *p = accumulate ? (*p + v) : v;
         }
       }
@@ -663,9 +671,10 @@ extern "C" int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cou
          ((long long)K * Cout * Cin < (1ll << 31));
 }
 
-extern "C" int es_spconv_fwd_bf16(const void* Xv, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out,
-                                  int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy,
-                                  int accumulate, void* stream) {
+static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out,
+                                int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy,
+                                int accumulate, const float* ep_scale, const float* ep_shift, const float* ep_res,
+                                int ep_ldr, int ep_act, void* stream) {
   if (n_out <= 0 || Cout <= 0) return 0;
   if (K > MAXK) return -2;
   hipStream_t st = (hipStream_t)stream;
@@ -675,19 +684,20 @@ extern "C" int es_spconv_fwd_bf16(const void* Xv, int x_is_bf16, int ldx, const 
               ((((uintptr_t)Wh) & 15) == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
               ((long long)K * Cout * Cin < (1ll << 31)) && (Cout % 64 == 0);
   if (x_is_bf16 && !fast) return -7;            // bf16 input rows are only supported by the fast kernels
+  if ((ep_scale || ep_res || ep_act) && !fast) return -9;   // fused epilogue: fast kernels only (host checks first)
   dim3 g128(es_cdiv(n_out, BM), Cout / 128), g64(es_cdiv(n_out, BM), Cout / 64);
   if (fast && x_is_bf16 && Cout % 128 == 0) {
     hipLaunchKernelGGL((k_spconv_bf16_fast<128, true>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                       Cout, bias, Y, ldy, accumulate);
+                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else if (fast && x_is_bf16) {
     hipLaunchKernelGGL((k_spconv_bf16_fast<64, true>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                       Cout, bias, Y, ldy, accumulate);
+                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else if (fast && Cout % 128 == 0) {
     hipLaunchKernelGGL((k_spconv_bf16_fast<128, false>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                       Cout, bias, Y, ldy, accumulate);
+                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else if (fast) {
     hipLaunchKernelGGL((k_spconv_bf16_fast<64, false>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                       Cout, bias, Y, ldy, accumulate);
+                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else if (Cout >= 128) {
     hipLaunchKernelGGL(k_spconv_bf16<128>, dim3(es_cdiv(n_out, BM), es_cdiv(Cout, 128)), dim3(256), 0, st, X, ldx, Wh,
                        nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
@@ -697,6 +707,19 @@ extern "C" int es_spconv_fwd_bf16(const void* Xv, int x_is_bf16, int ldx, const 
   }
   ES_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int es_spconv_fwd_bf16(const void* Xv, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out,
+                                  int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy,
+                                  int accumulate, void* stream) {
+  return spconv_fwd_bf16_impl(Xv, x_is_bf16, ldx, W_bf16, nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate,
+                              nullptr, nullptr, nullptr, 0, 0, stream);
+}
+// forward with the frozen-BN affine (+ residual) (+ ReLU) fused into the epilogue:  Y = act((X*W) * scale + shift + res)
+extern "C" int es_spconv_fwd_bf16_affine(const void* Xv, int ldx, const void* W_bf16, const int* nbr, int n_out,
+                                         int n_in, int K, int Cin, int Cout, const float* scale, const float* shift,
+                                         const float* res, int ldr, int act, float* Y, int ldy, void* stream) {
+  return spconv_fwd_bf16_impl(Xv, 0, ldx, W_bf16, nbr, n_out, n_in, K, Cin, Cout, nullptr, Y, ldy, 0, scale, shift, res,
+                              ldr, act, stream);
 }
 
 // f32 [K][A][B] -> bf16 natural [K][A][B] and/or bf16 transposed [K][B][A]
@@ -958,6 +981,33 @@ extern "C" int es_cast_rows_bf16(const float* x, int ldx, int n, int C, void* h,
   int g = es_cdiv(tot, 256);
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(k_cast_rows, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, (size_t)n, C, (unsigned short*)h);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+// all conv kernels of the model in ONE launch: table rows = {src f32 ptr, natural bf16 ptr, transposed bf16 ptr, K, A, B}
+__global__ void k_cast_weights_table(const long long* __restrict__ table, int n_entries) {
+  int e = blockIdx.y;
+  if (e >= n_entries) return;
+  const long long* t = table + (size_t)e * 6;
+  const float* w = (const float*)t[0];
+  unsigned short* nat = (unsigned short*)t[1];
+  unsigned short* tr = (unsigned short*)t[2];
+  int K = (int)t[3], A = (int)t[4], B = (int)t[5];
+  size_t tot = (size_t)K * A * B;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+    int b = (int)(i % B);
+    size_t ka = i / B;
+    int a = (int)(ka % A), k = (int)(ka / A);
+    unsigned short h = (unsigned short)(pack_bf16(w[i], 0.f) & 0xffff);
+    nat[i] = h;
+    tr[((size_t)k * B + b) * A + a] = h;
+  }
+}
+extern "C" int es_cast_weights_table(const void* table_dev, int n_entries, void* stream) {
+  if (n_entries <= 0) return 0;
+  hipLaunchKernelGGL(k_cast_weights_table, dim3(64, n_entries), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)table_dev, n_entries);
   ES_CHECK_LAUNCH();
   return 0;
 }

@@ -99,13 +99,32 @@ __global__ __launch_bounds__(1024) void k_tg_select(const float* __restrict__ ce
     if (threadIdx.x == 0) thr_out[g] = -1.f;
     return;
   }
+  // Most locations are outside the box (value -1): they would all hit one histogram bin (serialised LDS atomics), so
+  // they are counted separately: with fewer than k candidates (inside points, value >= 0) the threshold is -1,
+  // otherwise the k-th largest lies among the candidates and the -1 values can be ignored.
+  __shared__ unsigned int s_cand;
+  if (threadIdx.x == 0) s_cand = 0;
+  __syncthreads();
+  {
+    unsigned int c = 0;
+    for (int i = lb + threadIdx.x; i < le; i += blockDim.x) c += (cg[i] >= 0.f) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cand, c);
+  }
+  __syncthreads();
+  if (s_cand < s_remaining) {
+    if (threadIdx.x == 0) thr_out[g] = -1.f;
+    return;
+  }
   uint32_t pmask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t prefix = s_prefix;
     for (int i = lb + threadIdx.x; i < le; i += blockDim.x) {
-      uint32_t u = f2ord_t(cg[i]);
+      float v = cg[i];
+      if (v < 0.f) continue;
+      uint32_t u = f2ord_t(v);
       if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
     }
     __syncthreads();

@@ -11,7 +11,7 @@ from .hip import P, call, iarr
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return hip.stream()
 
 
 class Var:
@@ -46,17 +46,36 @@ class Param:
         self.d, self.g = d, g
         self.bf_n = self.bf_t = None
         self.bf_step = -1
+        if d.dim() == 3 and d.is_cuda:
+            CONV_PARAMS.append(self)
 
     def bf16(self):
-        """(natural [K][Cin][Cout], transposed [K][Cout][Cin]) bf16 copies, re-made when the weights changed."""
+        """(natural [K][Cin][Cout], transposed [K][Cout][Cin]) bf16 copies, re-made when the weights changed.
+        All registered conv kernels are refreshed together by ONE table-driven launch."""
         if self.bf_step != WEIGHT_VERSION[0]:
-            K, a, b = self.d.shape
-            if self.bf_n is None:
-                self.bf_n = torch.empty((K, a, b), dtype=torch.bfloat16, device=self.d.device)
-                self.bf_t = torch.empty((K, b, a), dtype=torch.bfloat16, device=self.d.device)
-            call('es_cast_weight_bf16', P(self.d), K, a, b, P(self.bf_n), P(self.bf_t), _stream())
-            self.bf_step = WEIGHT_VERSION[0]
+            if self.bf_n is None or self not in _CAST_TABLE.get('set', ()):
+                _build_cast_table()
+            call('es_cast_weights_table', P(_CAST_TABLE['dev']), _CAST_TABLE['n'], _stream())
+            for p in _CAST_TABLE['params']:
+                p.bf_step = WEIGHT_VERSION[0]
         return self.bf_n, self.bf_t
+
+
+CONV_PARAMS = []          # every 3-D (conv kernel) Param living on the GPU
+_CAST_TABLE = {}
+
+
+def _build_cast_table():
+    ps = [p for p in CONV_PARAMS if p.d.dim() == 3]
+    rows = []
+    for p in ps:
+        K, a, b = p.d.shape
+        if p.bf_n is None:
+            p.bf_n = torch.empty((K, a, b), dtype=torch.bfloat16, device=p.d.device)
+            p.bf_t = torch.empty((K, b, a), dtype=torch.bfloat16, device=p.d.device)
+        rows.append([p.d.data_ptr(), p.bf_n.data_ptr(), p.bf_t.data_ptr(), K, a, b])
+    dev = ps[0].d.device
+    _CAST_TABLE.update(dev=torch.tensor(rows, dtype=torch.int64).to(dev), n=len(rows), params=ps, set=set(ps))
 
 
 PRECISION = ['f32']       # 'f32': exact-f32 MFMA everywhere; 'bf16': bf16 MFMA (f32 accumulate) for conv fwd / dgrad
@@ -142,27 +161,59 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
     def bwd():
         if y.g is None:
             return
-        s = _stream()
         if DEBUG_GRADS is not None:
             DEBUG_GRADS[id(y)] = y.g.clone()
-        if w.g is not None:
-            call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), P(y.g),
-                 _ld(y.g), P(nbr), n_out, n_in, K, cin, cout, P(w.g), s)
-        if bias is not None and bias.g is not None:
-            ones = torch.ones((n_out, 1), dtype=torch.float32, device=x.d.device)
-            call('es_spconv_wgrad', P(ones), 1, y.g.data_ptr() + 4 * bias_from, _ld(y.g), 0, n_out, n_out, 1, 1,
-                 cout - bias_from, bias.g.data_ptr() + 4 * bias_from, s)
-        if need_dx and x.rg:
-            g, acc = _grad_target(x, x.d)
-            if bf and cout >= 16 and SHADOW[0] and _ld(y.g) == cout and _use_shadow(n_out, cout, K, cout, cin):
-                call('es_spconv_fwd_bf16', P(y.grad_shadow()), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout,
-                     cin, 0, P(g), _ld(g), acc, s)
-            elif bf and cout >= 16:
-                call('es_spconv_fwd_bf16', P(y.g), 0, _ld(y.g), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0,
-                     P(g), _ld(g), acc, s)
-            else:
-                call('es_spconv_fwd', P(y.g), _ld(y.g), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1,
-                     acc, s)
+        _conv_backward(x, w, nbr, inv, n_out, y, y.g, bias, bias_from, need_dx, bf)
+    TAPE.add(bwd)
+    return y
+
+
+def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf):
+    """wgrad (+ bias grad) and dgrad of a convolution whose output gradient is the row matrix `gy`."""
+    K, cin, cout = w.d.shape
+    n_in = x.d.shape[0]
+    s = _stream()
+    if w.g is not None:
+        call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), P(gy), _ld(gy),
+             P(nbr), n_out, n_in, K, cin, cout, P(w.g), s)
+    if bias is not None and bias.g is not None:
+        ones = torch.ones((n_out, 1), dtype=torch.float32, device=x.d.device)
+        call('es_spconv_wgrad', P(ones), 1, gy.data_ptr() + 4 * bias_from, _ld(gy), 0, n_out, n_out, 1, 1,
+             cout - bias_from, bias.g.data_ptr() + 4 * bias_from, s)
+    if need_dx and x.rg:
+        g, acc = _grad_target(x, x.d)
+        if bf and cout >= 16 and SHADOW[0] and _ld(gy) == cout and _use_shadow(n_out, cout, K, cout, cin):
+            call('es_spconv_fwd_bf16', P(y.grad_shadow()), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout,
+                 cin, 0, P(g), _ld(g), acc, s)
+        elif bf and cout >= 16:
+            call('es_spconv_fwd_bf16', P(gy), 0, _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0,
+                 P(g), _ld(g), acc, s)
+        else:
+            call('es_spconv_fwd', P(gy), _ld(gy), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1, acc, s)
+
+
+def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True):
+    """conv -> frozen-BN affine (+ residual) (+ ReLU) of the 2-D backbone.  In bf16 mode, for shapes the fast kernel
+    takes, this is ONE launch (affine fused into the conv epilogue); otherwise conv() followed by affine_act()."""
+    K, cin, cout = w.d.shape
+    n_in = x.d.shape[0]
+    fused = PRECISION[0] == 'bf16' and hip.raw('es_spconv_bf16_is_fast')(n_in, _ld(x.d), K, cin, cout) == 1
+    if not fused:
+        return affine_act(conv(x, w, nbr, inv, n_out, need_dx=need_dx), scale, shift, act=act, res=res)
+    y = Var(empty((n_out, cout), x.d))
+    call('es_spconv_fwd_bf16_affine', P(x.d), _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(scale),
+         P(shift), P(res.d) if res is not None else 0, _ld(res.d) if res is not None else 0, act, P(y.d), cout, _stream())
+
+    def bwd():
+        if y.g is None:
+            return
+        gr = accr = 0
+        if res is not None and res.rg:
+            t, accr = _grad_target(res, res.d)
+            gr = P(t)
+        gconv = torch.empty_like(y.d)           # gradient w.r.t. the (never materialised) conv output
+        call('es_affine_act_bwd', P(y.g), P(y.d), P(scale), n_out, cout, act, P(gconv), 0, gr, accr, _stream())
+        _conv_backward(x, w, nbr, inv, n_out, y, gconv, None, 0, need_dx, True)
     TAPE.add(bwd)
     return y
 

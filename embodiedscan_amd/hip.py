@@ -84,6 +84,23 @@ def raw(name):
     return _fn[name]
 
 
+_STREAM = [None]
+
+
+def stream():
+    """current HIP stream handle (cached: torch.cuda.current_stream() costs ~7 us per call, and a train step makes
+    ~500 launches); call refresh_stream() after switching streams."""
+    if _STREAM[0] is None:
+        refresh_stream()
+    return _STREAM[0]
+
+
+def refresh_stream():
+    import torch
+    _STREAM[0] = torch.cuda.current_stream().cuda_stream
+    return _STREAM[0]
+
+
 def P(t):
     """device/host pointer of a torch tensor (None -> NULL)."""
     return 0 if t is None else t.data_ptr()

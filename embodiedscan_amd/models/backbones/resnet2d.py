@@ -13,7 +13,7 @@ from ...registry import MODELS
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return hip.stream()
 
 
 class _Grid:
@@ -130,22 +130,22 @@ class ResNet:
                 p = f'layer{li + 1}.{bi}.'
                 stride = 2 if (bi == 0 and li > 0) else 1
                 g_in = gin if bi == 0 else grids[li]
-                o = E.conv(cur, self._par(p + 'conv1.weight'), None, None, cur.d.shape[0])
-                o = E.affine_act(o, *self.fold[p + 'bn1'], act=1)
+                o = E.conv_affine(cur, self._par(p + 'conv1.weight'), None, None, cur.d.shape[0], *self.fold[p + 'bn1'],
+                                  act=1)
                 nbr, inv, n_out, _, _ = g_in.conv_map(3, stride, 1)
-                o = E.conv(o, self._par(p + 'conv2.weight'), nbr, inv, n_out)
-                o = E.affine_act(o, *self.fold[p + 'bn2'], act=1)
-                o = E.conv(o, self._par(p + 'conv3.weight'), None, None, n_out)
+                o = E.conv_affine(o, self._par(p + 'conv2.weight'), nbr, inv, n_out, *self.fold[p + 'bn2'], act=1)
                 if bi == 0:
                     if stride == 1:
-                        idt = E.conv(cur, self._par(p + 'downsample.0.weight'), None, None, n_out)
+                        idt = E.conv_affine(cur, self._par(p + 'downsample.0.weight'), None, None, n_out,
+                                            *self.fold[p + 'downsample.1'], act=0)
                     else:
                         dn, di, _, _, _ = g_in.conv_map(1, stride, 0)
-                        idt = E.conv(cur, self._par(p + 'downsample.0.weight'), dn, di, n_out)
-                    idt = E.affine_act(idt, *self.fold[p + 'downsample.1'], act=0)
+                        idt = E.conv_affine(cur, self._par(p + 'downsample.0.weight'), dn, di, n_out,
+                                            *self.fold[p + 'downsample.1'], act=0)
                 else:
                     idt = cur
-                cur = E.affine_act(o, *self.fold[p + 'bn3'], act=1, res=idt)
+                cur = E.conv_affine(o, self._par(p + 'conv3.weight'), None, None, n_out, *self.fold[p + 'bn3'], act=1,
+                                    res=idt)
                 if not E.TAPE.enabled:
                     cur.rg = False
             if li in self.out_indices:

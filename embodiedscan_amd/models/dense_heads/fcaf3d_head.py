@@ -7,6 +7,7 @@ single fused kernels that also emit the gradients of the head outputs (no autogr
 per-sample host sync inside the loss).
 """
 import torch
+from ... import hip
 from ... import engine as E
 from ... import sparse
 from ...geometry import euler_to_matrix_zxy
@@ -17,7 +18,7 @@ from ...sparse import SparseTensor
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return hip.stream()
 
 
 def get_targets_device(points_per_level, gt_boxes, gt_labels, assign_thr, center_thr):

@@ -5,6 +5,7 @@ embodiedscan/models/detectors/sparse_featfusion_single_stage.py:28-330; `train_s
 BaseModel.train_step (preprocess -> forward(mode='loss') -> parse_losses -> optimiser update).
 """
 import torch
+from ... import hip
 from ... import engine as E
 from ... import sparse
 from ...hip import P, call
@@ -16,7 +17,7 @@ from ..layers.fusion_layers.point_fusion import (batch_point_sample_level, batch
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return hip.stream()
 
 
 @MODELS.register_module()
@@ -77,6 +78,16 @@ class SparseFeatureFusionSingleStage3DDetector:
     def extract_feat(self, batch_inputs_dict, batch_data_samples):
         """sparse_featfusion_single_stage.py:86-221.  Returns 4 SparseTensors with [3-D | image] channels."""
         self._bind()
+        # image features first: views folded into the batch dimension (:130-136), channels-last row matrices.  The 2-D
+        # backbone needs no host round trip, so its ~10 ms of kernels are queued BEFORE the coordinate pipeline, whose
+        # data-dependent row counts force a few stream synchronisations -- those then overlap with the queued work.
+        img = batch_inputs_dict['imgs']
+        B, V = img.shape[:2]
+        H, W = img.shape[-2:]
+        if img.stride(2) != 1:       # (B,V,3,H,W) given NCHW-contiguous: convert once to channels-last
+            img = img.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+        nhwc = img.permute(0, 1, 3, 4, 2).reshape(B * V, H, W, 3)
+        img_feats = self.backbone(nhwc)
         points = batch_inputs_dict['points']
         assert self.use_xyz_feat, 'shipped configs use use_xyz_feat=True'
         pts = [p if (p.dtype == torch.float32 and p.stride(-1) == 1) else p.float().contiguous() for p in points]
@@ -85,14 +96,6 @@ class SparseFeatureFusionSingleStage3DDetector:
         feats = torch.empty((cs.n, 3), dtype=torch.float32, device=allp.device)
         call('es_row_move', P(feats), 3, P(allp), allp.stride(0), P(src), cs.n, 3, 0, _stream())
         x = self.backbone_3d(SparseTensor(cs, E.Var(feats, rg=False)))
-        # image features: views folded into the batch dimension (:130-136), channels-last row matrices
-        img = batch_inputs_dict['imgs']
-        B, V = img.shape[:2]
-        H, W = img.shape[-2:]
-        if img.stride(2) != 1:       # (B,V,3,H,W) given NCHW-contiguous: convert once to channels-last
-            img = img.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
-        nhwc = img.permute(0, 1, 3, 4, 2).reshape(B * V, H, W, 3)
-        img_feats = self.backbone(nhwc)
         metas = [ds.metainfo for ds in batch_data_samples]
         meta_dev = build_fusion_meta(metas, self.coord_type, (H, W), V).to(self.device, non_blocking=True)
         outs = []
@@ -139,6 +142,7 @@ class SparseFeatureFusionSingleStage3DDetector:
     def train_step(self, data, optim_wrapper):
         """mmengine BaseModel.train_step: preprocess, loss forward, sum of the 'loss' entries, backward, update."""
         E.TAPE.clear()
+        hip.refresh_stream()
         if self.data_preprocessor is not None:
             data = self.data_preprocessor(data, True)
         self._bind()

@@ -4,6 +4,7 @@ small device block and launches the fused es_point_sample kernels once per level
 (the reference loops sample x level and replicates the points V times)."""
 import numpy as np
 import torch
+from .... import hip
 from .... import engine as E
 from ....hip import CONSTS, P, call
 
@@ -11,7 +12,7 @@ _OP = {'T': 1, 'S': 2, 'R': 3, 'HF': 4, 'VF': 5}
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return hip.stream()
 
 
 def build_fusion_meta(metas, coord_type, img_pad_shape, n_views):

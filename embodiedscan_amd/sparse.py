@@ -13,7 +13,7 @@ from .hip import P, call
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return hip.stream()
 
 
 def _pow2_cap(n):

@@ -75,9 +75,17 @@ int es_spconv_fwd_bf16(const void* X, int x_is_bf16, int ldx, const void* W_bf16
 /* X may also be a bf16 row matrix (x_is_bf16 = 1, ldx in bf16 elements): the shadow made by es_cast_rows_bf16; only for
  * shapes where es_spconv_bf16_is_fast() returns 1 */
 int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout);
+/* Y = act((X*W) * scale[c] + shift[c] (+ res)): conv2d + frozen BatchNorm2d (+ residual) (+ ReLU) of mmdet.ResNet in one
+ * launch (only for shapes with es_spconv_bf16_is_fast() == 1). */
+int es_spconv_fwd_bf16_affine(const void* X, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in, int K,
+                              int Cin, int Cout, const float* scale, const float* shift, const float* res, int ldr,
+                              int act, float* Y, int ldy, void* stream);
 int es_cast_rows_bf16(const float* x, int ldx, int n, int C, void* h /* (n,C) bf16 */, void* stream);
 /* per-step bf16 copies of an f32 [K][A][B] kernel: natural [K][A][B] and/or transposed [K][B][A] (either may be NULL) */
 int es_cast_weight_bf16(const float* w, int K, int A, int B, void* natural, void* transposed, void* stream);
+/* the same for every conv kernel of the model in one launch: table_dev = n_entries rows of 6 int64
+ * {src f32 ptr, natural bf16 ptr, transposed bf16 ptr, K, A, B} */
+int es_cast_weights_table(const void* table_dev, int n_entries, void* stream);
 /* dW[k] += X[nbr[:,k]]^T . dY */
 int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
                     int Cin, int Cout, float* dW, void* stream);
