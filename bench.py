@@ -39,10 +39,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device('cuda', local_rank % n_dev)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)          # "nccl" == RCCL on ROCm
+        # "nccl" == RCCL on ROCm.  ES_DIST_BACKEND=gloo lets the N>1 code path be exercised on a single-GPU box
+        # (several ranks sharing one device), which RCCL refuses.
+        backend = os.environ.get('ES_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from embodiedscan_amd import engine as E, hip, pipeline
     from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
@@ -87,8 +94,15 @@ def main():
     dt = time.perf_counter() - t0
     hip.PROFILE = None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    in_sync = True
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # data-parallel sanity (outside the timed region): every replica must hold the same parameters
+        chk = det.arena.data[:det.arena.n_train].double().abs().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(((hi - lo) <= 1e-9 * hi.abs()).item())
     dt = float(tmax.item())
 
     if rank != 0:
@@ -133,6 +147,8 @@ def main():
                                     f'100k points/scan, {args.precision} matrix cores with f32 accumulate / f32 master weights, full train step incl. AdamW',
                            scans_per_gpu_per_step=args.batch, views=args.views, parallelism=f'dp{world}'),
                losses={k: round(float(v), 6) for k, v in losses.items()}, roofline=roofline)
+    if world > 1:
+        out['replicas_in_sync'] = in_sync
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(scans[0], det, args)
     print(json.dumps(out))

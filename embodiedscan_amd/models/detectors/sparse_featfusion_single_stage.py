@@ -9,6 +9,7 @@ from ... import hip
 from ... import engine as E
 from ... import sparse
 from ...hip import P, call
+from ...parallel import BucketedGradReducer, is_dist
 from ...params import ParamArena, detector_specs
 from ...registry import MODELS
 from ...sparse import SparseTensor
@@ -88,6 +89,7 @@ class SparseFeatureFusionSingleStage3DDetector:
             img = img.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
         nhwc = img.permute(0, 1, 3, 4, 2).reshape(B * V, H, W, 3)
         img_feats = self.backbone(nhwc)
+        self._tape_marks = [len(E.TAPE.fns)]                   # end of the 2-D backbone's closures
         points = batch_inputs_dict['points']
         assert self.use_xyz_feat, 'shipped configs use use_xyz_feat=True'
         pts = [p if (p.dtype == torch.float32 and p.stride(-1) == 1) else p.float().contiguous() for p in points]
@@ -96,6 +98,7 @@ class SparseFeatureFusionSingleStage3DDetector:
         feats = torch.empty((cs.n, 3), dtype=torch.float32, device=allp.device)
         call('es_row_move', P(feats), 3, P(allp), allp.stride(0), P(src), cs.n, 3, 0, _stream())
         x = self.backbone_3d(SparseTensor(cs, E.Var(feats, rg=False)))
+        self._tape_marks.append(len(E.TAPE.fns))               # end of the 3-D backbone's closures
         metas = [ds.metainfo for ds in batch_data_samples]
         meta_dev = build_fusion_meta(metas, self.coord_type, (H, W), V).to(self.device, non_blocking=True)
         outs = []
@@ -148,6 +151,18 @@ class SparseFeatureFusionSingleStage3DDetector:
         self._bind()
         self.arena.grad.zero_()
         losses = self.forward(data['inputs'], data['data_samples'], mode='loss')
-        E.TAPE.backward()
+        if is_dist():
+            # bucketed gradient all-reduce overlapped with backward: markers fire when the tape (run in reverse) has
+            # finished the head (+ fusion) closures, then the 3-D backbone's, then everything
+            if getattr(self.arena, 'reducer', None) is None:
+                self.arena.reducer = BucketedGradReducer(self.arena)
+            red = self.arena.reducer
+            m2d, m3d = self._tape_marks
+            E.TAPE.fns.insert(m3d, lambda: red.launch(2))      # head gradients complete
+            E.TAPE.fns.insert(m2d, lambda: red.launch(1))      # 3-D backbone gradients complete
+            E.TAPE.backward()
+            red.launch(0)                                      # 2-D backbone gradients complete
+        else:
+            E.TAPE.backward()
         optim_wrapper.update_params(self.arena)
         return losses

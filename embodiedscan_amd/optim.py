@@ -24,7 +24,9 @@ class OptimWrapper:
         if self.m is None:
             self.state_init(arena)
         s = torch.cuda.current_stream().cuda_stream
-        allreduce_mean_(arena.grad)                           # RCCL over xGMI: one flat 346 MB buffer per step
+        reducer = getattr(arena, 'reducer', None)
+        if reducer is None or not reducer.finish():           # buckets launched during backward (parallel.py) ...
+            allreduce_mean_(arena.grad)                       # ... else one flat 346 MB all-reduce (RCCL over xGMI)
         n = arena.n_train
         self.step += 1
         call('es_grad_norm', P(arena.grad), n, P(self.partial), P(self.norm), s)

@@ -26,3 +26,41 @@ def reduce_mean(t):
     t = t.clone() / dist.get_world_size()
     dist.all_reduce(t)
     return t
+
+
+class BucketedGradReducer:
+    """Overlaps the gradient all-reduce with the backward pass.
+
+    The gradient arena is laid out [2-D backbone | 3-D backbone | head]; backward finishes those parts in the opposite
+    order, so each part is all-reduced asynchronously (torch.distributed `async_op=True`: RCCL runs it on its own
+    stream after an event on the compute stream) as soon as the tape has passed the marker behind it: the 86 MB head
+    bucket travels over xGMI under the 3-D backbone's backward, the 254 MB 3-D bucket under the 2-D backbone's.
+    The reference gets the same effect from DDP's bucketed reducer (mmengine MMDistributedDataParallel)."""
+
+    def __init__(self, arena, prefixes=('backbone.', 'backbone_3d.', 'bbox_head.')):
+        self.arena = arena
+        self.ranges = []
+        names = arena.trainable_names()
+        for pre in prefixes:
+            offs = [arena.offsets[n] for n in names if n.startswith(pre)]
+            if offs:
+                self.ranges.append((min(o for o, _ in offs), max(o + ((n + 3) // 4) * 4 for o, n in offs)))
+            else:
+                self.ranges.append((0, 0))
+        self.work = []
+
+    def launch(self, part):
+        """all-reduce (sum) part `part` of the gradient arena without blocking the compute stream"""
+        a, b = self.ranges[part]
+        if is_dist() and b > a:
+            self.work.append(dist.all_reduce(self.arena.grad[a:b], async_op=True))
+
+    def finish(self):
+        """wait for every launched bucket and turn the sums into means; returns True if anything was reduced"""
+        if not self.work:
+            return False
+        for w in self.work:
+            w.wait()
+        self.work = []
+        self.arena.grad.mul_(1.0 / dist.get_world_size())
+        return True

@@ -126,6 +126,23 @@ def _dp_worker():
     avg = reduce_mean(n_pos).clamp(min=1.0)
     assert torch.allclose(avg, torch.tensor([10.5, 1.0, 1.5]))
     assert torch.equal(n_pos, torch.tensor([10.0 + rank, 0.0, 3.0 * rank]))   # not modified in place
+    # bucketed, overlapped variant: buckets are launched in backward-completion order (head, 3-D backbone, 2-D backbone)
+    from embodiedscan_amd.parallel import BucketedGradReducer
+    from embodiedscan_amd.params import detector_specs
+    big = ParamArena([s for s in detector_specs(n_classes=5) if ('layer' not in s.name or '.0.' in s.name)], seed=0)
+    red = BucketedGradReducer(big)
+    assert red.ranges[0][0] == 0 and red.ranges[-1][1] == big.n_train
+    assert all(red.ranges[i][1] == red.ranges[i + 1][0] for i in range(2))
+    g2 = torch.Generator().manual_seed(7 + rank)
+    big.grad.copy_(torch.randn(big.n_train, generator=g2))
+    mine = big.grad.clone()
+    for part in (2, 1, 0):
+        red.launch(part)
+    assert red.finish()
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    assert torch.allclose(big.grad, torch.stack(gathered).mean(0), atol=1e-7)
+    assert not red.finish()                                      # nothing pending any more
     dist.destroy_process_group()
     print(f'rank {rank} ok')
 
