@@ -543,7 +543,7 @@ __global__ void k_affine_act(const float* __restrict__ x, const float* __restric
     int c = (int)(e % C);
     float z = x[e] * scale[c] + shift[c];
     if (res) z += res[e];
-    y[e] = act ? fmaxf(z, 0.f) : z;
+    y[e] = act == 1 ? fmaxf(z, 0.f) : (act == 2 ? (z > 0.f ? z : expf(z) - 1.f) : z);
   }
 }
 extern "C" int es_affine_act_fwd(const float* x, const float* scale, const float* shift, const float* res, size_t n,

@@ -60,7 +60,15 @@ class _BN:
 
     def __call__(self, x, act=0, res=None, training=True):
         n = x.d.shape[0]
-        return E.norm(x, self.w, self.b, [0, n], 1e-5, act=act, res=res, running=self.running if training else None)
+        if training:
+            return E.norm(x, self.w, self.b, [0, n], 1e-5, act=act, res=res, running=self.running)
+        # eval mode (nn.BatchNorm1d.eval()): running statistics folded to scale / shift, forward only
+        C = self.w.d.numel()
+        sc, sh = torch.empty(C, dtype=torch.float32, device=x.d.device), torch.empty(C, dtype=torch.float32, device=x.d.device)
+        call('es_bn_fold', P(self.w.d), P(self.b.d), P(self.running[0]), P(self.running[1]), C, 1e-5, P(sc), P(sh), _stream())
+        y = E.Var(torch.empty_like(x.d), rg=False)
+        call('es_affine_act_fwd', P(x.d), P(sc), P(sh), P(res.d) if res is not None else 0, n, C, act, P(y.d), _stream())
+        return y
 
 
 def conv3(st, w, out_set=None):
@@ -185,6 +193,63 @@ class FCAF3DHeadRotMat:
         return cp, bp, kp, pts
 
     __call__ = forward
+
+    # ------------------------------------------------------------------ predict
+    def predict(self, x, batch_data_samples, rescale=False):
+        """fcaf3d_head.py:1052-1089,1352-1431: list of InstanceData(bboxes_3d, scores_3d, labels_3d)."""
+        from ...structures import EulerDepthInstance3DBoxes, InstanceData
+        cfg = self.test_cfg or {}
+        nms_pre, score_thr, iou_thr = cfg.get('nms_pre', 1000), cfg.get('score_thr', 0.01), cfg.get('iou_thr', 0.5)
+        prev = E.TAPE.enabled
+        E.TAPE.enabled = False
+        try:
+            levels = self._levels(x)
+        finally:
+            E.TAPE.enabled = prev
+        dev = levels[0]['ho'].d.device
+        s = _stream()
+        B = levels[0]['cs'].n_batch
+        C = self.num_classes
+        per_level = []
+        for lv in levels:
+            n = lv['cs'].n
+            ho = lv['ho'].d
+            scores = torch.empty((n, C), dtype=torch.float32, device=dev)
+            maxs = torch.empty(n, dtype=torch.float32, device=dev)
+            call('es_predict_scores', P(ho), ho.shape[1], n, C, P(scores), P(maxs), s)
+            pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            call('es_coords_to_points', P(lv['cs'].coords), n, float(self.voxel_size), P(pts), s)
+            off = lv['cs'].offsets()
+            mask = torch.empty(n, dtype=torch.int32, device=dev)
+            call('es_topk_mask', P(maxs), iarr(off), B, int(nms_pre) if nms_pre > 0 else n + 1, P(mask), s)
+            kept_set, src = sparse.compact(lv['cs'], mask)           # rows kept by the per-sample top-nms_pre
+            boxes = torch.empty((kept_set.n, 9), dtype=torch.float32, device=dev)
+            call('es_decode_boxes', P(pts), P(lv['bbox']), P(src), kept_set.n, P(boxes), s)
+            sc_k = torch.empty((kept_set.n, C), dtype=torch.float32, device=dev)
+            call('es_row_move', P(sc_k), C, P(scores), C, P(src), kept_set.n, C, 0, s)
+            per_level.append((kept_set.offsets(), boxes, sc_k))
+        results = []
+        for b in range(B):
+            bx = torch.cat([bl[off[b]:off[b + 1]] for off, bl, _ in per_level])
+            sc = torch.cat([sl[off[b]:off[b + 1]] for off, _, sl in per_level])
+            M = int(bx.shape[0])
+            keep_idx = torch.empty((C, max(M, 1)), dtype=torch.int32, device=dev)
+            keep_cnt = torch.zeros(C, dtype=torch.int32, device=dev)
+            if M:
+                call('es_nms3d_multiclass', P(bx), P(sc), M, C, float(score_thr), float(iou_thr), P(keep_idx), P(keep_cnt), s)
+            cnt = keep_cnt.cpu().tolist()
+            ob, os_, ol = [], [], []
+            for c in range(C):
+                if cnt[c]:
+                    ids = keep_idx[c, :cnt[c]].long()
+                    ob.append(bx[ids]); os_.append(sc[ids, c])
+                    ol.append(torch.full((cnt[c],), c, dtype=torch.long, device=dev))
+            if ob:
+                rb, rs, rl = torch.cat(ob), torch.cat(os_), torch.cat(ol)
+            else:
+                rb, rs, rl = bx.new_zeros((0, 9)), bx.new_zeros((0,)), torch.zeros((0,), dtype=torch.long, device=dev)
+            results.append(InstanceData(bboxes_3d=EulerDepthInstance3DBoxes(rb), scores_3d=rs, labels_3d=rl))
+        return results
 
     # ------------------------------------------------------------------ loss
     def loss(self, x, batch_data_samples, **kwargs):

@@ -130,8 +130,21 @@ class SparseFeatureFusionSingleStage3DDetector:
         return self.bbox_head.loss(x, batch_data_samples, **kwargs)
 
     def predict(self, batch_inputs_dict, batch_data_samples, **kwargs):
-        raise NotImplementedError("mode='predict' (per-class rotated NMS, SURVEY section 8f N1) is the next row; "
-                                  'this round implements the train step')
+        """sparse_featfusion_single_stage.py:245-280: detections are attached to the data samples as
+        `pred_instances_3d` (and returned)."""
+        was = self.training
+        self.train(False)
+        prev = E.TAPE.enabled
+        E.TAPE.enabled = False
+        try:
+            x = self.extract_feat(batch_inputs_dict, batch_data_samples)
+            results = self.bbox_head.predict(x, batch_data_samples, **kwargs)
+        finally:
+            E.TAPE.enabled = prev
+            self.train(was)
+        for ds, r in zip(batch_data_samples, results):
+            ds.pred_instances_3d = r
+        return batch_data_samples
 
     def forward(self, inputs, data_samples=None, mode='tensor', **kwargs):
         if mode == 'loss':

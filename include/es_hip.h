@@ -175,6 +175,15 @@ int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, const float* po
                   void* const* dho_host, void* const* dbbox_host, int ldh, const float* center_t, const float* bbox_t,
                   const float* avg_factor_dev, float grad_scale, const float* group_w_host, float* loss_acc, void* stream);
 
+/* ---- N1 inference post-processing.  fcaf3d_head.py:1352-1399,1666-1725 + mmcv.ops.nms3d ------------------------- */
+/* scores[i,c] = sigmoid(cls[i,c]) * sigmoid(centerness[i]) from the head output rows (col 0 centerness, 13.. classes) */
+int es_predict_scores(const float* ho, int ldh, int n, int C, float* scores /* (n,C) */, float* max_scores, void* stream);
+/* rows idx[0..m) (NULL = identity): 12-d prediction + location -> 9-DoF box (m,9) */
+int es_decode_boxes(const float* points, const float* bbox, const int* idx, int m, float* out, void* stream);
+/* per-class greedy NMS on the rotated BEV IoU of (x,y,z,dx,dy,dz,alpha); M <= 4096.  keep_idx (C,M), keep_cnt (C) */
+int es_nms3d_multiclass(const float* boxes, const float* scores, int M, int C, float score_thr, float iou_thr,
+                        int* keep_idx, int* keep_cnt, void* stream);
+
 /* ---- optimiser.  configs/detection/mv-det3d_...py:219-223 ------------------------------------------ */
 int es_grad_norm(const float* grad, size_t n, double* partial /* 2048 */, float* norm_out, void* stream);
 int es_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,

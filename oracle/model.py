@@ -323,3 +323,13 @@ def detector_loss(sd, points, imgs, metas, gt_boxes, gt_labels, voxel_size=0.01,
     if return_aux:
         return losses, dict(xs=xs, outs=outs, targets=aux)
     return losses
+
+
+def detector_predict(sd, points, imgs, metas, voxel_size=0.01, thr=100000, nms_pre=1000, score_thr=0.01, iou_thr=0.5):
+    """SparseFeatureFusionSingleStage3DDetector.predict (eval mode): list over samples of (boxes (M,9), scores, labels)."""
+    from . import predict as PR
+    with torch.no_grad():
+        xs = extract_feat(sd, points, imgs, metas, voxel_size, training=False)
+        outs = head_forward(xs, sd, voxel_size=voxel_size, thr=thr, training=False)
+        return [PR.predict_single([outs[l][b] for l in range(len(outs))], nms_pre, score_thr, iou_thr)
+                for b in range(len(points))]
