@@ -531,7 +531,11 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
     if (t == 0) nTaps = __popcll(m);
   }
   __syncthreads();
-  const int nT = nTaps;
+  // tap split (gridDim.z > 1): launches with too few tiles to fill the chip share the tap list among gridDim.z
+  // workgroups which add their partial sums into a pre-zeroed Y with f32 atomics
+  const int nTall = nTaps;
+  const int tBeg = (int)(((long long)nTall * blockIdx.z) / gridDim.z);
+  const int nT = (int)(((long long)nTall * (blockIdx.z + 1)) / gridDim.z);
 
   f32x4 acc[2][NF];
 #pragma unroll
@@ -616,15 +620,15 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
         acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
   };
 
-  if (nT > 0) {
-    It i0 = {0, 0, 0, 0, 0};
+  if (nT > tBeg) {
+    It i0 = {tBeg, 0, 0, 0, 0};
     set_tap(i0);
     It i1 = i0;
     advance(i1);
     Regs r0, r1;
     load_chunk(r0, i0);
     load_chunk(r1, i1);
-    const int npairs = (nT * nC + 1) >> 1;
+    const int npairs = ((nT - tBeg) * nC + 1) >> 1;
     for (int pr = 0; pr < npairs; ++pr) {
       store_chunk(r0);
       __syncthreads();
@@ -655,11 +659,16 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
         int row = row0 + wv * 32 + mf * 16 + kq * 4 + r;
         if (row < n_out) {
           float* p = Y + (size_t)row * ldy + col;
-          float v = acc[mf][nf][r] + bv;
-          if (ep_scale) v = v * sc + sh;
-          if (ep_res) v += ep_res[(size_t)row * ep_ldr + col];
-          if (ep_act) v = fmaxf(v, 0.f);
-          *p = accumulate ? (*p + v) : v;
+          if (gridDim.z > 1) {
+            float v = acc[mf][nf][r] + (blockIdx.z == 0 ? bv : 0.f);
+            if (nT > tBeg || blockIdx.z == 0) atomicAdd(p, v);
+          } else {
+            float v = acc[mf][nf][r] + bv;
+            if (ep_scale) v = v * sc + sh;
+            if (ep_res) v += ep_res[(size_t)row * ep_ldr + col];
+            if (ep_act) v = fmaxf(v, 0.f);
+            *p = accumulate ? (*p + v) : v;
+          }
         }
       }
     }
@@ -686,6 +695,23 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
   if (x_is_bf16 && !fast) return -7;            // bf16 input rows are only supported by the fast kernels
   if ((ep_scale || ep_res || ep_act) && !fast) return -9;   // fused epilogue: fast kernels only (host checks first)
   dim3 g128(es_cdiv(n_out, BM), Cout / 128), g64(es_cdiv(n_out, BM), Cout / 64);
+  if (fast && !(ep_scale || ep_res || ep_act) && K > 1) {
+    // too few workgroups for 256 CUs: split the tap list over gridDim.z (partial sums via f32 atomics into zeroed Y)
+    int wgs = (Cout % 128 == 0) ? g128.x * g128.y : g64.x * g64.y;
+    int split = 1;
+    while (split < 8 && wgs * split < 192 && split * 3 <= K) split *= 2;
+    if (split > 1) {
+      if (!accumulate) {
+        if (ldy == Cout) {
+          hipError_t e = hipMemsetAsync(Y, 0, (size_t)n_out * Cout * 4, st);
+          if (e != hipSuccess) return (int)e;
+        } else {
+          split = 1;                       // strided outputs are not zero-filled here
+        }
+      }
+      g128.z = g64.z = split;
+    }
+  }
   if (fast && x_is_bf16 && Cout % 128 == 0) {
     hipLaunchKernelGGL((k_spconv_bf16_fast<128, true>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
                        Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
@@ -985,29 +1011,49 @@ extern "C" int es_cast_rows_bf16(const float* x, int ldx, int n, int C, void* h,
   return 0;
 }
 
-// all conv kernels of the model in ONE launch: table rows = {src f32 ptr, natural bf16 ptr, transposed bf16 ptr, K, A, B}
-__global__ void k_cast_weights_table(const long long* __restrict__ table, int n_entries) {
-  int e = blockIdx.y;
-  if (e >= n_entries) return;
-  const long long* t = table + (size_t)e * 6;
+// all conv kernels of the model in ONE launch.  table rows = {src f32 ptr, natural bf16 ptr, transposed bf16 ptr, K, A, B,
+// first tile}; one workgroup per 64x64 tile of one tap (found by binary search over the tile prefix), transposed through
+// LDS so that both copies are written with coalesced rows.
+__global__ __launch_bounds__(256) void k_cast_weights_table(const long long* __restrict__ table, int n_entries,
+                                                            int total_tiles) {
+  __shared__ unsigned short tile[64][66];
+  int tid = blockIdx.x;
+  if (tid >= total_tiles) return;
+  int lo = 0, hi = n_entries - 1;
+  while (lo < hi) {                                     // last entry with first_tile <= tid
+    int mid = (lo + hi + 1) >> 1;
+    if (table[(size_t)mid * 7 + 6] <= tid) lo = mid; else hi = mid - 1;
+  }
+  const long long* t = table + (size_t)lo * 7;
   const float* w = (const float*)t[0];
   unsigned short* nat = (unsigned short*)t[1];
   unsigned short* tr = (unsigned short*)t[2];
-  int K = (int)t[3], A = (int)t[4], B = (int)t[5];
-  size_t tot = (size_t)K * A * B;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
-    int b = (int)(i % B);
-    size_t ka = i / B;
-    int a = (int)(ka % A), k = (int)(ka / A);
-    unsigned short h = (unsigned short)(pack_bf16(w[i], 0.f) & 0xffff);
-    nat[i] = h;
-    tr[((size_t)k * B + b) * A + a] = h;
+  int A = (int)t[4], B = (int)t[5];
+  int local = tid - (int)t[6];
+  int ta = (A + 63) >> 6, tb = (B + 63) >> 6;
+  int k = local / (ta * tb), r = local % (ta * tb);
+  int a0 = (r / tb) * 64, b0 = (r % tb) * 64;
+  const size_t base = (size_t)k * A * B;
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {                    // read rows a0+i, columns b0+tx (coalesced along b)
+    int a = a0 + i, b = b0 + tx;
+    unsigned short h = 0;
+    if (a < A && b < B) {
+      h = (unsigned short)(pack_bf16(w[base + (size_t)a * B + b], 0.f) & 0xffff);
+      nat[base + (size_t)a * B + b] = h;
+    }
+    tile[i][tx] = h;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {                    // write rows b0+i of the transposed copy (coalesced along a)
+    int b = b0 + i, a = a0 + tx;
+    if (a < A && b < B) tr[base + (size_t)b * A + a] = tile[tx][i];
   }
 }
-extern "C" int es_cast_weights_table(const void* table_dev, int n_entries, void* stream) {
-  if (n_entries <= 0) return 0;
-  hipLaunchKernelGGL(k_cast_weights_table, dim3(64, n_entries), dim3(256), 0, (hipStream_t)stream,
-                     (const long long*)table_dev, n_entries);
+extern "C" int es_cast_weights_table(const void* table_dev, int n_entries, int total_tiles, void* stream) {
+  if (n_entries <= 0 || total_tiles <= 0) return 0;
+  hipLaunchKernelGGL(k_cast_weights_table, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)table_dev, n_entries, total_tiles);
   ES_CHECK_LAUNCH();
   return 0;
 }

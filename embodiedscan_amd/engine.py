@@ -55,7 +55,7 @@ class Param:
         if self.bf_step != WEIGHT_VERSION[0]:
             if self.bf_n is None or self not in _CAST_TABLE.get('set', ()):
                 _build_cast_table()
-            call('es_cast_weights_table', P(_CAST_TABLE['dev']), _CAST_TABLE['n'], _stream())
+            call('es_cast_weights_table', P(_CAST_TABLE['dev']), _CAST_TABLE['n'], _CAST_TABLE['tiles'], _stream())
             for p in _CAST_TABLE['params']:
                 p.bf_step = WEIGHT_VERSION[0]
         return self.bf_n, self.bf_t
@@ -67,15 +67,16 @@ _CAST_TABLE = {}
 
 def _build_cast_table():
     ps = [p for p in CONV_PARAMS if p.d.dim() == 3]
-    rows = []
+    rows, tiles = [], 0
     for p in ps:
         K, a, b = p.d.shape
         if p.bf_n is None:
             p.bf_n = torch.empty((K, a, b), dtype=torch.bfloat16, device=p.d.device)
             p.bf_t = torch.empty((K, b, a), dtype=torch.bfloat16, device=p.d.device)
-        rows.append([p.d.data_ptr(), p.bf_n.data_ptr(), p.bf_t.data_ptr(), K, a, b])
+        rows.append([p.d.data_ptr(), p.bf_n.data_ptr(), p.bf_t.data_ptr(), K, a, b, tiles])
+        tiles += K * ((a + 63) // 64) * ((b + 63) // 64)
     dev = ps[0].d.device
-    _CAST_TABLE.update(dev=torch.tensor(rows, dtype=torch.int64).to(dev), n=len(rows), params=ps, set=set(ps))
+    _CAST_TABLE.update(dev=torch.tensor(rows, dtype=torch.int64).to(dev), n=len(rows), tiles=tiles, params=ps, set=set(ps))
 
 
 PRECISION = ['f32']       # 'f32': exact-f32 MFMA everywhere; 'bf16': bf16 MFMA (f32 accumulate) for conv fwd / dgrad

@@ -83,9 +83,10 @@ int es_spconv_fwd_bf16_affine(const void* X, int ldx, const void* W_bf16, const 
 int es_cast_rows_bf16(const float* x, int ldx, int n, int C, void* h /* (n,C) bf16 */, void* stream);
 /* per-step bf16 copies of an f32 [K][A][B] kernel: natural [K][A][B] and/or transposed [K][B][A] (either may be NULL) */
 int es_cast_weight_bf16(const float* w, int K, int A, int B, void* natural, void* transposed, void* stream);
-/* the same for every conv kernel of the model in one launch: table_dev = n_entries rows of 6 int64
- * {src f32 ptr, natural bf16 ptr, transposed bf16 ptr, K, A, B} */
-int es_cast_weights_table(const void* table_dev, int n_entries, void* stream);
+/* the same for every conv kernel of the model in one launch: table_dev = n_entries rows of 7 int64
+ * {src f32 ptr, natural bf16 ptr, transposed bf16 ptr, K, A, B, first_tile}; one workgroup per 64x64 tile of a tap,
+ * first_tile = exclusive prefix sum of K*ceil(A/64)*ceil(B/64) */
+int es_cast_weights_table(const void* table_dev, int n_entries, int total_tiles, void* stream);
 /* dW[k] += X[nbr[:,k]]^T . dY */
 int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
                     int Cin, int Cout, float* dW, void* stream);
