@@ -209,3 +209,27 @@ def test_prune_path_and_ragged_batch(setup):
         print(f'prune/ragged/empty-GT {k}: hip {a:.6f} oracle {o:.6f}')
         assert abs(a - o) <= 1e-4 * max(abs(o), 1e-3)
     assert torch.isfinite(det.arena.grad).all()
+
+
+def test_training_reduces_the_loss(setup):
+    """Behavioural check of the whole train step (forward, backward, clip, AdamW on the flat arena): over-fitting one
+    small batch for 12 steps must lower the summed loss substantially in both precision modes."""
+    import os
+    from embodiedscan_amd import engine as E, pipeline
+    from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
+    _, scans, dscans, _ = setup
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_config(os.path.join(root, CFG))
+    for mode in ('f32', 'bf16'):
+        E.PRECISION[0] = mode
+        try:
+            det = build_detector(cfg, device='cuda:0', seed=1).to('cuda:0')
+            optim = build_optim_wrapper(cfg)
+            hist = []
+            for _ in range(12):
+                losses = det.train_step(pipeline.make_batch(dscans), optim)
+                hist.append(sum(float(v) for v in losses.values()))
+        finally:
+            E.PRECISION[0] = 'f32'
+        print(f'{mode}: total loss {hist[0]:.4f} -> {hist[-1]:.4f} (grad norm at last step {float(optim.last_norm):.3f})')
+        assert all(np.isfinite(hist)) and hist[-1] < 0.8 * hist[0], hist
