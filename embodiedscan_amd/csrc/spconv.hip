@@ -778,8 +778,43 @@ extern "C" int es_cast_weight_bf16(const float* w, int K, int A, int B, void* na
 // dW[k][c][n] += sum_j bf16(X[nbr[j,k]][c]) * bf16(dY[j][n]), f32 accumulate.  The reduction runs over rows, so both
 // operands are staged TRANSPOSED ([channel][row], row-contiguous): each thread converts the same channel of two
 // consecutive rows into one packed bf16x2 LDS word, which makes the MFMA fragments 16-byte k-contiguous reads.
-#define GR 32                 // rows per chunk (= MFMA K)
+//
+// Only 20-35 % of the (output row, tap) slots of a 3x3x3 map hold a neighbour, so a workgroup (one tap, one row slice)
+// first COMPACTS its slice: 256 map entries at a time are filtered by ballot into an LDS ring of (row, neighbour)
+// pairs, and the GEMM consumes the ring 32 pairs at a time.  Rows without that neighbour cost one map read, nothing else.
+#define GR 32                 // pairs per chunk (= MFMA K)
 #define GLD (GR + 8)
+#define QCAP 512              // ring capacity (max live: 63 left over + 256 appended)
+
+struct PairRing {
+  int* qj; int* qi; int* wcnt;
+  int head, tail, nextb;      // wave-uniform
+};
+
+// append the valid pairs among rows [nextb, nextb+256) of tap k
+__device__ __forceinline__ void ring_refill(PairRing& q, const int* __restrict__ nbr, int K, int k, int rend, int n_in) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int j = q.nextb + t, idx = -1;
+  if (j < rend) idx = nbr ? nbr[(size_t)j * K + k] : (j < n_in ? j : -1);
+  bool v = idx >= 0;
+  unsigned long long m = __ballot(v);
+  int pre = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) q.wcnt[wv] = __popcll(m);
+  __syncthreads();
+  int c0 = q.wcnt[0], c1 = q.wcnt[1], c2 = q.wcnt[2], c3 = q.wcnt[3];
+  int off = (wv > 0 ? c0 : 0) + (wv > 1 ? c1 : 0) + (wv > 2 ? c2 : 0);
+  if (v) {
+    int pos = (q.tail + off + pre) & (QCAP - 1);
+    q.qj[pos] = j; q.qi[pos] = idx;
+  }
+  q.tail += c0 + c1 + c2 + c3;
+  q.nextb += 256;
+  __syncthreads();
+}
+__device__ __forceinline__ void ring_fill(PairRing& q, const int* __restrict__ nbr, int K, int k, int rend, int n_in) {
+  while (q.tail - q.head < 2 * GR && q.nextb < rend) ring_refill(q, nbr, K, k, rend, n_in);
+}
+
 __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restrict__ X, int ldx,
                                                            const float* __restrict__ dY, int ldy,
                                                            const int* __restrict__ nbr, int n_out, int n_in, int K,
@@ -787,6 +822,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restri
                                                            float* __restrict__ dW) {
   __shared__ __attribute__((aligned(16))) unsigned short As[WM * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[WN * GLD];
+  __shared__ int s_qj[QCAP], s_qi[QCAP], s_wc[4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int nCt = (Cin + WM - 1) / WM;
   const int k = blockIdx.x / nCt, c0 = (blockIdx.x % nCt) * WM;
@@ -797,19 +833,20 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restri
   const bool vecB = ((ldy & 3) == 0) && ((((uintptr_t)dY) & 15) == 0);
   const int rp = t & 15, l4 = (t >> 4) * 4;
   const int li = lane & 15, kq = lane >> 4;
+  PairRing q{s_qj, s_qi, s_wc, 0, 0, rbeg};
 
   f32x4 acc[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   uint32_t ra[4], rb[4];
-  auto load_rows = [&](int r0) {
+  auto load_rows = [&]() {
     float xa[2][4], xb[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int j = r0 + 2 * rp + h;
-      int idx = -1;
-      if (j < rend) idx = nbr ? nbr[(size_t)j * K + k] : (j < n_in ? j : -1);
+      int qq = q.head + 2 * rp + h;
+      int j = -1, idx = -1;
+      if (qq < q.tail) { j = q.qj[qq & (QCAP - 1)]; idx = q.qi[qq & (QCAP - 1)]; }
       int c = c0 + l4, n = n0 + l4;
       if (idx >= 0 && c < Cin) {
         const float* p = X + (size_t)idx * ldx + c;
@@ -843,15 +880,18 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restri
     }
   };
 
-  if (rbeg < rend) load_rows(rbeg);
-  for (int r0 = rbeg; r0 < rend; r0 += GR) {
+  ring_fill(q, nbr, K, k, rend, n_in);
+  load_rows();
+  while (q.head < q.tail) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       *(uint32_t*)&As[(l4 + e) * GLD + 2 * rp] = ra[e];
       *(uint32_t*)&Bs[(l4 + e) * GLD + 2 * rp] = rb[e];
     }
     __syncthreads();
-    if (r0 + GR < rend) load_rows(r0 + GR);
+    q.head += GR;
+    ring_fill(q, nbr, K, k, rend, n_in);
+    load_rows();                                          // next chunk (all-zero past the tail)
     bf16x8_t a = *(const bf16x8_t*)&As[(wv * 16 + li) * GLD + kq * 8];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
@@ -860,6 +900,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restri
     }
     __syncthreads();
   }
+  if (q.tail == 0) return;                                // tap absent from this slice: nothing to add
 #pragma unroll
   for (int nf = 0; nf < 4; ++nf) {
     int col = n0 + nf * 16 + li;
@@ -873,8 +914,9 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restri
 }
 
 // Large-tile bf16 wgrad: one workgroup owns a 128 (C_in) x 128 (C_out) block of dW[k]; each wave a 32 x 128 slab
-// (16 MFMAs per 32-row chunk instead of 4).  For C = 128 layers X[nbr] and dY are then each read exactly once per tap.
-// Fast path only (Cin % 128 == 0, Cout % 128 == 0, aligned, 32-bit offsets); other shapes use k_spconv_wgrad_bf16.
+// (16 MFMAs per 32-pair chunk instead of 4).  For C = 128 layers X[nbr] and dY are then each read exactly once per
+// valid pair.  Fast path only (Cin % 128 == 0, Cout % 128 == 0, aligned, 32-bit offsets); other shapes use
+// k_spconv_wgrad_bf16.
 __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __restrict__ X, int ldx,
                                                                const float* __restrict__ dY, int ldy,
                                                                const int* __restrict__ nbr, int n_out, int n_in, int K,
@@ -882,16 +924,18 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __re
                                                                float* __restrict__ dW) {
   __shared__ __attribute__((aligned(16))) unsigned short As[128 * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[128 * GLD];
+  __shared__ int s_qj[QCAP], s_qi[QCAP], s_wc[4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int nCt = Cin / 128;
   const int k = blockIdx.x / nCt, c0 = (blockIdx.x % nCt) * 128;
   const int n0 = blockIdx.y * 128;
   const int rbeg = blockIdx.z * rows_per_split;
   const int rend = min(n_out, rbeg + rows_per_split);
-  // staging: thread = (row pair rp 0..15, channel group cg 0..15); it converts channels cg*8 .. cg*8+7 of rows
-  // 2rp, 2rp+1 into 8 packed bf16x2 words (same channel, two consecutive rows) -> As[c][2rp..2rp+1]
+  // staging: thread = (pair-of-pairs rp 0..15, channel group cg 0..15); it converts channels cg*8 .. cg*8+7 of ring
+  // entries 2rp, 2rp+1 into 8 packed bf16x2 words (same channel, two consecutive entries) -> As[c][2rp..2rp+1]
   const int rp = t & 15, c8 = (t >> 4) * 8;
   const int li = lane & 15, kq = lane >> 4;
+  PairRing q{s_qj, s_qi, s_wc, 0, 0, rbeg};
   f32x4 acc[2][8];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -900,15 +944,15 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __re
 
   float4 xa[2][2], xb[2][2];
   int va[2];
-  auto load_rows = [&](int r0) {
+  auto load_rows = [&]() {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int j = r0 + 2 * rp + h;
-      int jj = j < rend ? j : rbeg;                       // unconditional loads, masked when packed
-      int idx = nbr ? nbr[(size_t)jj * K + k] : jj;
-      va[h] = (j < rend) && (idx >= 0);
-      const float4* px = (const float4*)(X + (idx >= 0 ? idx : 0) * ldx + c0 + c8);
-      const float4* py = (const float4*)(dY + jj * ldy + n0 + c8);
+      int qq = q.head + 2 * rp + h;
+      va[h] = qq < q.tail;
+      int j = va[h] ? q.qj[qq & (QCAP - 1)] : rbeg;       // unconditional loads, masked when packed
+      int idx = va[h] ? q.qi[qq & (QCAP - 1)] : 0;
+      const float4* px = (const float4*)(X + idx * ldx + c0 + c8);
+      const float4* py = (const float4*)(dY + j * ldy + n0 + c8);
       xa[h][0] = px[0]; xa[h][1] = px[1];
       xb[h][0] = py[0]; xb[h][1] = py[1];
     }
@@ -926,11 +970,14 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __re
       *(uint32_t*)&Bs[(c8 + e) * GLD + 2 * rp] = pack_bf16(q0, q1);
     }
   };
-  if (rbeg < rend) load_rows(rbeg);
-  for (int r0 = rbeg; r0 < rend; r0 += GR) {
+  ring_fill(q, nbr, K, k, rend, n_in);
+  load_rows();
+  while (q.head < q.tail) {
     store_rows();
     __syncthreads();
-    load_rows(r0 + GR);                                   // rows past the slice are masked (and clamped) inside
+    q.head += GR;
+    ring_fill(q, nbr, K, k, rend, n_in);
+    load_rows();                                          // entries past the tail are masked (and clamped) inside
     bf16x8_t a[2], b[8];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) a[mf] = *(const bf16x8_t*)&As[(wv * 32 + mf * 16 + li) * GLD + kq * 8];
@@ -943,6 +990,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __re
         acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
     __syncthreads();
   }
+  if (q.tail == 0) return;
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
