@@ -566,11 +566,46 @@ __global__ void k_affine_act_bwd(const float* __restrict__ dy, const float* __re
     if (dres) dres[e] = acc_r ? dres[e] + g : g;
   }
 }
+// C % 4 == 0 and 16-byte aligned pointers: four channels per thread
+__global__ void k_affine_act_bwd4(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                  const float4* __restrict__ scale, size_t n4, int C4, int act,
+                                  float4* __restrict__ dx, int acc_x, float4* __restrict__ dres, int acc_r) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+    float4 g = dy[e];
+    if (act) {
+      float4 v = y[e];
+      if (!(v.x > 0.f)) g.x = 0.f;
+      if (!(v.y > 0.f)) g.y = 0.f;
+      if (!(v.z > 0.f)) g.z = 0.f;
+      if (!(v.w > 0.f)) g.w = 0.f;
+    }
+    if (dx) {
+      float4 s = scale[e % C4];
+      float4 o = {g.x * s.x, g.y * s.y, g.z * s.z, g.w * s.w};
+      if (acc_x) { float4 p = dx[e]; o.x = p.x + o.x; o.y = p.y + o.y; o.z = p.z + o.z; o.w = p.w + o.w; }
+      dx[e] = o;
+    }
+    if (dres) {
+      float4 o = g;
+      if (acc_r) { float4 p = dres[e]; o.x = p.x + g.x; o.y = p.y + g.y; o.z = p.z + g.z; o.w = p.w + g.w; }
+      dres[e] = o;
+    }
+  }
+}
 extern "C" int es_affine_act_bwd(const float* dy, const float* y, const float* scale, size_t n, int C, int act,
                                  float* dx, int acc_x, float* dres, int acc_r, void* stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_affine_act_bwd, dim3(8192), dim3(256), 0, (hipStream_t)stream, dy, y, scale, n, C, act, dx,
-                     acc_x, dres, acc_r);
+  bool v4 = (C % 4 == 0) && !((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)scale) | ((uintptr_t)dx) |
+                               ((uintptr_t)dres)) & 15);
+  if (v4) {
+    size_t n4 = n * (size_t)(C / 4);
+    int g = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_affine_act_bwd4, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float4*)dy,
+                       (const float4*)y, (const float4*)scale, n4, C / 4, act, (float4*)dx, acc_x, (float4*)dres, acc_r);
+  } else {
+    hipLaunchKernelGGL(k_affine_act_bwd, dim3(8192), dim3(256), 0, (hipStream_t)stream, dy, y, scale, n, C, act, dx,
+                       acc_x, dres, acc_r);
+  }
   ES_CHECK_LAUNCH();
   return 0;
 }

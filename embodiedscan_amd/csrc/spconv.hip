@@ -335,7 +335,10 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
                                                      const unsigned short* __restrict__ W /* [K][N][Kr] bf16 */,
                                                      const int* __restrict__ nbr, int n_out, int n_in, int K, int Cin,
                                                      int Cout, const float* __restrict__ bias, float* __restrict__ Y,
-                                                     int ldy, int accumulate) {
+                                                     int ldy, int accumulate,
+                                                     const float* __restrict__ ep_scale,
+                                                     const float* __restrict__ ep_shift,
+                                                     const float* __restrict__ ep_res, int ep_ldr, int ep_act) {
   constexpr int NF = BNT / 16;      // 16-wide output fragments per wave
   constexpr int NB = BNT / 64;      // 16-byte weight pieces per thread and chunk
   __shared__ __attribute__((aligned(16))) unsigned short As[BM * HLD];
@@ -472,12 +475,20 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
       int col = n0 + nf * 16 + li;
       if (col >= Cout) continue;
       float bv = bias ? bias[col] : 0.f;
+      float sc = ep_scale ? ep_scale[col] : 1.f, sh = ep_shift ? ep_shift[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = row0 + wv * 32 + mf * 16 + kq * 4 + r;
         if (row < n_out) {
           float* p = Y + (size_t)row * ldy + col;
           float v = acc[mf][nf][r] + bv;
+          if (ep_scale) v = v * sc + sh;                  // same fused frozen-BN epilogue as the fast kernels
+          if (ep_act == 3) {                              // gate: pass v only where ep_res > 0 (fused ReLU backward)
+            if (!(ep_res[(size_t)row * ep_ldr + col] > 0.f)) v = 0.f;
+          } else {
+            if (ep_res) v += ep_res[(size_t)row * ep_ldr + col];
+            if (ep_act) v = fmaxf(v, 0.f);
+          }
           *p = accumulate ? (*p + v) : v;
         }
       }
@@ -507,6 +518,9 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
   __shared__ int taps[32];
   __shared__ int nTaps;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  // (An XCD-aware row-tile order -- contiguous eighths of the tiles per XCD -- was measured: no gain, the halo rows
+  // already hit in MALL; plain order kept.)
+  const int bz = blockIdx.z;
   const int row0 = blockIdx.x * BM, n0 = blockIdx.y * BNT;
 
   __shared__ int tapFlag[32];
@@ -534,8 +548,8 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
   // tap split (gridDim.z > 1): launches with too few tiles to fill the chip share the tap list among gridDim.z
   // workgroups which add their partial sums into a pre-zeroed Y with f32 atomics
   const int nTall = nTaps;
-  const int tBeg = (int)(((long long)nTall * blockIdx.z) / gridDim.z);
-  const int nT = (int)(((long long)nTall * (blockIdx.z + 1)) / gridDim.z);
+  const int tBeg = (int)(((long long)nTall * bz) / gridDim.z);
+  const int nT = (int)(((long long)nTall * (bz + 1)) / gridDim.z);
 
   f32x4 acc[2][NF];
 #pragma unroll
@@ -653,20 +667,24 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
     for (int nf = 0; nf < NF; ++nf) {
       int col = n0 + nf * 16 + li;
       float bv = bias ? bias[col] : 0.f;
-      float sc = ep_scale ? ep_scale[col] : 1.f, sh = ep_scale ? ep_shift[col] : 0.f;
+      float sc = ep_scale ? ep_scale[col] : 1.f, sh = ep_shift ? ep_shift[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = row0 + wv * 32 + mf * 16 + kq * 4 + r;
         if (row < n_out) {
           float* p = Y + (size_t)row * ldy + col;
           if (gridDim.z > 1) {
-            float v = acc[mf][nf][r] + (blockIdx.z == 0 ? bv : 0.f);
-            if (nT > tBeg || blockIdx.z == 0) atomicAdd(p, v);
+            float v = acc[mf][nf][r] + (bz == 0 ? bv : 0.f);
+            if (nT > tBeg || bz == 0) atomicAdd(p, v);
           } else {
             float v = acc[mf][nf][r] + bv;
             if (ep_scale) v = v * sc + sh;
-            if (ep_res) v += ep_res[(size_t)row * ep_ldr + col];
-            if (ep_act) v = fmaxf(v, 0.f);
+            if (ep_act == 3) {                            // gate: pass v only where ep_res > 0 (fused ReLU backward)
+              if (!(ep_res[(size_t)row * ep_ldr + col] > 0.f)) v = 0.f;
+            } else {
+              if (ep_res) v += ep_res[(size_t)row * ep_ldr + col];
+              if (ep_act) v = fmaxf(v, 0.f);
+            }
             *p = accumulate ? (*p + v) : v;
           }
         }
@@ -693,7 +711,6 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
               ((((uintptr_t)Wh) & 15) == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
               ((long long)K * Cout * Cin < (1ll << 31)) && (Cout % 64 == 0);
   if (x_is_bf16 && !fast) return -7;            // bf16 input rows are only supported by the fast kernels
-  if ((ep_scale || ep_res || ep_act) && !fast) return -9;   // fused epilogue: fast kernels only (host checks first)
   dim3 g128(es_cdiv(n_out, BM), Cout / 128), g64(es_cdiv(n_out, BM), Cout / 64);
   if (fast && !(ep_scale || ep_res || ep_act) && K > 1) {
     // too few workgroups for 256 CUs: split the tap list over gridDim.z (partial sums via f32 atomics into zeroed Y)
@@ -726,10 +743,10 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
                        Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else if (Cout >= 128) {
     hipLaunchKernelGGL(k_spconv_bf16<128>, dim3(es_cdiv(n_out, BM), es_cdiv(Cout, 128)), dim3(256), 0, st, X, ldx, Wh,
-                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
+                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else {
     hipLaunchKernelGGL(k_spconv_bf16<64>, dim3(es_cdiv(n_out, BM), es_cdiv(Cout, 64)), dim3(256), 0, st, X, ldx, Wh,
-                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate);
+                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   }
   ES_CHECK_LAUNCH();
   return 0;
@@ -786,16 +803,30 @@ extern "C" int es_cast_weight_bf16(const float* w, int K, int A, int B, void* na
 #define GLD (GR + 8)
 #define QCAP 512              // ring capacity (max live: 63 left over + 256 appended)
 
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private L2.  All
+// (tap, channel-tile) workgroups of one row slice re-read the same X / dY rows, so they are mapped to the SAME XCD,
+// consecutively: XCD c walks slices c, c+8, c+16, ... and inside a slice all gridDim.x * gridDim.y tiles.  The launch
+// pads gridDim.z to a multiple of 8; slices >= n_slices exit.
+__device__ __forceinline__ bool xcd_slice_order(int n_slices, int& bx, int& by, int& bz) {
+  const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int c = L & 7, s = L >> 3, per = gridDim.x * gridDim.y;
+  const int inner = s % per;
+  bz = (s / per) * 8 + c;
+  bx = inner % gridDim.x;
+  by = inner / gridDim.x;
+  return bz < n_slices;
+}
+
 struct PairRing {
   int* qj; int* qi; int* wcnt;
   int head, tail, nextb;      // wave-uniform
 };
 
 // append the valid pairs among rows [nextb, nextb+256) of tap k
-__device__ __forceinline__ void ring_refill(PairRing& q, const int* __restrict__ nbr, int K, int k, int rend, int n_in) {
+__device__ __forceinline__ void ring_refill(PairRing& q, const int* __restrict__ nbr, long long sj, long long koff, int rend, int n_in) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   int j = q.nextb + t, idx = -1;
-  if (j < rend) idx = nbr ? nbr[(size_t)j * K + k] : (j < n_in ? j : -1);
+  if (j < rend) idx = nbr ? nbr[j * sj + koff] : (j < n_in ? j : -1);
   bool v = idx >= 0;
   unsigned long long m = __ballot(v);
   int pre = __popcll(m & ((1ull << lane) - 1ull));
@@ -811,23 +842,25 @@ __device__ __forceinline__ void ring_refill(PairRing& q, const int* __restrict__
   q.nextb += 256;
   __syncthreads();
 }
-__device__ __forceinline__ void ring_fill(PairRing& q, const int* __restrict__ nbr, int K, int k, int rend, int n_in) {
-  while (q.tail - q.head < 2 * GR && q.nextb < rend) ring_refill(q, nbr, K, k, rend, n_in);
+__device__ __forceinline__ void ring_fill(PairRing& q, const int* __restrict__ nbr, long long sj, long long koff, int rend, int n_in) {
+  while (q.tail - q.head < 2 * GR && q.nextb < rend) ring_refill(q, nbr, sj, koff, rend, n_in);
 }
 
 __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restrict__ X, int ldx,
                                                            const float* __restrict__ dY, int ldy,
                                                            const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                            int Cin, int Cout, int rows_per_split,
-                                                           float* __restrict__ dW) {
+                                                           int n_slices, float* __restrict__ dW) {
   __shared__ __attribute__((aligned(16))) unsigned short As[WM * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[WN * GLD];
   __shared__ int s_qj[QCAP], s_qi[QCAP], s_wc[4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int nCt = (Cin + WM - 1) / WM;
-  const int k = blockIdx.x / nCt, c0 = (blockIdx.x % nCt) * WM;
-  const int n0 = blockIdx.y * WN;
-  const int rbeg = blockIdx.z * rows_per_split;
+  int bx, by, bz;
+  if (!xcd_slice_order(n_slices, bx, by, bz)) return;
+  const int k = bx / nCt, c0 = (bx % nCt) * WM;
+  const int n0 = by * WN;
+  const int rbeg = bz * rows_per_split;
   const int rend = min(n_out, rbeg + rows_per_split);
   const bool vecA = ((ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
   const bool vecB = ((ldy & 3) == 0) && ((((uintptr_t)dY) & 15) == 0);
@@ -921,21 +954,24 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __re
                                                                const float* __restrict__ dY, int ldy,
                                                                const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                                int Cin, int Cout, int rows_per_split,
-                                                               float* __restrict__ dW) {
+                                                               int n_slices, float* __restrict__ dW) {
   __shared__ __attribute__((aligned(16))) unsigned short As[128 * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[128 * GLD];
   __shared__ int s_qj[QCAP], s_qi[QCAP], s_wc[4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int nCt = Cin / 128;
-  const int k = blockIdx.x / nCt, c0 = (blockIdx.x % nCt) * 128;
-  const int n0 = blockIdx.y * 128;
-  const int rbeg = blockIdx.z * rows_per_split;
+  int bx, by, bz;
+  if (!xcd_slice_order(n_slices, bx, by, bz)) return;
+  const int k = bx / nCt, c0 = (bx % nCt) * 128;
+  const int n0 = by * 128;
+  const int rbeg = bz * rows_per_split;
   const int rend = min(n_out, rbeg + rows_per_split);
   // staging: thread = (pair-of-pairs rp 0..15, channel group cg 0..15); it converts channels cg*8 .. cg*8+7 of ring
   // entries 2rp, 2rp+1 into 8 packed bf16x2 words (same channel, two consecutive entries) -> As[c][2rp..2rp+1]
   const int rp = t & 15, c8 = (t >> 4) * 8;
   const int li = lane & 15, kq = lane >> 4;
   PairRing q{s_qj, s_qi, s_wc, 0, 0, rbeg};
+  const long long sj = K, koff = k;
   f32x4 acc[2][8];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -970,13 +1006,13 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __re
       *(uint32_t*)&Bs[(c8 + e) * GLD + 2 * rp] = pack_bf16(q0, q1);
     }
   };
-  ring_fill(q, nbr, K, k, rend, n_in);
+  ring_fill(q, nbr, sj, koff, rend, n_in);
   load_rows();
   while (q.head < q.tail) {
     store_rows();
     __syncthreads();
     q.head += GR;
-    ring_fill(q, nbr, K, k, rend, n_in);
+    ring_fill(q, nbr, sj, koff, rend, n_in);
     load_rows();                                          // entries past the tail are masked (and clamped) inside
     bf16x8_t a[2], b[8];
 #pragma unroll
@@ -1012,15 +1048,15 @@ extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, in
              ((long long)n_out * ldy < (1ll << 31)) && n_out >= 512;
   if (big) {
     int base = K * (Cin / 128) * (Cout / 128);
-    int splits = es_cdiv(2048, base);
+    int splits = es_cdiv(8192, base);
     int max_splits = es_cdiv(n_out, 512);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
     splits = es_cdiv(n_out, rows_per_split);
-    dim3 grid(K * (Cin / 128), Cout / 128, splits);
+    dim3 grid(K * (Cin / 128), Cout / 128, es_cdiv(splits, 8) * 8);
     hipLaunchKernelGGL(k_spconv_wgrad_bf16_big, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out,
-                       n_in, K, Cin, Cout, rows_per_split, dW);
+                       n_in, K, Cin, Cout, rows_per_split, splits, dW);
     ES_CHECK_LAUNCH();
     return 0;
   }
@@ -1031,9 +1067,9 @@ extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, in
   if (splits < 1) splits = 1;
   int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
   splits = es_cdiv(n_out, rows_per_split);
-  dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), splits);
+  dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), es_cdiv(splits, 8) * 8);
   hipLaunchKernelGGL(k_spconv_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out, n_in,
-                     K, Cin, Cout, rows_per_split, dW);
+                     K, Cin, Cout, rows_per_split, splits, dW);
   ES_CHECK_LAUNCH();
   return 0;
 }

@@ -17,11 +17,13 @@ def _stream():
 class Var:
     """A row matrix (N, C) f32 on the device with an optional gradient (and lazily made bf16 shadows of both, the
     gather sources of the bf16 convolution kernels)."""
-    __slots__ = ('d', 'g', 'rg', 'dh', 'gh')
+    __slots__ = ('d', 'g', 'rg', 'dh', 'gh', 'gate', 'gated')
 
     def __init__(self, d, rg=True):
         self.d, self.g, self.rg = d, None, rg
         self.dh = self.gh = None
+        self.gate = None        # folded-BN scale of the fused conv+BN+ReLU that produced this Var (see conv_affine)
+        self.gated = False      # True: .g already is the gradient w.r.t. the producer's (pre-BN) conv output
 
     def shadow(self):
         if self.dh is None:
@@ -169,8 +171,10 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
     return y
 
 
-def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf):
-    """wgrad (+ bias grad) and dgrad of a convolution whose output gradient is the row matrix `gy`."""
+def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, gate=None):
+    """wgrad (+ bias grad) and dgrad of a convolution whose output gradient is the row matrix `gy`.
+    gate: folded-BN scale of x's producer -- the dgrad launch then also applies that layer's ReLU mask and BN scale
+    (x is its only consumer), leaving x.g as the gradient of the producer's raw conv output."""
     K, cin, cout = w.d.shape
     n_in = x.d.shape[0]
     s = _stream()
@@ -181,7 +185,12 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf):
         ones = torch.ones((n_out, 1), dtype=torch.float32, device=x.d.device)
         call('es_spconv_wgrad', P(ones), 1, gy.data_ptr() + 4 * bias_from, _ld(gy), 0, n_out, n_out, 1, 1,
              cout - bias_from, bias.g.data_ptr() + 4 * bias_from, s)
-    if need_dx and x.rg:
+    if need_dx and x.rg and gate is not None:
+        assert x.g is None and bf, 'gated dgrad: x must have exactly one consumer'
+        x.g, x.gated = torch.empty_like(x.d), True
+        call('es_spconv_fwd_bf16_affine', P(gy), _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, P(gate), 0,
+             P(x.d), _ld(x.d), 3, P(x.g), _ld(x.g), s)
+    elif need_dx and x.rg:
         g, acc = _grad_target(x, x.d)
         if bf and cout >= 16 and SHADOW[0] and _ld(gy) == cout and _use_shadow(n_out, cout, K, cout, cin):
             call('es_spconv_fwd_bf16', P(y.grad_shadow()), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout,
@@ -193,28 +202,38 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf):
             call('es_spconv_fwd', P(gy), _ld(gy), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1, acc, s)
 
 
-def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True):
-    """conv -> frozen-BN affine (+ residual) (+ ReLU) of the 2-D backbone.  In bf16 mode, for shapes the fast kernel
-    takes, this is ONE launch (affine fused into the conv epilogue); otherwise conv() followed by affine_act()."""
+def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True, sole_consumer=False):
+    """conv -> frozen-BN affine (+ residual) (+ ReLU) of the 2-D backbone.  In bf16 mode this is ONE launch (affine
+    fused into the conv epilogue); in f32 mode conv() followed by affine_act().
+    sole_consumer: promise that x feeds nothing but this conv; if x itself came out of a fused conv+BN+ReLU, its
+    ReLU/BN backward is then folded into this conv's data-gradient launch."""
     K, cin, cout = w.d.shape
     n_in = x.d.shape[0]
-    fused = PRECISION[0] == 'bf16' and hip.raw('es_spconv_bf16_is_fast')(n_in, _ld(x.d), K, cin, cout) == 1
-    if not fused:
+    if PRECISION[0] != 'bf16':
         return affine_act(conv(x, w, nbr, inv, n_out, need_dx=need_dx), scale, shift, act=act, res=res)
     y = Var(empty((n_out, cout), x.d))
     call('es_spconv_fwd_bf16_affine', P(x.d), _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(scale),
          P(shift), P(res.d) if res is not None else 0, _ld(res.d) if res is not None else 0, act, P(y.d), cout, _stream())
 
+    if act == 1 and res is None:
+        y.gate = scale
+    gate = x.gate if sole_consumer else None
+
     def bwd():
         if y.g is None:
             return
-        gr = accr = 0
-        if res is not None and res.rg:
-            t, accr = _grad_target(res, res.d)
-            gr = P(t)
-        gconv = torch.empty_like(y.d)           # gradient w.r.t. the (never materialised) conv output
-        call('es_affine_act_bwd', P(y.g), P(y.d), P(scale), n_out, cout, act, P(gconv), 0, gr, accr, _stream())
-        _conv_backward(x, w, nbr, inv, n_out, y, gconv, None, 0, need_dx, True)
+        if DEBUG_GRADS is not None:
+            DEBUG_GRADS[id(y)] = y.g.clone()
+        if y.gated:                             # the consumer's dgrad launch already applied mask and scale
+            gconv = y.g
+        else:
+            gr = accr = 0
+            if res is not None and res.rg:
+                t, accr = _grad_target(res, res.d)
+                gr = P(t)
+            gconv = torch.empty_like(y.d)       # gradient w.r.t. the (never materialised) conv output
+            call('es_affine_act_bwd', P(y.g), P(y.d), P(scale), n_out, cout, act, P(gconv), 0, gr, accr, _stream())
+        _conv_backward(x, w, nbr, inv, n_out, y, gconv, None, 0, need_dx, True, gate)
     TAPE.add(bwd)
     return y
 

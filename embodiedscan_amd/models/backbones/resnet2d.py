@@ -133,7 +133,8 @@ class ResNet:
                 o = E.conv_affine(cur, self._par(p + 'conv1.weight'), None, None, cur.d.shape[0], *self.fold[p + 'bn1'],
                                   act=1)
                 nbr, inv, n_out, _, _ = g_in.conv_map(3, stride, 1)
-                o = E.conv_affine(o, self._par(p + 'conv2.weight'), nbr, inv, n_out, *self.fold[p + 'bn2'], act=1)
+                o = E.conv_affine(o, self._par(p + 'conv2.weight'), nbr, inv, n_out, *self.fold[p + 'bn2'], act=1,
+                                  sole_consumer=True)
                 if bi == 0:
                     if stride == 1:
                         idt = E.conv_affine(cur, self._par(p + 'downsample.0.weight'), None, None, n_out,
@@ -145,7 +146,7 @@ class ResNet:
                 else:
                     idt = cur
                 cur = E.conv_affine(o, self._par(p + 'conv3.weight'), None, None, n_out, *self.fold[p + 'bn3'], act=1,
-                                    res=idt)
+                                    res=idt, sole_consumer=True)
                 if not E.TAPE.enabled:
                     cur.rg = False
             if li in self.out_indices:

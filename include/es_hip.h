@@ -76,7 +76,9 @@ int es_spconv_fwd_bf16(const void* X, int x_is_bf16, int ldx, const void* W_bf16
  * shapes where es_spconv_bf16_is_fast() returns 1 */
 int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout);
 /* Y = act((X*W) * scale[c] + shift[c] (+ res)): conv2d + frozen BatchNorm2d (+ residual) (+ ReLU) of mmdet.ResNet in one
- * launch (only for shapes with es_spconv_bf16_is_fast() == 1). */
+ * launch (any shape; the tap-split of under-filled launches is not applied to fused calls).  act: 0 none, 1 ReLU,
+ * 3 "gate": Y = (res > 0) ? (X*W) * scale[c] : 0 -- the data-gradient conv of layer i+1 fused with the ReLU / frozen-BN
+ * backward of layer i (res = layer i's output, scale = its folded BN scale; shift may be NULL). */
 int es_spconv_fwd_bf16_affine(const void* X, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in, int K,
                               int Cin, int Cout, const float* scale, const float* shift, const float* res, int ldr,
                               int act, float* Y, int ldy, void* stream);

@@ -133,18 +133,44 @@ def test_train_step_bf16_mode(setup):
     det, scans, dscans, sd = setup
     batch = pipeline.make_batch(dscans)
     points_host = [p.cpu() for p in batch['inputs']['points']]
-    E.PRECISION[0] = 'bf16'
+    grads, seeds = {}, None
     try:
-        E.TAPE.clear()
-        E.WEIGHT_VERSION[0] += 1
-        data = det.data_preprocessor(batch, True)
-        det._bind()
-        det.arena.grad.zero_()
-        losses = det.forward(data['inputs'], data['data_samples'], mode='loss')
-        E.TAPE.backward()
-        torch.cuda.synchronize()
+        for mode in ('f32', 'bf16'):
+            E.PRECISION[0] = mode
+            E.TAPE.clear()
+            E.WEIGHT_VERSION[0] += 1
+            data = det.data_preprocessor(batch, True)
+            det._bind()
+            det.arena.grad.zero_()
+            losses = det.forward(data['inputs'], data['data_samples'], mode='loss')
+            # The box-loss gradient is ill-conditioned at random init (normalising near-zero 6-D rotation vectors,
+            # nearest-corner assignment of the Chamfer loss): bf16-sized changes of the head outputs change it by ~70 %.
+            # To check the bf16 BACKWARD kernels, both passes therefore start from the same head-output gradient.
+            if mode == 'f32':
+                seeds = [lv['ho'].g.clone() for lv in det.bbox_head.last_levels]
+            else:
+                for lv, seed in zip(det.bbox_head.last_levels, seeds):
+                    assert lv['ho'].g.shape == seed.shape
+                    lv['ho'].g.copy_(seed)
+            E.TAPE.backward()
+            torch.cuda.synchronize()
+            grads[mode] = {k: v.clone() for k, v in det.arena.grad_dict().items()}
     finally:
         E.PRECISION[0] = 'f32'
+    # gradients of the bf16 path (fused epilogues, gated dgrad, bf16 wgrad) against the f32 HIP path: relative L2 per
+    # parameter tensor.  Through ~100 layers of batch-normalised random-init network the bf16 rounding of activations
+    # (2^-9) plus flipped ReLU gates grows to ~10 % at the far end (measured: median 0.10-0.14, max 0.28-0.41;
+    # a wrong kernel gives ~1).  Stated tolerance: median 0.25, worst 0.6.
+    rel = {}
+    for k, g32 in grads['f32'].items():
+        n = float(g32.norm())
+        if n > 1e-6:
+            rel[k] = float((grads['bf16'][k] - g32).norm()) / n
+    worst = max(rel, key=rel.get)
+    med = float(np.median(list(rel.values())))
+    print(f'bf16 vs f32 gradients (same head-output gradient): {len(rel)} tensors, median rel-L2 {med:.2e} (tol 2.5e-1), '
+          f'worst {rel[worst]:.2e} at {worst} (tol 6e-1)')
+    assert med < 0.25 and rel[worst] < 0.6
     imgs = torch.stack([OM.preprocess_img(torch.from_numpy(s['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])
                         for s in scans])
     with torch.no_grad():
