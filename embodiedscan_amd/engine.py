@@ -63,6 +63,13 @@ class Param:
         return self.bf_n, self.bf_t
 
 
+def refresh_weight_copies():
+    """bf16 mode: bring the bf16 copies of every registered conv kernel up to date now (one launch on the current
+    stream) instead of lazily at the first convolution that needs them."""
+    if PRECISION[0] == 'bf16' and CONV_PARAMS:
+        CONV_PARAMS[-1].bf16()
+
+
 CONV_PARAMS = []          # every 3-D (conv kernel) Param living on the GPU
 _CAST_TABLE = {}
 

@@ -61,6 +61,9 @@ class ResNet:
         self.arena, self.prefix = arena, prefix
         self._params = {}
         self.refresh()
+        for k, v in arena.p.items():             # all conv kernels up front (one complete bf16 cast table from step 1)
+            if k.startswith(prefix) and v.dim() == 3 and k != prefix + 'conv1.weight':
+                self._par(k[len(prefix):])
         return self
 
     def _par(self, n):
