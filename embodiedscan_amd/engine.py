@@ -5,6 +5,8 @@ torch is used for device memory (caching allocator) and the current HIP stream o
 Every forward function registers one closure on the tape; `TAPE.backward()` replays them in
 reverse.  Gradients w.r.t. parameters accumulate straight into the flat gradient arena.
 """
+import os
+
 import torch
 from . import hip
 from .hip import P, call, iarr
@@ -107,6 +109,7 @@ class Tape:
     def backward(self):
         for fn in reversed(self.fns):
             fn()
+        join_wgrad_streams()
         self.fns = []
 
     def clear(self):
@@ -114,6 +117,43 @@ class Tape:
 
 
 TAPE = Tape()
+
+# Weight gradients hang off the backward chain (nothing downstream reads them before the optimiser), so they are
+# launched on a second stream paired with the compute stream: the chain of data-gradient launches does not wait for them
+# and under-filled launches of both kinds overlap.
+WGRAD_ASYNC = [os.environ.get('ES_WGRAD_ASYNC', '1') != '0']
+_WGRAD_STREAMS = {}     # compute-stream handle -> dict(s=torch Stream, h=handle, fork=Event, join=Event, used=bool)
+_KEEP = []              # temporaries read by queued weight-gradient launches; released by the final join
+
+
+def _wgrad_stream(*keep):
+    """handle of the weight-gradient stream of the current compute stream, made to wait for everything queued on the
+    compute stream so far; `keep`: tensors the launch reads that nobody else references."""
+    if not WGRAD_ASYNC[0]:
+        return _stream()
+    h = _stream()
+    ws = _WGRAD_STREAMS.get(h)
+    if ws is None:
+        st = torch.cuda.Stream()
+        ws = _WGRAD_STREAMS[h] = dict(s=st, h=st.cuda_stream, fork=torch.cuda.Event(), join=torch.cuda.Event(), used=False)
+    ws['fork'].record(hip.stream_obj())
+    ws['s'].wait_event(ws['fork'])
+    ws['used'] = True
+    _KEEP.extend(keep)
+    return ws['h']
+
+
+def join_wgrad_streams(final=True):
+    """make the current stream wait for every queued weight-gradient launch (before the gradients are reduced or
+    consumed by the optimiser)"""
+    cur = hip.stream_obj()
+    for ws in _WGRAD_STREAMS.values():
+        if ws['used']:
+            ws['join'].record(ws['s'])
+            cur.wait_event(ws['join'])
+            ws['used'] = False
+    if final:
+        _KEEP.clear()
 DEBUG_GRADS = None      # tools/debug_grads.py sets a dict: id(Var) -> snapshot of its gradient when consumed
 
 
@@ -178,6 +218,19 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
     return y
 
 
+_ONES = {}
+
+
+def _ones(n, device):
+    """(>= n, 1) column of ones (cached, grows): the left operand of the bias-gradient GEMM"""
+    t = _ONES.get(device)
+    if t is None or t.shape[0] < n:
+        if t is not None:
+            _KEEP.append(t)
+        t = _ONES[device] = torch.ones((max(n, 1 << 16), 1), dtype=torch.float32, device=device)
+    return t
+
+
 def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, gate=None):
     """wgrad (+ bias grad) and dgrad of a convolution whose output gradient is the row matrix `gy`.
     gate: folded-BN scale of x's producer -- the dgrad launch then also applies that layer's ReLU mask and BN scale
@@ -185,13 +238,15 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     K, cin, cout = w.d.shape
     n_in = x.d.shape[0]
     s = _stream()
+    if w.g is not None or (bias is not None and bias.g is not None):
+        sw = _wgrad_stream(gy, x.d)
     if w.g is not None:
         call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), P(gy), _ld(gy),
-             P(nbr), n_out, n_in, K, cin, cout, P(w.g), s)
+             P(nbr), n_out, n_in, K, cin, cout, P(w.g), sw)
     if bias is not None and bias.g is not None:
-        ones = torch.ones((n_out, 1), dtype=torch.float32, device=x.d.device)
+        ones = _ones(n_out, x.d.device)
         call('es_spconv_wgrad', P(ones), 1, gy.data_ptr() + 4 * bias_from, _ld(gy), 0, n_out, n_out, 1, 1,
-             cout - bias_from, bias.g.data_ptr() + 4 * bias_from, s)
+             cout - bias_from, bias.g.data_ptr() + 4 * bias_from, sw)
     if need_dx and x.rg and gate is not None:
         assert x.g is None and bf, 'gated dgrad: x must have exactly one consumer'
         x.g, x.gated = torch.empty_like(x.d), True
@@ -266,11 +321,12 @@ def gen_conv_transpose(x, w):
             return
         s = _stream()
         g, acc = _grad_target(x, x.d) if x.rg else (None, 0)
+        sw = _wgrad_stream(y.g, x.d) if w.g is not None else s
         for k in range(8):
             gy = y.g.data_ptr() + 4 * k * cout
             if w.g is not None:
                 call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), gy,
-                     8 * cout, 0, n, n, 1, cin, cout, w.g.data_ptr() + 4 * k * cin * cout, s)
+                     8 * cout, 0, n, n, 1, cin, cout, w.g.data_ptr() + 4 * k * cin * cout, sw)
             if g is not None and bf:
                 call('es_spconv_fwd_bf16', gy, 0, 8 * cout, w.bf16()[0].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cout,
                      cin, 0, P(g), _ld(g), 1 if (acc or k > 0) else 0, s)

@@ -85,6 +85,7 @@ def raw(name):
 
 
 _STREAM = [None]
+_STREAM_OBJ = [None]
 
 
 def stream():
@@ -97,8 +98,16 @@ def stream():
 
 def refresh_stream():
     import torch
-    _STREAM[0] = torch.cuda.current_stream().cuda_stream
+    _STREAM_OBJ[0] = torch.cuda.current_stream()
+    _STREAM[0] = _STREAM_OBJ[0].cuda_stream
     return _STREAM[0]
+
+
+def stream_obj():
+    """the torch.cuda.Stream behind stream() (cached the same way)"""
+    if _STREAM_OBJ[0] is None:
+        refresh_stream()
+    return _STREAM_OBJ[0]
 
 
 def P(t):

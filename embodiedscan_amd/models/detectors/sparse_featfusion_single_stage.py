@@ -225,6 +225,7 @@ class SparseFeatureFusionSingleStage3DDetector:
         for fn in reversed(fns[m3d:]):
             fn()
         if red is not None:
+            E.join_wgrad_streams(final=False)
             red.launch(2)                                      # head gradients complete
         img, pts = fns[:m2d][::-1], fns[m2d:m3d][::-1]
         if self.two_streams and self.device.type == 'cuda' and img and pts:
@@ -237,15 +238,18 @@ class SparseFeatureFusionSingleStage3DDetector:
                 for fn in pts[len(pts) * c // nchunk: len(pts) * (c + 1) // nchunk]:
                     fn()
             if red is not None:
+                E.join_wgrad_streams(final=False)
                 red.launch(1)                                  # 3-D backbone gradients complete
             self._join_side()
         else:
             for fn in pts:
                 fn()
             if red is not None:
+                E.join_wgrad_streams(final=False)
                 red.launch(1)
             for fn in img:
                 fn()
+        E.join_wgrad_streams()
         if red is not None:
             red.launch(0)                                      # 2-D backbone gradients complete
         E.TAPE.fns = []
