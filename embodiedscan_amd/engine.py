@@ -118,6 +118,47 @@ class Tape:
 
 TAPE = Tape()
 
+# ------------------------------------------------------------------ side stream
+# Independent branches of the step (image branch vs. point branch, samples of the loss) are issued on two HIP streams so
+# that under-filled launches overlap.  Discipline that keeps the caching allocator safe without record_stream():
+# (1) the side stream always starts ordered after everything queued on the main stream (fork event), (2) the main stream
+# joins before it touches anything the side stream produced, (3) tensors crossing streams stay referenced until the
+# join, so a block is only recycled by its own stream after the other stream's readers were ordered before it.
+TWO_STREAMS = [os.environ.get('ES_TWO_STREAMS', '1') != '0']
+_SIDE = {}
+
+
+class side_stream:
+    """with side_stream(): ... -- run the enclosed launches on the side stream.  fork=True (default): ordered after
+    everything queued on the current stream so far; fork=False: just continue on the side stream."""
+
+    def __init__(self, fork=True):
+        self.fork = fork
+
+    def __enter__(self):
+        if not _SIDE:
+            _SIDE.update(s=torch.cuda.Stream(), fork=torch.cuda.Event(), join=torch.cuda.Event())
+        if self.fork:
+            _SIDE['fork'].record(hip.stream_obj())
+            _SIDE['s'].wait_event(_SIDE['fork'])
+        self.ctx = torch.cuda.stream(_SIDE['s'])
+        self.ctx.__enter__()
+        hip.refresh_stream()
+        return self
+
+    def __exit__(self, *exc):
+        _SIDE['join'].record(_SIDE['s'])
+        r = self.ctx.__exit__(*exc)
+        hip.refresh_stream()
+        return r
+
+
+def join_side():
+    """the current (main) stream waits for everything issued on the side stream so far"""
+    if _SIDE:
+        hip.stream_obj().wait_event(_SIDE['join'])
+
+
 # Weight gradients hang off the backward chain (nothing downstream reads them before the optimiser), so they are
 # launched on a second stream paired with the compute stream: the chain of data-gradient launches does not wait for them
 # and under-filled launches of both kinds overlap.

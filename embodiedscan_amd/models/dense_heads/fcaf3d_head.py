@@ -21,9 +21,35 @@ def _stream():
     return hip.stream()
 
 
-def get_targets_device(points_per_level, gt_boxes, gt_labels, assign_thr, center_thr):
+def upload_gts(gts, dev):
+    """Ground truth of a whole batch -> device in ONE copy from pinned memory (issued before the head runs, so the
+    loss section never waits on a host-to-device transfer).  gts: [(boxes (G,9), labels (G,))] per sample.
+    Returns per sample (boxes (G,9) f32, R(-euler) (G,9) f32, labels (G,) int32) device views."""
+    Gs = [int(b.shape[0]) for b, _ in gts]
+    tot = sum(Gs)
+    host = torch.empty(max(tot, 1) * 19, dtype=torch.float32, pin_memory=dev.type == 'cuda')
+    hb, hr, hl = host[:tot * 9].view(tot, 9), host[tot * 9:tot * 18].view(tot, 9), host[tot * 18:tot * 19].view(torch.int32)
+    a = 0
+    for (b, l), G in zip(gts, Gs):
+        if G:
+            bh = b.detach().float().cpu()
+            hb[a:a + G] = bh
+            hr[a:a + G] = euler_to_matrix_zxy(-bh[:, 6:9]).reshape(G, 9)
+            hl[a:a + G] = l.detach().to(torch.int32).cpu()
+        a += G
+    d = host.to(dev, non_blocking=True)
+    db, dr, dl = d[:tot * 9].view(tot, 9), d[tot * 9:tot * 18].view(tot, 9), d[tot * 18:tot * 19].view(torch.int32)
+    out, a = [], 0
+    for G in Gs:
+        out.append((db[a:a + G], dr[a:a + G], dl[a:a + G]))
+        a += G
+    return out
+
+
+def get_targets_device(points_per_level, gt_boxes, gt_labels, assign_thr, center_thr, dev_gt=None):
     """A12 for one sample.  points_per_level: device (n_l,3) f32 tensors (or one concatenated tensor +
-    level offsets as a tuple).  gt_boxes (G,9) / gt_labels (G,) may live on the host.
+    level offsets as a tuple).  gt_boxes (G,9) / gt_labels (G,) may live on the host; dev_gt: the sample's entry of
+    upload_gts() when the batch was uploaded ahead of time.
     Returns center_t (N,), bbox_t (N,9), cls_t (N,) int32, box_idx (N,) int32, n_pos (1,) int32 (device)."""
     if isinstance(points_per_level, tuple):
         points, level_off = points_per_level
@@ -34,11 +60,14 @@ def get_targets_device(points_per_level, gt_boxes, gt_labels, assign_thr, center
             level_off.append(level_off[-1] + int(p.shape[0]))
     dev = points.device
     N, G = int(points.shape[0]), int(gt_boxes.shape[0])
-    boxes_h = gt_boxes.detach().float().cpu()
-    rot_neg = euler_to_matrix_zxy(-boxes_h[:, 6:9]).reshape(G, 9) if G else torch.zeros((0, 9))
-    boxes = boxes_h.to(dev).contiguous()
-    rot = rot_neg.to(dev).contiguous()
-    labels = gt_labels.detach().to(torch.int32).to(dev).contiguous()
+    if dev_gt is not None:
+        boxes, rot, labels = dev_gt
+    else:
+        boxes_h = gt_boxes.detach().float().cpu()
+        rot_neg = euler_to_matrix_zxy(-boxes_h[:, 6:9]).reshape(G, 9) if G else torch.zeros((0, 9))
+        boxes = boxes_h.to(dev).contiguous()
+        rot = rot_neg.to(dev).contiguous()
+        labels = gt_labels.detach().to(torch.int32).to(dev).contiguous()
     n_lvl = len(level_off) - 1
     scratch = torch.empty(max(G, 1) * max(N, 1) + (n_lvl + 2) * max(G, 1) + 8, dtype=torch.float32, device=dev)
     center_t = torch.empty(N, dtype=torch.float32, device=dev)
@@ -256,11 +285,15 @@ class FCAF3DHeadRotMat:
         """fcaf3d_head.py:1022-1050.  Returns dict(loss_center, loss_bbox, loss_cls) (device scalars) and
         seeds the gradients of the head outputs on the tape (call engine.TAPE.backward())."""
         gts = [(ds.gt_instances_3d.bboxes_3d, ds.gt_instances_3d.labels_3d) for ds in batch_data_samples]
+        gts = [(getattr(b, 'tensor', b), l) for b, l in gts]
+        dev_gts = upload_gts(gts, x[0].F.d.device)             # before the head's launches are queued
         levels = self._levels(x)
-        return self.loss_by_levels(levels, [(getattr(b, 'tensor', b), l) for b, l in gts])
+        return self.loss_by_levels(levels, gts, dev_gts)
 
-    def loss_by_levels(self, levels, gts):
+    def loss_by_levels(self, levels, gts, dev_gts=None):
         dev = levels[0]['ho'].d.device
+        if dev_gts is None:
+            dev_gts = upload_gts(gts, dev)
         B = len(gts)
         n_lvl = len(levels)
         s = _stream()
@@ -273,23 +306,37 @@ class FCAF3DHeadRotMat:
             lv['dho'] = torch.zeros_like(lv['ho'].d)
             lv['dbbox'] = torch.zeros_like(lv['bbox'])
         # phase 1: targets per sample (points of a sample concatenated fine->coarse, fcaf3d_head.py:1595-1600)
-        per = []
+        # Samples are independent until the avg_factor below and again after it: odd samples go to the side stream.
+        two = E.TWO_STREAMS[0] and B > 1
+        on_main = [b for b in range(B) if not (two and b % 2)]
+        on_side = [b for b in range(B) if two and b % 2]
+        per = [None] * B
         n_pos_all = torch.empty(B, dtype=torch.int32, device=dev)
-        for b in range(B):
+
+        def targets(b):
             lo = [0]
             for l in range(n_lvl):
                 lo.append(lo[-1] + offs[l][b + 1] - offs[l][b])
             pts = torch.cat([levels[l]['points'][offs[l][b]:offs[l][b + 1]] for l in range(n_lvl)])
             ct, bt, kt, bi, npos = get_targets_device((pts, lo), gts[b][0], gts[b][1], self.pts_assign_threshold,
-                                                      self.pts_center_threshold)
+                                                      self.pts_center_threshold, dev_gt=dev_gts[b])
             n_pos_all[b:b + 1] = npos
-            per.append((pts, lo, ct, bt, kt, npos))
+            per[b] = (pts, lo, ct, bt, kt, npos)
+
+        if on_side:
+            with E.side_stream():
+                for b in on_side:
+                    targets(b)
+        for b in on_main:
+            targets(b)
+        if on_side:
+            E.join_side()
         # phase 2: avg_factor = max(reduce_mean(n_pos), 1) for all samples in ONE collective
         avg = reduce_mean(n_pos_all.float()).clamp(min=1.0).contiguous()
         # phase 3: losses + gradients, per (sample, level) slice, no host sync
         loss_cls = torch.zeros(B, dtype=torch.float32, device=dev)
         loss_acc = torch.zeros((B, 2), dtype=torch.float32, device=dev)
-        partial = torch.empty(2048, dtype=torch.float64, device=dev)
+        partials = [torch.empty(2048, dtype=torch.float64, device=dev) for _ in range(2)]   # one scratch per stream
         gw = [w * self.bbox_loss_weight for w in self.decouple_weights]
         if not self.decouple_bbox_loss:
             gw = [0., 0., 0., self.bbox_loss_weight]
@@ -297,7 +344,8 @@ class FCAF3DHeadRotMat:
             gw = gw[:3] + [0.]
         gwa = farr(gw)
         gscale = 1.0 / B
-        for b in range(B):
+        def sample_losses(b, partial):
+            s = _stream()
             pts, lo, ct, bt, kt, npos = per[b]
             ncol = levels[0]['ho'].d.shape[1]
             hos, bbs, dhos, dbbs = [], [], [], []
@@ -315,6 +363,16 @@ class FCAF3DHeadRotMat:
                          P(partial), loss_cls.data_ptr() + 4 * b, s)
             call('es_pos_losses', P(kt), lo[-1], P(npos), P(pts), n_lvl, iarr(lo), parr(hos), parr(bbs), parr(dhos),
                  parr(dbbs), ncol, P(ct), P(bt), avg.data_ptr() + 4 * b, gscale, gwa, loss_acc.data_ptr() + 8 * b, s)
+
+        if on_side:
+            with E.side_stream():
+                for b in on_side:
+                    sample_losses(b, partials[1])
+        for b in on_main:
+            sample_losses(b, partials[0])
+        if on_side:
+            E.join_side()
+        s = _stream()
         # chain through exp/Scale/clamp and seed the head GEMM gradients
         for lv in levels:
             n = lv['cs'].n

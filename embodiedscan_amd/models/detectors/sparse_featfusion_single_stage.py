@@ -4,9 +4,6 @@ Same registry name, constructor arguments, `forward(inputs, data_samples, mode)`
 embodiedscan/models/detectors/sparse_featfusion_single_stage.py:28-330; `train_step` follows mmengine's
 BaseModel.train_step (preprocess -> forward(mode='loss') -> parse_losses -> optimiser update).
 """
-import os
-from contextlib import contextmanager
-
 import torch
 from ... import hip
 from ... import engine as E
@@ -47,34 +44,8 @@ class SparseFeatureFusionSingleStage3DDetector:
         self.training = True
         self._bound = False
         # The image branch (2-D backbone forward, and its backward) and the point branch (coordinate pipeline + 3-D
-        # backbone) only meet in the fusion layer, so they are issued on two HIP streams: the deep, under-filled sparse
-        # launches of the point branch then run in the shadow of the image branch's full-chip launches.
-        self.two_streams = os.environ.get('ES_TWO_STREAMS', '1') != '0'
-        self._side = None
-
-    # ------------------------------------------------------------------ streams
-    @contextmanager
-    def _on_side_stream(self):
-        """Run the enclosed launches on the side stream, ordered after everything queued on the main stream so far.
-        Tensors allocated inside belong to the side stream's pool; the caller joins with _join_side() before the main
-        stream touches them, and every Var stays referenced by the tape until the step ends, so no block is recycled
-        while the other stream can still read it."""
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
-        main = torch.cuda.current_stream()
-        self._ev_fork.record(main)
-        self._side.wait_event(self._ev_fork)
-        with torch.cuda.stream(self._side):
-            hip.refresh_stream()
-            try:
-                yield
-            finally:
-                self._ev_join.record(self._side)
-        hip.refresh_stream()
-
-    def _join_side(self):
-        torch.cuda.current_stream().wait_event(self._ev_join)
+        # backbone) only meet in the fusion layer, so they are issued on two HIP streams (engine.side_stream): the deep,
+        # under-filled sparse launches of the point branch then run in the shadow of the image branch's full-chip ones.
 
     # ------------------------------------------------------------------ parameters
     def to(self, device):
@@ -120,10 +91,10 @@ class SparseFeatureFusionSingleStage3DDetector:
         if img.stride(2) != 1:       # (B,V,3,H,W) given NCHW-contiguous: convert once to channels-last
             img = img.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
         nhwc = img.permute(0, 1, 3, 4, 2).reshape(B * V, H, W, 3)
-        forked = self.two_streams and self.device.type == 'cuda'
+        forked = E.TWO_STREAMS[0]
         if forked:
             E.refresh_weight_copies()            # one cast launch for all kernels, before the branches split
-            with self._on_side_stream():
+            with E.side_stream():
                 img_feats = self.backbone(nhwc)
         else:
             img_feats = self.backbone(nhwc)
@@ -140,7 +111,7 @@ class SparseFeatureFusionSingleStage3DDetector:
         metas = [ds.metainfo for ds in batch_data_samples]
         meta_dev = build_fusion_meta(metas, self.coord_type, (H, W), V).to(self.device, non_blocking=True)
         if forked:
-            self._join_side()                    # image features are needed from here on
+            E.join_side()                        # image features are needed from here on
         outs = []
         for lvl, xl in enumerate(x):
             f2d, Hf, Wf = img_feats[lvl]
@@ -228,11 +199,11 @@ class SparseFeatureFusionSingleStage3DDetector:
             E.join_wgrad_streams(final=False)
             red.launch(2)                                      # head gradients complete
         img, pts = fns[:m2d][::-1], fns[m2d:m3d][::-1]
-        if self.two_streams and self.device.type == 'cuda' and img and pts:
+        if E.TWO_STREAMS[0] and img and pts:
             # issue the two branches in alternating chunks so that neither queue runs dry while the host is busy
             nchunk = 6
             for c in range(nchunk):
-                with self._on_side_stream() if c == 0 else self._resume_side():
+                with E.side_stream(fork=(c == 0)):
                     for fn in img[len(img) * c // nchunk: len(img) * (c + 1) // nchunk]:
                         fn()
                 for fn in pts[len(pts) * c // nchunk: len(pts) * (c + 1) // nchunk]:
@@ -240,7 +211,7 @@ class SparseFeatureFusionSingleStage3DDetector:
             if red is not None:
                 E.join_wgrad_streams(final=False)
                 red.launch(1)                                  # 3-D backbone gradients complete
-            self._join_side()
+            E.join_side()
         else:
             for fn in pts:
                 fn()
@@ -253,14 +224,3 @@ class SparseFeatureFusionSingleStage3DDetector:
         if red is not None:
             red.launch(0)                                      # 2-D backbone gradients complete
         E.TAPE.fns = []
-
-    @contextmanager
-    def _resume_side(self):
-        """continue issuing on the side stream without a new dependency on the main stream"""
-        with torch.cuda.stream(self._side):
-            hip.refresh_stream()
-            try:
-                yield
-            finally:
-                self._ev_join.record(self._side)
-        hip.refresh_stream()
