@@ -74,8 +74,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # time EXACTLY `steps` steps; the convolution engine launches are bracketed by HIP events on the same stream
-    prof = {'names': {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_wgrad', 'es_spconv_wgrad_bf16'}, 'records': [],
+    # time EXACTLY `steps` steps; the convolution engine launches are bracketed by HIP events recorded on the stream
+    # each kernel is launched on (the step runs on four streams: point branch, image branch, and their wgrad streams)
+    prof = {'names': {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_affine', 'es_spconv_wgrad',
+                      'es_spconv_wgrad_bf16'}, 'records': [],
             'event': lambda: torch.cuda.Event(enable_timing=True)}
     t0 = time.perf_counter()
     for it in range(args.steps):
@@ -127,7 +129,7 @@ def main():
             nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
         pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
         tot_flop += 2.0 * pairs * cin * cout
-        wbytes = 2 if name.endswith('bf16') and not name.startswith('es_spconv_wgrad') else 4
+        wbytes = 2 if 'bf16' in name and not name.startswith('es_spconv_wgrad') else 4
         tot_bytes += pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wbytes
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=K_PEAK_HBM, unit='GB/s',
@@ -137,7 +139,9 @@ def main():
                     launches_per_step=n_launch, kernel_ms_per_step=round(tot_ms, 3),
                     algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                     note='algorithmic bytes = sum over launches of P*(Cin+Cout)*4 + K*Cin*Cout*sizeof(w), P = valid '
-                         '(output,tap) pairs; algorithmic flops = 2*P*Cin*Cout; traffic: see profiles/ (PMC), null here')
+                         '(output,tap) pairs; algorithmic flops = 2*P*Cin*Cout; launch durations are HIP-event times on the '
+                         'launch stream under the concurrent 4-stream schedule (kernels of different streams share the chip, '
+                         'so the sum exceeds wall time); traffic: see profiles/ (PMC), null here')
 
     out = dict(metric='scans/sec (train step) mv-3ddet, 20x(480x640) RGB-D views', value=round(world * args.batch * args.steps / dt, 4),
                unit='scans/s', n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -66,13 +66,26 @@ def register_map(nbr):
     return nbr
 
 
+_EXT_STREAMS = {}
+
+
+def _stream_of(handle):
+    """torch view of a raw hipStream_t (events must be recorded on the stream the kernel is launched on)"""
+    import torch
+    st = _EXT_STREAMS.get(handle)
+    if st is None:
+        st = _EXT_STREAMS[handle] = torch.cuda.ExternalStream(handle) if handle else torch.cuda.default_stream()
+    return st
+
+
 def call(name, *args):
     prof = PROFILE
     if prof is not None and name in prof['names']:
         e0, e1 = prof['event'](), prof['event']()
-        e0.record()
+        st = _stream_of(args[-1])                 # every entry point takes its hipStream_t last
+        e0.record(st)
         rc = _fn[name](*args)
-        e1.record()
+        e1.record(st)
         prof['records'].append((name, e0, e1, args))          # bench.py resolves PAIRS[map pointer] right after
     else:
         rc = _fn[name](*args)
