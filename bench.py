@@ -117,26 +117,52 @@ def main():
     # utilisation: it is bandwidth bound, so the roofline is quoted against HBM bandwidth with the ALGORITHMIC bytes of
     # sum over launches of P*(Cin + Cout)*4 + weights, P = valid (output, tap) pairs of the kernel map.
     K_PEAK_HBM = 8000.0               # GB/s, MI355X_MICROARCH.md
-    tot_ms, tot_flop, tot_bytes, n_launch = 0.0, 0.0, 0.0, 0
-    for name, e0, e1, a, pairs_dev in prof['records']:
-        tot_ms += e0.elapsed_time(e1)
-        n_launch += 1
-        if name == 'es_spconv_fwd_bf16':
-            nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
-        elif not name.startswith('es_spconv_wgrad'):
-            nbr, n_out, n_in, K, cin, cout = a[3], a[4], a[5], a[6], a[7], a[8]
-        else:
-            nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
-        pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
-        tot_flop += 2.0 * pairs * cin * cout
-        wbytes = 2 if 'bf16' in name and not name.startswith('es_spconv_wgrad') else 4
-        tot_bytes += pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wbytes
+
+    def engine_totals(records):
+        tot_ms, tot_flop, tot_bytes, n_launch = 0.0, 0.0, 0.0, 0
+        for name, e0, e1, a, pairs_dev in records:
+            tot_ms += e0.elapsed_time(e1)
+            n_launch += 1
+            if name == 'es_spconv_fwd_bf16':
+                nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
+            elif not name.startswith('es_spconv_wgrad'):
+                nbr, n_out, n_in, K, cin, cout = a[3], a[4], a[5], a[6], a[7], a[8]
+            else:
+                nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
+            pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
+            tot_flop += 2.0 * pairs * cin * cout
+            wbytes = 2 if 'bf16' in name and not name.startswith('es_spconv_wgrad') else 4
+            tot_bytes += pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wbytes
+        return tot_ms, tot_flop, tot_bytes, n_launch
+
+    tot_ms, tot_flop, tot_bytes, n_launch = engine_totals(prof['records'])
+    # One extra, UNTIMED step on the single-stream schedule: the same launches without other streams sharing the chip,
+    # i.e. the stand-alone duration of each kernel (what a per-kernel roofline is usually quoted on).
+    single = None
+    if world == 1:
+        from embodiedscan_amd import engine as E
+        saved = (E.TWO_STREAMS[0], E.WGRAD_ASYNC[0])
+        E.TWO_STREAMS[0] = E.WGRAD_ASYNC[0] = False
+        prof1 = dict(prof, records=[])
+        hip.PROFILE = prof1
+        step()
+        hip.PROFILE = None
+        E.TWO_STREAMS[0], E.WGRAD_ASYNC[0] = saved
+        r1 = prof1['records']
+        r1 = [(n_, e0, e1, a, hip.PAIRS.get(a[4] if (n_.startswith('es_spconv_wgrad') or n_ == 'es_spconv_fwd_bf16') else a[3]))
+              for n_, e0, e1, a in r1]
+        torch.cuda.synchronize()
+        ms1, fl1, by1, nl1 = engine_totals(r1)
+        if ms1 > 0:
+            single = dict(achieved=round(by1 / (ms1 * 1e-3) / 1e9, 1), frac=round(by1 / (ms1 * 1e-3) / 1e9 / K_PEAK_HBM, 4),
+                          kernel_ms_per_step=round(ms1, 3), algorithmic_tflops=round(fl1 / (ms1 * 1e-3) / 1e12, 2),
+                          note='same launches, one extra untimed step with ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0')
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
     roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=K_PEAK_HBM, unit='GB/s',
                     frac=round(achieved / K_PEAK_HBM, 4), traffic=None,
                     kernel='convolution engine: k_spconv_bf16* (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
                     else 'convolution engine: k_spconv / k_spconv_wgrad (exact-f32 MFMA)',
-                    launches_per_step=n_launch, kernel_ms_per_step=round(tot_ms, 3),
+                    launches_per_step=n_launch, kernel_ms_per_step=round(tot_ms, 3), single_stream=single,
                     algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                     note='algorithmic bytes = sum over launches of P*(Cin+Cout)*4 + K*Cin*Cout*sizeof(w), P = valid '
                          '(output,tap) pairs; algorithmic flops = 2*P*Cin*Cout; launch durations are HIP-event times on the '
