@@ -20,5 +20,8 @@ imports those functions from /root/reference (with thin stand-ins for the absent
 third-party modules) and writes ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
 checks this restatement against them.  The MinkowskiEngine-owned arithmetic
 (coordinate maps, sparse convolution, pooling, norms) is restated from the
-published ME v0.5.4 semantics and is "parity unpinned".
+published ME v0.5.4 semantics (SURVEY.md section 8c) and is "parity unpinned";
+``tests/test_oracle_dense_crosscheck.py`` anchors those operators on PyTorch's dense
+conv3d / conv_transpose3d / max_pool3d / instance_norm over the voxelised grid
+(semantics pinned; ME's internal row and kernel-offset order stays our convention).
 """
