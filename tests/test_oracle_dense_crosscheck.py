@@ -129,3 +129,28 @@ def test_union_add_equals_dense_add():
     dense = _to_dense(a, fa, 1, 2) + _to_dense(bc, fb, 1, 2)
     assert torch.allclose(out.feats, _gather_dense(dense, out.coords, 1))
     assert len(out.coords) == len(np.unique(np.concatenate([a, bc]), axis=0))
+
+
+def test_features_at_coordinates_equals_dense_trilinear():
+    """MinkowskiInterpolation: trilinear weights over the 8 surrounding sites of the coarse grid, absent sites contribute
+    zero and the weights are NOT renormalised == grid_sample(bilinear, zeros padding, align_corners) on the dense grid."""
+    ts = 2
+    table = _random_set(14, fill=0.3, ts=ts)
+    table = table[(table[:, 1:] < G).all(1)]
+    g = torch.Generator().manual_seed(15)
+    f = torch.randn(len(table), 5, generator=g, dtype=torch.float32)
+    query = _random_set(16, fill=0.2)
+    query = query[(query[:, 1:] < G - ts).all(1)]
+    out = S.features_at_coordinates(S.SpT(table, f, ts, 2, {}), query)
+    n = G // ts
+    d = torch.zeros((2, 5, n, n, n))
+    c = torch.from_numpy(table.astype(np.int64))
+    d[c[:, 0], :, c[:, 3] // ts, c[:, 2] // ts, c[:, 1] // ts] = f
+    q = torch.from_numpy(query.astype(np.float32))
+    for b in range(2):
+        qb = q[q[:, 0] == b][:, 1:] / ts                                           # coarse-grid units (x, y, z)
+        grid = (qb / (n - 1) * 2 - 1).view(1, -1, 1, 1, 3)                          # grid_sample wants (x, y, z) in [-1, 1]
+        ref = F.grid_sample(d[b:b + 1], grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+        ref = ref[0, :, :, 0, 0].t()
+        got = out[torch.from_numpy(query[:, 0] == b)]
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
