@@ -158,8 +158,18 @@ def main():
                           kernel_ms_per_step=round(ms1, 3), algorithmic_tflops=round(fl1 / (ms1 * 1e-3) / 1e12, 2),
                           note='same launches, one extra untimed step with ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0')
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    # HBM traffic of the same kernel family from the PMC passes of this command (FETCH_SIZE / WRITE_SIZE need separate
+    # rocprofv3 runs, so the figure is read from the committed summary, bytes per launch like `achieved`'s numerator)
+    traffic, traffic_note = None, 'traffic: null (no profiles/r1_final_pmc_traffic.json)'
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_final_pmc_traffic.json')
+    if args.precision == 'bf16' and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        traffic = pmc['bytes_per_launch']
+        traffic_note = (f"traffic = HBM bytes per launch from PMC (profiles/r1_final_pmc_traffic.json: "
+                        f"{pmc['bytes_per_step'] / 1e9:.1f} GB per step over {pmc['launches'] // pmc['steps']} launches) vs "
+                        f"{tot_bytes / max(n_launch, 1) / 1e6:.0f} MB algorithmic bytes per launch")
     roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=K_PEAK_HBM, unit='GB/s',
-                    frac=round(achieved / K_PEAK_HBM, 4), traffic=None,
+                    frac=round(achieved / K_PEAK_HBM, 4), traffic=traffic,
                     kernel='convolution engine: k_spconv_bf16* (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
                     else 'convolution engine: k_spconv / k_spconv_wgrad (exact-f32 MFMA)',
                     launches_per_step=n_launch, kernel_ms_per_step=round(tot_ms, 3), single_stream=single,
@@ -167,7 +177,7 @@ def main():
                     note='algorithmic bytes = sum over launches of P*(Cin+Cout)*4 + K*Cin*Cout*sizeof(w), P = valid '
                          '(output,tap) pairs; algorithmic flops = 2*P*Cin*Cout; launch durations are HIP-event times on the '
                          'launch stream under the concurrent 4-stream schedule (kernels of different streams share the chip, '
-                         'so the sum exceeds wall time); traffic: see profiles/ (PMC), null here')
+                         'so the sum exceeds wall time); ' + traffic_note)
 
     out = dict(metric='scans/sec (train step) mv-3ddet, 20x(480x640) RGB-D views', value=round(world * args.batch * args.steps / dt, 4),
                unit='scans/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
