@@ -66,11 +66,13 @@ class SparseFeatureFusionSingleStage3DDetector:
     def state_dict(self):
         return self.arena.state_dict()
 
-    def load_state_dict(self, sd):
-        self.arena.load_state_dict(sd)
-        E.WEIGHT_VERSION[0] += 1
+    def load_state_dict(self, sd, strict=False):
+        """reference-named state dict -> arena; returns (missing, unexpected) keys like torch.nn.Module does"""
+        res = self.arena.load_state_dict(sd, strict=strict)
+        E.WEIGHT_VERSION[0] += 1                 # bf16 weight copies are stale
         if self._bound:
-            self.backbone.refresh()
+            self.backbone.refresh()              # re-fold the frozen BatchNorm2d statistics
+        return res
 
     def train(self, mode=True):
         self.training = mode

@@ -20,6 +20,27 @@ class OptimWrapper:
         self.partial = torch.empty(2048, dtype=torch.float64, device=arena.data.device)
         self.norm = torch.zeros(1, dtype=torch.float32, device=arena.data.device)
 
+    def state_dict(self, arena):
+        """Resume state: AdamW moments keyed by the reference's parameter names (reference shapes), the step count
+        and the hyper-parameters.  (torch.optim's own state_dict is keyed by parameter index in module registration
+        order, which this framework does not reproduce; the names are what both sides share.)"""
+        if self.m is None:
+            self.state_init(arena)
+        return dict(step=self.step, exp_avg=arena.flat_to_ref(self.m), exp_avg_sq=arena.flat_to_ref(self.v),
+                    param_groups=[dict(lr=self.lr, weight_decay=self.wd, betas=tuple(self.betas), eps=self.eps,
+                                       max_norm=self.max_norm)])
+
+    def load_state_dict(self, arena, sd):
+        if self.m is None:
+            self.state_init(arena)
+        self.step = int(sd['step'])
+        arena.ref_to_flat(sd['exp_avg'], self.m)
+        arena.ref_to_flat(sd['exp_avg_sq'], self.v)
+        g = sd.get('param_groups', [{}])[0]
+        self.lr, self.wd = g.get('lr', self.lr), g.get('weight_decay', self.wd)
+        self.betas, self.eps = tuple(g.get('betas', self.betas)), g.get('eps', self.eps)
+        self.max_norm = g.get('max_norm', self.max_norm)
+
     def update_params(self, arena):
         if self.m is None:
             self.state_init(arena)

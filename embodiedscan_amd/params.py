@@ -171,27 +171,67 @@ class ParamArena:
         self._views()
         return self
 
+    # ---- reference <-> arena layout conversions, shared by parameters, gradients and optimiser moments
+    @staticmethod
+    def _emit(s, t, out):
+        """arena-layout tensor t of spec s -> its reference-named / reference-shaped entries in `out`"""
+        if s.ref is None:
+            out[s.name] = t.clone()
+        elif s.ref[0] == 'oihw':
+            o, i, kh, kw = s.ref[1]
+            out[s.name] = t.reshape(kh, kw, i, o).permute(3, 2, 0, 1).contiguous()
+        elif s.ref[0] == 'squeeze0':
+            out[s.name] = t[0].clone()
+        elif s.ref[0] == 'head_out':
+            pre = s.name[:-len('head_out.kernel')]
+            nr = s.ref[1]
+            out[pre + 'conv_center.kernel'] = t[0, :, 0:1].clone()
+            out[pre + 'conv_reg.kernel'] = t[0, :, 1:1 + nr].clone()
+            out[pre + 'conv_cls.kernel'] = t[0, :, 1 + nr:].clone()
+        elif s.ref[0] == 'head_bias':
+            pre = s.name[:-len('head_out.bias')]
+            out[pre + 'conv_cls.bias'] = t[1 + s.ref[1]:].reshape(1, -1).clone()
+
+    @staticmethod
+    def _absorb(s, dst, sd):
+        """inverse of _emit: copy the entries of spec s found in `sd` into the arena-layout view dst; returns the
+        reference names it consumed"""
+        if s.ref is None or s.ref[0] == 'squeeze0':
+            if s.name in sd:
+                dst.copy_(sd[s.name].reshape(dst.shape))
+                return [s.name]
+        elif s.ref[0] == 'oihw':
+            if s.name in sd:
+                o, i, kh, kw = s.ref[1]
+                dst.copy_(sd[s.name].permute(2, 3, 1, 0).reshape(kh * kw, i, o))
+                return [s.name]
+        elif s.ref[0] == 'head_out':
+            pre = s.name[:-len('head_out.kernel')]
+            nr = s.ref[1]
+            names = [pre + 'conv_center.kernel', pre + 'conv_reg.kernel', pre + 'conv_cls.kernel']
+            if all(n in sd for n in names):
+                dst[0, :, 0:1].copy_(sd[names[0]])
+                dst[0, :, 1:1 + nr].copy_(sd[names[1]])
+                dst[0, :, 1 + nr:].copy_(sd[names[2]])
+                return names
+        elif s.ref[0] == 'head_bias':
+            pre = s.name[:-len('head_out.bias')]
+            if pre + 'conv_cls.bias' in sd:
+                dst[1 + s.ref[1]:].copy_(sd[pre + 'conv_cls.bias'].reshape(-1))
+                return [pre + 'conv_cls.bias']
+        return []
+
+    def ref_names(self, s):
+        """reference key(s) spec s maps to"""
+        probe = OrderedDict()
+        self._emit(s, self.p[s.name].detach(), probe)
+        return list(probe)
+
     def state_dict(self):
         """Reference-named, reference-shaped copy (what `model.state_dict()` gives in the reference)."""
         out = OrderedDict()
         for s in self.specs:
-            t = self.p[s.name].detach()
-            if s.ref is None:
-                out[s.name] = t.clone()
-            elif s.ref[0] == 'oihw':
-                o, i, kh, kw = s.ref[1]
-                out[s.name] = t.reshape(kh, kw, i, o).permute(3, 2, 0, 1).contiguous()
-            elif s.ref[0] == 'squeeze0':
-                out[s.name] = t[0].clone()
-            elif s.ref[0] == 'head_out':
-                pre = s.name[:-len('head_out.kernel')]
-                nr = s.ref[1]
-                out[pre + 'conv_center.kernel'] = t[0, :, 0:1].clone()
-                out[pre + 'conv_reg.kernel'] = t[0, :, 1:1 + nr].clone()
-                out[pre + 'conv_cls.kernel'] = t[0, :, 1 + nr:].clone()
-            elif s.ref[0] == 'head_bias':
-                pre = s.name[:-len('head_out.bias')]
-                out[pre + 'conv_cls.bias'] = t[1 + s.ref[1]:].reshape(1, -1).clone()
+            self._emit(s, self.p[s.name].detach(), out)
         return out
 
     def _to_ref(self, which):
@@ -199,55 +239,43 @@ class ParamArena:
         src = self.g if which == 'g' else self.p
         out = OrderedDict()
         for s in self.specs:
-            if s.name not in src:
-                continue
-            t = src[s.name].detach()
-            if s.ref is None:
-                out[s.name] = t.clone()
-            elif s.ref[0] == 'oihw':
-                o, i, kh, kw = s.ref[1]
-                out[s.name] = t.reshape(kh, kw, i, o).permute(3, 2, 0, 1).contiguous()
-            elif s.ref[0] == 'squeeze0':
-                out[s.name] = t[0].clone()
-            elif s.ref[0] == 'head_out':
-                pre = s.name[:-len('head_out.kernel')]
-                nr = s.ref[1]
-                out[pre + 'conv_center.kernel'] = t[0, :, 0:1].clone()
-                out[pre + 'conv_reg.kernel'] = t[0, :, 1:1 + nr].clone()
-                out[pre + 'conv_cls.kernel'] = t[0, :, 1 + nr:].clone()
-            elif s.ref[0] == 'head_bias':
-                pre = s.name[:-len('head_out.bias')]
-                out[pre + 'conv_cls.bias'] = t[1 + s.ref[1]:].reshape(1, -1).clone()
+            if s.name in src:
+                self._emit(s, src[s.name].detach(), out)
         return out
 
     def grad_dict(self):
         return self._to_ref('g')
 
-    def load_state_dict(self, sd):
-        """Accepts a reference-named state dict (the inverse of state_dict())."""
+    def flat_to_ref(self, flat):
+        """a flat buffer laid out like the TRAINABLE part of the arena (optimiser moments) -> reference-named dict"""
+        out = OrderedDict()
         for s in self.specs:
-            dst = self.p[s.name]
-            if s.ref is None:
-                if s.name in sd:
-                    dst.copy_(sd[s.name].reshape(dst.shape))
-            elif s.ref[0] == 'oihw':
-                if s.name in sd:
-                    o, i, kh, kw = s.ref[1]
-                    dst.copy_(sd[s.name].permute(2, 3, 1, 0).reshape(kh * kw, i, o))
-            elif s.ref[0] == 'squeeze0':
-                if s.name in sd:
-                    dst.copy_(sd[s.name].reshape(dst.shape))
-            elif s.ref[0] == 'head_out':
-                pre = s.name[:-len('head_out.kernel')]
-                nr = s.ref[1]
-                if pre + 'conv_center.kernel' in sd:
-                    dst[0, :, 0:1].copy_(sd[pre + 'conv_center.kernel'])
-                    dst[0, :, 1:1 + nr].copy_(sd[pre + 'conv_reg.kernel'])
-                    dst[0, :, 1 + nr:].copy_(sd[pre + 'conv_cls.kernel'])
-            elif s.ref[0] == 'head_bias':
-                pre = s.name[:-len('head_out.bias')]
-                if pre + 'conv_cls.bias' in sd:
-                    dst[1 + s.ref[1]:].copy_(sd[pre + 'conv_cls.bias'].reshape(-1))
+            if s.trainable:
+                o, n = self.offsets[s.name]
+                self._emit(s, flat[o:o + n].view(s.shape).detach(), out)
+        return out
+
+    def ref_to_flat(self, sd, flat):
+        """inverse of flat_to_ref, in place"""
+        for s in self.specs:
+            if s.trainable:
+                o, n = self.offsets[s.name]
+                self._absorb(s, flat[o:o + n].view(s.shape), sd)
+        return flat
+
+    def load_state_dict(self, sd, strict=False):
+        """Accepts a reference-named state dict (the inverse of state_dict()).  Returns (missing, unexpected)
+        reference keys; strict=True raises if either is non-empty (torch.nn.Module.load_state_dict semantics)."""
+        used, missing = set(), []
+        for s in self.specs:
+            got = self._absorb(s, self.p[s.name], sd)
+            used.update(got)
+            if not got:
+                missing.extend(self.ref_names(s))
+        unexpected = [k for k in sd if k not in used]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'load_state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...')
+        return missing, unexpected
 
     def trainable_names(self):
         return [s.name for s in self.specs if s.trainable]

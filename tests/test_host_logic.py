@@ -159,3 +159,43 @@ def test_data_parallel_exchange_two_gloo_ranks():
 if __name__ == '__main__' and '--dp-worker' in sys.argv:
     sys.path.insert(0, ROOT)
     _dp_worker()
+
+
+def test_checkpoint_roundtrip_reference_layout(tmp_path):
+    """N3: a checkpoint is an mmengine-style file whose state_dict uses the reference's names / shapes; weights and the
+    AdamW moments survive save -> load into a fresh arena bit for bit; missing / unexpected keys are reported."""
+    import torch
+    from embodiedscan_amd.checkpoint import load_checkpoint, save_checkpoint
+    from embodiedscan_amd.optim import OptimWrapper
+    from embodiedscan_amd.params import ParamArena, detector_specs
+    a = ParamArena(detector_specs(284), seed=3)
+    opt = OptimWrapper(lr=2e-3)
+    opt.m = torch.randn(a.n_train)
+    opt.v = torch.rand(a.n_train)
+    opt.step = 17
+    path = save_checkpoint(a, str(tmp_path / 'ck.pth'), optim=opt, meta=dict(epoch=5))
+    raw = torch.load(path, weights_only=False)
+    sd = raw['state_dict']
+    assert sd['backbone.layer2.0.conv2.weight'].shape == (32, 32, 3, 3)           # torch (O, I, KH, KW)
+    assert sd['backbone_3d.layer1.0.conv1.kernel'].shape == (27, 64, 64)          # ME (K, I, O)
+    assert sd['bbox_head.conv_cls.kernel'].shape == (128, 284) and sd['bbox_head.conv_reg.kernel'].shape == (128, 12)
+    b = ParamArena(detector_specs(284), seed=99)
+    opt2 = OptimWrapper()
+    opt2.m, opt2.v = torch.zeros(b.n_train), torch.zeros(b.n_train)
+    missing, unexpected, meta = load_checkpoint(b, path, optim=opt2)
+    assert not missing and not unexpected and meta['epoch'] == 5
+    # compared in the reference's view: arena padding and the 13 never-trained centre / regression bias slots of the
+    # fused head GEMM are not part of the reference's state
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb) and all(torch.equal(sa[k], sb[k]) for k in sa)
+    for x, y in ((opt.m, opt2.m), (opt.v, opt2.v)):
+        ra, rb = a.flat_to_ref(x), b.flat_to_ref(y)
+        assert list(ra) == list(rb) and all(torch.equal(ra[k], rb[k]) for k in ra)
+    assert opt2.step == 17 and opt2.lr == 2e-3
+    # partial / foreign checkpoints
+    del sd['bbox_head.conv_cls.bias']
+    sd['module.extra.weight'] = torch.zeros(3)
+    torch.save(dict(state_dict={'module.' + k if not k.startswith('module.') else k: v for k, v in sd.items()}),
+               str(tmp_path / 'ddp.pth'))
+    missing, unexpected, _ = load_checkpoint(ParamArena(detector_specs(284), seed=1), str(tmp_path / 'ddp.pth'))
+    assert missing == ['bbox_head.conv_cls.bias'] and unexpected == ['extra.weight']
