@@ -97,7 +97,13 @@ def main():
     hip.PROFILE = None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     in_sync = True
+    rank_ms = None
     if world > 1:
+        # per-rank time of the timed region (voxel counts differ per rank -> stragglers; SURVEY 8e asks for the spread)
+        every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(every, tmax.clone())
+        per = sorted(float(t.item()) / args.steps * 1e3 for t in every)
+        rank_ms = dict(min=round(per[0], 3), median=round(per[len(per) // 2], 3), max=round(per[-1], 3))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # data-parallel sanity (outside the timed region): every replica must hold the same parameters
         chk = det.arena.data[:det.arena.n_train].double().abs().sum().reshape(1)
@@ -189,6 +195,7 @@ def main():
                losses={k: round(float(v), 6) for k, v in losses.items()}, roofline=roofline)
     if world > 1:
         out['replicas_in_sync'] = in_sync
+        out['rank_ms_per_step'] = rank_ms
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(scans[0], det, args)
     print(json.dumps(out))
