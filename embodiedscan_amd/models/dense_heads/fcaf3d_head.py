@@ -275,6 +275,9 @@ class FCAF3DHeadRotMat:
                     ol.append(torch.full((cnt[c],), c, dtype=torch.long, device=dev))
             if ob:
                 rb, rs, rl = torch.cat(ob), torch.cat(os_), torch.cat(ol)
+                # Reference quirk, reproduced literally (fcaf3d_head.py:1681-1682 keeps only (x,y,z,dx,dy,dz,alpha)
+                # through NMS, then euler_box3d.py:44-48 pads beta = gamma = 0): the emitted boxes are yaw-only.
+                rb[:, 7:] = 0
             else:
                 rb, rs, rl = bx.new_zeros((0, 9)), bx.new_zeros((0,)), torch.zeros((0,), dtype=torch.long, device=dev)
             results.append(InstanceData(bboxes_3d=EulerDepthInstance3DBoxes(rb), scores_3d=rs, labels_3d=rl))

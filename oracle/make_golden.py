@@ -135,6 +135,80 @@ def main(out_dir=None):
     np.savez_compressed(os.path.join(out_dir, 'box_coder_cdloss.npz'), points=pp.numpy(), pred=pred.numpy(), decoded=dec.numpy(),
              target=tgt.numpy(), loss=crit(dec, tgt).numpy(),
              loss_none=crit(dec, tgt, reduction_override='none').numpy())
+    # ---- A14-A16 composition of the per-sample loss: the reference's own _loss_by_feat_single (targets, positive
+    # selection, avg_factor, decoupled corner loss, empty-positive branch) driven through a stand-in `self`.  Only the
+    # two mmdet criteria are restated (mmdet is absent): FocalLoss(use_sigmoid, gamma 2, alpha .25) and
+    # CrossEntropyLoss(use_sigmoid) with mmdet's weight_reduce_loss rule  sum / (avg_factor + float32 eps).
+    import torch.nn.functional as Fn
+    eps = torch.finfo(torch.float32).eps
+
+    def focal(pred, target, avg_factor):
+        t = Fn.one_hot(target.clamp(min=0), pred.shape[1] + 1)[:, :pred.shape[1]].float()
+        t = t * (target >= 0)[:, None]                      # label -1 (background): all-negative row
+        p = pred.sigmoid()
+        pt = (1 - p) * t + p * (1 - t)
+        w = (0.25 * t + 0.75 * (1 - t)) * pt.pow(2.0)
+        return (Fn.binary_cross_entropy_with_logits(pred, t, reduction='none') * w).sum() / (avg_factor + eps)
+
+    def bce(pred, target, avg_factor):
+        return Fn.binary_cross_entropy_with_logits(pred, target.float(), reduction='none').mean(1).sum() / (avg_factor + eps)
+
+    for name, nb in (('loss_single', 6), ('loss_single_empty', 0)):
+        lv = []
+        for ts in (8, 16, 32, 64):
+            r = torch.arange(-96, 96, ts)
+            gx, gy, gz = torch.meshgrid(r, r, torch.arange(0, 96, ts), indexing='ij')
+            p = torch.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], 1).float() * 0.01
+            lv.append(p[torch.rand(len(p), generator=g) < 0.6])
+        gtb = torch.cat([rnd(nb, 2, lo=-.7, hi=.7), rnd(nb, 1, lo=.3, hi=.7), rnd(nb, 3, lo=.3, hi=1.2),
+                         rnd(nb, 1, lo=-3.1, hi=3.1), rnd(nb, 2, lo=-.2, hi=.2)], 1)
+        gtl = torch.randint(0, 24, (nb,), generator=g)        # 24 classes keep the fixture small; the code is class-count agnostic
+        cen = [rnd(len(p), 1) for p in lv]
+        box = [torch.cat([rnd(len(p), 6, lo=.05, hi=1.2), rnd(len(p), 6, lo=-1, hi=1)], 1) for p in lv]
+        cls = [rnd(len(p), 24, lo=-6., hi=0.5).half().float() for p in lv]     # stored as f16: round first
+        me = types.SimpleNamespace(pts_assign_threshold=27, pts_center_threshold=18,
+                                   _get_face_distances=FCAF3DHeadRotMat._get_face_distances,
+                                   _get_centerness=FCAF3DHeadRotMat._get_centerness,
+                                   _bbox_pred_to_bbox=FCAF3DHeadRotMat._bbox_pred_to_bbox,
+                                   cls_loss=focal, center_loss=bce, bbox_loss=BBoxCDLoss(mode='l1', group='g8', loss_weight=1.0),
+                                   decouple_bbox_loss=True, decouple_groups=4, decouple_weights=[0.2, 0.2, 0.2, 0.4],
+                                   norm_decouple_loss=False)
+        me.get_targets = lambda pts, b, l, me=me: FCAF3DHeadRotMat.get_targets(me, pts, b, l)
+        lc, lb, lk = FCAF3DHeadRotMat._loss_by_feat_single(me, [c.clone() for c in cen], [b.clone() for b in box],
+                                                          [c.clone() for c in cls], [p.clone() for p in lv],
+                                                          EulerDepthInstance3DBoxes(gtb), gtl, {})
+        np.savez_compressed(os.path.join(out_dir, name + '.npz'), gt_boxes=gtb.numpy(), gt_labels=gtl.numpy(),
+                            losses=np.array([float(lc), float(lb), float(lk)], np.float64),
+                            **{f'points{i}': p.numpy() for i, p in enumerate(lv)},
+                            **{f'center{i}': c.numpy() for i, c in enumerate(cen)},
+                            **{f'bbox{i}': b.numpy() for i, b in enumerate(box)},
+                            **{f'cls{i}': c.numpy().astype(np.float16) for i, c in enumerate(cls)})
+    # ---- N1 predict wrapper: the reference's _predict_by_feat_single + _single_scene_multiclass_nms (per-level top-k,
+    # score threshold, per-class loop, output layout).  mmcv.ops.nms3d is CUDA-only and absent: the module-level name is
+    # bound to the oracle's restated greedy rotated-BEV NMS, so the suppression rule itself stays unpinned; everything
+    # around it is the reference's code -- including its quirk that only (x,y,z,dx,dy,dz,alpha) survive NMS and the Euler
+    # box constructor pads beta = gamma = 0.
+    import embodiedscan.models.dense_heads.fcaf3d_head as ref_head
+    from oracle.predict import nms3d as oracle_nms3d
+    ref_head.nms3d = lambda b, sc, thr: oracle_nms3d(b.detach(), sc.detach(), thr)
+    me = types.SimpleNamespace(test_cfg=types.SimpleNamespace(nms_pre=300, iou_thr=0.5, score_thr=0.05),
+                               _bbox_pred_to_bbox=FCAF3DHeadRotMat._bbox_pred_to_bbox)
+    me._single_scene_multiclass_nms = lambda b, sc, m, me=me: FCAF3DHeadRotMat._single_scene_multiclass_nms(me, b, sc, m)
+    lv = []
+    for n_l in (900, 500, 200, 40):
+        pts = rnd(n_l, 3, lo=-2.5, hi=2.5)
+        cen = rnd(n_l, 1, lo=-1., hi=3.)
+        box = torch.cat([rnd(n_l, 6, lo=.1, hi=.9), rnd(n_l, 6, lo=-1, hi=1)], 1)
+        cls = rnd(n_l, 12, lo=-7., hi=-1.)
+        hot = torch.rand(n_l, generator=g) < 0.15
+        cls[hot, torch.randint(0, 12, (int(hot.sum()),), generator=g)] += 6.0
+        lv.append((cen, box, cls, pts))
+    res = FCAF3DHeadRotMat._predict_by_feat_single(me, [l[0] for l in lv], [l[1] for l in lv], [l[2] for l in lv],
+                                                   [l[3] for l in lv], dict(box_type_3d=EulerDepthInstance3DBoxes))
+    np.savez_compressed(os.path.join(out_dir, 'predict_single.npz'), nms_pre=300, iou_thr=0.5, score_thr=0.05,
+                        boxes=res.bboxes_3d.tensor.numpy(), scores=res.scores_3d.numpy(), labels=res.labels_3d.numpy(),
+                        **{f'center{i}': l[0].numpy() for i, l in enumerate(lv)}, **{f'bbox{i}': l[1].numpy() for i, l in enumerate(lv)},
+                        **{f'cls{i}': l[2].numpy() for i, l in enumerate(lv)}, **{f'points{i}': l[3].numpy() for i, l in enumerate(lv)})
     print('golden vectors written to', out_dir)
 
 

@@ -126,7 +126,9 @@ def predict_single(level_preds, nms_pre=1000, score_thr=0.01, iou_thr=0.5):
         if ids.numel() == 0:
             continue
         keep = nms3d(boxes[ids][:, :7], scores[ids, c], iou_thr)
-        out_b.append(boxes[ids][keep]); out_s.append(scores[ids, c][keep])
+        kept = boxes[ids][keep].clone()
+        kept[:, 7:] = 0        # fcaf3d_head.py:1681-1682 + euler_box3d.py:44-48: beta, gamma do not survive the NMS wrapper
+        out_b.append(kept); out_s.append(scores[ids, c][keep])
         out_l.append(torch.full((len(keep),), c, dtype=torch.long))
     if out_b:
         return torch.cat(out_b), torch.cat(out_s), torch.cat(out_l)
