@@ -14,3 +14,9 @@ def euler_to_matrix_zxy(a):
     rx = torch.stack([one, zero, zero, zero, cb, -sb, zero, sb, cb], -1).reshape(a.shape[:-1] + (3, 3))
     ry = torch.stack([cc, zero, sc, zero, one, zero, -sc, zero, cc], -1).reshape(a.shape[:-1] + (3, 3))
     return torch.matmul(torch.matmul(rz, rx), ry)
+
+
+def matrix_to_euler_zxy(m):
+    """inverse of euler_to_matrix_zxy on its principal branch (pytorch3d matrix_to_euler_angles(m, 'ZXY'))"""
+    return torch.stack([torch.atan2(-m[..., 0, 1], m[..., 1, 1]), torch.asin(m[..., 2, 1]),
+                        torch.atan2(-m[..., 2, 0], m[..., 2, 2])], -1)

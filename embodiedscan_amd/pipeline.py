@@ -46,6 +46,31 @@ def depth_to_points(dscan):
     return out
 
 
+def augment_gt_boxes(boxes, aug):
+    """Ground-truth side of RandomFlip3D + GlobalRotScaleTrans (augmentation.py:140-168,322-420) for (G,9) Euler boxes,
+    host-side like the reference (a few dozen boxes per scan).  The POINT side of the same augmentation runs inside
+    es_depth_to_points.  Follows the reference's box class literally -- flips edit the Euler angles in place
+    (alpha -> pi - alpha, gamma -> -gamma for X; alpha -> -alpha, beta -> pi - beta for Y: euler_box3d.py:263-281),
+    which for a tilted box is not its exact mirror image; the rotation composes matrices and re-extracts ZXY angles.
+    aug: dict(hflip, vflip, rot = rot_mat_T as stored in `pcd_rotation`, scale, trans)."""
+    import math
+    from .geometry import euler_to_matrix_zxy, matrix_to_euler_zxy
+    b = torch.as_tensor(boxes, dtype=torch.float32).clone()
+    if b.shape[0] == 0:
+        return b
+    sx, sy = (-1.0 if aug['hflip'] else 1.0), (-1.0 if aug['vflip'] else 1.0)
+    xyz = b[:, :3] * torch.tensor([sx, sy, 1.0])
+    alpha, beta, gamma = b[:, 6], b[:, 7], b[:, 8]
+    if aug['hflip']:
+        alpha, gamma = math.pi - alpha, -gamma
+    if aug['vflip']:
+        alpha, beta = -alpha, math.pi - beta
+    rot = torch.as_tensor(aug['rot'], dtype=torch.float32)                  # R^T
+    ang = matrix_to_euler_zxy(torch.matmul(rot.t()[None], euler_to_matrix_zxy(torch.stack([alpha, beta, gamma], 1))))
+    s, t = float(aug['scale']), torch.as_tensor(aug['trans'], dtype=torch.float32)
+    return torch.cat([(xyz @ rot) * s + t, b[:, 3:6] * s, ang], 1)
+
+
 def make_batch(dscans):
     """-> the `data` dict of mmengine's train_step: {'inputs': {'points', 'img'}, 'data_samples'}."""
     points = [depth_to_points(d) for d in dscans]

@@ -209,6 +209,29 @@ def main(out_dir=None):
                         boxes=res.bboxes_3d.tensor.numpy(), scores=res.scores_3d.numpy(), labels=res.labels_3d.numpy(),
                         **{f'center{i}': l[0].numpy() for i, l in enumerate(lv)}, **{f'bbox{i}': l[1].numpy() for i, l in enumerate(lv)},
                         **{f'cls{i}': l[2].numpy() for i, l in enumerate(lv)}, **{f'points{i}': l[3].numpy() for i, l in enumerate(lv)})
+    # ---- A3 augmentation of points AND boxes: RandomFlip3D.random_flip_data_3d / GlobalRotScaleTrans._rot_bbox_points,
+    # _scale_bbox_points, _trans_bbox_points (augmentation.py:140-168,322-420) are thin wrappers over the box / point
+    # classes' flip / rotate / scale / translate, which are called here directly with fixed "random" decisions.
+    for name, hf, vf in (('augment_hv', True, True), ('augment_h', True, False), ('augment_none', False, False)):
+        pts = rnd(200, 3, lo=-3, hi=3)
+        bx = torch.cat([rnd(9, 3, lo=-2, hi=2), rnd(9, 3, lo=.3, hi=1.5), rnd(9, 1, lo=-3.1, hi=3.1), rnd(9, 2, lo=-.3, hi=.3)], 1)
+        boxes = EulerDepthInstance3DBoxes(bx.clone())
+        p = pts.clone()
+        if hf:
+            p = boxes.flip('horizontal', points=p)
+        if vf:
+            p = boxes.flip('vertical', points=p)
+        angle = -float(rnd(1, lo=-0.087266, hi=0.087266))             # rot_dof 1: noise_rotation *= -1
+        p, rot_mat_T = boxes.rotate(angle, p)
+        scale = float(rnd(1, lo=.9, hi=1.1))
+        boxes.scale(scale)
+        p = p * scale                                                   # BasePoints.scale
+        trans = rnd(3, lo=-.3, hi=.3).numpy()
+        boxes.translate(trans)
+        p = p + torch.from_numpy(trans)                                 # BasePoints.translate
+        np.savez_compressed(os.path.join(out_dir, name + '.npz'), points=pts.numpy(), boxes=bx.numpy(), hflip=hf, vflip=vf,
+                            angle=np.float32(angle), rot_mat_T=rot_mat_T.numpy(), scale=np.float32(scale), trans=trans,
+                            points_out=p.numpy(), boxes_out=boxes.tensor.numpy())
     print('golden vectors written to', out_dir)
 
 

@@ -199,3 +199,17 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path):
                str(tmp_path / 'ddp.pth'))
     missing, unexpected, _ = load_checkpoint(ParamArena(detector_specs(284), seed=1), str(tmp_path / 'ddp.pth'))
     assert missing == ['bbox_head.conv_cls.bias'] and unexpected == ['extra.weight']
+
+
+def test_gt_box_augmentation_matches_reference(golden_dir):
+    """product host function pipeline.augment_gt_boxes against the golden vectors made by the reference's box class"""
+    import torch
+    from embodiedscan_amd.pipeline import augment_gt_boxes
+    for name in ('augment_hv', 'augment_h', 'augment_none'):
+        d = np.load(os.path.join(golden_dir, name + '.npz'))
+        aug = dict(hflip=bool(d['hflip']), vflip=bool(d['vflip']), rot=d['rot_mat_T'], scale=float(d['scale']), trans=d['trans'])
+        b = augment_gt_boxes(torch.from_numpy(d['boxes']), aug).numpy()
+        np.testing.assert_allclose(b[:, :6], d['boxes_out'][:, :6], rtol=2e-6, atol=2e-6)
+        da = (b[:, 6:] - d['boxes_out'][:, 6:] + np.pi) % (2 * np.pi) - np.pi
+        assert np.abs(da).max() < 5e-6
+    assert augment_gt_boxes(torch.zeros((0, 9)), aug).shape == (0, 9)

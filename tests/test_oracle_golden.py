@@ -103,3 +103,18 @@ def test_predict_wrapper(golden_dir):
     np.testing.assert_allclose(scores.numpy(), d['scores'], rtol=1e-6)
     np.testing.assert_allclose(boxes.numpy(), d['boxes'], rtol=1e-5, atol=1e-6)
     assert (d['boxes'][:, 7:] == 0).all()
+
+
+def test_augmentation_points_and_boxes(golden_dir):
+    """A3: RandomFlip3D + GlobalRotScaleTrans on points and on 9-DoF boxes, against the reference's own box / point
+    classes (fixed decisions).  f32 tolerance 2e-6 (angles compared modulo 2 pi)."""
+    from oracle import pipeline as OP
+    for name in ('augment_hv', 'augment_h', 'augment_none'):
+        d = _load(golden_dir, name)
+        aug = dict(hflip=bool(d['hflip']), vflip=bool(d['vflip']), rot=d['rot_mat_T'], scale=float(d['scale']), trans=d['trans'])
+        p = OP.augment_points(torch.from_numpy(d['points']), aug).numpy()
+        np.testing.assert_allclose(p, d['points_out'], rtol=2e-6, atol=2e-6)
+        b = OP.augment_boxes(torch.from_numpy(d['boxes']), aug).numpy()
+        np.testing.assert_allclose(b[:, :6], d['boxes_out'][:, :6], rtol=2e-6, atol=2e-6)
+        da = (b[:, 6:] - d['boxes_out'][:, 6:] + np.pi) % (2 * np.pi) - np.pi
+        assert np.abs(da).max() < 5e-6, np.abs(da).max()
