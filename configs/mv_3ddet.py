@@ -21,3 +21,6 @@ model = dict(
 optim_wrapper = dict(type='OptimWrapper', optimizer=dict(type='AdamW', lr=0.001, weight_decay=0.0001),
                      clip_grad=dict(max_norm=10, norm_type=2))
 train_dataloader = dict(batch_size=4)
+# reference config :214,225-230: 12 epochs, learning rate x0.1 after epochs 8 and 11
+train_cfg = dict(type='EpochBasedTrainLoop', max_epochs=12, val_interval=1)
+param_scheduler = dict(type='MultiStepLR', begin=0, end=12, by_epoch=True, milestones=[8, 11], gamma=0.1)

@@ -43,3 +43,16 @@ def build_optim_wrapper(cfg):
     return OptimWrapper(lr=opt.get('lr', 1e-3), weight_decay=opt.get('weight_decay', 1e-2),
                         betas=opt.get('betas', (0.9, 0.999)), eps=opt.get('eps', 1e-8),
                         max_norm=clip.get('max_norm', 0.0))
+
+
+def build_param_scheduler(cfg, optim):
+    """`param_scheduler` of the config (a dict or a list of dicts) -> scheduler objects bound to the optimiser wrapper"""
+    from .optim import MultiStepLR
+    ps = cfg.get('param_scheduler') or []
+    ps = [ps] if isinstance(ps, dict) else list(ps)
+    out = []
+    for p in ps:
+        assert p.get('type') == 'MultiStepLR', f"only MultiStepLR is configured for this path, got {p.get('type')}"
+        out.append(MultiStepLR(optim, p['milestones'], p.get('gamma', 0.1), p.get('begin', 0), p.get('end', 10 ** 9),
+                               p.get('by_epoch', True)))
+    return out

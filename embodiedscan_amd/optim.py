@@ -57,3 +57,32 @@ class OptimWrapper:
         self.last_norm = self.norm
         from . import engine
         engine.WEIGHT_VERSION[0] += 1          # bf16 weight copies are stale now
+
+
+class MultiStepLR:
+    """mmengine MultiStepLR(by_epoch=True) as configured at configs/detection/mv-det3d_...py:225-230: the learning rate
+    of the wrapper is base_lr * gamma ** (number of milestones already passed), inside [begin, end) epochs."""
+
+    def __init__(self, optim, milestones, gamma=0.1, begin=0, end=10 ** 9, by_epoch=True):
+        assert by_epoch, 'the shipped configs schedule by epoch'
+        self.optim, self.milestones, self.gamma = optim, sorted(int(m) for m in milestones), float(gamma)
+        self.begin, self.end = int(begin), int(end)
+        self.base_lr = optim.lr
+        self.epoch = 0
+
+    def lr_at(self, epoch):
+        e = min(max(epoch, self.begin), self.end)
+        return self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= e)
+
+    def step(self):
+        """call once after every training epoch (ParamSchedulerHook.after_train_epoch)"""
+        self.epoch += 1
+        self.optim.lr = self.lr_at(self.epoch)
+        return self.optim.lr
+
+    def state_dict(self):
+        return dict(epoch=self.epoch, base_lr=self.base_lr)
+
+    def load_state_dict(self, sd):
+        self.epoch, self.base_lr = int(sd['epoch']), float(sd['base_lr'])
+        self.optim.lr = self.lr_at(self.epoch)

@@ -213,3 +213,20 @@ def test_gt_box_augmentation_matches_reference(golden_dir):
         da = (b[:, 6:] - d['boxes_out'][:, 6:] + np.pi) % (2 * np.pi) - np.pi
         assert np.abs(da).max() < 5e-6
     assert augment_gt_boxes(torch.zeros((0, 9)), aug).shape == (0, 9)
+
+
+def test_lr_schedule_matches_torch_multistep():
+    """param_scheduler of the reference config (MultiStepLR, milestones [8, 11], gamma 0.1, 12 epochs) against
+    torch.optim.lr_scheduler.MultiStepLR stepped once per epoch"""
+    import torch
+    from embodiedscan_amd.config import build_optim_wrapper, build_param_scheduler, load_config
+    cfg = load_config(os.path.join(ROOT, 'configs', 'mv_3ddet.py'))
+    ow = build_optim_wrapper(cfg)
+    sched, = build_param_scheduler(cfg, ow)
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.AdamW([p], lr=ow.lr)
+    tsch = torch.optim.lr_scheduler.MultiStepLR(topt, milestones=[8, 11], gamma=0.1)
+    for epoch in range(12):
+        assert abs(ow.lr - topt.param_groups[0]['lr']) < 1e-12, (epoch, ow.lr)
+        topt.step(); tsch.step(); sched.step()
+    assert abs(ow.lr - 1e-5) < 1e-12
