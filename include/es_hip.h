@@ -92,7 +92,10 @@ int es_cast_weights_table(const void* table_dev, int n_entries, int total_tiles,
 /* dW[k] += X[nbr[:,k]]^T . dY */
 int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
                     int Cin, int Cout, float* dW, void* stream);
-/* bf16-MFMA variant of es_spconv_wgrad (operands rounded to bf16 while staged, f32 accumulate / atomics) */
+/* bf16-MFMA variant of es_spconv_wgrad (operands rounded to bf16 while staged, f32 accumulate / atomics into dW, which
+ * the caller zeroes once per step).  Each (tap, row slice) workgroup compacts the valid (row, neighbour) pairs of its
+ * slice before the GEMM, so absent neighbours cost one map read; the accumulation order across slices is not fixed
+ * (atomics), results are reproducible to f32 rounding only. */
 int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
                          int Cin, int Cout, float* dW, void* stream);
 int es_image_map(int n_img, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int* nbr, void* stream);
