@@ -230,3 +230,19 @@ def test_lr_schedule_matches_torch_multistep():
         assert abs(ow.lr - topt.param_groups[0]['lr']) < 1e-12, (epoch, ow.lr)
         topt.step(); tsch.step(); sched.step()
     assert abs(ow.lr - 1e-5) < 1e-12
+
+
+def test_upload_gts_layout():
+    """one packed buffer for the ground truth of a batch: per-sample views carry boxes, R(-euler) and int32 labels"""
+    import torch
+    from embodiedscan_amd.models.dense_heads.fcaf3d_head import upload_gts
+    from oracle import geometry as G
+    g = torch.Generator().manual_seed(5)
+    gts = [(torch.randn(n, 9, generator=g), torch.randint(0, 284, (n,), generator=g)) for n in (3, 0, 5)]
+    out = upload_gts(gts, torch.device('cpu'))
+    assert [o[0].shape[0] for o in out] == [3, 0, 5]
+    for (b, l), (db, dr, dl) in zip(gts, out):
+        assert torch.equal(db, b) and dl.dtype == torch.int32 and torch.equal(dl.long(), l)
+        if len(b):
+            assert torch.allclose(dr.view(-1, 3, 3), G.euler_to_matrix_zxy(-b[:, 6:9]), atol=1e-7)
+    assert upload_gts([(torch.zeros(0, 9), torch.zeros(0, dtype=torch.long))], torch.device('cpu'))[0][0].shape == (0, 9)
