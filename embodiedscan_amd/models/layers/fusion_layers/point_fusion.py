@@ -5,7 +5,6 @@ small device block and launches the fused es_point_sample kernels once per level
 import numpy as np
 import torch
 from .... import hip
-from .... import engine as E
 from ....hip import CONSTS, P, call
 
 _OP = {'T': 1, 'S': 2, 'R': 3, 'HF': 4, 'VF': 5}

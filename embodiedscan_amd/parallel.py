@@ -3,7 +3,6 @@ processes its own scans end to end; the only collectives are ONE all-reduce of t
 ONE all-reduce of the per-sample positive counts (the reference issues `reduce_mean` once per sample inside a Python
 loop, embodiedscan/utils/dist_utils.py:4-10 called from dense_heads/fcaf3d_head.py:1183).
 Backend: "nccl" (== RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests."""
-import torch
 import torch.distributed as dist
 
 

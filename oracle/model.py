@@ -11,7 +11,6 @@ Functional restatement, driven by a reference-named state dict, of:
                                                 models/detectors/sparse_featfusion_single_stage.py:86-243
   * FCAF3DHeadRotMat forward / loss             models/dense_heads/fcaf3d_head.py:993-1020,1091-1350
 """
-import math
 import numpy as np
 import torch
 import torch.nn.functional as F

@@ -10,7 +10,6 @@ Restates
     to THIS restatement and also evaluates the overlap in float64.
 """
 import math
-import numpy as np
 import torch
 from . import geometry as G
 

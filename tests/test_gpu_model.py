@@ -192,7 +192,6 @@ def test_prune_path_and_ragged_batch(setup):
     interpolated-score top-k, compaction and row gather all run), a ragged batch (different point counts per sample)
     and one sample WITHOUT ground-truth boxes (fcaf3d_head.py:1603-1607,1283-1285).  Exact-f32 mode, losses and target
     labels against the oracle run with the same threshold."""
-    import copy
     from embodiedscan_amd import engine as E, pipeline
     from embodiedscan_amd.structures import Det3DDataSample, EulerDepthInstance3DBoxes, InstanceData
     from oracle import model as OM

@@ -9,7 +9,6 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle import coords as C
 from oracle import sparse as S
 
 G = 12        # dense grid edge (voxels at tensor stride 1)
