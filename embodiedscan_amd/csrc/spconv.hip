@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
   const int w_tap = Cout * Cin;
   const float* X = (const float*)Xv;
   const unsigned short* Xh = (const unsigned short*)Xv;
-  struct Regs { float4 a[4]; uint4 b[NB]; int valid; };      // XH: only a[0], a[1] are used (2 x 8 bf16)
+  struct Regs { float4 a[XH ? 2 : 4]; uint4 b[NB]; int valid; };   // XH: 2 x 8 bf16, else 4 x 4 f32
   struct It { int ti, ci, a_off, b_off, valid; };
   // Loads are UNCONDITIONAL (an absent neighbour reads row 0 and is zeroed when written to LDS, a chunk past the end
   // re-reads the last tap) so that the compiler can keep the second prefetched chunk in flight with a counted
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
     } else {
       const float4* p = (const float4*)(X + it.a_off + c0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) R.a[q] = p[q];
+      for (int q = 0; q < (XH ? 2 : 4); ++q) R.a[q] = p[q];
     }
 #pragma unroll
     for (int h = 0; h < NB; ++h) R.b[h] = *(const uint4*)(W + it.b_off + h * 64 * Cin + c0);
@@ -603,14 +603,17 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
   auto store_chunk = [&](const Regs& R) {
     uint4* pa = (uint4*)&As[a_r * HLD + a_kk];
     uint4 v0, v1;
-    if (XH) {
-      v0 = *(const uint4*)&R.a[0];
-      v1 = *(const uint4*)&R.a[1];
+    if (XH) {                         // bit copies (a pointer cast here made the compiler keep R in scratch memory)
+      v0 = make_uint4(__float_as_uint(R.a[0].x), __float_as_uint(R.a[0].y), __float_as_uint(R.a[0].z),
+                      __float_as_uint(R.a[0].w));
+      v1 = make_uint4(__float_as_uint(R.a[1].x), __float_as_uint(R.a[1].y), __float_as_uint(R.a[1].z),
+                      __float_as_uint(R.a[1].w));
     } else {
+      constexpr int H = XH ? 0 : 2;      // (a[2], a[3] only exist in the f32 layout)
       v0 = make_uint4(pack_bf16(R.a[0].x, R.a[0].y), pack_bf16(R.a[0].z, R.a[0].w), pack_bf16(R.a[1].x, R.a[1].y),
                       pack_bf16(R.a[1].z, R.a[1].w));
-      v1 = make_uint4(pack_bf16(R.a[2].x, R.a[2].y), pack_bf16(R.a[2].z, R.a[2].w), pack_bf16(R.a[3].x, R.a[3].y),
-                      pack_bf16(R.a[3].z, R.a[3].w));
+      v1 = make_uint4(pack_bf16(R.a[H].x, R.a[H].y), pack_bf16(R.a[H].z, R.a[H].w), pack_bf16(R.a[H + 1].x, R.a[H + 1].y),
+                      pack_bf16(R.a[H + 1].z, R.a[H + 1].w));
     }
     if (!R.valid) v0 = v1 = make_uint4(0u, 0u, 0u, 0u);
     pa[0] = v0;
