@@ -51,8 +51,9 @@ def build_param_scheduler(cfg, optim):
     ps = cfg.get('param_scheduler') or []
     ps = [ps] if isinstance(ps, dict) else list(ps)
     out = []
+    base_lr = cfg.get('optim_wrapper', {}).get('optimizer', {}).get('lr', optim.initial_lr)
     for p in ps:
         assert p.get('type') == 'MultiStepLR', f"only MultiStepLR is configured for this path, got {p.get('type')}"
         out.append(MultiStepLR(optim, p['milestones'], p.get('gamma', 0.1), p.get('begin', 0), p.get('end', 10 ** 9),
-                               p.get('by_epoch', True)))
+                               p.get('by_epoch', True), base_lr=base_lr))
     return out

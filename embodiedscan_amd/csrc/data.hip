@@ -47,25 +47,37 @@ extern "C" int es_depth_to_points(const float* depth, int H, int W, const int* s
   return 0;
 }
 
-// in: (NI, 3, H, W) u8 BGR ; out: (NI, H, W, 3) f32 RGB normalised (channels-last feeds the conv engine)
-__global__ void k_preprocess_img(const unsigned char* __restrict__ in, int NI, int HW, float m0, float m1, float m2,
-                                 float s0, float s1, float s2, float* __restrict__ out) {
-  size_t tot = (size_t)NI * HW;
+// in: (NI, 3, H, W) u8 ; out: (NI, Hp, Wp, 3) f32 normalised, channels-last (feeds the conv engine).  flip != 0: output
+// channel c reads input channel 2-c (bgr_to_rgb / rgb_to_bgr, data_preprocessor.py:256-258).  Rows >= H / columns >= W of
+// the padded output (pad_size_divisor, bottom/right padding of multiview_img_stack_batch, data_preprocessors/utils.py:9-63)
+// hold pad_value, which the reference applies AFTER normalisation.
+__global__ void k_preprocess_img(const unsigned char* __restrict__ in, int NI, int H, int W, int Hp, int Wp, int flip,
+                                 float m0, float m1, float m2, float s0, float s1, float s2, float pad_value,
+                                 float* __restrict__ out) {
+  size_t HWp = (size_t)Hp * Wp, HW = (size_t)H * W;
+  size_t tot = (size_t)NI * HWp;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
-    size_t im = e / HW, px = e - im * HW;
-    const unsigned char* b = in + im * 3 * HW + px;
-    float r0 = ((float)b[2 * (size_t)HW] - m0) / s0;     // channel flip [2,1,0]
-    float r1 = ((float)b[(size_t)HW] - m1) / s1;
-    float r2 = ((float)b[0] - m2) / s2;
+    size_t im = e / HWp, px = e - im * HWp;
+    int y = (int)(px / Wp), x = (int)(px - (size_t)y * Wp);
     float* o = out + e * 3;
-    o[0] = r0; o[1] = r1; o[2] = r2;
+    if (y >= H || x >= W) {
+      o[0] = pad_value; o[1] = pad_value; o[2] = pad_value;
+      continue;
+    }
+    const unsigned char* b = in + im * 3 * HW + (size_t)y * W + x;
+    float c0 = (float)b[0], c1 = (float)b[HW], c2 = (float)b[2 * HW];
+    if (flip) { float t = c0; c0 = c2; c2 = t; }
+    o[0] = (c0 - m0) / s0;
+    o[1] = (c1 - m1) / s1;
+    o[2] = (c2 - m2) / s2;
   }
 }
-extern "C" int es_preprocess_img(const unsigned char* img, int n_img, int H, int W, const float* mean,
-                                 const float* std, float* out, void* stream) {
+extern "C" int es_preprocess_img(const unsigned char* img, int n_img, int H, int W, int Hp, int Wp, int flip,
+                                 const float* mean, const float* std, float pad_value, float* out, void* stream) {
   if (n_img <= 0) return 0;
-  hipLaunchKernelGGL(k_preprocess_img, dim3(4096), dim3(256), 0, (hipStream_t)stream, img, n_img, H * W, mean[0],
-                     mean[1], mean[2], std[0], std[1], std[2], out);
+  if (Hp < H || Wp < W) return -2;
+  hipLaunchKernelGGL(k_preprocess_img, dim3(4096), dim3(256), 0, (hipStream_t)stream, img, n_img, H, W, Hp, Wp, flip,
+                     mean[0], mean[1], mean[2], std[0], std[1], std[2], pad_value, out);
   ES_CHECK_LAUNCH();
   return 0;
 }

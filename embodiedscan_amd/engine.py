@@ -44,23 +44,26 @@ class Var:
 
 class Param:
     """View into the parameter / gradient arenas (+ lazily refreshed bf16 copies for the bf16 MFMA path)."""
-    __slots__ = ('d', 'g', 'bf_n', 'bf_t', 'bf_step')
+    __slots__ = ('d', 'g', 'bf_n', 'bf_t', 'bf_step', 'owner')
 
     def __init__(self, d, g=None):
         self.d, self.g = d, g
         self.bf_n = self.bf_t = None
         self.bf_step = -1
+        self.owner = _OWNER[0]
         if d.dim() == 3 and d.is_cuda:
-            CONV_PARAMS.append(self)
+            CONV_PARAMS.setdefault(d.device, []).append(self)
 
     def bf16(self):
         """(natural [K][Cin][Cout], transposed [K][Cout][Cin]) bf16 copies, re-made when the weights changed.
-        All registered conv kernels are refreshed together by ONE table-driven launch."""
+        All conv kernels registered for this device are refreshed together by ONE table-driven launch."""
         if self.bf_step != WEIGHT_VERSION[0]:
-            if self.bf_n is None or self not in _CAST_TABLE.get('set', ()):
-                _build_cast_table()
-            call('es_cast_weights_table', P(_CAST_TABLE['dev']), _CAST_TABLE['n'], _CAST_TABLE['tiles'], _stream())
-            for p in _CAST_TABLE['params']:
+            dev = self.d.device
+            tab = _CAST_TABLE.get(dev)
+            if tab is None or self.bf_n is None or self not in tab['set']:
+                tab = _build_cast_table(dev)
+            call('es_cast_weights_table', P(tab['dev']), tab['n'], tab['tiles'], _stream())
+            for p in tab['params']:
                 p.bf_step = WEIGHT_VERSION[0]
         return self.bf_n, self.bf_t
 
@@ -68,26 +71,56 @@ class Param:
 def refresh_weight_copies():
     """bf16 mode: bring the bf16 copies of every registered conv kernel up to date now (one launch on the current
     stream) instead of lazily at the first convolution that needs them."""
-    if PRECISION[0] == 'bf16' and CONV_PARAMS:
-        CONV_PARAMS[-1].bf16()
+    if PRECISION[0] != 'bf16':
+        return
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ps = CONV_PARAMS.get(dev)
+    if ps:
+        ps[-1].bf16()
 
 
-CONV_PARAMS = []          # every 3-D (conv kernel) Param living on the GPU
-_CAST_TABLE = {}
+# Registry of the conv kernels (3-D Params) living on each GPU, the input of the one-launch bf16 weight cast.  Entries are
+# tagged with the owner that was binding when they were made (a detector passes id(self) to begin_bind()); re-binding or
+# releasing an owner drops its old entries, so a process that builds several detectors neither leaks their arenas nor
+# keeps re-casting stale weights, and the tables of different devices never mix pointers.
+CONV_PARAMS = {}          # torch.device -> [Param]
+_CAST_TABLE = {}          # torch.device -> dict(dev=table tensor, n, tiles, params, set)
+_OWNER = [None]
 
 
-def _build_cast_table():
-    ps = [p for p in CONV_PARAMS if p.d.dim() == 3]
+def begin_bind(owner):
+    """drop every conv Param `owner` registered earlier and tag the ones created from now on with it"""
+    release(owner)
+    _OWNER[0] = owner
+
+
+def end_bind():
+    _OWNER[0] = None
+
+
+def release(owner):
+    for dev in list(CONV_PARAMS):
+        keep = [p for p in CONV_PARAMS[dev] if p.owner != owner]
+        if len(keep) != len(CONV_PARAMS[dev]):
+            CONV_PARAMS[dev] = keep
+            _CAST_TABLE.pop(dev, None)
+        if not keep:
+            CONV_PARAMS.pop(dev, None)
+
+
+def _build_cast_table(dev):
+    ps = [p for p in CONV_PARAMS.get(dev, ()) if p.d.dim() == 3]
     rows, tiles = [], 0
     for p in ps:
         K, a, b = p.d.shape
         if p.bf_n is None:
-            p.bf_n = torch.empty((K, a, b), dtype=torch.bfloat16, device=p.d.device)
-            p.bf_t = torch.empty((K, b, a), dtype=torch.bfloat16, device=p.d.device)
+            p.bf_n = torch.empty((K, a, b), dtype=torch.bfloat16, device=dev)
+            p.bf_t = torch.empty((K, b, a), dtype=torch.bfloat16, device=dev)
         rows.append([p.d.data_ptr(), p.bf_n.data_ptr(), p.bf_t.data_ptr(), K, a, b, tiles])
         tiles += K * ((a + 63) // 64) * ((b + 63) // 64)
-    dev = ps[0].d.device
-    _CAST_TABLE.update(dev=torch.tensor(rows, dtype=torch.int64).to(dev), n=len(rows), tiles=tiles, params=ps, set=set(ps))
+    tab = _CAST_TABLE[dev] = dict(dev=torch.tensor(rows, dtype=torch.int64).to(dev), n=len(rows), tiles=tiles, params=ps,
+                                  set=set(ps))
+    return tab
 
 
 PRECISION = ['f32']       # 'f32': exact-f32 MFMA everywhere; 'bf16': bf16 MFMA (f32 accumulate) for conv fwd / dgrad

@@ -35,7 +35,7 @@ class SparseFeatureFusionSingleStage3DDetector:
         bbox_head = dict(bbox_head)
         bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
         self.bbox_head = MODELS.build(bbox_head)
-        self.data_preprocessor = MODELS.build(data_preprocessor) if data_preprocessor else None
+        self.data_preprocessor = MODELS.build(data_preprocessor, device=self.device) if data_preprocessor else None
         self.voxel_size = self.bbox_head.voxel_size
         self.use_xyz_feat = use_xyz_feat
         self.coord_type = coord_type
@@ -51,6 +51,8 @@ class SparseFeatureFusionSingleStage3DDetector:
     def to(self, device):
         self.device = torch.device(device)
         self.arena.to(self.device)
+        if self.data_preprocessor is not None:
+            self.data_preprocessor.to(self.device)
         self._bound = False
         return self
 
@@ -58,10 +60,20 @@ class SparseFeatureFusionSingleStage3DDetector:
         if not self._bound:
             if self.arena.data.device != self.device:
                 self.arena.to(self.device)
-            self.backbone.bind(self.arena, 'backbone.')
-            self.backbone_3d.bind(self.arena, 'backbone_3d.')
-            self.bbox_head.bind(self.arena, 'bbox_head.')
+            E.begin_bind(id(self))               # conv kernels of an earlier bind of this detector are dropped
+            try:
+                self.backbone.bind(self.arena, 'backbone.')
+                self.backbone_3d.bind(self.arena, 'backbone_3d.')
+                self.bbox_head.bind(self.arena, 'bbox_head.')
+            finally:
+                E.end_bind()
             self._bound = True
+
+    def __del__(self):
+        try:
+            E.release(id(self))
+        except Exception:
+            pass
 
     def state_dict(self):
         return self.arena.state_dict()
@@ -160,6 +172,7 @@ class SparseFeatureFusionSingleStage3DDetector:
         return batch_data_samples
 
     def forward(self, inputs, data_samples=None, mode='tensor', **kwargs):
+        hip.refresh_stream()                     # launches follow torch's CURRENT stream of this call
         if mode == 'loss':
             return self.loss(inputs, data_samples, **kwargs)
         elif mode == 'predict':

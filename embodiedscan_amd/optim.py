@@ -9,6 +9,7 @@ from .parallel import allreduce_mean_
 class OptimWrapper:
     def __init__(self, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=10.0):
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.initial_lr = lr
         self.step = 0
         self.m = self.v = None
         self.last_norm = None
@@ -63,11 +64,13 @@ class MultiStepLR:
     """mmengine MultiStepLR(by_epoch=True) as configured at configs/detection/mv-det3d_...py:225-230: the learning rate
     of the wrapper is base_lr * gamma ** (number of milestones already passed), inside [begin, end) epochs."""
 
-    def __init__(self, optim, milestones, gamma=0.1, begin=0, end=10 ** 9, by_epoch=True):
+    def __init__(self, optim, milestones, gamma=0.1, begin=0, end=10 ** 9, by_epoch=True, base_lr=None):
         assert by_epoch, 'the shipped configs schedule by epoch'
         self.optim, self.milestones, self.gamma = optim, sorted(int(m) for m in milestones), float(gamma)
         self.begin, self.end = int(begin), int(end)
-        self.base_lr = optim.lr
+        # the INITIAL learning rate (mmengine keeps it as param_group['initial_lr']): taken from the config, never from
+        # the live optim.lr, which after a resume is already decayed
+        self.base_lr = float(base_lr if base_lr is not None else getattr(optim, 'initial_lr', optim.lr))
         self.epoch = 0
 
     def lr_at(self, epoch):

@@ -203,8 +203,11 @@ int es_depth_to_points(const float* depth, int H, int W, const int* sel_view, co
  * w is [49][3][Cout] (tap = ky*7+kx).  y: (n_img, Ho, Wo, Cout), Ho = (H-1)/2+1. */
 int es_stem_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, int n_img, int H, int W,
                      int Cout, float* y, void* stream);
-int es_preprocess_img(const unsigned char* img, int n_img, int H, int W, const float* mean_host,
-                      const float* std_host, float* out /* (n_img,H,W,3) */, void* stream);
+/* u8 (n_img,3,H,W) -> f32 channels-last (n_img,Hp,Wp,3): optional channel flip (bgr_to_rgb), (x-mean)/std, bottom/right
+ * padding to (Hp,Wp) with pad_value.  data_preprocessor.py:249-264,286-305; data_preprocessors/utils.py:9-63 */
+int es_preprocess_img(const unsigned char* img, int n_img, int H, int W, int Hp, int Wp, int flip,
+                      const float* mean_host, const float* std_host, float pad_value,
+                      float* out /* (n_img,Hp,Wp,3) */, void* stream);
 
 #ifdef __cplusplus
 }

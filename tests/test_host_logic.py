@@ -179,6 +179,9 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path):
     assert sd['backbone.layer2.0.conv2.weight'].shape == (32, 32, 3, 3)           # torch (O, I, KH, KW)
     assert sd['backbone_3d.layer1.0.conv1.kernel'].shape == (27, 64, 64)          # ME (K, I, O)
     assert sd['bbox_head.conv_cls.kernel'].shape == (128, 284) and sd['bbox_head.conv_reg.kernel'].shape == (128, 12)
+    # nn.BatchNorm buffers a strict load on the reference side expects; resume state under its own (non-mmengine) key
+    assert int(sd['backbone_3d.layer1.0.norm1.bn.num_batches_tracked']) == 17 and int(sd['backbone.bn1.num_batches_tracked']) == 0
+    assert 'optimizer' not in raw and 'optimizer_flat' in raw
     b = ParamArena(detector_specs(284), seed=99)
     opt2 = OptimWrapper()
     opt2.m, opt2.v = torch.zeros(b.n_train), torch.zeros(b.n_train)
@@ -230,6 +233,40 @@ def test_lr_schedule_matches_torch_multistep():
         assert abs(ow.lr - topt.param_groups[0]['lr']) < 1e-12, (epoch, ow.lr)
         topt.step(); tsch.step(); sched.step()
     assert abs(ow.lr - 1e-5) < 1e-12
+
+
+def test_resume_continues_lr_schedule(tmp_path):
+    """save at epoch 9 (lr already decayed to 1e-4), resume into fresh objects: the lr must stay 1e-4, the
+    next epochs must follow the original schedule (no reset to 1e-3, no double decay), whatever the construction order."""
+    from embodiedscan_amd.checkpoint import load_checkpoint, save_checkpoint
+    from embodiedscan_amd.config import build_optim_wrapper, build_param_scheduler, load_config
+    from embodiedscan_amd.params import ParamArena, detector_specs
+    cfg = load_config(os.path.join(ROOT, 'configs', 'mv_3ddet.py'))
+    a = ParamArena(detector_specs(284), seed=3)
+    ow = build_optim_wrapper(cfg)
+    sch = build_param_scheduler(cfg, ow)
+    expect = []
+    for epoch in range(12):
+        if epoch == 9:
+            save_checkpoint(a, str(tmp_path / 'e9.pth'), optim=ow, schedulers=sch, meta=dict(epoch=9))
+        expect.append(ow.lr)
+        sch[0].step()
+    assert abs(expect[9] - 1e-4) < 1e-12
+    for order in ('sched_before_load', 'sched_after_load'):
+        b = ParamArena(detector_specs(284), seed=4)
+        ow2 = build_optim_wrapper(cfg)
+        if order == 'sched_before_load':
+            sch2 = build_param_scheduler(cfg, ow2)
+            load_checkpoint(b, str(tmp_path / 'e9.pth'), optim=ow2, schedulers=sch2)
+        else:
+            load_checkpoint(b, str(tmp_path / 'e9.pth'), optim=ow2)
+            sch2 = build_param_scheduler(cfg, ow2)              # base_lr comes from the config, not the decayed live lr
+            load_checkpoint(b, str(tmp_path / 'e9.pth'), schedulers=sch2)
+        got = []
+        for epoch in range(9, 12):
+            got.append(ow2.lr)
+            sch2[0].step()
+        assert all(abs(g - e) < 1e-12 for g, e in zip(got, expect[9:])), (order, got, expect[9:])
 
 
 def test_upload_gts_layout():
