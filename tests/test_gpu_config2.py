@@ -1,0 +1,176 @@
+"""Parity AT THE BENCHMARKED CONFIGURATION (BASELINE.json config 2: 20 views of 480x640, 100 k points per scan, the
+bench's default schedule: bf16 matrix cores, four HIP streams, tap-split and big-tile kernels live) against the CPU
+oracle.  Integer outputs (voxel coordinates of every level, level sizes, target labels and assigned boxes) are checked
+bit for bit on the full batch of 4 scans; head logits and the three losses of one scan are checked against the oracle's
+f32 forward with the tolerances `north_star` asks to be stated: printed next to the measured error."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CFG = 'configs/mv_3ddet.py'
+MEAN, STD = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope='module')
+def setup():
+    import os
+    from embodiedscan_amd.config import build_detector
+    from embodiedscan_amd.synth import make_scan
+    from embodiedscan_amd import pipeline
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = torch.device('cuda:0')
+    det = build_detector(os.path.join(root, CFG), device=dev, seed=0).to(dev)
+    g = torch.Generator().manual_seed(1)
+    sd = {k: v.cpu() for k, v in det.state_dict().items()}
+    for k in sd:                    # non-trivial frozen-BN statistics
+        if k.startswith('backbone.') and k.endswith('running_var'):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+        if k.startswith('backbone.') and (k.endswith('running_mean') or k.endswith('bn1.bias') or k.endswith('bn2.bias')):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+    det.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    scans = [make_scan(1234 + i, render_device='cuda:0') for i in range(4)]       # the bench's scans of rank 0
+    dscans = [pipeline.upload_scan(s, dev) for s in scans]
+    return det, scans, dscans, sd
+
+
+def _forward(det, dscans, mode, backward=False):
+    from embodiedscan_amd import engine as E, pipeline
+    E.PRECISION[0] = mode
+    try:
+        E.TAPE.clear()
+        E.WEIGHT_VERSION[0] += 1
+        batch = pipeline.make_batch(dscans)
+        points_host = [p.cpu() for p in batch['inputs']['points']]
+        data = det.data_preprocessor(batch, True)
+        det._bind()
+        det.arena.grad.zero_()
+        losses = det.forward(data['inputs'], data['data_samples'], mode='loss')
+        if backward:
+            det._backward(None)
+        else:
+            E.TAPE.clear()
+            E.join_wgrad_streams()
+        torch.cuda.synchronize()
+    finally:
+        E.PRECISION[0] = 'f32'
+    return losses, points_host
+
+
+def _oracle_levels(points_np, n_batch, voxel_size=0.01):
+    """integer side of the oracle's forward only (no convolutions): voxel set, backbone level sets, head level sets"""
+    from oracle import coords as C
+    c, _ = C.voxelize(points_np, voxel_size)
+    cur, ts = C.stride_coords(C.stride_coords(c, 2), 4), 4
+    lv = []
+    for _ in range(4):
+        ts *= 2
+        cur = C.stride_coords(cur, ts)
+        lv.append(cur)
+    heads, x = [None] * 4, lv[3]
+    heads[3] = x
+    for i in (2, 1, 0):
+        ch = C.gen_transpose_coords(x, 8 * 2 ** (i + 1))
+        x, _, _ = C.union_coords(lv[i], ch, n_batch)
+        heads[i] = x
+    return c, lv, heads
+
+
+def test_integer_outputs_batch4_bit_exact(setup):
+    """4 scans x 20 views x 100 k points, bf16 default schedule: voxel coordinates of every head level (values AND row
+    order), level sizes, target labels, assigned boxes and centerness targets equal the oracle's bit for bit."""
+    from oracle import geometry as G
+    det, scans, dscans, sd = setup
+    losses, points_host = _forward(det, dscans, 'bf16')
+    _, lv, heads = _oracle_levels([p.numpy() for p in points_host], 4)
+    levels = det.bbox_head.last_levels
+    sizes = []
+    for l in range(4):
+        hc = levels[l]['cs'].coords.cpu().numpy()
+        sizes.append(hc.shape[0])
+        np.testing.assert_array_equal(hc, heads[l])
+    print(f'head level rows (batch 4, fine->coarse): {sizes}; all coordinates bit-exact')
+    assert sizes[0] > 300000           # the 480 k-row regime the fast kernels / tap split are built for
+    tg = det.bbox_head.last_targets
+    n_pos = 0
+    for b in range(4):
+        pts = [torch.from_numpy(h[h[:, 0] == b][:, 1:]).float() * 0.01 for h in heads]
+        ct, bt, kt = G.get_targets(pts, torch.from_numpy(scans[b]['gt_boxes']), torch.from_numpy(scans[b]['gt_labels']))
+        np.testing.assert_array_equal(tg[b][2].cpu().numpy(), kt.numpy())
+        np.testing.assert_array_equal(tg[b][1].cpu().numpy(), bt.numpy())
+        np.testing.assert_array_equal(tg[b][0].cpu().numpy(), ct.numpy())
+        n_pos += int((kt >= 0).sum())
+    print(f'target labels / boxes / centerness bit-exact on {sum(sizes)} locations, {n_pos} positives')
+    assert all(np.isfinite(float(v)) for v in losses.values())
+
+
+@pytest.fixture(scope='module')
+def oracle_one_scan(setup):
+    from oracle import model as OM
+    from embodiedscan_amd import pipeline
+    det, scans, dscans, sd = setup
+    pts = [pipeline.depth_to_points(dscans[0]).cpu()]
+    imgs = OM.preprocess_img(torch.from_numpy(scans[0]['img']), MEAN, STD)[None]
+    with torch.no_grad():
+        ol, aux = OM.detector_loss(sd, pts, imgs, [scans[0]['meta']], [torch.from_numpy(scans[0]['gt_boxes'])],
+                                   [torch.from_numpy(scans[0]['gt_labels'])], return_aux=True, training=True)
+    return ol, aux
+
+
+# stated tolerances at config 2 (relative): losses, head logits (relative L2 per level over centerness + class logits),
+# decoded box distances.  f32 = exact-f32 matrix cores; bf16 = the bench default.
+TOL = {'f32': dict(loss=1e-3, logits=1e-3, bbox=1e-3), 'bf16': dict(loss=2e-2, logits=5e-2, bbox=5e-2)}
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'f32'])
+def test_losses_and_logits_one_scan(setup, oracle_one_scan, mode):
+    det, scans, dscans, sd = setup
+    ol, aux = oracle_one_scan
+    losses, _ = _forward(det, dscans[:1], mode)
+    tol = TOL[mode]
+    levels = det.bbox_head.last_levels
+    for l in range(4):
+        ho = levels[l]['ho'].d.cpu()
+        oc, ob, ok, _ = aux['outs'][l][0]
+        assert ho.shape[0] == oc.shape[0]
+        e_logit = _rel(torch.cat([ho[:, 0:1], ho[:, 13:]], 1), torch.cat([oc, ok], 1))
+        e_box = _rel(levels[l]['bbox'].cpu(), ob)
+        print(f'{mode} level {l} ({ho.shape[0]} rows): logits rel-L2 {e_logit:.2e} (tol {tol["logits"]:.0e}), '
+              f'decoded bbox rel-L2 {e_box:.2e} (tol {tol["bbox"]:.0e})')
+        assert e_logit < tol['logits'] and e_box < tol['bbox']
+    np.testing.assert_array_equal(det.bbox_head.last_targets[0][2].cpu().numpy(), aux['targets'][0][2].numpy())
+    for k in ol:
+        e = abs(float(losses[k]) - float(ol[k])) / abs(float(ol[k]))
+        print(f'{mode} {k}: hip {float(losses[k]):.6f} oracle(f32) {float(ol[k]):.6f} rel err {e:.2e} (tol {tol["loss"]:.0e})')
+        assert e < tol['loss']
+
+
+def test_run_to_run_noise_is_bounded(setup):
+    """f32 atomics (weight gradients, tap-split forward of under-filled launches) make two runs of the same step differ
+    in the last bits.  Stated bound on the same inputs / weights, bf16 default schedule, batch 4: head logits relative
+    L2 <= 1e-5 per level, losses <= 1e-5 relative, parameter gradients <= 1e-3 relative L2 per tensor (median <= 1e-5);
+    integer outputs identical."""
+    det, scans, dscans, sd = setup
+    runs = []
+    for _ in range(2):
+        losses, _ = _forward(det, dscans, 'bf16', backward=True)
+        lv = det.bbox_head.last_levels
+        runs.append(dict(losses={k: float(v) for k, v in losses.items()}, ho=[l['ho'].d.clone() for l in lv],
+                         kt=[t[2].clone() for t in det.bbox_head.last_targets],
+                         grads={k: v.clone() for k, v in det.arena.grad_dict().items()}))
+    a, b = runs
+    for x, y in zip(a['kt'], b['kt']):
+        assert torch.equal(x, y)
+    e_logit = max(_rel(x, y) for x, y in zip(a['ho'], b['ho']))
+    e_loss = max(abs(a['losses'][k] - b['losses'][k]) / abs(b['losses'][k]) for k in a['losses'])
+    rel = {k: _rel(a['grads'][k], b['grads'][k]) for k in a['grads'] if float(b['grads'][k].norm()) > 1e-12}
+    worst = max(rel, key=rel.get)
+    med = float(np.median(list(rel.values())))
+    print(f'run-to-run: logits rel-L2 {e_logit:.2e} (bound 1e-5), losses {e_loss:.2e} (bound 1e-5), gradients median '
+          f'{med:.2e} (bound 1e-5) worst {rel[worst]:.2e} at {worst} (bound 1e-3)')
+    assert e_logit <= 1e-5 and e_loss <= 1e-5 and med <= 1e-5 and rel[worst] <= 1e-3

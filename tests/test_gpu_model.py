@@ -57,6 +57,20 @@ def test_data_side_kernels(setup):
     err = float((img - ref).abs().max())
     print(f'A18 max abs err {err:.3e} (tol 1e-6)')
     assert img.shape == ref.shape and err < 1e-6
+    assert data['inputs']['imgs'].device == det.device == det.arena.data.device      # follows the detector, not cuda:0
+    # behaviours the shipped 480x480 inputs do not exercise: no channel flip, bottom/right padding to the size divisor
+    # with pad_value applied after normalisation (data_preprocessor.py:256-264, data_preprocessors/utils.py:43-62)
+    import torch.nn.functional as F
+    from embodiedscan_amd.models.data_preprocessors.data_preprocessor import Det3DDataPreprocessor
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    u8 = torch.randint(0, 256, (1, 2, 3, 50, 70), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    for flip in (False, True):
+        pp = Det3DDataPreprocessor(mean=mean, std=std, bgr_to_rgb=flip, pad_size_divisor=32, pad_value=0.5, device='cuda:0')
+        got = pp({'inputs': {'img': u8}, 'data_samples': None}, True)['inputs']['imgs'].cpu()
+        x = (u8.flip(2) if flip else u8).float()
+        x = (x - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+        want = F.pad(x, (0, 96 - 70, 0, 64 - 50), value=0.5)
+        assert got.shape == want.shape == (1, 2, 3, 64, 96) and float((got - want).abs().max()) < 1e-6
 
 
 def test_train_step_parity(setup):
