@@ -2,11 +2,13 @@
 """bench.py -- mv-3ddet train-step throughput on MI355X (BASELINE.json metric: scans/sec).
 
 One "step" = one full train step of SparseFeatureFusionSingleStage3DDetector on a batch of synthetic
-20 x (480x640) RGB-D scans already resident in HBM: depth->points (A1-A3), image normalisation (A18), 2-D and
-3-D backbones, projection fusion, FCAF3D head, target assignment, losses, backward, gradient all-reduce
-(N > 1), clip + AdamW.  Prints ONE JSON line (rank 0).
+20 x (480x640) RGB-D scans: host->device copy of the raw batch (pinned buffers, copy stream, double-buffered slots:
+the copy of step i+1 runs under the kernels of step i, the step waits for its own batch) -> depth->points (A1-A3) ->
+image normalisation (A18) -> 2-D and 3-D backbones -> projection fusion -> FCAF3D head -> target assignment -> losses ->
+backward -> gradient all-reduce (N > 1) -> clip + AdamW.  The timed region rotates through `--rotate` distinct batches.
+Prints ONE JSON line (rank 0).
 
-  python bench.py --gpus 1 --steps 5 --warmup 2
+  python bench.py --gpus 1 --steps 8 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus N --steps K --warmup W
 """
@@ -19,6 +21,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
+K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
+ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_affine', 'es_spconv_wgrad', 'es_spconv_wgrad_bf16'}
+SCATTER = {'es_voxel_keys', 'es_unique_first', 'es_morton_sort', 'es_stride_keys', 'es_kernel_map', 'es_inverse_map',
+           'es_union_plan', 'es_point_sample_fwd', 'es_point_sample_bwd', 'es_depth_to_points'}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -27,10 +35,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=4, help='scans per GPU per step (reference config: 8xb4)')
     ap.add_argument('--views', type=int, default=20)
+    ap.add_argument('--rotate', type=int, default=3, help='distinct synthetic batches the timed steps cycle through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'],
                     help='conv fwd/dgrad matrix-core type: bf16 MFMA with f32 accumulate (BASELINE config) or exact-f32 MFMA')
-    ap.add_argument('--cpu-views', type=int, default=20)
+    ap.add_argument('--resident', action='store_true', help='skip the per-step host->device copy (inputs resident in HBM)')
     args = ap.parse_args()
 
     import torch
@@ -60,13 +69,66 @@ def main():
     det = build_detector(cfg, device=dev, seed=0).to(dev)          # same initial weights on every rank
     optim = build_optim_wrapper(cfg)
 
-    # per-rank synthetic scans: seed = 1234 + rank*10007 + i ; rendered on the GPU, untimed
-    scans = [make_scan(1234 + rank * 10007 + i, n_views=args.views, render_device=str(dev)) for i in range(args.batch)]
-    dscans = [pipeline.upload_scan(s, dev) for s in scans]        # inputs resident in HBM before timing
+    # per-rank synthetic scans: seed = 1234 + rank*10007 + i ; rendered on the GPU, untimed.  `rotate`
+    # distinct batches live in PINNED host memory; every timed step copies its batch host->device.
+    n_rot = max(1, args.rotate)
+    scans = [make_scan(1234 + rank * 10007 + i, n_views=args.views, render_device=str(dev))
+             for i in range(args.batch * n_rot)]
+    pinned = [pipeline.pin_scan(s) for s in scans]
+    batches = [pinned[r * args.batch:(r + 1) * args.batch] for r in range(n_rot)]
+    h2d_bytes = sum(pipeline.scan_h2d_bytes(p) for p in batches[0])
+    slots = [[pipeline.alloc_slot(p, dev) for p in batches[0]] for _ in range(2)]
+    copy_stream = torch.cuda.Stream()
+    ready = [torch.cuda.Event(), torch.cuda.Event()]          # slot s holds its batch
+    freed = [torch.cuda.Event(), torch.cuda.Event()]          # the step that read slot s has been queued completely
+    state = dict(i=0, dscans=[None, None])
+
+    def prefetch(i):
+        """queue the host->device copy of step i's batch into slot i%2 on the copy stream"""
+        s = i % 2
+        with torch.cuda.stream(copy_stream):
+            if i >= 2:
+                copy_stream.wait_event(freed[s])              # step i-2 (last reader of this slot) is done
+            state['dscans'][s] = [pipeline.upload_into(sl, p) for sl, p in zip(slots[s], batches[i % n_rot])]
+            ready[s].record(copy_stream)
+
+    # ---- parity at the benchmarked configuration, part 1 (untimed): losses of scans[0] alone from the PRE-training
+    # weights on the HIP path; cpu_baseline() below runs the oracle on the same scan / weights and asserts agreement
+    parity_hip = None
+    sd0 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd0 = {k: v.cpu() for k, v in det.state_dict().items()}
+        d0 = pipeline.upload_scan(scans[0], dev)
+        b0 = pipeline.make_batch([d0])
+        E.TAPE.clear()
+        data = det.data_preprocessor(b0, True)
+        det._bind()
+        l0 = det.forward(data['inputs'], data['data_samples'], mode='loss')
+        E.TAPE.clear()
+        E.join_wgrad_streams()
+        parity_hip = {k: float(v) for k, v in l0.items()}
+        del d0, b0, data, l0
 
     def step():
-        batch = pipeline.make_batch(dscans)                       # A1-A3 on device
-        return det.train_step(batch, optim)
+        i = state['i']
+        s = i % 2
+        if args.resident:
+            if state['dscans'][0] is None:
+                state['dscans'][0] = [pipeline.upload_scan(sc, dev) for sc in scans[:args.batch]]
+            dscans = state['dscans'][0]
+        else:
+            if i == 0:
+                prefetch(0)
+            torch.cuda.current_stream().wait_event(ready[s])  # this step's batch has landed in HBM
+            prefetch(i + 1)                                   # next step's copy runs under this step's kernels
+            dscans = state['dscans'][s]
+        E.mark('_begin')
+        batch = pipeline.make_batch(dscans)                   # A1-A3 on device
+        out = det.train_step(batch, optim)
+        if not args.resident:
+            freed[s].record(torch.cuda.current_stream())
+        state['i'] = i + 1
+        return out
 
     for _ in range(args.warmup):
         losses = step()
@@ -74,21 +136,15 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # time EXACTLY `steps` steps; the convolution engine launches are bracketed by HIP events recorded on the stream
-    # each kernel is launched on (the step runs on four streams: point branch, image branch, and their wgrad streams)
-    prof = {'names': {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_affine', 'es_spconv_wgrad',
-                      'es_spconv_wgrad_bf16'}, 'records': [],
-            'event': lambda: torch.cuda.Event(enable_timing=True)}
+    # time EXACTLY `steps` steps; the convolution engine launches of the last timed step are bracketed by HIP events
+    # recorded on the stream each kernel is launched on (the step runs on four compute streams + the copy stream)
+    prof = {'names': ENGINE, 'records': [], 'event': lambda: torch.cuda.Event(enable_timing=True)}
     t0 = time.perf_counter()
     for it in range(args.steps):
-        # the engine launches of the LAST timed step are bracketed by HIP events (2 events per launch and one pair
-        # counter per kernel map cost ~3 ms of host time per step, so they are not recorded on every step)
+        # (2 events per launch and one pair counter per kernel map cost ~3 ms of host time, so only the last step)
         hip.PROFILE = prof if it == args.steps - 1 else None
         losses = step()
-    recs = prof['records']
-    for i in range(len(recs)):              # resolve map pointer -> pair counter while the maps are still alive
-        name, e0, e1, a = recs[i]
-        recs[i] = (name, e0, e1, a, hip.PAIRS.get(a[4] if (name.startswith('es_spconv_wgrad') or name == 'es_spconv_fwd_bf16') else a[3]))
+    recs = resolve_pairs(hip, prof['records'])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -118,99 +174,195 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel family (the convolution engine), from the live HIP-event timings.
-    # The PMC passes (profiles/r1_conv_pmc*.txt) show the engine moving ~9 TB/s between L2 and the CUs at 16 % MFMA
-    # utilisation: it is bandwidth bound, so the roofline is quoted against HBM bandwidth with the ALGORITHMIC bytes of
-    # sum over launches of P*(Cin + Cout)*4 + weights, P = valid (output, tap) pairs of the kernel map.
-    K_PEAK_HBM = 8000.0               # GB/s, MI355X_MICROARCH.md
+    mfma_peak = K_PEAK_MFMA[args.precision]
+    eng = engine_totals(recs, mfma_peak)
 
-    def engine_totals(records):
-        tot_ms, tot_flop, tot_bytes, n_launch = 0.0, 0.0, 0.0, 0
-        for name, e0, e1, a, pairs_dev in records:
-            tot_ms += e0.elapsed_time(e1)
-            n_launch += 1
-            if name == 'es_spconv_fwd_bf16':
-                nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
-            elif not name.startswith('es_spconv_wgrad'):
-                nbr, n_out, n_in, K, cin, cout = a[3], a[4], a[5], a[6], a[7], a[8]
-            else:
-                nbr, n_out, n_in, K, cin, cout = a[4], a[5], a[6], a[7], a[8], a[9]
-            pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
-            tot_flop += 2.0 * pairs * cin * cout
-            wbytes = 2 if 'bf16' in name and not name.startswith('es_spconv_wgrad') else 4
-            tot_bytes += pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wbytes
-        return tot_ms, tot_flop, tot_bytes, n_launch
-
-    tot_ms, tot_flop, tot_bytes, n_launch = engine_totals(prof['records'])
-    # One extra, UNTIMED step on the single-stream schedule: the same launches without other streams sharing the chip,
-    # i.e. the stand-alone duration of each kernel (what a per-kernel roofline is usually quoted on).
-    single = None
+    # ---- one extra UNTIMED step on the single-stream schedule: stand-alone duration of every engine launch, the
+    # scatter-path kernels (north_star: "achieved HBM GB/s for the scatter path") and per-stage times
+    single = scatter = stages = None
     if world == 1:
-        from embodiedscan_amd import engine as E
         saved = (E.TWO_STREAMS[0], E.WGRAD_ASYNC[0])
         E.TWO_STREAMS[0] = E.WGRAD_ASYNC[0] = False
-        prof1 = dict(prof, records=[])
+        prof1 = dict(prof, names=ENGINE | SCATTER, records=[])
         hip.PROFILE = prof1
+        E.MARKS = []
         step()
+        marks, E.MARKS = E.MARKS, None
         hip.PROFILE = None
         E.TWO_STREAMS[0], E.WGRAD_ASYNC[0] = saved
-        r1 = prof1['records']
-        r1 = [(n_, e0, e1, a, hip.PAIRS.get(a[4] if (n_.startswith('es_spconv_wgrad') or n_ == 'es_spconv_fwd_bf16') else a[3]))
-              for n_, e0, e1, a in r1]
+        r1 = resolve_pairs(hip, prof1['records'])
         torch.cuda.synchronize()
-        ms1, fl1, by1, nl1 = engine_totals(r1)
-        if ms1 > 0:
-            single = dict(achieved=round(by1 / (ms1 * 1e-3) / 1e9, 1), frac=round(by1 / (ms1 * 1e-3) / 1e9 / K_PEAK_HBM, 4),
-                          kernel_ms_per_step=round(ms1, 3), algorithmic_tflops=round(fl1 / (ms1 * 1e-3) / 1e12, 2),
-                          note='same launches, one extra untimed step with ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0')
-    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-    # HBM traffic of the same kernel family from the PMC passes of this command (FETCH_SIZE / WRITE_SIZE need separate
-    # rocprofv3 runs, so the figure is read from the committed summary, bytes per launch like `achieved`'s numerator)
-    traffic, traffic_note = None, 'traffic: null (no profiles/r1_final_pmc_traffic.json)'
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_final_pmc_traffic.json')
-    if args.precision == 'bf16' and os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file))
-        traffic = pmc['bytes_per_launch']
-        traffic_note = (f"traffic = HBM bytes per launch from PMC (profiles/r1_final_pmc_traffic.json: "
-                        f"{pmc['bytes_per_step'] / 1e9:.1f} GB per step over {pmc['launches'] // pmc['steps']} launches) vs "
-                        f"{tot_bytes / max(n_launch, 1) / 1e6:.0f} MB algorithmic bytes per launch")
-    roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=K_PEAK_HBM, unit='GB/s',
-                    frac=round(achieved / K_PEAK_HBM, 4), traffic=traffic,
+        e1 = engine_totals([r for r in r1 if r[0] in ENGINE], mfma_peak)
+        single = dict(kernel_ms_per_step=e1['ms'], launches=e1['launches'], algorithmic_tflops=e1['tflops'],
+                      frac_of_binding_roof=e1['frac_binding'], pair_bytes_GBps=e1['pair_GBps'],
+                      note='same launches, one extra untimed step with ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0 (stand-alone '
+                           'durations); rocprofv3 summary of this schedule: profiles/r2_single_stream_kernel_stats.txt')
+        scatter = scatter_totals([r for r in r1 if r[0] in SCATTER])
+        stages = {}
+        for (n0, ev0), (n1, ev1) in zip(marks[:-1], marks[1:]):
+            stages[n1] = round(stages.get(n1, 0.0) + ev0.elapsed_time(ev1), 3)
+        stages['_note'] = 'single-stream schedule, HIP-event time between stage boundaries of ONE untimed step; includes ' \
+                          'host-induced gaps; the default four-stream schedule overlaps A7 with A4-A6 and the two backward branches'
+
+    # static PMC figures of the same command (separate rocprofv3 --pmc passes, see profiles/): bytes per engine launch
+    traffic, traffic_note = None, 'traffic: null (no PMC summary for this precision under profiles/)'
+    for name in ('r2_pmc_traffic.json', 'r1_final_pmc_traffic.json'):
+        pmc_file = os.path.join(ROOT, 'profiles', name)
+        if args.precision == 'bf16' and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            traffic = pmc['bytes_per_launch']
+            traffic_note = (f"traffic is STATIC: HBM bytes per engine launch from the committed PMC passes of this command "
+                            f"(profiles/{name}: {pmc['bytes_per_step'] / 1e9:.1f} GB per step over "
+                            f"{pmc['launches'] // pmc['steps']} launches), not re-measured by this run")
+            break
+    if eng['t_mfma'] >= eng['t_hbm']:
+        roof = dict(bound='mfma', achieved=eng['tflops'], peak=mfma_peak, unit='TFLOP/s',
+                    frac=round(eng['tflops'] / mfma_peak, 4))
+    else:
+        roof = dict(bound='hbm', achieved=eng['comp_GBps'], peak=K_PEAK_HBM, unit='GB/s',
+                    frac=round(eng['comp_GBps'] / K_PEAK_HBM, 4))
+    roofline = dict(roof, traffic=traffic,
                     kernel='convolution engine: k_spconv_bf16* (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
                     else 'convolution engine: k_spconv / k_spconv_wgrad (exact-f32 MFMA)',
-                    launches_per_step=n_launch, kernel_ms_per_step=round(tot_ms, 3), single_stream=single,
-                    algorithmic_tflops=round(tot_flop / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
-                    note='algorithmic bytes = sum over launches of P*(Cin+Cout)*4 + K*Cin*Cout*sizeof(w), P = valid '
-                         '(output,tap) pairs; algorithmic flops = 2*P*Cin*Cout; launch durations are HIP-event times on the '
-                         'launch stream under the concurrent 4-stream schedule (kernels of different streams share the chip, '
-                         'so the sum exceeds wall time); ' + traffic_note)
+                    launches_per_step=eng['launches'], kernel_ms_per_step=eng['ms'],
+                    frac_of_binding_roof=eng['frac_binding'],
+                    mfma=dict(achieved_tflops=eng['tflops'], peak_tflops=mfma_peak, frac=round(eng['tflops'] / mfma_peak, 4)),
+                    hbm_compulsory=dict(achieved_GBps=eng['comp_GBps'], frac=round(eng['comp_GBps'] / K_PEAK_HBM, 4),
+                                        bytes_per_step=eng['comp_bytes']),
+                    hbm_pair_bytes=dict(achieved_GBps=eng['pair_GBps'], frac=round(eng['pair_GBps'] / K_PEAK_HBM, 4),
+                                        bytes_per_step=eng['pair_bytes']),
+                    single_stream=single,
+                    note='per launch: algorithmic flops = 2*P*Cin*Cout (P = valid (output,tap) pairs), compulsory bytes = '
+                         'every input row, output row and weight once, pair bytes = SURVEY 8(d) P*(Cin+Cout)*4 + weights; '
+                         'binding roof per launch = max(flops/MFMA peak, compulsory bytes/HBM peak); frac_of_binding_roof = '
+                         'sum of binding-roof times / sum of HIP-event launch durations; bound/achieved/peak/frac = the '
+                         'roof that binds the family in total; durations are HIP-event times on the launch stream under the '
+                         'concurrent 4-stream schedule (kernels of different streams share the chip, so the sum exceeds wall '
+                         'time); ' + traffic_note)
 
     out = dict(metric='scans/sec (train step) mv-3ddet, 20x(480x640) RGB-D views', value=round(world * args.batch * args.steps / dt, 4),
                unit='scans/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak', vs_baseline=None,
                dtype=args.precision, data='synthetic',
                config=dict(workload='mv-3ddet ResNet-50(w16) + MinkResNet34 + FCAF3DHeadRotMat, 20 views 480x640, '
-                                    f'100k points/scan, {args.precision} matrix cores with f32 accumulate / f32 master weights, full train step incl. AdamW',
-                           scans_per_gpu_per_step=args.batch, views=args.views, parallelism=f'dp{world}'),
+                                    f'100k points/scan, {args.precision} matrix cores with f32 accumulate / f32 master weights, '
+                                    'full train step incl. H2D of the batch and AdamW',
+                           scans_per_gpu_per_step=args.batch, views=args.views, parallelism=f'dp{world}',
+                           distinct_batches=n_rot,
+                           h2d='resident (no per-step copy)' if args.resident else
+                           f'{h2d_bytes / 1e6:.0f} MB per step from pinned host memory on a copy stream, double-buffered'),
                losses={k: round(float(v), 6) for k, v in losses.items()}, roofline=roofline)
+    if scatter is not None:
+        out['scatter_path'] = scatter
+        out['stage_ms'] = stages
     if world > 1:
         out['replicas_in_sync'] = in_sync
         out['rank_ms_per_step'] = rank_ms
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(scans[0], det, args)
+        out['cpu_baseline'], out['parity'] = cpu_baseline(scans[0], sd0, det, parity_hip, args)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if out.get('parity') and not out['parity']['ok']:
+        raise SystemExit('parity check at the benchmarked configuration FAILED: ' + json.dumps(out['parity']))
 
 
-def cpu_baseline(scan, det, args):
+def resolve_pairs(hip, records):
+    """map pointer -> pair counter while the maps are still alive"""
+    out = []
+    for name, e0, e1, a in records:
+        key = None
+        if name in ENGINE:
+            key = a[4] if (name.startswith('es_spconv_wgrad') or name == 'es_spconv_fwd_bf16') else a[3]
+        out.append((name, e0, e1, a, hip.PAIRS.get(key)))
+    return out
+
+
+def engine_args(name, a):
+    if name == 'es_spconv_fwd_bf16':
+        return a[4], a[5], a[6], a[7], a[8], a[9]
+    if not name.startswith('es_spconv_wgrad'):
+        return a[3], a[4], a[5], a[6], a[7], a[8]
+    return a[4], a[5], a[6], a[7], a[8], a[9]
+
+
+def engine_totals(records, mfma_peak):
+    """sums over the convolution-engine launches of one step: HIP-event ms, algorithmic flops, SURVEY-8(d) pair bytes,
+    compulsory bytes, and the per-launch binding roof time"""
+    ms = flop = pair_b = comp_b = t_bind = t_mfma = t_hbm = 0.0
+    n = 0
+    for name, e0, e1, a, pairs_dev in records:
+        ms += e0.elapsed_time(e1)
+        n += 1
+        nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
+        pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
+        wgrad = name.startswith('es_spconv_wgrad')
+        wb = 2 if ('bf16' in name and not wgrad) else 4
+        f = 2.0 * pairs * cin * cout
+        pb = pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wb
+        # compulsory: fwd/dgrad read n_in rows of Cin, write n_out rows of Cout, read the weights once;
+        # wgrad reads both row matrices once and read-modify-writes the f32 weight gradient
+        cb = (float(n_in) * cin + float(n_out) * cout) * 4.0 + float(K) * cin * cout * (8.0 if wgrad else wb)
+        tm, th = f / (mfma_peak * 1e12), cb / (K_PEAK_HBM * 1e9)
+        flop, pair_b, comp_b = flop + f, pair_b + pb, comp_b + cb
+        t_mfma, t_hbm, t_bind = t_mfma + tm, t_hbm + th, t_bind + max(tm, th)
+    s = ms * 1e-3
+    return dict(ms=round(ms, 3), launches=n, tflops=round(flop / s / 1e12, 2) if s else 0.0,
+                pair_GBps=round(pair_b / s / 1e9, 1) if s else 0.0, comp_GBps=round(comp_b / s / 1e9, 1) if s else 0.0,
+                pair_bytes=pair_b, comp_bytes=comp_b, t_mfma=t_mfma, t_hbm=t_hbm,
+                frac_binding=round(t_bind / s, 4) if s else 0.0)
+
+
+def scatter_totals(records):
+    """achieved HBM GB/s of the scatter path (A1-A4, A6, A8): algorithmic bytes of each launch from its arguments"""
+    per = {}
+    for name, e0, e1, a, _ in records:
+        t = e0.elapsed_time(e1)
+        if name == 'es_voxel_keys':            # (points, n, ld, batch, vs, keys)
+            b = a[1] * (12 + 8)
+        elif name == 'es_unique_first':        # (keys, n, tkeys, tvals, cap, ...): read keys, insert (key,row), emit (key,src)
+            b = a[1] * (8 + 12 + 12)
+        elif name == 'es_morton_sort':         # (keys, src, n, ...): 64-bit key + payload through the radix passes once
+            b = a[2] * (12 + 12)
+        elif name == 'es_stride_keys':
+            b = a[1] * 16
+        elif name == 'es_kernel_map':          # (out_keys, n_out, tk, tv, cap, ksize, in_ts, nbr): K probes of 12 B + 4 B out
+            b = a[1] * (8 + a[5] ** 3 * (12 + 4))
+        elif name == 'es_inverse_map':         # (nbr, n_out, K, n_in, inv)
+            b = (a[1] + a[3]) * a[2] * 4
+        elif name == 'es_union_plan':          # (ka, na, tk, tv, cap, kb, nb, ...)
+            b = (a[1] + a[6]) * (8 + 12 + 4 + 8)
+        elif name == 'es_point_sample_fwd':    # (coords, n, vs, meta, ms, V, feats, Hf, Wf, C, out, ldo, pix, cnt)
+            b = a[1] * (16 + a[5] * a[9] * 4 + a[9] * 4 + a[5] * 4 + 4)
+        elif name == 'es_point_sample_bwd':    # (coords, n, V, dout, ldo, pix, cnt, Hf, Wf, C, dfeats)
+            b = a[1] * (a[9] * 4 + a[2] * 4 + 4 + a[2] * a[9] * 8)
+        elif name == 'es_depth_to_points':     # (depth, H, W, sel_view, sel_pix, n, ...)
+            b = a[5] * (4 + 4 + 4 + 12)
+        else:
+            continue
+        d = per.setdefault(name, [0.0, 0.0, 0])
+        d[0] += t
+        d[1] += b
+        d[2] += 1
+    tot_ms = sum(v[0] for v in per.values())
+    tot_b = sum(v[1] for v in per.values())
+    return dict(achieved_GBps=round(tot_b / (tot_ms * 1e-3) / 1e9, 1) if tot_ms else 0.0, peak_GBps=K_PEAK_HBM,
+                frac=round(tot_b / (tot_ms * 1e-3) / 1e9 / K_PEAK_HBM, 4) if tot_ms else 0.0, ms_per_step=round(tot_ms, 3),
+                per_kernel={k: dict(ms=round(v[0], 3), launches=v[2], GBps=round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] else 0.0)
+                            for k, v in sorted(per.items())},
+                note='A1-A4/A6/A8 kernels of one untimed single-stream step; algorithmic bytes per launch (keys, table '
+                     'probes of 12 B, map entries, gathered feature vectors), HIP events on the launch stream')
+
+
+def cpu_baseline(scan, sd0, det, parity_hip, args):
     """The CPU oracle (a restatement, kind='port') timed on this box's host cores on ONE scan of the same workload:
-    forward + backward of the detector loss (no optimiser).  Bounded sample, reported next to the GPU number."""
+    forward + backward of the detector loss (no optimiser), from the PRE-training weights.  Bounded sample, reported
+    next to the GPU number.  The same run is the parity check at the benchmarked configuration: its three losses
+    against the HIP path's on the same scan / weights (tolerance 2e-2 in bf16 mode, 1e-3 in f32 mode)."""
     import torch
     from oracle import model as OM, pipeline as OP
-    sd = {k: v.cpu() for k, v in det.state_dict().items()}
     names = set(det.arena.grad_dict().keys())
-    sd = {k: v.requires_grad_(k in names) for k, v in sd.items()}
+    sd = {k: v.clone().requires_grad_(k in names) for k, v in sd0.items()}
     t0 = time.perf_counter()
     pts = [OP.scan_to_points(scan)]
     imgs = OM.preprocess_img(torch.from_numpy(scan['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])[None]
@@ -218,9 +370,15 @@ def cpu_baseline(scan, det, args):
                               [torch.from_numpy(scan['gt_labels'])])
     sum(losses.values()).backward()
     dt = time.perf_counter() - t0
-    return dict(value=round(1.0 / dt, 5), unit='scans/s', cores=torch.get_num_threads(), kind='port',
+    tol = 2e-2 if args.precision == 'bf16' else 1e-3
+    rel = {k: abs(parity_hip[k] - float(losses[k])) / abs(float(losses[k])) for k in losses}
+    parity = dict(what='three losses of scans[0] (20 views, 100k points), pre-training weights, HIP path vs CPU oracle (f32)',
+                  hip={k: round(v, 6) for k, v in parity_hip.items()}, oracle={k: round(float(v), 6) for k, v in losses.items()},
+                  rel_err={k: float(f'{v:.3e}') for k, v in rel.items()}, tol=tol, ok=bool(max(rel.values()) < tol))
+    base = dict(value=round(1.0 / dt, 5), unit='scans/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'1 scan x {scan["depth"].shape[0]} views 480x640, 100k points, one forward+backward of the '
                        f'PyTorch-f32 CPU oracle (no optimiser step), {dt:.1f} s; os.cpu_count()={os.cpu_count()}')
+    return base, parity
 
 
 if __name__ == '__main__':

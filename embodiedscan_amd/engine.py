@@ -229,6 +229,17 @@ def join_wgrad_streams(final=True):
             ws['used'] = False
     if final:
         _KEEP.clear()
+MARKS = None            # bench.py sets a list: stage boundaries as (name, event) recorded on the current stream
+
+
+def mark(name):
+    """stage boundary for the per-stage timing of bench.py (SURVEY 8d "Reporting"); free when MARKS is None"""
+    if MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(hip.stream_obj())
+        MARKS.append((name, ev))
+
+
 DEBUG_GRADS = None      # tools/debug_grads.py sets a dict: id(Var) -> snapshot of its gradient when consumed
 
 

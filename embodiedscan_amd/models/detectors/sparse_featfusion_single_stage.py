@@ -106,12 +106,15 @@ class SparseFeatureFusionSingleStage3DDetector:
             img = img.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
         nhwc = img.permute(0, 1, 3, 4, 2).reshape(B * V, H, W, 3)
         forked = E.TWO_STREAMS[0]
+        E.mark('A18 preprocess + weight cast' if not forked else 'A18 preprocess')
         if forked:
             E.refresh_weight_copies()            # one cast launch for all kernels, before the branches split
             with E.side_stream():
                 img_feats = self.backbone(nhwc)
         else:
+            E.refresh_weight_copies()
             img_feats = self.backbone(nhwc)
+        E.mark('A7 2-D backbone fwd')
         self._tape_marks = [len(E.TAPE.fns)]                   # end of the 2-D backbone's closures
         points = batch_inputs_dict['points']
         assert self.use_xyz_feat, 'shipped configs use use_xyz_feat=True'
@@ -120,7 +123,9 @@ class SparseFeatureFusionSingleStage3DDetector:
         allp = torch.cat([p[:, :3] for p in pts]) if len(pts) > 1 else pts[0][:, :3].contiguous()
         feats = torch.empty((cs.n, 3), dtype=torch.float32, device=allp.device)
         call('es_row_move', P(feats), 3, P(allp), allp.stride(0), P(src), cs.n, 3, 0, _stream())
+        E.mark('A4 voxelise')
         x = self.backbone_3d(SparseTensor(cs, E.Var(feats, rg=False)))
+        E.mark('A5+A6 3-D backbone fwd + maps')
         self._tape_marks.append(len(E.TAPE.fns))               # end of the 3-D backbone's closures
         metas = [ds.metainfo for ds in batch_data_samples]
         meta_dev = build_fusion_meta(metas, self.coord_type, (H, W), V).to(self.device, non_blocking=True)
@@ -147,6 +152,7 @@ class SparseFeatureFusionSingleStage3DDetector:
                 batch_point_sample_level_bwd(xl.cs, V, y.g, C3, pix, cnt, f2d, Hf, Wf)
             E.TAPE.add(bwd)
             outs.append(SparseTensor(xl.cs, y))
+        E.mark('A8+A9 projection fusion')
         return outs
 
     # ------------------------------------------------------------------ reference protocol
@@ -185,11 +191,13 @@ class SparseFeatureFusionSingleStage3DDetector:
         """mmengine BaseModel.train_step: preprocess, loss forward, sum of the 'loss' entries, backward, update."""
         E.TAPE.clear()
         hip.refresh_stream()
+        E.mark('A1-A3 depth->points')            # whatever the caller queued before train_step (pipeline.make_batch)
         if self.data_preprocessor is not None:
             data = self.data_preprocessor(data, True)
         self._bind()
         self.arena.grad.zero_()
         losses = self.forward(data['inputs'], data['data_samples'], mode='loss')
+        E.mark('A10-A16 head fwd + targets + losses')
         if is_dist():
             # bucketed gradient all-reduce overlapped with backward: markers fire when the tape (run in reverse) has
             # finished the head (+ fusion) closures, then the 3-D backbone's, then everything
@@ -199,7 +207,9 @@ class SparseFeatureFusionSingleStage3DDetector:
             self._backward(red)
         else:
             self._backward(None)
+        E.mark('backward (head, 3-D, 2-D)')
         optim_wrapper.update_params(self.arena)
+        E.mark('all-reduce wait + clip + AdamW')
         return losses
 
     def _backward(self, red):

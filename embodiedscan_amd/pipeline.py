@@ -36,6 +36,37 @@ def upload_scan(scan, device):
                 gt_boxes=torch.from_numpy(scan['gt_boxes']), gt_labels=torch.from_numpy(scan['gt_labels']))
 
 
+_DEV_KEYS = ('depth', 'img', 'sel_view', 'sel_pix', 'mats', 'aug')
+
+
+def pin_scan(scan):
+    """raw inputs of one scan as PINNED host tensors (what a data-loader worker hands over): source of the per-step
+    host->device copy that bench.py keeps inside the timed step"""
+    mats, aug = scan_matrices(scan)
+    host = dict(depth=torch.from_numpy(scan['depth']), img=torch.from_numpy(scan['img']),
+                sel_view=torch.from_numpy(scan['sel_view']), sel_pix=torch.from_numpy(scan['sel_pix']), mats=mats, aug=aug)
+    out = {k: v.contiguous().pin_memory() for k, v in host.items()}
+    out.update(meta=scan['meta'], gt_boxes=torch.from_numpy(scan['gt_boxes']), gt_labels=torch.from_numpy(scan['gt_labels']))
+    return out
+
+
+def alloc_slot(pinned, device):
+    """preallocated device buffers shaped like one pinned scan (double-buffered by the caller: no allocation and no
+    allocator traffic on the copy stream)"""
+    return {k: torch.empty_like(pinned[k], device=device) for k in _DEV_KEYS}
+
+
+def upload_into(slot, pinned):
+    """async host->device copy of one scan into a slot on the CURRENT stream; returns the dscan dict make_batch takes"""
+    for k in _DEV_KEYS:
+        slot[k].copy_(pinned[k], non_blocking=True)
+    return dict(slot, meta=pinned['meta'], gt_boxes=pinned['gt_boxes'], gt_labels=pinned['gt_labels'])
+
+
+def scan_h2d_bytes(pinned):
+    return sum(pinned[k].numel() * pinned[k].element_size() for k in _DEV_KEYS)
+
+
 def depth_to_points(dscan):
     depth = dscan['depth']
     V, H, W = depth.shape
