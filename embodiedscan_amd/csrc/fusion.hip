@@ -56,8 +56,11 @@ __device__ inline int project_view(const float* m, const float* P, float x, floa
   return (int)iy * Wf + (int)ix;
 }
 
-// one wave per point; lanes stride over channels
-__global__ __launch_bounds__(256) void k_point_sample_fwd(const int* __restrict__ coords, int n, float voxel_size,
+// one wave per point; lanes stride over channels.  PTS: the location comes from a float (n,3) array (the prior points of
+// the occupancy detector, dense_fusion_occ.py:156-202) instead of integer voxel coordinates * voxel_size.
+template <bool PTS>
+__global__ __launch_bounds__(256) void k_point_sample_fwd(const int* __restrict__ coords, const float* __restrict__ pts,
+                                                          int n, float voxel_size,
                                                           const float* __restrict__ meta, int meta_stride, int V,
                                                           const float* __restrict__ feats, int Hf, int Wf, int C,
                                                           float* __restrict__ out, int ldo, int* __restrict__ pix,
@@ -66,8 +69,12 @@ __global__ __launch_bounds__(256) void k_point_sample_fwd(const int* __restrict_
   if (i >= n) return;
   int4 c = ((const int4*)coords)[i];
   const float* m = meta + (size_t)c.x * meta_stride;
-  float x = __fmul_rn((float)c.y, voxel_size), y = __fmul_rn((float)c.z, voxel_size),
-        z = __fmul_rn((float)c.w, voxel_size);
+  float x, y, z;
+  if (PTS) {
+    x = pts[(size_t)i * 3]; y = pts[(size_t)i * 3 + 1]; z = pts[(size_t)i * 3 + 2];
+  } else {
+    x = __fmul_rn((float)c.y, voxel_size); y = __fmul_rn((float)c.z, voxel_size); z = __fmul_rn((float)c.w, voxel_size);
+  }
   undo_aug(m, x, y, z);
   int nvalid = 0;
   const int MAXC = 8;                                   // supports C <= 512
@@ -101,8 +108,18 @@ extern "C" int es_point_sample_fwd(const int* coords, int n, float voxel_size, c
                                    int* cnt, void* stream) {
   if (n <= 0) return 0;
   if (C > 512) return -4;
-  hipLaunchKernelGGL(k_point_sample_fwd, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords, n,
-                     voxel_size, meta, meta_stride, V, feats, Hf, Wf, C, out, ldo, pix, cnt);
+  hipLaunchKernelGGL(k_point_sample_fwd<false>, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords,
+                     (const float*)nullptr, n, voxel_size, meta, meta_stride, V, feats, Hf, Wf, C, out, ldo, pix, cnt);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int es_point_sample_fwd_pts(const int* coords, const float* points, int n, const float* meta, int meta_stride,
+                                       int V, const float* feats, int Hf, int Wf, int C, float* out, int ldo, int* pix,
+                                       int* cnt, void* stream) {
+  if (n <= 0) return 0;
+  if (C > 512) return -4;
+  hipLaunchKernelGGL(k_point_sample_fwd<true>, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords, points, n,
+                     0.f, meta, meta_stride, V, feats, Hf, Wf, C, out, ldo, pix, cnt);
   ES_CHECK_LAUNCH();
   return 0;
 }

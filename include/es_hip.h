@@ -151,6 +151,11 @@ int es_affine_act_bwd(const float* dy, const float* y, const float* scale, size_
 int es_point_sample_fwd(const int* coords, int n, float voxel_size, const float* meta, int meta_stride, int V,
                         const float* feats /* (B,V,Hf,Wf,C) */, int Hf, int Wf, int C, float* out, int ldo,
                         int* pix /* (n,V) */, int* cnt /* (n) */, void* stream);
+/* the same for explicit float locations (n,3) (coords[:,0] still gives the sample): the 40x40x16 prior points of the
+ * occupancy detector, dense_fusion_occ.py:156-202 */
+int es_point_sample_fwd_pts(const int* coords, const float* points, int n, const float* meta, int meta_stride, int V,
+                            const float* feats, int Hf, int Wf, int C, float* out, int ldo, int* pix, int* cnt,
+                            void* stream);
 int es_point_sample_bwd(const int* coords, int n, int V, const float* dout, int ldo, const int* pix, const int* cnt,
                         int Hf, int Wf, int C, float* dfeats, void* stream);
 
@@ -208,6 +213,39 @@ int es_stem_conv_fwd(const float* x, const float* w, const float* scale, const f
 int es_preprocess_img(const unsigned char* img, int n_img, int H, int W, int Hp, int Wp, int flip,
                       const float* mean_host, const float* std_host, float pad_value,
                       float* out /* (n_img,Hp,Wp,3) */, void* stream);
+
+/* ---- A20 occupancy path (BASELINE config 5).  detectors/dense_fusion_occ.py:120-259, necks/imvoxel_neck.py:34-143,
+ * dense_heads/imvoxel_occ_head.py:73-184, losses/occ_loss.py:7-141 ------------------------------------------------------ */
+/* neighbour map of a dense (B,X,Y,Z) grid for nn.Conv3d(k, stride, pad): nbr (B*Xo*Yo*Zo, k^3), row = ((b*X+x)*Y+y)*Z+z,
+ * tap = (kx*k+ky)*k+kz (torch (O,I,kD,kH,kW) order, D = x); feeds es_spconv_* (imvoxel_neck.py:84-86,121-137) */
+int es_volume_map(int n_batch, int X, int Y, int Z, int Xo, int Yo, int Zo, int ksize, int stride, int pad, int* nbr,
+                  void* stream);
+/* nn.ConvTranspose3d(k=2,s=2) (imvoxel_neck.py:100-101) = 8 row GEMMs into rows 8*i+tap; idx (B*2X*2Y*2Z) = that row per
+ * dense output voxel (gathered with es_row_move) */
+int es_volume_up_index(int n_batch, int X, int Y, int Z, int* idx, void* stream);
+/* keys = pack(batch, clamp(trunc((p - min) / voxel_size), 0, cmax)); rng_host = 9 HOST floats {min xyz, voxel size xyz,
+ * clamp max xyz}.  dense_fusion_occ.py:227-245 */
+int es_voxel_keys_range(const float* points, int n, int ld, int batch, const float* rng_host, int64_t* keys, void* stream);
+/* SparseTensor.dense(): idx[i] = dense row ((b*X + x/ts)*Y + y/ts)*Z + z/ts of sparse row i (-1 outside).
+ * dense_fusion_occ.py:252-255 */
+int es_dense_index(const int* coords, int n, int ts, int X, int Y, int Z, int* idx, void* stream);
+/* mmdet.FPN top-down: fine += nearest-upsampled coarse (channels-last, C % 4 == 0), and its gradient */
+int es_upsample_nearest_add_fwd(float* fine, const float* coarse, int n_img, int Hf, int Wf, int Hc, int Wc, int C,
+                                void* stream);
+int es_upsample_nearest_add_bwd(const float* dfine, float* dcoarse, int n_img, int Hf, int Wf, int Hc, int Wc, int C,
+                                int accumulate, void* stream);
+int es_row_argmax(const float* x, int ldx, int n, int C, int* out, void* stream);
+/* occ_multiscale_supervision for one sample: gt (X,Y,Z) int32 from gt_occ (n,4) int32 {x,y,z,label} at full resolution,
+ * coords / ratio, last occurrence wins; mask (X*ratio, Y*ratio, Z*ratio) u8 or NULL: windows with no visible voxel
+ * become 255.  winner_scratch: X*Y*Z ints.  occ_loss.py:7-36, imvoxel_occ_head.py:163-171 */
+int es_occ_targets(const int* gt_occ, int n, int ratio, int X, int Y, int Z, const unsigned char* mask,
+                   int* winner_scratch, int* gt, void* stream);
+/* one level of ImVoxelOccHead.loss: weight * (CrossEntropy(ignore 255) + sem_scal_loss + geo_scal_loss) and its gradient
+ * w.r.t. the (n,C) logits (dlogits may be NULL).  stats: 3C+2 doubles, coeff: 2C+1 floats (scratch).
+ * loss_out[0..3] = CE, sem, geo, weighted total; total_acc[0] += weighted total (may be NULL).  C <= 256.
+ * occ_loss.py:39-141, imvoxel_occ_head.py:156-181 */
+int es_occ_loss(const float* logits, int ld, const int* gt, int n, int C, float weight, double* stats, float* coeff,
+                float* dlogits, int ldg, float* loss_out, float* total_acc, void* stream);
 
 #ifdef __cplusplus
 }

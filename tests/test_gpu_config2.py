@@ -81,25 +81,46 @@ def _oracle_levels(points_np, n_batch, voxel_size=0.01):
     return c, lv, heads
 
 
+def _keys(c):
+    c = c.astype(np.int64)
+    return ((c[:, 0] << 54) | ((c[:, 1] + (1 << 17)) << 36) | ((c[:, 2] + (1 << 17)) << 18) | (c[:, 3] + (1 << 17)))
+
+
 def test_integer_outputs_batch4_bit_exact(setup):
     """4 scans x 20 views x 100 k points, bf16 default schedule: voxel coordinates of every head level (values AND row
-    order), level sizes, target labels, assigned boxes and centerness targets equal the oracle's bit for bit."""
+    order), level sizes, target labels, assigned boxes and centerness targets equal the oracle's bit for bit.
+    At this size the finest level of some samples exceeds pts_prune_threshold = 100 000 rows, so FCAF3D's pruning is
+    live: WHICH rows survive is a float decision (top-k of interpolated scores, checked against the full oracle in the
+    one-scan tests below and in test_gpu_model.py::test_prune_path_and_ragged_batch); here the pruned samples must keep
+    exactly `thr` rows forming an order-preserving subset of the oracle's candidate set."""
     from oracle import geometry as G
     det, scans, dscans, sd = setup
     losses, points_host = _forward(det, dscans, 'bf16')
     _, lv, heads = _oracle_levels([p.numpy() for p in points_host], 4)
     levels = det.bbox_head.last_levels
-    sizes = []
-    for l in range(4):
-        hc = levels[l]['cs'].coords.cpu().numpy()
-        sizes.append(hc.shape[0])
-        np.testing.assert_array_equal(hc, heads[l])
-    print(f'head level rows (batch 4, fine->coarse): {sizes}; all coordinates bit-exact')
-    assert sizes[0] > 300000           # the 480 k-row regime the fast kernels / tap split are built for
+    thr = det.bbox_head.pts_prune_threshold
+    hips = [levels[l]['cs'].coords.cpu().numpy() for l in range(4)]
+    for l in (3, 2, 1):
+        np.testing.assert_array_equal(hips[l], heads[l])
+    pruned = []
+    for b in range(4):
+        cand, got = heads[0][heads[0][:, 0] == b], hips[0][hips[0][:, 0] == b]
+        if len(cand) <= thr:
+            np.testing.assert_array_equal(got, cand)
+        else:
+            pruned.append(b)
+            assert len(got) == thr, (b, len(got), len(cand))
+            pos = {int(k): i for i, k in enumerate(_keys(cand))}
+            idx = np.array([pos.get(int(k), -1) for k in _keys(got)])
+            assert (idx >= 0).all() and (np.diff(idx) > 0).all()           # subset, original row order kept
+    sizes = [h.shape[0] for h in hips]
+    print(f'head level rows (batch 4, fine->coarse): {sizes}; candidates at level 0: {heads[0].shape[0]}; '
+          f'pruned samples: {pruned}; coordinates bit-exact')
+    assert sizes[0] > 300000           # the regime the fast kernels / tap split are built for
     tg = det.bbox_head.last_targets
     n_pos = 0
     for b in range(4):
-        pts = [torch.from_numpy(h[h[:, 0] == b][:, 1:]).float() * 0.01 for h in heads]
+        pts = [torch.from_numpy(h[h[:, 0] == b][:, 1:]).float() * 0.01 for h in hips]
         ct, bt, kt = G.get_targets(pts, torch.from_numpy(scans[b]['gt_boxes']), torch.from_numpy(scans[b]['gt_labels']))
         np.testing.assert_array_equal(tg[b][2].cpu().numpy(), kt.numpy())
         np.testing.assert_array_equal(tg[b][1].cpu().numpy(), bt.numpy())
@@ -134,16 +155,32 @@ def test_losses_and_logits_one_scan(setup, oracle_one_scan, mode):
     losses, _ = _forward(det, dscans[:1], mode)
     tol = TOL[mode]
     levels = det.bbox_head.last_levels
+    same_rows = True
     for l in range(4):
         ho = levels[l]['ho'].d.cpu()
-        oc, ob, ok, _ = aux['outs'][l][0]
-        assert ho.shape[0] == oc.shape[0]
-        e_logit = _rel(torch.cat([ho[:, 0:1], ho[:, 13:]], 1), torch.cat([oc, ok], 1))
-        e_box = _rel(levels[l]['bbox'].cpu(), ob)
+        bb = levels[l]['bbox'].cpu()
+        oc, ob, ok, opts = aux['outs'][l][0]
+        # rows are matched by voxel coordinate: identical sets except where pruning is live (level 0 above 100 k rows),
+        # where bf16 rounding of near-tied scores may swap a few rows at the top-k boundary (stated: <= 0.5 % of rows)
+        hk = _keys(levels[l]['cs'].coords.cpu().numpy())
+        okk = _keys(np.concatenate([np.zeros((opts.shape[0], 1), np.int64),
+                                    np.rint(opts.numpy().astype(np.float64) / 0.01).astype(np.int64)], 1))
+        if hk.shape == okk.shape and (hk == okk).all():
+            ih = io = np.arange(len(hk))
+        else:
+            same_rows = False
+            _, ih, io = np.intersect1d(hk, okk, return_indices=True)
+            frac = 1.0 - len(ih) / max(len(okk), 1)
+            print(f'{mode} level {l}: {len(hk)} rows vs oracle {len(okk)}, {frac:.3%} of the oracle rows not kept (tol 0.5 %)')
+            assert len(hk) == len(okk) and frac <= (5e-3 if mode == 'bf16' else 1e-4)
+        ih, io = torch.from_numpy(ih), torch.from_numpy(io)
+        e_logit = _rel(torch.cat([ho[:, 0:1], ho[:, 13:]], 1)[ih], torch.cat([oc, ok], 1)[io])
+        e_box = _rel(bb[ih], ob[io])
         print(f'{mode} level {l} ({ho.shape[0]} rows): logits rel-L2 {e_logit:.2e} (tol {tol["logits"]:.0e}), '
               f'decoded bbox rel-L2 {e_box:.2e} (tol {tol["bbox"]:.0e})')
         assert e_logit < tol['logits'] and e_box < tol['bbox']
-    np.testing.assert_array_equal(det.bbox_head.last_targets[0][2].cpu().numpy(), aux['targets'][0][2].numpy())
+    if same_rows:
+        np.testing.assert_array_equal(det.bbox_head.last_targets[0][2].cpu().numpy(), aux['targets'][0][2].numpy())
     for k in ol:
         e = abs(float(losses[k]) - float(ol[k])) / abs(float(ol[k]))
         print(f'{mode} {k}: hip {float(losses[k]):.6f} oracle(f32) {float(ol[k]):.6f} rel err {e:.2e} (tol {tol["loss"]:.0e})')
