@@ -554,3 +554,41 @@ def copy_cols(dst, col, src):
 def add_into(dst, src):
     n, C = src.shape
     call('es_axpy2d', P(dst), dst.stride(0), P(src), src.stride(0), n, C, 1.0, 1, _stream())
+
+
+def add(a, b):
+    """y = a + b of two row matrices of the same shape (dense residual / lateral sums)."""
+    n, C = a.d.shape
+    y = Var(empty((n, C), a.d))
+    s = _stream()
+    call('es_axpy2d', P(y.d), C, P(a.d), _ld(a.d), n, C, 1.0, 0, s)
+    call('es_axpy2d', P(y.d), C, P(b.d), _ld(b.d), n, C, 1.0, 1, s)
+
+    def bwd():
+        if y.g is None:
+            return
+        for v in (a, b):
+            if not v.rg:
+                continue
+            if v.g is None:
+                v.g = y.g if v is a and not b.rg else y.g.clone()
+            else:
+                call('es_axpy2d', P(v.g), _ld(v.g), P(y.g), _ld(y.g), n, C, 1.0, 1, _stream())
+    TAPE.add(bwd)
+    return y
+
+
+def upsample_add_(fine, coarse, n_img, Hf, Wf, Hc, Wc):
+    """mmdet.FPN top-down step, in place: fine += nearest_upsample(coarse, size=(Hf, Wf)).  `fine` keeps its identity
+    (its producer's backward sees the same gradient); the gradient reaching `coarse` is accumulated when the tape passes
+    this point, i.e. after every later consumer of `fine` has contributed."""
+    C = fine.d.shape[1]
+    call('es_upsample_nearest_add_fwd', P(fine.d), P(coarse.d), n_img, Hf, Wf, Hc, Wc, C, _stream())
+
+    def bwd():
+        if fine.g is None or not coarse.rg:
+            return
+        g, acc = _grad_target(coarse, coarse.d)
+        call('es_upsample_nearest_add_bwd', P(fine.g), P(g), n_img, Hf, Wf, Hc, Wc, C, acc, _stream())
+    TAPE.add(bwd)
+    return fine

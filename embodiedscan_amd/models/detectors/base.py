@@ -1,0 +1,109 @@
+"""What every detector of this package shares with mmengine's BaseModel protocol: parameter arena binding, reference-named
+state dicts, `forward(inputs, data_samples, mode)` dispatch and `train_step(data, optim_wrapper)`
+(preprocess -> forward(mode='loss') -> backward over the tape -> optimiser update)."""
+import torch
+from ... import engine as E
+from ... import hip
+from ...params import ParamArena
+
+
+class DetectorBase:
+    _version = 2
+
+    def _init_base(self, specs, device, seed, data_preprocessor):
+        from ...registry import MODELS
+        self.device = torch.device(device)
+        self.data_preprocessor = MODELS.build(data_preprocessor, device=self.device) if data_preprocessor else None
+        self.arena = ParamArena(specs, seed=seed)
+        self.training = True
+        self._bound = False
+
+    def _children(self):
+        """[(module, arena prefix)] -- every module with a bind(arena, prefix)"""
+        raise NotImplementedError
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self.arena.to(self.device)
+        if self.data_preprocessor is not None:
+            self.data_preprocessor.to(self.device)
+        self._bound = False
+        return self
+
+    def _bind(self):
+        if not self._bound:
+            if self.arena.data.device != self.device:
+                self.arena.to(self.device)
+            E.begin_bind(id(self))
+            try:
+                for m, prefix in self._children():
+                    m.bind(self.arena, prefix)
+            finally:
+                E.end_bind()
+            self._bound = True
+
+    def __del__(self):
+        try:
+            E.release(id(self))
+        except Exception:
+            pass
+
+    def state_dict(self):
+        return self.arena.state_dict()
+
+    def load_state_dict(self, sd, strict=False):
+        res = self.arena.load_state_dict(sd, strict=strict)
+        E.WEIGHT_VERSION[0] += 1
+        if self._bound:
+            for m, _ in self._children():
+                if hasattr(m, 'refresh'):
+                    m.refresh()
+        return res
+
+    def train(self, mode=True):
+        self.training = mode
+        for m, _ in self._children():
+            if hasattr(m, 'training'):
+                m.training = mode
+        return self
+
+    def forward(self, inputs, data_samples=None, mode='tensor', **kwargs):
+        hip.refresh_stream()
+        if mode == 'loss':
+            return self.loss(inputs, data_samples, **kwargs)
+        elif mode == 'predict':
+            return self.predict(inputs, data_samples, **kwargs)
+        raise RuntimeError(f'Invalid mode "{mode}". Only supports loss, predict and tensor mode')
+
+    __call__ = forward
+
+    def _predict_guard(self):
+        """context: eval mode + tape off"""
+        det = self
+
+        class _G:
+            def __enter__(self):
+                self.was, self.prev = det.training, E.TAPE.enabled
+                det.train(False)
+                E.TAPE.enabled = False
+
+            def __exit__(self, *exc):
+                E.TAPE.enabled = self.prev
+                det.train(self.was)
+        return _G()
+
+    def train_step(self, data, optim_wrapper):
+        E.TAPE.clear()
+        hip.refresh_stream()
+        E.mark('data (caller)')
+        if self.data_preprocessor is not None:
+            data = self.data_preprocessor(data, True)
+        self._bind()
+        self.arena.grad.zero_()
+        losses = self.forward(data['inputs'], data['data_samples'], mode='loss')
+        E.mark('forward + losses')
+        E.TAPE.backward()
+        E.mark('backward')
+        optim_wrapper.update_params(self.arena)
+        E.mark('all-reduce + clip + AdamW')
+        return losses

@@ -1,0 +1,145 @@
+"""DenseFusionOccPredictor (embodiedscan/models/detectors/dense_fusion_occ.py:26-330) on the MI355X kernels.
+
+Same registry name, constructor arguments and `forward(inputs, data_samples, mode)` protocol.  Data flow (BASELINE
+config 5): multi-view images -> mmdet.ResNet-50 -> mmdet.FPN level 0 -> projection of the 40x40x16 prior voxel centres
+into every view (the A8 kernel with explicit float locations) -> image volume (25 600, 256); points -> range
+voxelisation at 2.5 mm -> MinkResNet34 -> last level (stride 64 = one voxel of the volume) scattered densely
+(25 600, 512); both written into ONE channels-last (25 600, 768) buffer (no cat) -> IndoorImVoxelNeck -> ImVoxelOccHead.
+"""
+import torch
+from ... import engine as E
+from ... import hip
+from ... import sparse
+from ...hip import P, call
+from ...params import occ_detector_specs
+from ...registry import MODELS, TASK_UTILS
+from ...sparse import SparseTensor
+from ..layers.fusion_layers.point_fusion import build_fusion_meta
+from .base import DetectorBase
+
+
+@MODELS.register_module()
+class DenseFusionOccPredictor(DetectorBase):
+    def __init__(self, backbone, backbone_3d, neck, neck_3d, bbox_head, prior_generator, n_voxels, coord_type,
+                 use_valid_mask=True, use_xyz_feat=False, point_cloud_range=None, train_cfg=None, test_cfg=None,
+                 data_preprocessor=None, init_cfg=None, seed=0, device='cuda:0'):
+        from .. import task_modules  # noqa: F401  (registers the prior generator)
+        assert use_xyz_feat, 'shipped config: use_xyz_feat=True (the other branch of the reference has a precedence bug, SURVEY Q15)'
+        assert not use_valid_mask, 'use_valid_mask=True appends a 4th "level" the reference head cannot consume; shipped: False'
+        self.backbone = MODELS.build(backbone)
+        self.backbone_3d = MODELS.build(backbone_3d)
+        self.neck = MODELS.build(neck)
+        self.neck_3d = MODELS.build(neck_3d)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = MODELS.build(bbox_head)
+        self.n_voxels = list(n_voxels)
+        self.point_cloud_range = list(point_cloud_range)
+        pr = prior_generator['ranges'][0]
+        self.voxel_stride = 2 ** 6 if backbone_3d['type'] == 'MinkResNet' else 1
+        self.voxel_size = [(pr[3] - pr[0]) / self.n_voxels[0] / self.voxel_stride,
+                           (pr[4] - pr[1]) / self.n_voxels[1] / self.voxel_stride,
+                           (pr[5] - pr[2]) / self.n_voxels[2] / self.voxel_stride]
+        self.prior_generator = TASK_UTILS.build(prior_generator)
+        self.coord_type = coord_type
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.use_valid_mask, self.use_xyz_feat = use_valid_mask, use_xyz_feat
+        specs = occ_detector_specs(base_channels=self.backbone.base, fpn_out=self.neck.out_channels,
+                                   neck_in=self.neck_3d.in_channels, neck_out=self.neck_3d.out_channels,
+                                   n_blocks=self.neck_3d.n_blocks, num_classes=self.bbox_head.num_classes,
+                                   head_in=self.bbox_head.in_channels)
+        self._init_base(specs, device, seed, data_preprocessor)
+        self._prior = None
+
+    def _children(self):
+        return [(self.backbone, 'backbone.'), (self.neck, 'neck.'), (self.backbone_3d, 'backbone_3d.'),
+                (self.neck_3d, 'neck_3d.'), (self.bbox_head, 'bbox_head.')]
+
+    def prior_points(self, origin=None):
+        """(X*Y*Z, 3) f32 prior voxel centres in VOLUME row order ((x*Y + y)*Z + z), + the scan origin
+        (dense_fusion_occ.py:156-162); the reference's list is z-major, re-ordered exactly like its volume reshape/permute
+        (:216-217)."""
+        if self._prior is None:
+            X, Y, Z = self.n_voxels
+            a = self.prior_generator.grid_anchors([self.n_voxels[::-1]], device='cpu')[0][:, :3]
+            self._prior = a.reshape(Z, Y, X, 3).permute(2, 1, 0, 3).reshape(-1, 3).contiguous()
+        p = self._prior
+        if origin is not None:
+            p = p + torch.as_tensor(origin, dtype=torch.float32)
+        return p
+
+    def extract_feat(self, batch_inputs_dict, batch_data_samples):
+        """dense_fusion_occ.py:120-259.  Returns [(Var (X_i*Y_i*Z_i, 128), (X_i, Y_i, Z_i))] fine -> coarse."""
+        self._bind()
+        img = batch_inputs_dict['imgs']
+        B, V = img.shape[:2]
+        H, W = img.shape[-2:]
+        assert B == 1, 'only support batch_size=1 here (dense_fusion_occ.py:160,251)'
+        if img.stride(2) != 1:
+            img = img.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+        nhwc = img.permute(0, 1, 3, 4, 2).reshape(B * V, H, W, 3)
+        E.refresh_weight_copies()
+        f2d, Hf, Wf = self.neck(self.backbone(nhwc), B * V, levels=[0])[0]
+        E.mark('2-D backbone + FPN')
+        metas = [ds.metainfo for ds in batch_data_samples]
+        X, Y, Z = self.n_voxels
+        nvox = X * Y * Z
+        origin = metas[0]['depth2img'].get('origin') if isinstance(metas[0].get('depth2img'), dict) else None
+        prior = self.prior_points(origin).to(self.device, non_blocking=True)
+        meta_dev = build_fusion_meta(metas, self.coord_type, (H, W), V).to(self.device, non_blocking=True)
+        C2 = f2d.d.shape[1]
+        C3 = 512
+        vol = torch.zeros((B * nvox, C2 + C3), dtype=torch.float32, device=self.device)
+        bidx = torch.zeros((B * nvox, 4), dtype=torch.int32, device=self.device)       # column 0 = sample index
+        pix = torch.empty((B * nvox, V), dtype=torch.int32, device=self.device)
+        cnt = torch.empty(B * nvox, dtype=torch.int32, device=self.device)
+        call('es_point_sample_fwd_pts', P(bidx), P(prior), B * nvox, P(meta_dev), meta_dev.shape[1], V, P(f2d.d), Hf, Wf, C2,
+             P(vol), C2 + C3, P(pix), P(cnt), hip.stream())
+        E.mark('image volume (projection)')
+        # sparse branch
+        pts = [p if (p.dtype == torch.float32 and p.stride(-1) == 1) else p.float().contiguous() for p in batch_inputs_dict['points']]
+        rmin = self.point_cloud_range[:3]
+        cmax = [n * self.voxel_stride - 1 for n in self.n_voxels]
+        cs, src = sparse.voxelize_range(pts, rmin, self.voxel_size, cmax)
+        allp = torch.cat([p[:, :3] for p in pts]) if len(pts) > 1 else pts[0][:, :3].contiguous()
+        feats = torch.empty((cs.n, 3), dtype=torch.float32, device=self.device)
+        call('es_row_move', P(feats), 3, P(allp), allp.stride(0), P(src), cs.n, 3, 0, hip.stream())
+        x3 = self.backbone_3d(SparseTensor(cs, E.Var(feats, rg=False)))[-1]
+        assert x3.F.d.shape[1] == C3 and x3.cs.ts == self.voxel_stride
+        didx = torch.empty(x3.cs.n, dtype=torch.int32, device=self.device)
+        call('es_dense_index', P(x3.cs.coords), x3.cs.n, x3.cs.ts, X, Y, Z, P(didx), hip.stream())
+        # SparseTensor.dense(): scatter the rows into columns [C2, C2+C3) of the volume buffer
+        call('es_row_move', vol.data_ptr() + 4 * C2, C2 + C3, P(x3.F.d), C3, P(didx), x3.cs.n, C3, 2, hip.stream())
+        E.mark('point branch (voxelise + MinkResNet + dense)')
+        v = E.Var(vol)
+
+        def bwd(v=v, x3=x3, f2d=f2d):
+            if v.g is None:
+                return
+            g3 = torch.empty_like(x3.F.d)
+            call('es_row_move', P(g3), C3, v.g.data_ptr() + 4 * C2, C2 + C3, P(didx), x3.cs.n, C3, 0, hip.stream())
+            if x3.F.g is None:
+                x3.F.g = g3
+            else:
+                E.add_into(x3.F.g, g3)
+            if f2d.rg:
+                if f2d.g is None:
+                    f2d.g = torch.zeros_like(f2d.d)
+                call('es_point_sample_bwd', P(bidx), B * nvox, V, P(v.g), C2 + C3, P(pix), P(cnt), Hf, Wf, C2, P(f2d.g),
+                     hip.stream())
+        E.TAPE.add(bwd)
+        outs = self.neck_3d(v, (X, Y, Z), B)
+        E.mark('IndoorImVoxelNeck')
+        return outs
+
+    def loss(self, batch_inputs_dict, batch_data_samples, **kwargs):
+        x = self.extract_feat(batch_inputs_dict, batch_data_samples)
+        return self.bbox_head.loss(x, batch_data_samples, **kwargs)
+
+    def predict(self, batch_inputs_dict, batch_data_samples, **kwargs):
+        with self._predict_guard():
+            x = self.extract_feat(batch_inputs_dict, batch_data_samples)
+            pred = self.bbox_head.predict(x, batch_data_samples)
+        for i, ds in enumerate(batch_data_samples):
+            ds.pred_occupancy = pred[i]
+        return batch_data_samples

@@ -111,6 +111,79 @@ def detector_specs(n_classes=284):
     return resnet50_specs() + mink_resnet34_specs() + fcaf3d_head_specs(n_classes=n_classes)
 
 
+# ---------------------------------------------------------------- occupancy path (BASELINE config 5)
+def _conv3d(name, o, i, k, stride_fan=None):
+    """nn.Conv3d weight (O, I, k, k, k), default PyTorch init (kaiming_uniform a=sqrt(5) == U(+-1/sqrt(fan_in)))"""
+    return Spec(name, (k ** 3, i, o), ('uniform_fan', i * k ** 3), ref=('oidhw', (o, i, k, k, k)))
+
+
+def _bn3d(specs, p, c):
+    specs += [Spec(p + '.weight', (c,), ('const', 1.)), Spec(p + '.bias', (c,), ('const', 0.)),
+              Spec(p + '.running_mean', (c,), ('const', 0.), False, True),
+              Spec(p + '.running_var', (c,), ('const', 1.), False, True)]
+
+
+def fpn_specs(prefix='neck.', in_channels=(256, 512, 1024, 2048), out_channels=256):
+    """mmdet.FPN: lateral_convs.i.conv (1x1, bias), fpn_convs.i.conv (3x3, bias); xavier-uniform init"""
+    s = []
+    for i, c in enumerate(in_channels):
+        s.append(Spec(f'{prefix}lateral_convs.{i}.conv.weight', (1, c, out_channels), ('xavier', (c, out_channels)),
+                      ref=('oihw', (out_channels, c, 1, 1))))
+        s.append(Spec(f'{prefix}lateral_convs.{i}.conv.bias', (out_channels,), ('const', 0.)))
+    for i in range(len(in_channels)):
+        s.append(Spec(f'{prefix}fpn_convs.{i}.conv.weight', (9, out_channels, out_channels),
+                      ('xavier', (out_channels * 9, out_channels * 9)), ref=('oihw', (out_channels, out_channels, 3, 3))))
+        s.append(Spec(f'{prefix}fpn_convs.{i}.conv.bias', (out_channels,), ('const', 0.)))
+    return s
+
+
+def imvoxel_neck_specs(prefix='neck_3d.', in_channels=768, out_channels=128, n_blocks=(1, 1, 1)):
+    """IndoorImVoxelNeck (embodiedscan/models/necks/imvoxel_neck.py:19-143) under its state-dict names"""
+    s = []
+    c = in_channels
+
+    def res(p, ci, co, stride):
+        s.append(_conv3d(p + '.conv1.weight', co, ci, 3))
+        _bn3d(s, p + '.norm1', co)
+        s.append(_conv3d(p + '.conv2.weight', co, co, 3))
+        _bn3d(s, p + '.norm2', co)
+        if stride != 1:
+            s.append(_conv3d(p + '.downsample.0.weight', co, ci, 1))
+            _bn3d(s, p + '.downsample.1', co)
+
+    for i, nb in enumerate(n_blocks):
+        stride = 1 if i == 0 else 2
+        for b in range(nb):
+            if b == 0 and stride != 1:
+                res(f'{prefix}down_layer_{i}.{b}', c, c * 2, stride)
+                c *= 2
+            else:
+                res(f'{prefix}down_layer_{i}.{b}', c, c, 1)
+        if i > 0:
+            p = f'{prefix}up_block_{i}'
+            # nn.ConvTranspose3d weight (I, O, 2, 2, 2); PyTorch's fan_in for it is size(1) * 8
+            s.append(Spec(p + '.0.weight', (8, c, c // 2), ('uniform_fan', (c // 2) * 8), ref=('iodhw', (c, c // 2, 2, 2, 2))))
+            _bn3d(s, p + '.1', c // 2)
+            s.append(_conv3d(p + '.3.weight', c // 2, c // 2, 3))
+            _bn3d(s, p + '.4', c // 2)
+        p = f'{prefix}out_block_{i}'
+        s.append(_conv3d(p + '.0.weight', out_channels, c, 3))
+        _bn3d(s, p + '.1', out_channels)
+    return s
+
+
+def occ_head_specs(prefix='bbox_head.', in_channels=(128, 128, 128), num_classes=81):
+    return [_conv3d(f'{prefix}occ.{i}.weight', num_classes, c, 1) for i, c in enumerate(in_channels)]
+
+
+def occ_detector_specs(base_channels=64, fpn_out=256, neck_in=768, neck_out=128, n_blocks=(1, 1, 1), num_classes=81,
+                       head_in=(128, 128, 128)):
+    b = base_channels
+    return (resnet50_specs(base=b) + fpn_specs(in_channels=(4 * b, 8 * b, 16 * b, 32 * b), out_channels=fpn_out) +
+            mink_resnet34_specs() + imvoxel_neck_specs(in_channels=neck_in, out_channels=neck_out, n_blocks=n_blocks) +
+            occ_head_specs(in_channels=head_in, num_classes=num_classes))
+
+
 def _fill(t, init, gen):
     kind, a = init
     if kind == 'const':
@@ -119,6 +192,9 @@ def _fill(t, init, gen):
         t.normal_(0, math.sqrt(2.0 / a), generator=gen)
     elif kind == 'uniform_fan':
         b = 1.0 / math.sqrt(a)
+        t.uniform_(-b, b, generator=gen)
+    elif kind == 'xavier':
+        b = math.sqrt(6.0 / (a[0] + a[1]))
         t.uniform_(-b, b, generator=gen)
     elif kind == 'normal':
         t.normal_(0, a, generator=gen)
@@ -182,6 +258,12 @@ class ParamArena:
             out[s.name] = t.reshape(kh, kw, i, o).permute(3, 2, 0, 1).contiguous()
         elif s.ref[0] == 'squeeze0':
             out[s.name] = t[0].clone()
+        elif s.ref[0] == 'oidhw':                      # arena [kd*kh*kw][I][O] -> nn.Conv3d (O, I, kd, kh, kw)
+            o, i, kd, kh, kw = s.ref[1]
+            out[s.name] = t.reshape(kd, kh, kw, i, o).permute(4, 3, 0, 1, 2).contiguous()
+        elif s.ref[0] == 'iodhw':                      # arena [kd*kh*kw][I][O] -> nn.ConvTranspose3d (I, O, kd, kh, kw)
+            i, o, kd, kh, kw = s.ref[1]
+            out[s.name] = t.reshape(kd, kh, kw, i, o).permute(3, 4, 0, 1, 2).contiguous()
         elif s.ref[0] == 'head_out':
             pre = s.name[:-len('head_out.kernel')]
             nr = s.ref[1]
@@ -204,6 +286,16 @@ class ParamArena:
             if s.name in sd:
                 o, i, kh, kw = s.ref[1]
                 dst.copy_(sd[s.name].permute(2, 3, 1, 0).reshape(kh * kw, i, o))
+                return [s.name]
+        elif s.ref[0] == 'oidhw':
+            if s.name in sd:
+                o, i, kd, kh, kw = s.ref[1]
+                dst.copy_(sd[s.name].permute(2, 3, 4, 1, 0).reshape(kd * kh * kw, i, o))
+                return [s.name]
+        elif s.ref[0] == 'iodhw':
+            if s.name in sd:
+                i, o, kd, kh, kw = s.ref[1]
+                dst.copy_(sd[s.name].permute(2, 3, 4, 0, 1).reshape(kd * kh * kw, i, o))
                 return [s.name]
         elif s.ref[0] == 'head_out':
             pre = s.name[:-len('head_out.kernel')]

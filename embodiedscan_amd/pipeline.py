@@ -109,3 +109,14 @@ def make_batch(dscans):
     samples = [Det3DDataSample(d['meta'], InstanceData(bboxes_3d=EulerDepthInstance3DBoxes(d['gt_boxes']),
                                                        labels_3d=d['gt_labels'])) for d in dscans]
     return {'inputs': {'points': points, 'img': imgs}, 'data_samples': samples}
+
+
+def make_occ_batch(dscans, occ_gts):
+    """`data` dict for DenseFusionOccPredictor.train_step: the detection batch plus `gt_occupancy` (N,4) and
+    `gt_occupancy_masks` (X,Y,Z) on every data sample (Pack3DDetInputs, datasets/transforms/formatting.py:254-264)."""
+    data = make_batch(dscans)
+    for ds, occ in zip(data['data_samples'], occ_gts):
+        ds.gt_occupancy = torch.as_tensor(occ['gt_occupancy'])
+        m = occ.get('gt_occupancy_masks')
+        ds.gt_occupancy_masks = None if m is None else torch.as_tensor(m)
+    return data

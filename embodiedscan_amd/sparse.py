@@ -136,6 +136,22 @@ def voxelize(points, voxel_size):
     return morton_sorted(cs, src)
 
 
+def voxelize_range(points, range_min, voxel_size, clamp_max):
+    """occupancy detector voxelisation (dense_fusion_occ.py:227-245): coords = clamp(trunc((p - range_min) / voxel_size),
+    0, clamp_max) per axis.  -> (CoordSet at stride 1, src rows into cat(points))."""
+    dev = points[0].device
+    n = sum(int(p.shape[0]) for p in points)
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    rng = hip.farr(list(range_min) + list(voxel_size) + [float(c) for c in clamp_max])
+    o = 0
+    for b, p in enumerate(points):
+        assert p.dtype == torch.float32 and p.stride(1) == 1
+        call('es_voxel_keys_range', P(p), p.shape[0], p.stride(0), b, rng, keys.data_ptr() + 8 * o, _stream())
+        o += int(p.shape[0])
+    cs, src = unique_first(keys, n, 1, len(points))
+    return morton_sorted(cs, src)
+
+
 def morton_sorted(cs, src):
     """re-order a unique set (and its source rows) along a Z-curve; see csrc/sort.hip."""
     m = cs.n

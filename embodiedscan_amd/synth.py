@@ -133,3 +133,36 @@ def make_scan(seed, n_views=20, height=480, width=640, img_size=(480, 480), n_bo
     img = rng.integers(0, 256, (n_views, 3, img_size[0], img_size[1]), dtype=np.uint8)
     return dict(depth=depth, img=img, extrinsic=np.stack(extr), intrinsic=np.stack(intr), sel_view=sel_view,
                 sel_pix=sel_pix, gt_boxes=gt.astype(np.float32), gt_labels=labels.astype(np.int64), meta=meta, aug=aug)
+
+
+def make_occ_gt(scan, n_voxels=(40, 40, 16), prior_range=(-3.2, -3.2, -1.28, 3.2, 3.2, 1.28), n_classes=81, seed=0,
+                visible_frac=0.85):
+    """Synthetic occupancy ground truth for BASELINE config 5: the scan's furniture voxelised on the
+    (X,Y,Z) grid, `gt_occupancy` (N,4) int64 rows {x, y, z, label in 1..n_classes-1} (what LoadAnnotations3D hands to
+    ImVoxelOccHead.loss, datasets/transforms/loading.py:428) and a boolean visibility mask `gt_occupancy_masks` (X,Y,Z)
+    (ConstructMultiViewMasks, datasets/transforms/multiview.py:250-273)."""
+    rng = np.random.default_rng(seed)
+    X, Y, Z = n_voxels
+    lo, hi = np.asarray(prior_range[:3]), np.asarray(prior_range[3:])
+    cell = (hi - lo) / np.asarray(n_voxels)
+    ix, iy, iz = np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing='ij')
+    idx = np.stack([ix.ravel(), iy.ravel(), iz.ravel()], 1)
+    centres = lo[None] + (idx + 0.5) * cell[None]
+    origin = np.asarray(scan['meta']['depth2img'].get('origin', np.zeros(3)), np.float64)
+    centres = centres + origin[None]
+    label = np.zeros(len(idx), np.int64)
+    cls = rng.integers(1, n_classes, len(scan['gt_boxes']))
+    for b, c in zip(scan['gt_boxes'].astype(np.float64), cls):
+        R = _euler_zxy(b[6:9])
+        local = (centres - b[None, :3]) @ R                      # R^T (p - c)
+        inside = (np.abs(local) <= b[None, 3:6] / 2 + cell[None] * 0.25).all(1)
+        label[inside] = c
+    occ = np.concatenate([idx[label > 0], label[label > 0, None]], 1)
+    occ = occ[rng.permutation(len(occ))]
+    dup = occ[rng.integers(0, max(len(occ), 1), min(len(occ), 16))] if len(occ) else occ     # duplicate rows: last wins
+    if len(dup):
+        dup = dup.copy()
+        dup[:, 3] = rng.integers(1, n_classes, len(dup))
+        occ = np.concatenate([occ, dup], 0)
+    mask = rng.random((X, Y, Z)) < visible_frac
+    return dict(gt_occupancy=occ.astype(np.int64), gt_occupancy_masks=mask)

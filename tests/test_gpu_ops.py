@@ -296,7 +296,7 @@ def test_bf16_kernels_on_large_maps_vs_oracle(dev):
     from embodiedscan_amd.hip import P, call
     from embodiedscan_amd.synth import make_scan
     from oracle import sparse as S
-    scans = [make_scan(77 + i, n_views=20, render_device='cuda:0') for i in range(2)]
+    scans = [make_scan(77 + i, n_views=20, render_device='cuda:0') for i in range(3)]
     pts = [pipeline.depth_to_points(pipeline.upload_scan(s, dev)) for s in scans]
     cs, _ = sparse.voxelize(pts, 0.01)
     st = torch.cuda.current_stream().cuda_stream

@@ -118,3 +118,64 @@ def test_augmentation_points_and_boxes(golden_dir):
         np.testing.assert_allclose(b[:, :6], d['boxes_out'][:, :6], rtol=2e-6, atol=2e-6)
         da = (b[:, 6:] - d['boxes_out'][:, 6:] + np.pi) % (2 * np.pi) - np.pi
         assert np.abs(da).max() < 5e-6, np.abs(da).max()
+
+
+# ----------------------------------------------------------------------------- occupancy path (A20)
+def test_occ_prior_grid_matches_reference(golden_dir):
+    """oracle.occ.prior_points and the product's host-side AlignedAnchor3DRangeGenerator against the reference
+    generator's own output (bit exact: same f32 linspace arithmetic)."""
+    import torch
+    from oracle import occ as OO
+    from embodiedscan_amd.models.task_modules.anchor_3d_generator import AlignedAnchor3DRangeGenerator
+    d = np.load(os.path.join(golden_dir, 'occ_anchors.npz'))
+    rng = [float(v) for v in d['range']]
+    np.testing.assert_array_equal(OO.prior_points([40, 40, 16], rng).numpy(), d['full_xyz'])
+    gen = AlignedAnchor3DRangeGenerator(ranges=[rng], rotations=[.0])
+    full = gen.grid_anchors([[16, 40, 40]])[0]
+    np.testing.assert_array_equal(full[:, :3].numpy(), d['full_xyz'])
+    np.testing.assert_array_equal(full[:3, 3:].numpy(), d['full_rest'])
+    np.testing.assert_array_equal(gen.grid_anchors([[4, 6, 8]])[0].numpy(), d['small'])
+
+
+def test_occ_losses_match_reference(golden_dir):
+    """oracle.occ supervision scatter (last write wins, masks -> 255) bit exact; CE / sem_scal / geo_scal values and
+    the gradient of their sum within 1e-6 of the reference's occ_loss.py"""
+    import torch
+    import torch.nn.functional as F
+    from oracle import occ as OO
+    d = np.load(os.path.join(golden_dir, 'occ_loss.npz'))
+    pred, occ, mask = torch.from_numpy(d['pred']), torch.from_numpy(d['gt_occ']), torch.from_numpy(d['mask'])
+    for ratio in (1, 2):
+        shape = (1, pred.shape[1]) + tuple(s // ratio for s in pred.shape[2:])
+        pooled = F.max_pool3d(mask.float()[None], ratio, stride=ratio)[0].bool()
+        np.testing.assert_array_equal(OO.occ_multiscale_supervision([occ], ratio, shape, [pooled]).numpy(), d[f'gt_r{ratio}_masked'])
+        np.testing.assert_array_equal(OO.occ_multiscale_supervision([occ], ratio, shape, None).numpy(), d[f'gt_r{ratio}'])
+    for tag, key in (('masked', 'gt_r1_masked'), ('plain', 'gt_r1')):
+        gt = torch.from_numpy(d[key])
+        p = pred.clone().requires_grad_(True)
+        ce = F.cross_entropy(p, gt, ignore_index=255)
+        sem, geo = OO.sem_scal_loss(p, gt), OO.geo_scal_loss(p, gt)
+        (ce + sem + geo).backward()
+        for name, v in (('ce', ce), ('sem', sem), ('geo', geo)):
+            assert abs(float(v) - float(d[f'{name}_{tag}'])) < 1e-6 * max(1.0, abs(float(d[f'{name}_{tag}'])))
+        np.testing.assert_allclose(p.grad.numpy(), d[f'grad_{tag}'], rtol=1e-5, atol=1e-8)
+
+
+def test_occ_neck_matches_reference(golden_dir):
+    """oracle.occ.imvoxel_neck (functional, state-dict driven) against the reference IndoorImVoxelNeck module: forward of
+    the three scales, input gradient and two weight gradients"""
+    import torch
+    from oracle import occ as OO
+    d = np.load(os.path.join(golden_dir, 'occ_neck.npz'))
+    sd = {'neck_3d.' + k[3:]: torch.from_numpy(d[k]).clone() for k in d.files if k.startswith('sd.')}
+    for k in sd:
+        if k.endswith('.weight') and sd[k].dim() == 5:
+            sd[k].requires_grad_(True)
+    x = torch.from_numpy(d['x']).clone().requires_grad_(True)
+    outs = OO.imvoxel_neck(x, sd, training=True)
+    sum((o * o).sum() for o in outs).backward()
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), d[f'out{i}'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), d['dx'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sd['neck_3d.down_layer_0.0.conv1.weight'].grad.numpy(), d['dw_conv1'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sd['neck_3d.up_block_1.0.weight'].grad.numpy(), d['dw_up'], rtol=1e-4, atol=1e-5)
