@@ -376,3 +376,77 @@ extern "C" int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, cons
   ES_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------ grounding box loss (GroundingHead.loss_by_feat_single,
+// dense_heads/grounding_head.py:750-822): the same four decoupled corner-Chamfer terms, but on DIRECT 9-DoF predictions
+// (centre, size, Euler) of the Hungarian-matched queries of a whole batch; mean over (pairs x 8 corners), no avg_factor.
+// q2g (B*Q): matched ground-truth index local to the sample or -1; gt rows of sample b start at gt_off[b].
+// Four consecutive lanes share one query (one decouple group each), like k_pos_losses.
+__global__ __launch_bounds__(64) void k_box_cd_pairs(const float* __restrict__ pred, const int* __restrict__ q2g, int Q,
+                                                     int n_rows, const float* __restrict__ gt_boxes,
+                                                     const int* __restrict__ gt_off, float inv_mean, float grad_scale,
+                                                     float w0, float w1, float w2, float w3, float* __restrict__ dpred,
+                                                     float* __restrict__ loss_acc) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = tid >> 2, grp = tid & 3;
+  float lb = 0.f;
+  const bool active = (i < n_rows) && (q2g[i] >= 0);
+  if (active) {
+    const int b = i / Q;
+    const float* tgt = gt_boxes + (size_t)(gt_off[b] + q2g[i]) * 9;
+    Dual dec[9], tb[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { dec[c] = dvar(pred[(size_t)i * 9 + c], c); tb[c] = dconst(tgt[c]); }
+    real tc[24];
+    {
+      Dual Rt[9];
+      deuler_to_mat(tb + 6, Rt);
+      const real SX[8] = {1, 1, 1, 1, -1, -1, -1, -1}, SY[8] = {1, 1, -1, -1, 1, 1, -1, -1},
+                 SZ[8] = {1, -1, 1, -1, 1, -1, 1, -1};
+      for (int a = 0; a < 8; ++a) {
+        real ex = tb[3].v * 0.5 * SX[a], ey = tb[4].v * 0.5 * SY[a], ez = tb[5].v * 0.5 * SZ[a];
+        tc[a * 3 + 0] = tb[0].v + (ex * Rt[0].v + ey * Rt[1].v + ez * Rt[2].v);
+        tc[a * 3 + 1] = tb[1].v + (ex * Rt[3].v + ey * Rt[4].v + ez * Rt[5].v);
+        tc[a * 3 + 2] = tb[2].v + (ex * Rt[6].v + ey * Rt[7].v + ez * Rt[8].v);
+      }
+    }
+    const real wg = grp == 0 ? (real)w0 : (grp == 1 ? (real)w1 : (grp == 2 ? (real)w2 : (real)w3));
+    Dual tot;
+    if (grp == 3) {
+      tot = corner_cd(dec, tc) * wg;
+    } else {
+      Dual v[9];
+      for (int c = 0; c < 9; ++c) v[c] = (c / 3 == grp) ? dec[c] : tb[c];
+      tot = corner_cd(v, tc) * wg;
+    }
+    real red[10];
+    red[0] = tot.v;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) red[c + 1] = tot.d[c];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      red[c] += __shfl_xor(red[c], 1, 64);
+      red[c] += __shfl_xor(red[c], 2, 64);
+    }
+    if (grp == 0) {
+      lb = (float)(red[0] * (real)inv_mean);
+      if (dpred) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) dpred[(size_t)i * 9 + c] = (float)(red[c + 1] * (real)inv_mean * (real)grad_scale);
+      }
+    }
+  }
+  lb = es_wave_sum(lb);
+  if ((threadIdx.x & 63) == 0 && lb != 0.f) atomicAdd(loss_acc, lb);
+}
+extern "C" int es_box_cd_pairs(const float* pred, const int* q2g, int B, int Q, const float* gt_boxes, const int* gt_off_dev,
+                               int n_pairs, float grad_scale, const float* group_w, float* dpred, float* loss_acc,
+                               void* stream) {
+  int n = B * Q;
+  if (n <= 0 || n_pairs <= 0) return 0;
+  hipLaunchKernelGGL(k_box_cd_pairs, dim3(es_cdiv(n * 4, 64)), dim3(64), 0, (hipStream_t)stream, pred, q2g, Q, n, gt_boxes,
+                     gt_off_dev, 1.0f / ((float)n_pairs * 8.0f), grad_scale, group_w[0], group_w[1], group_w[2], group_w[3], dpred,
+                     loss_acc);
+  ES_CHECK_LAUNCH();
+  return 0;
+}

@@ -592,3 +592,90 @@ def upsample_add_(fine, coarse, n_img, Hf, Wf, Hc, Wc):
         call('es_upsample_nearest_add_bwd', P(fine.g), P(g), n_img, Hf, Wf, Hc, Wc, C, acc, _stream())
     TAPE.add(bwd)
     return fine
+
+
+# ------------------------------------------------------------------ transformer operators (grounding decoder, A19)
+class ParamSlice:
+    """tap j of a (K, Cin, Cout) Param as a (1, Cin, Cout) kernel of its own (the q / k / v blocks of an attention
+    in-projection): shares storage, gradient and the parent's bf16 copies"""
+    __slots__ = ('parent', 'j', 'd', 'g')
+
+    def __init__(self, parent, j):
+        self.parent, self.j = parent, j
+        self.d = parent.d[j:j + 1]
+        self.g = parent.g[j:j + 1] if parent.g is not None else None
+
+    def bf16(self):
+        n, t = self.parent.bf16()
+        return n[self.j:self.j + 1], t[self.j:self.j + 1]
+
+
+def linear(x, w, b=None, need_dx=True):
+    """y = x @ W + b as a row GEMM on the convolution engine (w: Param / ParamSlice (1, Cin, Cout))"""
+    return conv(x, w, None, None, x.d.shape[0], bias=b, need_dx=need_dx)
+
+
+def relu_(x):
+    """in-place ReLU on x.d; the gradient of x is masked in place when the tape passes here"""
+    call('es_relu_fwd', P(x.d), x.d.numel(), _stream())
+
+    def bwd():
+        if x.g is not None:
+            call('es_relu_bwd', P(x.g), P(x.d), x.d.numel(), _stream())
+    TAPE.add(bwd)
+    return x
+
+
+def layernorm(x, w, b, res=None, eps=1e-5):
+    """y = LayerNorm(x (+ res)) over channels; w, b: Params (C,)"""
+    n, C = x.d.shape
+    assert x.d.is_contiguous() and (res is None or res.d.is_contiguous())
+    y = Var(empty((n, C), x.d))
+    z = empty((n, C), x.d) if res is not None else x.d
+    mean, rstd = empty((n,), x.d), empty((n,), x.d)
+    call('es_layernorm_fwd', P(x.d), P(res.d) if res is not None else 0, n, C, P(w.d), P(b.d), float(eps), P(y.d),
+         P(z) if res is not None else 0, P(mean), P(rstd), _stream())
+
+    def bwd():
+        if y.g is None:
+            return
+        s = _stream()
+        tgt = [v for v in ((x, res) if res is not None else (x,)) if v.rg]
+        dz = torch.empty_like(y.d)
+        call('es_layernorm_bwd', P(y.g), P(z), n, C, P(w.d), P(mean), P(rstd), P(dz), 0, P(w.g), P(b.g), s)
+        owned = False                            # dz may be handed to exactly one input as its gradient buffer
+        for v in tgt:
+            if v.g is None:
+                v.g = dz if not owned else dz.clone()
+                owned = True
+            else:
+                call('es_axpy2d', P(v.g), _ld(v.g), P(dz), C, n, C, 1.0, 1, s)
+    TAPE.add(bwd)
+    return y
+
+
+def attention(q, k, v, B, H, Lq, Lk, klen=None):
+    """softmax(q k^T / sqrt(32)) v per (sample, head); q (B*Lq, H*32), k / v (B*Lk, H*32) projected row matrices (Vars,
+    possibly column slices of wider buffers); klen: device int32 (B,) valid key counts or None"""
+    bf = 1 if PRECISION[0] == 'bf16' else 0
+    o = Var(empty((B * Lq, H * 32), q.d))
+    lse = empty((B * H * Lq,), q.d)
+    call('es_attn_fwd', P(q.d), _ld(q.d), P(k.d), _ld(k.d), P(v.d), _ld(v.d), B, H, Lq, Lk, P(klen), P(o.d), H * 32, P(lse), bf,
+         _stream())
+
+    def bwd():
+        if o.g is None:
+            return
+        delta = empty((B * H * Lq,), q.d)
+        gs = []
+        for t in (q, k, v):
+            if t.g is None:
+                t.g = torch.empty_like(t.d)
+                gs.append(0)
+            else:
+                gs.append(1)
+        assert gs[0] == gs[1] == gs[2], 'attention inputs must be fresh projections (single consumer)'
+        call('es_attn_bwd', P(q.d), _ld(q.d), P(k.d), _ld(k.d), P(v.d), _ld(v.d), P(o.d), H * 32, P(o.g), _ld(o.g), P(lse), B, H,
+             Lq, Lk, P(klen), P(delta), P(q.g), _ld(q.g), P(k.g), _ld(k.g), P(v.g), _ld(v.g), gs[0], bf, _stream())
+    TAPE.add(bwd)
+    return o

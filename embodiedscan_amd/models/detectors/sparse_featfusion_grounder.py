@@ -1,0 +1,160 @@
+"""SparseFeatureFusion3DGrounder (embodiedscan/models/detectors/sparse_featfusion_grounder.py:29-766) on the MI355X
+kernels.  Same registry name, constructor arguments and forward(inputs, data_samples, mode) protocol.
+
+extract_feat is the mv-3ddet feature path (2-D / 3-D backbones + projection fusion, inherited) followed by MinkNeck;
+pre_decoder / forward_decoder / the head run on padded channels-last token matrices.  Text: see embodiedscan_amd/text.py."""
+import torch
+from ... import engine as E
+from ... import hip
+from ...hip import P, call
+from ...params import ParamArena, grounder_specs
+from ...registry import MODELS
+from ...text import HashTokenizer, build_text_encoder, create_positive_map
+from ..layers.ground_transformer.decoder import SparseFeatureFusionTransformerDecoder, _Lin
+from .sparse_featfusion_single_stage import SparseFeatureFusionSingleStage3DDetector
+
+
+@MODELS.register_module()
+class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
+    _version = 2
+
+    def __init__(self, backbone, backbone_3d, bbox_head, neck=None, neck_3d=None, decoder=None, voxel_size=0.01,
+                 num_queries=512, max_num_entities=256, coord_type='CAMERA', train_cfg=None, test_cfg=None,
+                 data_preprocessor=None, use_xyz_feat=False, init_cfg=None, seed=0, device='cuda:0', text_encoder_cfg=None,
+                 tokenizer=None):
+        assert neck is None and neck_3d is not None and decoder is not None
+        self.device = torch.device(device)
+        self.backbone = MODELS.build(backbone)
+        self.backbone_3d = MODELS.build(backbone_3d)
+        self.neck_3d = MODELS.build(neck_3d)
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = MODELS.build(bbox_head)
+        self.decoder = SparseFeatureFusionTransformerDecoder(**decoder)
+        self.embed_dims = self.decoder.embed_dims
+        self.data_preprocessor = MODELS.build(data_preprocessor, device=self.device) if data_preprocessor else None
+        self.coord_type, self.train_cfg, self.test_cfg = coord_type, train_cfg, test_cfg
+        self.num_queries = num_queries
+        self.max_num_entities = self.bbox_head.contrastive_cfg.get('max_text_len', max_num_entities)
+        self.voxel_size, self.use_xyz_feat = voxel_size, use_xyz_feat
+        # text side (roberta-base vocabulary / weights are not available offline: stand-ins, see text.py)
+        self.tokenizer = tokenizer or HashTokenizer()
+        self.text_encoder = build_text_encoder(text_encoder_cfg, seed=seed)
+        self.text_dim = self.text_encoder.config.hidden_size
+        self.arena = ParamArena(grounder_specs(text_dim=self.text_dim, E=self.embed_dims, num_layers=self.decoder.num_layers,
+                                               ffn=self.decoder.ffn_channels, in_channels=self.neck_3d.in_channels), seed=seed)
+        self.training = True
+        self._bound = False
+
+    # ------------------------------------------------------------------ parameters
+    def to(self, device):
+        super().to(device)
+        self.text_encoder.to(self.device)
+        return self
+
+    def _bind(self):
+        if not self._bound:
+            if self.arena.data.device != self.device:
+                self.arena.to(self.device)
+            if next(self.text_encoder.parameters()).device != self.device:
+                self.text_encoder.to(self.device)
+            E.begin_bind(id(self))
+            try:
+                self.backbone.bind(self.arena, 'backbone.')
+                self.backbone_3d.bind(self.arena, 'backbone_3d.')
+                self.neck_3d.bind(self.arena, 'neck_3d.')
+                self.decoder.bind(self.arena, 'decoder.')
+                self.bbox_head.bind(self.arena, 'bbox_head.')
+                self.text_feat_map = _Lin(self.arena, 'text_feat_map.weight', 'text_feat_map.bias')
+            finally:
+                E.end_bind()
+            self._bound = True
+
+    def train(self, mode=True):
+        self.training = mode
+        for m in (self.backbone_3d, self.neck_3d, self.decoder, self.bbox_head):
+            m.training = mode
+        return self
+
+    # ------------------------------------------------------------------ text
+    def encode_text(self, batch_data_samples):
+        """:475-498: tokenise, positive maps, frozen RoBERTa, text_feat_map.  Returns (text Var (B*T, E), mask (B,T) bool
+        on the device, tlen (B,) int32 on the device, T) and attaches positive_maps / text_token_mask to the samples."""
+        texts = [ds.text for ds in batch_data_samples]
+        tok = self.tokenizer.batch_encode_plus(texts, padding='longest', return_tensors='pt')
+        if all(getattr(ds, 'tokens_positive', None) is not None for ds in batch_data_samples):
+            tps = [ds.tokens_positive for ds in batch_data_samples]
+        else:
+            tps = [[[0, 1]] for _ in batch_data_samples]
+        pmaps = [create_positive_map(tok, tp, i, self.max_num_entities) for i, tp in enumerate(tps)]
+        tok = tok.to(self.device)
+        with torch.no_grad():
+            hs = self.text_encoder(input_ids=tok.input_ids, attention_mask=tok.attention_mask).last_hidden_state
+        B, T = tok.input_ids.shape
+        mask = tok.attention_mask.bool()
+        for i, ds in enumerate(batch_data_samples):
+            pm = pmaps[i].bool().float()
+            ds.gt_instances_3d.positive_maps = pm
+            ds.gt_instances_3d.text_token_mask = mask[i].unsqueeze(0).repeat(len(pm), 1)
+        text = self.text_feat_map(E.Var(hs.reshape(B * T, self.text_dim).float().contiguous(), rg=False), need_dx=False)
+        tlen = tok.attention_mask.sum(1).to(torch.int32).contiguous()
+        self.last_text = dict(hidden=hs, mask=mask, input_ids=tok.input_ids)
+        return text, mask, tlen, T
+
+    # ------------------------------------------------------------------ features
+    def extract_feat(self, batch_inputs_dict, batch_data_samples):
+        """:176-310: fused sparse levels (inherited) -> MinkNeck -> (feats, scores, coords) per-sample lists"""
+        x = super().extract_feat(batch_inputs_dict, batch_data_samples)
+        return self.neck_3d(x, len(batch_data_samples))
+
+    def forward_transformer(self, text, tlen, T, batch_data_samples):
+        """pre_decoder + forward_decoder (:312-447) on the padded buffers of the neck"""
+        nk = self.neck_3d.last
+        feats, coords, lens, Lmax = nk['feats'], nk['points'], nk['lens'], nk['Lmax']
+        B = len(lens)
+        dev = feats.d.device
+        s = hip.stream()
+        klen = torch.tensor(lens, dtype=torch.int32).to(dev, non_blocking=True)
+        # query selection: ContrastiveEmbed scores of every point token, max over text tokens, top-k per sample
+        _, rowmax = self.bbox_head.cls_branch(feats, text, B, Lmax, T, tlen, vlen=klen, want_logits=False, want_max=True)
+        Q = min(self.num_queries, min(lens))
+        idx = torch.empty((B, Q), dtype=torch.int32, device=dev)
+        call('es_topk_sorted', P(rowmax), B, Lmax, P(klen), Q, P(idx), s)
+        gidx = (idx + (torch.arange(B, device=dev, dtype=torch.int32) * Lmax)[:, None]).reshape(-1).contiguous()
+        query = E.gather_rows(feats, gidx)
+        qcoords = torch.empty((B * Q, 3), dtype=torch.float32, device=dev)
+        call('es_row_move', P(qcoords), 3, P(coords), 3, P(gidx), B * Q, 3, 0, s)
+        prev = E.TAPE.enabled
+        E.TAPE.enabled = False                   # proposals: reg_branches[num_layers] on the selected tokens, detached
+        try:
+            pred0 = self.bbox_head.decode(qcoords, self.bbox_head.reg_branch(E.Var(query.d, rg=False))).d
+        finally:
+            E.TAPE.enabled = prev
+        self.last_queries = dict(idx=idx, gidx=gidx, rowmax=rowmax, pred0=pred0, Q=Q, klen=klen)
+        return self.decoder(query, feats, coords, qcoords, pred0, text, B, Q, Lmax, T, klen, tlen, self.bbox_head)
+
+    # ------------------------------------------------------------------ reference protocol
+    def loss(self, batch_inputs_dict, batch_data_samples, **kwargs):
+        self._bind()
+        self.extract_feat(batch_inputs_dict, batch_data_samples)
+        text, mask, tlen, T = self.encode_text(batch_data_samples)
+        hidden, boxes = self.forward_transformer(text, tlen, T, batch_data_samples)
+        return self.bbox_head.loss(hidden, boxes, text, mask, batch_data_samples, tlen=tlen)
+
+    def predict(self, batch_inputs_dict, batch_data_samples, **kwargs):
+        was = self.training
+        self.train(False)
+        prev = E.TAPE.enabled
+        E.TAPE.enabled = False
+        try:
+            self._bind()
+            self.extract_feat(batch_inputs_dict, batch_data_samples)
+            text, mask, tlen, T = self.encode_text(batch_data_samples)
+            hidden, boxes = self.forward_transformer(text, tlen, T, batch_data_samples)
+            results = self.bbox_head.predict(hidden, boxes, text, mask, batch_data_samples, tlen=tlen)
+        finally:
+            E.TAPE.enabled = prev
+            self.train(was)
+        for ds, r in zip(batch_data_samples, results):
+            ds.pred_instances_3d = r
+        return batch_data_samples

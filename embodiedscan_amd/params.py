@@ -17,11 +17,14 @@ class Spec:
     """One arena tensor.  `ref` describes how it appears in the reference state dict:
     None = same name / shape; ('oihw', (O,I,KH,KW)) = a conv2d weight kept as [KH*KW, I, O] for the
     row-matrix conv engine; ('head_out',) = the fused 1x1 head kernels (see fcaf3d_head_specs)."""
-    __slots__ = ('name', 'shape', 'init', 'trainable', 'buffer', 'ref')
+    __slots__ = ('name', 'shape', 'init', 'trainable', 'buffer', 'ref', 'aliases')
 
-    def __init__(self, name, shape, init, trainable=True, buffer=False, ref=None):
+    def __init__(self, name, shape, init, trainable=True, buffer=False, ref=None, aliases=()):
         self.name, self.shape, self.init, self.trainable, self.buffer = name, tuple(shape), init, trainable, buffer
         self.ref = ref
+        # further reference keys holding the SAME tensor (modules shared through an nn.ModuleList, e.g. GroundingHead's
+        # share_pred_layer=True branches): emitted as copies, absorbed from whichever key is present
+        self.aliases = tuple(aliases)
 
 
 def _conv2d(name, o, i, kh, kw, fan, trainable):
@@ -111,6 +114,88 @@ def detector_specs(n_classes=284):
     return resnet50_specs() + mink_resnet34_specs() + fcaf3d_head_specs(n_classes=n_classes)
 
 
+# ---------------------------------------------------------------- grounding path (BASELINE config 4)
+def _linear(name, cin, cout, init=None, trainable=True, aliases=()):
+    return Spec(name, (1, cin, cout), init or ('uniform_fan', cin), trainable, ref=('linear',), aliases=aliases)
+
+
+def mink_neck_specs(prefix='neck_3d.', in_channels=(128, 256, 512, 1024), out_channels=256, num_classes=1):
+    """MinkNeck (embodiedscan/models/necks/mink_neck.py:46-131): the FCAF3D-style sparse FPN + a 1x1 score conv"""
+    s = []
+    for i, c in enumerate(in_channels):
+        if i > 0:
+            p = f'{prefix}up_block_{i}'
+            co = in_channels[i - 1]
+            s.append(Spec(p + '.0.kernel', (8, c, co), ('uniform_fan', co * 8)))
+            _mbn(s, p + '.1', co)
+            s.append(Spec(p + '.3.kernel', (27, co, co), ('uniform_fan', co * 27)))
+            _mbn(s, p + '.4', co)
+        p = f'{prefix}out_block_{i}'
+        s.append(Spec(p + '.0.kernel', (27, c, out_channels), ('uniform_fan', c * 27)))
+        _mbn(s, p + '.1', out_channels)
+    # conv_cls only ranks voxels for pruning (under no_grad in the reference): it never receives a gradient
+    s.append(Spec(prefix + 'conv_cls.kernel', (1, out_channels, num_classes), ('normal', .01), False, ref=('squeeze0',)))
+    s.append(Spec(prefix + 'conv_cls.bias', (1, num_classes), ('const', -math.log((1 - .01) / .01)), False))
+    return s
+
+
+def _posembed_specs(s, p, cin, E, trainable=True):
+    """PositionEmbeddingLearned (ground_transformer/decoder.py:20-34): Conv1d(cin,E,1) BN1d ReLU Conv1d(E,E,1)"""
+    q = p + '.position_embedding_head'
+    s.append(Spec(q + '.0.weight', (1, cin, E), ('uniform_fan', cin), trainable, ref=('conv1d',)))
+    s.append(Spec(q + '.0.bias', (E,), ('uniform_fan', cin), trainable))
+    s += [Spec(q + '.1.weight', (E,), ('const', 1.), trainable), Spec(q + '.1.bias', (E,), ('const', 0.), trainable),
+          Spec(q + '.1.running_mean', (E,), ('const', 0.), False, True), Spec(q + '.1.running_var', (E,), ('const', 1.), False, True)]
+    s.append(Spec(q + '.3.weight', (1, E, E), ('uniform_fan', E), trainable, ref=('conv1d',)))
+    s.append(Spec(q + '.3.bias', (E,), ('uniform_fan', E), trainable))
+
+
+def ground_decoder_specs(prefix='decoder.', num_layers=6, E=256, ffn=2048):
+    """SparseFeatureFusionTransformerDecoder (decoder.py:182-297) with mmcv MultiheadAttention / FFN key names"""
+    s = []
+    for i in range(num_layers):
+        p = f'{prefix}layers.{i}.'
+        for a in ('self_attn', 'cross_attn_text', 'cross_attn'):
+            s.append(Spec(p + a + '.attn.in_proj_weight', (3, E, E), ('xavier', (E, 3 * E)), ref=('inproj',)))
+            s.append(Spec(p + a + '.attn.in_proj_bias', (3, E), ('const', 0.), ref=('reshape', (3 * E,))))
+            s.append(_linear(p + a + '.attn.out_proj.weight', E, E))
+            s.append(Spec(p + a + '.attn.out_proj.bias', (E,), ('const', 0.)))
+        s.append(_linear(p + 'ffn.layers.0.0.weight', E, ffn))
+        s.append(Spec(p + 'ffn.layers.0.0.bias', (ffn,), ('uniform_fan', E)))
+        s.append(_linear(p + 'ffn.layers.1.weight', ffn, E))
+        s.append(Spec(p + 'ffn.layers.1.bias', (E,), ('uniform_fan', ffn)))
+        for k in range(4):
+            s += [Spec(p + f'norms.{k}.weight', (E,), ('const', 1.)), Spec(p + f'norms.{k}.bias', (E,), ('const', 0.))]
+        # the per-layer self_posembed exists in the reference module but its forward never uses it (decoder.py:98,
+        # 267-271 use the decoder-level embeddings): parameters without a gradient, kept frozen
+        _posembed_specs(s, p + 'self_posembed', 3, E, trainable=False)
+    _posembed_specs(s, prefix + 'self_posembed', 9, E)
+    _posembed_specs(s, prefix + 'cross_posembed', 3, E)
+    s += [Spec(prefix + 'norm.weight', (E,), ('const', 1.)), Spec(prefix + 'norm.bias', (E,), ('const', 0.))]
+    return s
+
+
+def grounding_head_specs(prefix='bbox_head.', E=256, num_reg=9, num_pred_layer=7):
+    """GroundingHead with share_pred_layer=True (grounding_head.py:188-224): ONE ContrastiveEmbed bias and ONE
+    Linear-ReLU-Linear-ReLU-Linear regression branch, visible under 7 ModuleList indices in the reference state dict"""
+    al = lambda fmt: [prefix + fmt.format(i) for i in range(1, num_pred_layer)]
+    s = [Spec(prefix + 'cls_branches.0.bias', (1,), ('const', -math.log((1 - 0.01) / 0.01)), aliases=al('cls_branches.{}.bias'))]
+    for j, (ci, co) in zip((0, 2, 4), ((E, E), (E, E), (E, num_reg))):
+        last = j == 4
+        s.append(_linear(prefix + f'reg_branches.0.{j}.weight', ci, co, ('const', 0.) if last else None,
+                         aliases=al('reg_branches.{}.' + f'{j}.weight')))
+        s.append(Spec(prefix + f'reg_branches.0.{j}.bias', (co,), ('reg_bias', -2.0) if last else ('uniform_fan', ci),
+                      aliases=al('reg_branches.{}.' + f'{j}.bias')))
+    return s
+
+
+def grounder_specs(text_dim=768, E=256, num_layers=6, ffn=2048, in_channels=(128, 256, 512, 1024)):
+    return (resnet50_specs() + mink_resnet34_specs() + mink_neck_specs(in_channels=in_channels, out_channels=E) +
+            ground_decoder_specs(num_layers=num_layers, E=E, ffn=ffn) +
+            [_linear('text_feat_map.weight', text_dim, E), Spec('text_feat_map.bias', (E,), ('uniform_fan', text_dim))] +
+            grounding_head_specs(E=E, num_pred_layer=num_layers + 1))
+
+
 # ---------------------------------------------------------------- occupancy path (BASELINE config 5)
 def _conv3d(name, o, i, k, stride_fan=None):
     """nn.Conv3d weight (O, I, k, k, k), default PyTorch init (kaiming_uniform a=sqrt(5) == U(+-1/sqrt(fan_in)))"""
@@ -198,6 +283,9 @@ def _fill(t, init, gen):
         t.uniform_(-b, b, generator=gen)
     elif kind == 'normal':
         t.normal_(0, a, generator=gen)
+    elif kind == 'reg_bias':                # GroundingHead.init_weights: last reg layer bias 0, bias[2:] = -2 (grounding_head.py:220-224)
+        t.zero_()
+        t[2:] = a
     elif kind == 'head_bias':
         t.zero_()
         t[a[0]:] = a[1]
@@ -258,6 +346,14 @@ class ParamArena:
             out[s.name] = t.reshape(kh, kw, i, o).permute(3, 2, 0, 1).contiguous()
         elif s.ref[0] == 'squeeze0':
             out[s.name] = t[0].clone()
+        elif s.ref[0] == 'linear':                     # arena [1][in][out] -> nn.Linear (out, in)
+            out[s.name] = t[0].t().contiguous()
+        elif s.ref[0] == 'conv1d':                     # arena [1][in][out] -> nn.Conv1d (out, in, 1)
+            out[s.name] = t[0].t().contiguous().unsqueeze(-1)
+        elif s.ref[0] == 'inproj':                     # arena [3][in][out] (q, k, v) -> in_proj_weight (3*out, in)
+            out[s.name] = t.transpose(1, 2).reshape(-1, t.shape[1]).contiguous()
+        elif s.ref[0] == 'reshape':
+            out[s.name] = t.reshape(s.ref[1]).clone()
         elif s.ref[0] == 'oidhw':                      # arena [kd*kh*kw][I][O] -> nn.Conv3d (O, I, kd, kh, kw)
             o, i, kd, kh, kw = s.ref[1]
             out[s.name] = t.reshape(kd, kh, kw, i, o).permute(4, 3, 0, 1, 2).contiguous()
@@ -287,6 +383,18 @@ class ParamArena:
                 o, i, kh, kw = s.ref[1]
                 dst.copy_(sd[s.name].permute(2, 3, 1, 0).reshape(kh * kw, i, o))
                 return [s.name]
+        elif s.ref[0] in ('linear', 'conv1d'):
+            if s.name in sd:
+                dst[0].copy_(sd[s.name].reshape(dst.shape[2], dst.shape[1]).t())
+                return [s.name]
+        elif s.ref[0] == 'inproj':
+            if s.name in sd:
+                dst.copy_(sd[s.name].reshape(3, dst.shape[2], dst.shape[1]).transpose(1, 2))
+                return [s.name]
+        elif s.ref[0] == 'reshape':
+            if s.name in sd:
+                dst.copy_(sd[s.name].reshape(dst.shape))
+                return [s.name]
         elif s.ref[0] == 'oidhw':
             if s.name in sd:
                 o, i, kd, kh, kw = s.ref[1]
@@ -313,6 +421,23 @@ class ParamArena:
                 return [pre + 'conv_cls.bias']
         return []
 
+    @classmethod
+    def _emit_all(cls, s, t, out):
+        cls._emit(s, t, out)
+        for a in s.aliases:
+            out[a] = out[s.name].clone()
+
+    @classmethod
+    def _absorb_all(cls, s, dst, sd):
+        got = cls._absorb(s, dst, sd)
+        if not got:
+            for a in s.aliases:
+                if a in sd:
+                    cls._absorb(s, dst, {s.name: sd[a]})
+                    got = [a]
+                    break
+        return got + [a for a in s.aliases if a in sd and a not in got] if got else got
+
     def ref_names(self, s):
         """reference key(s) spec s maps to"""
         probe = OrderedDict()
@@ -323,7 +448,7 @@ class ParamArena:
         """Reference-named, reference-shaped copy (what `model.state_dict()` gives in the reference)."""
         out = OrderedDict()
         for s in self.specs:
-            self._emit(s, self.p[s.name].detach(), out)
+            self._emit_all(s, self.p[s.name].detach(), out)
         return out
 
     def _to_ref(self, which):
@@ -360,7 +485,7 @@ class ParamArena:
         reference keys; strict=True raises if either is non-empty (torch.nn.Module.load_state_dict semantics)."""
         used, missing = set(), []
         for s in self.specs:
-            got = self._absorb(s, self.p[s.name], sd)
+            got = self._absorb_all(s, self.p[s.name], sd)
             used.update(got)
             if not got:
                 missing.extend(self.ref_names(s))

@@ -247,6 +247,58 @@ int es_occ_targets(const int* gt_occ, int n, int ratio, int X, int Y, int Z, con
 int es_occ_loss(const float* logits, int ld, const int* gt, int n, int C, float weight, double* stats, float* coeff,
                 float* dlogits, int ldg, float* loss_out, float* total_acc, void* stream);
 
+/* ---- A19 grounding path (BASELINE config 4) + N2 device-side assignment --------------------------------------------------
+ * layers/ground_transformer/decoder.py:37-297, dense_heads/grounding_head.py:20-824, detectors/sparse_featfusion_grounder.py:
+ * 324-447, task_modules/assigners/hungarian_assigner.py:56-138, losses/match_cost.py:49-265 */
+/* scaled dot-product attention core of nn.MultiheadAttention (mmcv MultiheadAttention, decoder.py:103-179), head_dim 32:
+ * rows (b*L + i) of the projected Q/K/V matrices, head h in columns [32h, 32h+32); keys >= klen_dev[b] are masked
+ * (key_padding_mask, always a prefix mask here; NULL = none).  O (B*Lq, H*32), lse (B,H,Lq).  bf16 != 0: bf16 matrix cores
+ * with f32 softmax / accumulation; 0: exact-f32 matrix cores.  All leading dims multiples of 4 floats. */
+int es_attn_fwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, int B, int H, int Lq, int Lk,
+                const int* klen_dev, float* O, int ldo, float* lse, int bf16, void* stream);
+/* gradients of the same (recomputing the probabilities from lse); delta_scratch: B*H*Lq floats */
+int es_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                const float* dO, int ldd, const float* lse, int B, int H, int Lq, int Lk, const int* klen_dev,
+                float* delta_scratch, float* dQ, int ldgq, float* dK, int ldgk, float* dV, int ldgv, int accumulate, int bf16,
+                void* stream);
+/* y = LayerNorm(x (+ res)) over the C columns of (n,C) rows (C <= 512); z = x + res is stored when z != NULL */
+int es_layernorm_fwd(const float* x, const float* res, int n, int C, const float* w, const float* b, float eps, float* y,
+                     float* z, float* mean, float* rstd, void* stream);
+int es_layernorm_bwd(const float* dy, const float* z, int n, int C, const float* w, const float* mean, const float* rstd,
+                     float* dz, int accumulate, float* dw, float* db, void* stream);
+int es_relu_fwd(float* x, size_t n, void* stream);
+int es_relu_bwd(float* dy, const float* y, size_t n, void* stream);
+/* ContrastiveEmbed (grounding_head.py:62-99, log_scale='auto', bias): logits (B,L,Tout) = <v, text> / sqrt(C) + bias for
+ * t < tlen[b] (and rows < vlen[b]), -inf elsewhere; rowmax (B,L) = max over tokens (either output may be NULL) */
+int es_contrastive_fwd(const float* v, int B, int L, const float* text, int T, int C, const int* tlen_dev, const int* vlen_dev,
+                       const float* bias_dev, float* logits, int Tout, float* rowmax, void* stream);
+int es_contrastive_bwd(const float* dlogits, int Tout, const float* v, int B, int L, const float* text, int T, int C,
+                       const int* tlen_dev, float* dv, int acc_v, float* dtext /* += */, float* dbias /* += */, void* stream);
+/* GroundingHead._bbox_pred_to_bbox, box_coder 'baseline', 9 outputs: (pred[:3] + point, clamp(exp(pred[3:6]), 2e-2), pred[6:]) */
+int es_ground_decode_fwd(const float* pred, int ldp, const float* points, int n, float* box /* (n,9) */, void* stream);
+int es_ground_decode_bwd(const float* pred, int ldp, const float* dbox, int n, float* dpred, int ldg, int accumulate,
+                         void* stream);
+/* N2: exact IoU of 9-DoF Euler (ZXY) boxes, (N,M) -- EulerInstance3DBoxes.overlaps / pytorch3d box3d_overlap */
+int es_box3d_iou(const float* boxes1, int N, const float* boxes2, int M, float* iou, void* stream);
+/* N2: HungarianAssigner3D for every sample of one decoder layer: costs (BinaryFocalLossCost w_cls, BBox3DL1Cost w_l1,
+ * IoU3DCost w_iou) + scipy-compatible rectangular assignment.  logits (B,Q,Tout), boxes (B,Q,9), gt_boxes (sum G,9),
+ * pos_map (sum G,T) u8, gt_off_dev (B+1).  cost: B*Gmax*Q doubles, work: B*(Gmax+2Q) doubles, iwork: B*(4Q+2Gmax) ints.
+ * q2g (B,Q): matched ground-truth index (local to the sample) or -1.  Gmax <= Q. */
+int es_ground_match(const float* logits, int Tout, const float* boxes, int B, int Q, const float* gt_boxes,
+                    const unsigned char* pos_map, const int* gt_off_dev, int Gmax, const int* tlen_dev, int T, float w_cls,
+                    float w_l1, float w_iou, double* cost, double* work, int* iwork, int* q2g, void* stream);
+/* labels from the assignment + mmdet FocalLoss (sigmoid, py_sigmoid_focal_loss) over the un-padded tokens:
+ * loss_sum[0] += sum; dlogits = d(sum / (avg_factor + eps)) * grad_scale (0 at padded tokens) */
+int es_ground_focal(const float* logits, int Tout, int B, int Q, const int* q2g, const unsigned char* pos_map,
+                    const int* gt_off_dev, const int* tlen_dev, int T, float alpha, float gamma, const float* avg_factor_dev,
+                    float grad_scale, float* dlogits, double* loss_sum, void* stream);
+/* 4-group decoupled corner-Chamfer loss on the matched (prediction, target) pairs of a batch: loss_acc[0] += weighted mean
+ * over n_pairs*8 corners; dpred (B*Q,9) written at matched rows.  grounding_head.py:750-822, losses/chamfer_distance.py */
+int es_box_cd_pairs(const float* pred, const int* q2g, int B, int Q, const float* gt_boxes, const int* gt_off_dev, int n_pairs,
+                    float grad_scale, const float* group_w_host, float* dpred, float* loss_acc, void* stream);
+/* per-sample indices of the k largest values, descending, ties by lower row; segment length <= 8192 */
+int es_topk_sorted(const float* vals, int B, int L, const int* vlen_dev, int k, int* idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,6 +139,45 @@ def _populate(module):
         module.bias_init_with_prob = lambda p: float(-torch.log(torch.tensor((1 - p) / p)))
 
 
+    if n == 'mmengine.structures':
+        class InstanceData:
+            """attribute bag; len() = length of its first tensor-like field (what the assigner relies on)"""
+
+            def __init__(self, **kw):
+                self.__dict__.update(kw)
+
+            def __len__(self):
+                for v in self.__dict__.values():
+                    if hasattr(v, '__len__'):
+                        return len(v)
+                return 0
+
+            def __contains__(self, k):
+                return k in self.__dict__
+        module.InstanceData = InstanceData
+    if n == 'mmdet.models.task_modules':
+        class AssignResult:
+            def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+                self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+        module.AssignResult = AssignResult
+        module.BaseAssigner = object
+    if n == 'mmdet.models.utils':
+        from functools import partial
+
+        def multi_apply(func, *args, **kwargs):
+            pfunc = partial(func, **kwargs) if kwargs else func
+            return tuple(map(list, zip(*map(pfunc, *args))))
+        module.multi_apply = multi_apply
+    if n == 'mmdet.utils':
+        module.reduce_mean = lambda t: t
+    if n == 'mmcv.cnn':
+        module.Linear = torch.nn.Linear
+    if n == 'pytorch3d.ops':
+        def box3d_overlap(corners1, corners2, eps=1e-4):
+            raise RuntimeError('bind pytorch3d.ops.box3d_overlap to the oracle restatement before use')
+        module.box3d_overlap = box3d_overlap
+
+
 def install(reference_root='/root/reference'):
     if not any(isinstance(f, _Finder) for f in sys.meta_path):
         sys.meta_path.insert(0, _Finder())

@@ -179,3 +179,63 @@ def test_occ_neck_matches_reference(golden_dir):
     np.testing.assert_allclose(x.grad.numpy(), d['dx'], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(sd['neck_3d.down_layer_0.0.conv1.weight'].grad.numpy(), d['dw_conv1'], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(sd['neck_3d.up_block_1.0.weight'].grad.numpy(), d['dw_up'], rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- grounding path (A19) + assignment (N2)
+def test_box3d_iou_two_restatements_agree():
+    """pytorch3d's box3d_overlap is un-vendored: the oracle's face-clipping IoU against an independent computation
+    (scipy half-space intersection + convex hull) on random oriented boxes, plus closed-form cases"""
+    from oracle import grounding as OG
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(60):
+        a = np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(.3, 2., 3), rng.uniform(-3.1, 3.1, 3)])
+        b = a + np.concatenate([rng.normal(0, .4, 3), rng.normal(0, .2, 3), rng.normal(0, .5, 3)])
+        b[3:6] = np.abs(b[3:6]) + .1
+        i1, i2 = OG.box3d_iou(a, b), OG.box3d_iou_qhull(a, b)
+        worst = max(worst, abs(i1 - i2))
+    print(f'face-clipping vs qhull IoU: worst abs difference {worst:.2e} over 60 pairs (tol 1e-9)')
+    assert worst < 1e-9
+    box = np.array([0.2, -0.1, 0.3, 1.0, 2.0, 0.5, 0.7, 0.2, -0.4])
+    assert abs(OG.box3d_iou(box, box) - 1.0) < 1e-12                       # identical boxes: coincident faces counted once
+    a = np.array([0., 0, 0, 2, 2, 2, 0, 0, 0])
+    for shift, want in ((1.0, (1 * 2 * 2) / (16 - 4)), (2.0, 0.0), (3.0, 0.0)):  # half overlap, touching, apart
+        b = a.copy(); b[0] = shift
+        assert abs(OG.box3d_iou(a, b) - want) < 1e-12, (shift, OG.box3d_iou(a, b))
+    inner = np.array([0.1, 0.1, -0.2, .5, .5, .5, 1.0, .3, .2])
+    assert abs(OG.box3d_iou(a, inner) - 0.125 / 8.0) < 1e-12               # containment
+
+
+def test_grounding_head_matches_reference(golden_dir):
+    """oracle.grounding against the reference's ContrastiveEmbed, box coder, match costs, HungarianAssigner3D (scipy) and
+    GroundingHead.loss_by_feat_single (values + gradients), and PositionEmbeddingLearned"""
+    from oracle import grounding as OG
+    d = np.load(os.path.join(golden_dir, 'ground_head.npz'))
+    hidden, text, mask = torch.from_numpy(d['hidden']), torch.from_numpy(d['text']), torch.from_numpy(d['mask'])
+    bias = torch.from_numpy(d['ce_bias'])
+    cls = OG.contrastive_embed(hidden, text, mask, bias, max_text_len=32)
+    ref = torch.from_numpy(d['cls'])
+    assert torch.equal(torch.isinf(cls), torch.isinf(ref))
+    np.testing.assert_allclose(torch.nan_to_num(cls, 0, 0, 0).numpy(), torch.nan_to_num(ref, 0, 0, 0).numpy(), rtol=1e-5, atol=1e-6)
+    boxes = OG.bbox_pred_to_bbox(torch.from_numpy(d['points']), torch.from_numpy(d['reg']))
+    np.testing.assert_allclose(boxes.numpy(), d['boxes'], rtol=1e-6, atol=1e-7)
+    B = hidden.shape[0]
+    gtb = [torch.from_numpy(d[f'gt_boxes{b}']) for b in range(B)]
+    pms = [torch.from_numpy(d[f'pos_map{b}']) for b in range(B)]
+    for b in range(B):
+        tm = mask[b][None].repeat(len(gtb[b]), 1)
+        gi, cost = OG.hungarian_assign(ref[b], torch.from_numpy(d['boxes'][b]), gtb[b], pms[b], tm, return_cost=True)
+        np.testing.assert_allclose(cost.numpy(), d[f'costs{b}'].sum(0), rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(gi.numpy(), d[f'gt_inds{b}'])
+    c = ref.clone().requires_grad_(True)
+    bx = torch.from_numpy(d['boxes']).clone().requires_grad_(True)
+    lc, lb = OG.loss_by_feat_single(c, bx, gtb, pms, mask)
+    (lc + lb).backward()
+    assert abs(float(lc) - float(d['loss_cls'])) < 1e-6 * max(1, abs(float(d['loss_cls'])))
+    assert abs(float(lb) - float(d['loss_bbox'])) < 1e-6 * max(1, abs(float(d['loss_bbox'])))
+    np.testing.assert_allclose(torch.nan_to_num(c.grad, 0, 0, 0).numpy(), d['dcls'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(bx.grad.numpy(), d['dboxes'], rtol=1e-4, atol=1e-7)
+    sd = {'pe.position_embedding_head.' + k[3:].split('position_embedding_head.')[1]: torch.from_numpy(d[k]) for k in d.files
+          if k.startswith('pe.position')}
+    y = OG.posembed(torch.from_numpy(d['pe_x']), sd, 'pe', training=True)
+    np.testing.assert_allclose(y.numpy(), d['pe_y'], rtol=1e-5, atol=1e-6)
