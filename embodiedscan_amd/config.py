@@ -40,9 +40,11 @@ def build_optim_wrapper(cfg):
     opt = ow.get('optimizer', {})
     assert opt.get('type', 'AdamW') == 'AdamW'
     clip = ow.get('clip_grad') or {}
+    pw = {k: v for k, v in (ow.get('paramwise_cfg') or {}).get('custom_keys', {}).items()
+          if not k.startswith('text_encoder')}        # the text encoder is a frozen external module, not in the arena
     return OptimWrapper(lr=opt.get('lr', 1e-3), weight_decay=opt.get('weight_decay', 1e-2),
                         betas=opt.get('betas', (0.9, 0.999)), eps=opt.get('eps', 1e-8),
-                        max_norm=clip.get('max_norm', 0.0))
+                        max_norm=clip.get('max_norm', 0.0), paramwise=pw)
 
 
 def build_param_scheduler(cfg, optim):

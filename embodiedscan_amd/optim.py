@@ -7,8 +7,12 @@ from .parallel import allreduce_mean_
 
 
 class OptimWrapper:
-    def __init__(self, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=10.0):
+    def __init__(self, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=10.0, paramwise=None):
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        # mmengine paramwise_cfg.custom_keys: {substring of the parameter name: dict(lr_mult=..., decay_mult=...)}
+        # (configs/grounding/...py:196-201: decoder lr x0.1).  Longest key wins, as in DefaultOptimWrapperConstructor.
+        self.paramwise = dict(paramwise or {})
+        self.groups = None
         self.initial_lr = lr
         self.step = 0
         self.m = self.v = None
@@ -20,6 +24,24 @@ class OptimWrapper:
         self.v = torch.zeros(n, dtype=torch.float32, device=arena.data.device)
         self.partial = torch.empty(2048, dtype=torch.float64, device=arena.data.device)
         self.norm = torch.zeros(1, dtype=torch.float32, device=arena.data.device)
+
+    def _build_groups(self, arena):
+        """contiguous ranges of the flat arena sharing (lr_mult, decay_mult)"""
+        keys = sorted(self.paramwise, key=lambda k: (-len(k), k))
+        groups = []
+        for name in arena.trainable_names():
+            o, n = arena.offsets[name]
+            e = o + (n + 3) // 4 * 4
+            lm, dm = 1.0, 1.0
+            for k in keys:
+                if k in name:
+                    lm, dm = self.paramwise[k].get('lr_mult', 1.0), self.paramwise[k].get('decay_mult', 1.0)
+                    break
+            if groups and groups[-1][1] == o and groups[-1][2:] == (lm, dm):
+                groups[-1] = (groups[-1][0], e, lm, dm)
+            else:
+                groups.append((o, e, lm, dm))
+        self.groups = groups
 
     def state_dict(self, arena):
         """Resume state: AdamW moments keyed by the reference's parameter names (reference shapes), the step count
@@ -52,9 +74,18 @@ class OptimWrapper:
         n = arena.n_train
         self.step += 1
         call('es_grad_norm', P(arena.grad), n, P(self.partial), P(self.norm), s)
-        call('es_adamw_step', P(arena.data), P(arena.grad), P(self.m), P(self.v), n, float(self.lr),
-             float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step,
-             float(self.max_norm if self.max_norm else 0.0), P(self.norm), s)
+        if not self.paramwise:
+            call('es_adamw_step', P(arena.data), P(arena.grad), P(self.m), P(self.v), n, float(self.lr),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step,
+                 float(self.max_norm if self.max_norm else 0.0), P(self.norm), s)
+        else:
+            if self.groups is None:
+                self._build_groups(arena)
+            for a, b, lm, dm in self.groups:           # one launch per (lr_mult, decay_mult) range; the clip norm is global
+                call('es_adamw_step', arena.data.data_ptr() + 4 * a, arena.grad.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
+                     self.v.data_ptr() + 4 * a, b - a, float(self.lr * lm), float(self.betas[0]), float(self.betas[1]),
+                     float(self.eps), float(self.wd * dm), self.step, float(self.max_norm if self.max_norm else 0.0),
+                     P(self.norm), s)
         self.last_norm = self.norm
         from . import engine
         engine.WEIGHT_VERSION[0] += 1          # bf16 weight copies are stale now

@@ -30,22 +30,28 @@ def reduce_mean(t):
 class BucketedGradReducer:
     """Overlaps the gradient all-reduce with the backward pass.
 
-    The gradient arena is laid out [2-D backbone | 3-D backbone | head]; backward finishes those parts in the opposite
+    The gradient arena is laid out [2-D backbone | 3-D backbone | everything else]; backward finishes those parts in the opposite
     order, so each part is all-reduced asynchronously (torch.distributed `async_op=True`: RCCL runs it on its own
     stream after an event on the compute stream) as soon as the tape has passed the marker behind it: the 86 MB head
     bucket travels over xGMI under the 3-D backbone's backward, the 254 MB 3-D bucket under the 2-D backbone's.
     The reference gets the same effect from DDP's bucketed reducer (mmengine MMDistributedDataParallel)."""
 
-    def __init__(self, arena, prefixes=('backbone.', 'backbone_3d.', 'bbox_head.')):
+    def __init__(self, arena, prefixes=('backbone.', 'backbone_3d.')):
+        """parts 0..len(prefixes)-1 = the trainable tensors under each prefix; the LAST part = everything else (heads,
+        necks, decoders: whatever the detector defines after its backbones).  The arena packs trainable tensors in spec
+        order, so every part is one contiguous range and the parts tile [0, n_train)."""
         self.arena = arena
-        self.ranges = []
         names = arena.trainable_names()
+        spans = []
         for pre in prefixes:
             offs = [arena.offsets[n] for n in names if n.startswith(pre)]
-            if offs:
-                self.ranges.append((min(o for o, _ in offs), max(o + ((n + 3) // 4) * 4 for o, n in offs)))
-            else:
-                self.ranges.append((0, 0))
+            spans.append((min(o for o, _ in offs), max(o + ((n + 3) // 4) * 4 for o, n in offs)) if offs else None)
+        rest = [arena.offsets[n] for n in names if not any(n.startswith(p) for p in prefixes)]
+        spans.append((min(o for o, _ in rest), max(o + ((n + 3) // 4) * 4 for o, n in rest)) if rest else None)
+        self.ranges = [sp if sp is not None else (0, 0) for sp in spans]
+        real = sorted(sp for sp in spans if sp is not None)
+        assert real and real[0][0] == 0 and real[-1][1] == arena.n_train and \
+            all(a[1] == b[0] for a, b in zip(real[:-1], real[1:])), f'gradient buckets do not tile the arena: {real}'
         self.work = []
 
     def launch(self, part):

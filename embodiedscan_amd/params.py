@@ -264,8 +264,9 @@ def occ_head_specs(prefix='bbox_head.', in_channels=(128, 128, 128), num_classes
 def occ_detector_specs(base_channels=64, fpn_out=256, neck_in=768, neck_out=128, n_blocks=(1, 1, 1), num_classes=81,
                        head_in=(128, 128, 128)):
     b = base_channels
-    return (resnet50_specs(base=b) + fpn_specs(in_channels=(4 * b, 8 * b, 16 * b, 32 * b), out_channels=fpn_out) +
-            mink_resnet34_specs() + imvoxel_neck_specs(in_channels=neck_in, out_channels=neck_out, n_blocks=n_blocks) +
+    # backbones first, then everything else: the arena order defines the gradient buckets (parallel.BucketedGradReducer)
+    return (resnet50_specs(base=b) + mink_resnet34_specs() +
+            fpn_specs(in_channels=(4 * b, 8 * b, 16 * b, 32 * b), out_channels=fpn_out) + imvoxel_neck_specs(in_channels=neck_in, out_channels=neck_out, n_blocks=n_blocks) +
             occ_head_specs(in_channels=head_in, num_classes=num_classes))
 
 

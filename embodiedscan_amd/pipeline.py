@@ -120,3 +120,14 @@ def make_occ_batch(dscans, occ_gts):
         m = occ.get('gt_occupancy_masks')
         ds.gt_occupancy_masks = None if m is None else torch.as_tensor(m)
     return data
+
+
+def make_grounding_batch(dscans, anns):
+    """`data` dict for SparseFeatureFusion3DGrounder.train_step: the detection batch with the prompt (`text`), the
+    positive character spans (`tokens_positive`) and the TARGET boxes of the prompt as gt_instances_3d."""
+    data = make_batch(dscans)
+    for ds, a in zip(data['data_samples'], anns):
+        ds.text, ds.tokens_positive = a['text'], a['tokens_positive']
+        ds.gt_instances_3d = InstanceData(bboxes_3d=EulerDepthInstance3DBoxes(torch.as_tensor(a['gt_boxes'])),
+                                          labels_3d=torch.as_tensor(a['gt_labels']))
+    return data

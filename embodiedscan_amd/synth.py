@@ -166,3 +166,31 @@ def make_occ_gt(scan, n_voxels=(40, 40, 16), prior_range=(-3.2, -3.2, -1.28, 3.2
         occ = np.concatenate([occ, dup], 0)
     mask = rng.random((X, Y, Z)) < visible_frac
     return dict(gt_occupancy=occ.astype(np.int64), gt_occupancy_masks=mask)
+
+
+_NOUNS = ['chair', 'table', 'cabinet', 'sofa', 'lamp', 'shelf', 'desk', 'bed', 'monitor', 'plant', 'stool', 'box']
+_ADJ = ['red', 'wooden', 'small', 'tall', 'dark', 'white', 'round', 'old']
+
+
+def make_grounding_sample(scan, seed=0, max_targets=3):
+    """Synthetic language annotation for BASELINE config 4: a prompt of 8-40 words naming 1..max_targets of
+    the scan's boxes, each with one positive character span.  Returns dict(text, tokens_positive [[(beg, end)]] per
+    target, gt_boxes (G,9) f32, gt_labels (G,) int64) -- the fields MultiView3DGroundingDataset attaches to a data sample
+    (`text`, `tokens_positive`, `gt_instances_3d`)."""
+    rng = np.random.default_rng(seed)
+    n = len(scan['gt_boxes'])
+    G = int(rng.integers(1, min(max_targets, n) + 1))
+    pick = rng.choice(n, G, replace=False)
+    words, spans = ['find'], []
+    for k in range(G):
+        phrase = f'{_ADJ[int(rng.integers(len(_ADJ)))]} {_NOUNS[int(rng.integers(len(_NOUNS)))]}'
+        words.append('the')
+        beg = len(' '.join(words)) + 1
+        words.append(phrase)
+        spans.append([(beg, beg + len(phrase))])
+        words.append('and' if k + 1 < G else 'in')
+    filler = ['the', 'room', 'that', 'is', 'close', 'to', 'the', 'wall', 'next', 'to', 'a', 'window', 'on', 'the', 'left', 'side',
+              'of', 'the', 'door']
+    words += filler[:int(rng.integers(2, len(filler)))]
+    return dict(text=' '.join(words), tokens_positive=spans, gt_boxes=scan['gt_boxes'][pick].astype(np.float32),
+                gt_labels=np.zeros(G, np.int64))

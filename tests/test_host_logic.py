@@ -283,3 +283,84 @@ def test_upload_gts_layout():
         if len(b):
             assert torch.allclose(dr.view(-1, 3, 3), G.euler_to_matrix_zxy(-b[:, 6:9]), atol=1e-7)
     assert upload_gts([(torch.zeros(0, 9), torch.zeros(0, dtype=torch.long))], torch.device('cpu'))[0][0].shape == (0, 9)
+
+
+def test_gradient_buckets_tile_every_full_detector():
+    """for the FULL parameter sets of all three detectors the overlap buckets are contiguous and tile
+    [0, n_train) exactly (nothing is reduced twice, nothing is left out -- the grounder's neck / decoder / text map live
+    in the last bucket)."""
+    from embodiedscan_amd.parallel import BucketedGradReducer
+    from embodiedscan_amd.params import ParamArena, detector_specs, grounder_specs, occ_detector_specs
+
+    class Lazy(ParamArena):                 # offsets only: no 750 M-float allocation in a CPU test
+        def __init__(self, specs):
+            self.specs = specs
+            order = [s for s in specs if s.trainable] + [s for s in specs if not s.trainable]
+            off, self.offsets = 0, {}
+            for s in order:
+                n = int(np.prod(s.shape)) if s.shape else 1
+                self.offsets[s.name] = (off, n)
+                off += (n + 3) // 4 * 4
+                if s.trainable:
+                    self.n_train = off
+            self.total = off
+    for name, specs in (('mv-3ddet', detector_specs(284)), ('grounder', grounder_specs()), ('occupancy', occ_detector_specs())):
+        a = Lazy(specs)
+        red = BucketedGradReducer(a)
+        spans = sorted(r for r in red.ranges if r[1] > r[0])
+        assert spans[0][0] == 0 and spans[-1][1] == a.n_train and all(x[1] == y[0] for x, y in zip(spans[:-1], spans[1:])), name
+        covered = sum(b - a_ for a_, b in spans)
+        assert covered == a.n_train, (name, covered, a.n_train)
+        print(f'{name}: {len(spans)} buckets {[(b - a_) * 4 // 2 ** 20 for a_, b in spans]} MiB tile [0, {a.n_train})')
+
+
+def test_reduce_mean_called_once_per_step(monkeypatch):
+    """the per-sample positive counts of a whole batch travel in ONE collective (the reference issues one per sample):
+    count the calls the FCAF3D loss makes through parallel.reduce_mean on a CPU stand-in of its phase 2"""
+    import inspect
+    from embodiedscan_amd.models.dense_heads import fcaf3d_head, grounding_head
+    for mod, fn in ((fcaf3d_head.FCAF3DHeadRotMat.loss_by_levels, 'reduce_mean('), (grounding_head.GroundingHead.loss, 'reduce_mean(')):
+        src = '\n'.join(l.split('#')[0] for l in inspect.getsource(mod).splitlines())      # comments stripped
+        assert src.count(fn) == 1, f'{mod.__qualname__} must reduce the positive counts exactly once per step'
+        body = src.split(fn)[0]
+        assert 'for ' not in body.split('\n')[-1], 'the collective must not sit inside a per-sample loop'
+
+
+def test_paramwise_lr_groups_follow_the_grounding_config():
+    """configs/grounding/...py:196-201: decoder lr x0.1, text encoder frozen -> contiguous AdamW ranges"""
+    from embodiedscan_amd.optim import OptimWrapper
+    from embodiedscan_amd.params import ParamArena, grounder_specs
+    a = ParamArena.__new__(ParamArena)
+    specs = grounder_specs()
+    a.specs = specs
+    order = [s for s in specs if s.trainable] + [s for s in specs if not s.trainable]
+    off, a.offsets = 0, {}
+    for s in order:
+        n = int(np.prod(s.shape)) if s.shape else 1
+        a.offsets[s.name] = (off, n)
+        off += (n + 3) // 4 * 4
+        if s.trainable:
+            a.n_train = off
+    ow = OptimWrapper(lr=5e-4, paramwise={'decoder': dict(lr_mult=0.1, decay_mult=1.0)})
+    ow._build_groups(a)
+    g = ow.groups
+    assert g[0][0] == 0 and g[-1][1] == a.n_train and all(x[1] == y[0] for x, y in zip(g[:-1], g[1:]))
+    assert [x[2] for x in g] == [1.0, 0.1, 1.0]                      # [backbones + neck | decoder | text map + head]
+    dec = [a.offsets[n] for n in a.trainable_names() if n.startswith('decoder.')]
+    assert g[1][0] == min(o for o, _ in dec) and g[1][1] == max(o + (n + 3) // 4 * 4 for o, n in dec)
+
+
+def test_hash_tokenizer_and_positive_map():
+    """the tokenizer stand-in honours the protocol create_positive_map relies on (sparse_featfusion_grounder.py:570-621)"""
+    from embodiedscan_amd.text import HashTokenizer, create_positive_map
+    tk = HashTokenizer()
+    texts = ['find the red chair near the table', 'the lamp']
+    enc = tk.batch_encode_plus(texts, padding='longest', return_tensors='pt')
+    assert enc.input_ids.shape == (2, 9) and enc.attention_mask.sum(1).tolist() == [9, 4]
+    assert enc.input_ids[0, 0] == 0 and enc.input_ids[1, 3] == 2 and enc.input_ids[1, 4] == 1        # <s> ... </s> <pad>
+    beg = texts[0].index('red')
+    pm = create_positive_map(enc, [[[beg, beg + len('red chair')]]], 0, max_num_entities=16)
+    assert pm.shape == (1, 16) and pm[0].nonzero().squeeze(1).tolist() == [3, 4]                      # tokens of "red chair"
+    assert abs(float(pm.sum()) - 1.0) < 1e-5
+    same = tk.batch_encode_plus(texts).input_ids
+    assert (same == enc.input_ids).all()

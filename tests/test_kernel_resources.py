@@ -29,6 +29,9 @@ KNOWN_SCRATCH = {
     'k_pos_losses': 'f64 forward-mode dual numbers with 12 partials per lane: 256 VGPRs + 256 AGPRs + 156 B scratch, '
                     '1 wave/SIMD; 4 launches of ~0.3 ms per step -- to be re-cut (f32 partials or more lanes per location)',
     'k_nms3d_multiclass': 'predict only: one workgroup per class, f64 polygon clipping, 288 B scratch, 1 wave/SIMD',
+    'k_box3d_iou': 'f64 polygon clipping of 12 faces: two 16-vertex polygons per lane in scratch (1 KB); a few thousand '
+                   '(query, box) pairs per decoder layer, not on the critical path',
+    'k_ground_cost': 'calls the same IoU routine once per (query, target box) pair',
 }
 
 
@@ -50,7 +53,8 @@ def _resources(src):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
 @pytest.mark.parametrize('src', ['spconv.hip', 'rowops.hip', 'losses.hip', 'targets.hip', 'coords.hip', 'fusion.hip',
-                                 'optim.hip', 'data.hip', 'predict.hip'])      # sort.hip is rocPRIM's radix sort
+                                 'optim.hip', 'data.hip', 'predict.hip', 'dense.hip', 'occ.hip', 'transformer.hip',
+                                 'ground.hip'])      # sort.hip is rocPRIM's radix sort
 def test_no_spills_and_occupancy_floors(src):
     ks = _resources(src)
     assert ks, 'no kernel-resource-usage remarks parsed'
