@@ -104,10 +104,11 @@ def test_layernorm_contrastive_decode_topk_vs_torch(dev):
     dl = torch.randn(B, L, Tout, generator=g) * keep
     (ref * dl).sum().backward()
     vd, td, bd2, dld = v.to(dev), t.to(dev), bias.to(dev), dl.to(dev).contiguous()
+    tld, vld = tl.to(dev), vl.to(dev)                       # keep the device copies alive across the launches
     lo, rm = torch.empty(B, L, Tout, device=dev), torch.empty(B, L, device=dev)
-    call('es_contrastive_fwd', P(vd), B, L, P(td), T, C, P(tl.to(dev)), P(vl.to(dev)), P(bd2), P(lo), Tout, P(rm), st)
+    call('es_contrastive_fwd', P(vd), B, L, P(td), T, C, P(tld), P(vld), P(bd2), P(lo), Tout, P(rm), st)
     dvv, dtt, dbb = torch.empty_like(vd), torch.zeros_like(td), torch.zeros(1, device=dev)
-    call('es_contrastive_bwd', P(dld), Tout, P(vd), B, L, P(td), T, C, P(tl.to(dev)), P(dvv), 0, P(dtt), P(dbb), st)
+    call('es_contrastive_bwd', P(dld), Tout, P(vd), B, L, P(td), T, C, P(tld), P(dvv), 0, P(dtt), P(dbb), st)
     torch.cuda.synchronize()
     refm = ref.detach().masked_fill(~keep, float('-inf'))
     assert torch.equal(torch.isinf(lo.cpu()), torch.isinf(refm))
@@ -121,7 +122,8 @@ def test_layernorm_contrastive_decode_topk_vs_torch(dev):
     vals[0, 10] = vals[0, 400] = 7.0
     vlen = torch.tensor([500, 123, 77], dtype=torch.int32)
     idx = torch.empty(3, 64, dtype=torch.int32, device=dev)
-    call('es_topk_sorted', P(vals.to(dev)), 3, 500, P(vlen.to(dev)), 64, P(idx), st)
+    valsd, vlend = vals.to(dev), vlen.to(dev)
+    call('es_topk_sorted', P(valsd), 3, 500, P(vlend), 64, P(idx), st)
     for bb in range(3):
         want = torch.argsort(vals[bb, :int(vlen[bb])], descending=True, stable=True)[:64]
         assert torch.equal(idx[bb].cpu().long(), want)
@@ -133,8 +135,9 @@ def test_layernorm_contrastive_decode_topk_vs_torch(dev):
     gb = torch.randn(50, 9, generator=g)
     (refb * gb).sum().backward()
     box, dp = torch.empty(50, 9, device=dev), torch.empty(50, 9, device=dev)
-    call('es_ground_decode_fwd', P(pred.to(dev)), 9, P(pts.to(dev)), 50, P(box), st)
-    call('es_ground_decode_bwd', P(pred.to(dev)), 9, P(gb.to(dev)), 50, P(dp), 9, 0, st)
+    predd, ptsd, gbd = pred.to(dev), pts.to(dev), gb.to(dev)
+    call('es_ground_decode_fwd', P(predd), 9, P(ptsd), 50, P(box), st)
+    call('es_ground_decode_bwd', P(predd), 9, P(gbd), 50, P(dp), 9, 0, st)
     torch.cuda.synchronize()
     assert _rel(box, refb.detach()) < 1e-6 and _rel(dp, pt.grad) < 1e-6
 
@@ -152,7 +155,8 @@ def test_box3d_iou_vs_oracle(dev):
     a[1] = [0, 0, 0, 2, 2, 2, 0, 0, 0]; b[1] = [2, 0, 0, 2, 2, 2, 0, 0, 0]           # touching faces
     b[2] = [50, 50, 50, 1, 1, 1, 0, 0, 0]                   # far away
     out = torch.empty(40, 9, device=dev)
-    call('es_box3d_iou', P(torch.from_numpy(a).to(dev)), 40, P(torch.from_numpy(b).to(dev)), 9, P(out), torch.cuda.current_stream().cuda_stream)
+    ad, bd = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    call('es_box3d_iou', P(ad), 40, P(bd), 9, P(out), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     want = OG.overlaps(torch.from_numpy(a), torch.from_numpy(b))
     err = float((out.cpu() - want).abs().max())
@@ -317,7 +321,9 @@ def test_grounder_train_step_vs_oracle(dev, mode):
     assert all(np.isfinite(float(v)) for v in losses.values()) and torch.isfinite(det.arena.grad).all()
     if mode == 'f32':
         sum(ol.values()).backward()
-        rel = {k: _rel(v, osd[k].grad) for k, v in grads.items() if osd[k].grad is not None and float(osd[k].grad.norm()) > 1e-9}
+        # tensors whose true gradient is zero are skipped (norm < 1e-6): the last bias of cross_posembed shifts every key of a
+        # sample by the same vector, which softmax cancels exactly -- both sides hold rounding noise only
+        rel = {k: _rel(v, osd[k].grad) for k, v in grads.items() if osd[k].grad is not None and float(osd[k].grad.norm()) > 1e-6}
         worst = max(rel, key=rel.get)
         med = float(np.median(list(rel.values())))
         dec = [v for k, v in rel.items() if k.startswith(('decoder.', 'bbox_head.', 'text_feat_map.'))]
