@@ -33,7 +33,7 @@ def save_checkpoint(model, path, optim=None, meta=None, schedulers=None):
     return path
 
 
-def load_checkpoint(model, path, optim=None, strict=False, map_location='cpu', schedulers=None):
+def load_checkpoint(model, path, optim=None, strict=False, map_location='cpu', schedulers=None, tap_order=None):
     """Returns (missing, unexpected, meta).  Accepts a full mmengine checkpoint or a bare state dict; strips the
     'module.' prefix DistributedDataParallel adds.  After loading, frozen-BN folds and bf16 weight copies are refreshed
     through model.load_state_dict when `model` is a detector."""
@@ -44,7 +44,10 @@ def load_checkpoint(model, path, optim=None, strict=False, map_location='cpu', s
     dev = arena.data.device
     sd = {k: v.to(dev) for k, v in sd.items() if torch.is_tensor(v) and not k.endswith('.num_batches_tracked')}
     # a detector also refreshes its derived state (frozen-BN folds, bf16 weight copies); a bare arena just copies
-    missing, unexpected = model.load_state_dict(sd, strict=strict)
+    # tap_order: numbering of the sparse kernels' offsets in the file (ParamArena.tap_permutation); the released reference
+    # checkpoints were written by MinkowskiEngine, whose order cannot be verified offline
+    missing, unexpected = model.load_state_dict(sd, strict=strict, tap_order=tap_order) if tap_order is not None \
+        else model.load_state_dict(sd, strict=strict)
     okey = 'optimizer_flat' if isinstance(ckpt, dict) and 'optimizer_flat' in ckpt else 'optimizer'   # 'optimizer': round-1 files
     if optim is not None and isinstance(ckpt, dict) and okey in ckpt and 'exp_avg' in ckpt[okey]:
         od = ckpt[okey]

@@ -501,7 +501,10 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
 // MFMA utilisation.  Here the per-tap offsets are computed once per tap, the per-chunk work is add + load + cvt + store.
 // XH = true: X is a bf16 row matrix (the "shadow" copy made by es_cast_rows_bf16) -> half the gather bytes and no
 // conversion instructions; XH = false: f32 rows converted while staged.
-template <int BNT, bool XH>
+// PP = true: ping-pong LDS buffers -- chunk c is computed from buffer c&1 while chunk c+1 is written into the other one, so
+// the loop needs ONE workgroup barrier per 16-MFMA chunk instead of two and the LDS stores overlap the matrix
+// instructions of the current chunk (46 KB LDS per workgroup, still 3 workgroups per CU).
+template <int BNT, bool XH, bool PP>
 __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restrict__ Xv, int ldx,
                                                           const unsigned short* __restrict__ W,
                                                           const int* __restrict__ nbr, int n_out, int n_in, int K,
@@ -512,8 +515,13 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
                                                           const float* __restrict__ ep_res, int ep_ldr, int ep_act) {
   constexpr int NF = BNT / 16;
   constexpr int NB = BNT / 64;
-  __shared__ __attribute__((aligned(16))) unsigned short As[BM * HLD];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[BNT * HLD];
+  constexpr int NBUF = PP ? 2 : 1;
+  // PP tiles are unpadded (64-B rows) with an XOR swizzle of the four 16-B granules of a row by ((row >> 2) & 3): the 16
+  // rows a fragment read touches land in 16 distinct 16-B bank slots, and 2 x (8 + 8) KB + the map tile = 46 KB keeps
+  // three workgroups on a CU (the padded 80-B rows would cost 55 KB: two)
+  constexpr int LDP = PP ? HBK : HLD;
+  __shared__ __attribute__((aligned(16))) unsigned short As[NBUF * BM * LDP];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[NBUF * BNT * LDP];
   __shared__ int nbrS[BM * MAXK];
   __shared__ int taps[32];
   __shared__ int nTaps;
@@ -600,8 +608,9 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
     for (int h = 0; h < NB; ++h) R.b[h] = *(const uint4*)(W + it.b_off + h * 64 * Cin + c0);
     R.valid = it.valid;
   };
-  auto store_chunk = [&](const Regs& R) {
-    uint4* pa = (uint4*)&As[a_r * HLD + a_kk];
+  const int a_sw = PP ? ((a_r >> 2) & 3) : 0, b_sw = PP ? ((b_n >> 2) & 3) : 0;
+  auto store_chunk = [&](const Regs& R, int buf = 0) {
+    uint4* pa = (uint4*)&As[buf * BM * LDP + a_r * LDP + (PP ? 0 : a_kk)];
     uint4 v0, v1;
     if (XH) {                         // bit copies (a pointer cast here made the compiler keep R in scratch memory)
       v0 = make_uint4(__float_as_uint(R.a[0].x), __float_as_uint(R.a[0].y), __float_as_uint(R.a[0].z),
@@ -616,20 +625,29 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
                       pack_bf16(R.a[H + 1].z, R.a[H + 1].w));
     }
     if (!R.valid) v0 = v1 = make_uint4(0u, 0u, 0u, 0u);
-    pa[0] = v0;
-    pa[1] = v1;
+    if (PP) {
+      const int g0 = (t & 1) * 2;
+      pa[(g0 ^ a_sw)] = v0;
+      pa[((g0 + 1) ^ a_sw)] = v1;
 #pragma unroll
-    for (int h = 0; h < NB; ++h) *(uint4*)&Bs[(b_n + h * 64) * HLD + b_kk] = R.b[h];
+      for (int h = 0; h < NB; ++h) *(uint4*)&Bs[buf * BNT * LDP + (b_n + h * 64) * LDP + (((t & 3) ^ b_sw) * 8)] = R.b[h];
+    } else {
+      pa[0] = v0;
+      pa[1] = v1;
+#pragma unroll
+      for (int h = 0; h < NB; ++h) *(uint4*)&Bs[(b_n + h * 64) * HLD + b_kk] = R.b[h];
+    }
   };
   const int li = lane & 15, kq = lane >> 4;
-  const unsigned short* a_base = &As[(wv * 32 + li) * HLD + kq * 8];
-  const unsigned short* b_base = &Bs[li * HLD + kq * 8];
-  auto compute = [&]() {
+  const int f_sw = PP ? ((li >> 2) & 3) : 0;              // swizzle of the fragment rows (row = 16 * j + li)
+  const unsigned short* a_base = &As[(wv * 32 + li) * LDP + (kq ^ f_sw) * 8];
+  const unsigned short* b_base = &Bs[li * LDP + (kq ^ f_sw) * 8];
+  auto compute = [&](int buf = 0) {
     bf16x8_t a[2], b[NF];
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) a[mf] = *(const bf16x8_t*)(a_base + mf * 16 * HLD);
+    for (int mf = 0; mf < 2; ++mf) a[mf] = *(const bf16x8_t*)(a_base + buf * BM * LDP + mf * 16 * LDP);
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) b[nf] = *(const bf16x8_t*)(b_base + nf * 16 * HLD);
+    for (int nf = 0; nf < NF; ++nf) b[nf] = *(const bf16x8_t*)(b_base + buf * BNT * LDP + nf * 16 * LDP);
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
@@ -646,21 +664,43 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
     load_chunk(r0, i0);
     load_chunk(r1, i1);
     const int npairs = ((nT - tBeg) * nC + 1) >> 1;
-    for (int pr = 0; pr < npairs; ++pr) {
-      store_chunk(r0);
-      __syncthreads();
+    if (PP) {
+      store_chunk(r0, 0);             // chunk 0 -> buffer 0
       i0 = i1;
-      advance(i0);                    // chunk 2*pr + 2
-      load_chunk(r0, i0);
-      compute();
+      advance(i0);
+      load_chunk(r0, i0);             // chunk 2 in flight
       __syncthreads();
-      store_chunk(r1);                // (a zeroed A tile when the chunk count is odd)
-      __syncthreads();
-      i1 = i0;
-      advance(i1);                    // chunk 2*pr + 3
-      load_chunk(r1, i1);
-      compute();
-      __syncthreads();
+      for (int pr = 0; pr < npairs; ++pr) {
+        store_chunk(r1, 1);           // chunk 2*pr + 1 -> buffer 1 (its last readers passed the barrier below)
+        i1 = i0;
+        advance(i1);
+        load_chunk(r1, i1);           // chunk 2*pr + 3
+        compute(0);                   // chunk 2*pr
+        __syncthreads();
+        store_chunk(r0, 0);           // chunk 2*pr + 2 -> buffer 0 (stored past the end: never computed)
+        i0 = i1;
+        advance(i0);
+        load_chunk(r0, i0);           // chunk 2*pr + 4
+        compute(1);                   // chunk 2*pr + 1 (a zeroed A tile when the chunk count is odd)
+        __syncthreads();
+      }
+    } else {
+      for (int pr = 0; pr < npairs; ++pr) {
+        store_chunk(r0);
+        __syncthreads();
+        i0 = i1;
+        advance(i0);                    // chunk 2*pr + 2
+        load_chunk(r0, i0);
+        compute();
+        __syncthreads();
+        store_chunk(r1);                // (a zeroed A tile when the chunk count is odd)
+        __syncthreads();
+        i1 = i0;
+        advance(i1);                    // chunk 2*pr + 3
+        load_chunk(r1, i1);
+        compute();
+        __syncthreads();
+      }
     }
   }
   // epilogue: optional fused frozen-BN affine (+ residual) (+ ReLU) of the 2-D backbone
@@ -693,6 +733,13 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
         }
       }
     }
+}
+
+// run-time tuning switches (A/B measurements without a rebuild): key 1 = ping-pong LDS in the fast bf16 kernels
+static int ES_OPT_PINGPONG = 1;
+extern "C" int es_set_option(int key, int value) {
+  if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
+  return -2;
 }
 
 // 1 if (shape, alignment) is served by the fast kernels -- the host uses it to decide whether a bf16 shadow of X pays
@@ -732,17 +779,30 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
       g128.z = g64.z = split;
     }
   }
-  if (fast && x_is_bf16 && Cout % 128 == 0) {
-    hipLaunchKernelGGL((k_spconv_bf16_fast<128, true>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+  if (fast && ES_OPT_PINGPONG) {
+    if (x_is_bf16 && Cout % 128 == 0)
+      hipLaunchKernelGGL((k_spconv_bf16_fast<128, true, true>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+    else if (x_is_bf16)
+      hipLaunchKernelGGL((k_spconv_bf16_fast<64, true, true>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+    else if (Cout % 128 == 0)
+      hipLaunchKernelGGL((k_spconv_bf16_fast<128, false, true>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+    else
+      hipLaunchKernelGGL((k_spconv_bf16_fast<64, false, true>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+  } else if (fast && x_is_bf16 && Cout % 128 == 0) {
+    hipLaunchKernelGGL((k_spconv_bf16_fast<128, true, false>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
                        Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else if (fast && x_is_bf16) {
-    hipLaunchKernelGGL((k_spconv_bf16_fast<64, true>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+    hipLaunchKernelGGL((k_spconv_bf16_fast<64, true, false>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
                        Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else if (fast && Cout % 128 == 0) {
-    hipLaunchKernelGGL((k_spconv_bf16_fast<128, false>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+    hipLaunchKernelGGL((k_spconv_bf16_fast<128, false, false>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
                        Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else if (fast) {
-    hipLaunchKernelGGL((k_spconv_bf16_fast<64, false>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
+    hipLaunchKernelGGL((k_spconv_bf16_fast<64, false, false>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
                        Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   } else if (Cout >= 128) {
     hipLaunchKernelGGL(k_spconv_bf16<128>, dim3(es_cdiv(n_out, BM), es_cdiv(Cout, 128)), dim3(256), 0, st, X, ldx, Wh,

@@ -124,9 +124,9 @@ def _build_cast_table(dev):
 
 
 PRECISION = ['f32']       # 'f32': exact-f32 MFMA everywhere; 'bf16': bf16 MFMA (f32 accumulate) for conv fwd / dgrad
-SHADOW = [os.environ.get('ES_SHADOW', '0') == '1']   # gather from bf16 shadow copies of activations / gradients
-                          # (off by default: measured 'no gain' while the shadow kernels still spilled to scratch;
-                          # re-measured after the fix: see DESIGN.md section 5)
+SHADOW = [os.environ.get('ES_SHADOW', '1') == '1']   # gather from bf16 shadow copies of activations / gradients: half the
+                          # gather bytes, no conversion instructions in the staging loop; on by default since round 2 (the GPU
+                          # suite passes identically with it; ES_SHADOW=0 restores f32 gathers)
 WGRAD_BF16 = [True]       # in bf16 mode also run the weight-gradient GEMMs on the bf16 matrix cores
 WEIGHT_VERSION = [0]      # bumped by the optimiser: invalidates the bf16 weight copies
 

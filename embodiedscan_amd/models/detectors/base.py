@@ -51,8 +51,8 @@ class DetectorBase:
     def state_dict(self):
         return self.arena.state_dict()
 
-    def load_state_dict(self, sd, strict=False):
-        res = self.arena.load_state_dict(sd, strict=strict)
+    def load_state_dict(self, sd, strict=False, tap_order=None):
+        res = self.arena.load_state_dict(sd, strict=strict, tap_order=tap_order)
         E.WEIGHT_VERSION[0] += 1
         if self._bound:
             for m, _ in self._children():

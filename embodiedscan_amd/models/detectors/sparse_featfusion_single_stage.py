@@ -78,9 +78,9 @@ class SparseFeatureFusionSingleStage3DDetector:
     def state_dict(self):
         return self.arena.state_dict()
 
-    def load_state_dict(self, sd, strict=False):
+    def load_state_dict(self, sd, strict=False, tap_order=None):
         """reference-named state dict -> arena; returns (missing, unexpected) keys like torch.nn.Module does"""
-        res = self.arena.load_state_dict(sd, strict=strict)
+        res = self.arena.load_state_dict(sd, strict=strict, tap_order=tap_order)
         E.WEIGHT_VERSION[0] += 1                 # bf16 weight copies are stale
         if self._bound:
             self.backbone.refresh()              # re-fold the frozen BatchNorm2d statistics

@@ -481,12 +481,36 @@ class ParamArena:
                 self._absorb(s, flat[o:o + n].view(s.shape), sd)
         return flat
 
-    def load_state_dict(self, sd, strict=False):
+    @staticmethod
+    def tap_permutation(order, ksize):
+        """index list p with arena_kernel[k] = checkpoint_kernel[p[k]] for a sparse ksize^3 kernel.
+        The arena (and the oracle) number the taps with x fastest: k = (iz*ks + iy)*ks + ix (ParamArena docstring).
+        MinkowskiEngine's own region iterator order cannot be verified offline, so a checkpoint written by the
+        reference may use another numbering: 'x_fastest' (identity), 'z_fastest' (k' = (ix*ks + iy)*ks + iz), or an
+        explicit list of ks^3 indices."""
+        n = ksize ** 3
+        if order in (None, 'x_fastest'):
+            return list(range(n))
+        if order == 'z_fastest':
+            return [((k % ksize) * ksize + (k // ksize) % ksize) * ksize + k // (ksize * ksize) for k in range(n)]
+        order = list(order)
+        assert sorted(order) == list(range(n)), f'tap order must be a permutation of range({n})'
+        return order
+
+    def load_state_dict(self, sd, strict=False, tap_order=None):
         """Accepts a reference-named state dict (the inverse of state_dict()).  Returns (missing, unexpected)
-        reference keys; strict=True raises if either is non-empty (torch.nn.Module.load_state_dict semantics)."""
+        reference keys; strict=True raises if either is non-empty (torch.nn.Module.load_state_dict semantics).
+        tap_order: numbering of the 3^3 / 2^3 kernel offsets in the CHECKPOINT's sparse kernels ('x_fastest' = ours,
+        'z_fastest', or {27: [...], 8: [...]} explicit permutations); the kernels are re-ordered while loading."""
         used, missing = set(), []
+        perms = {}
+        if tap_order not in (None, 'x_fastest'):
+            for ks in (3, 2):
+                perms[ks ** 3] = self.tap_permutation(tap_order.get(ks ** 3) if isinstance(tap_order, dict) else tap_order, ks)
         for s in self.specs:
             got = self._absorb_all(s, self.p[s.name], sd)
+            if got and perms and s.ref is None and s.name.endswith('.kernel') and len(s.shape) == 3 and s.shape[0] in perms:
+                self.p[s.name].copy_(self.p[s.name][torch.tensor(perms[s.shape[0]], device=self.p[s.name].device)].clone())
             used.update(got)
             if not got:
                 missing.extend(self.ref_names(s))

@@ -75,6 +75,8 @@ int es_spconv_fwd_bf16(const void* X, int x_is_bf16, int ldx, const void* W_bf16
 /* X may also be a bf16 row matrix (x_is_bf16 = 1, ldx in bf16 elements): the shadow made by es_cast_rows_bf16; only for
  * shapes where es_spconv_bf16_is_fast() returns 1 */
 int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout);
+/* run-time tuning switch for A/B measurements: key 1 = ping-pong LDS buffers in the fast bf16 kernels (default 1) */
+int es_set_option(int key, int value);
 /* Y = act((X*W) * scale[c] + shift[c] (+ res)): conv2d + frozen BatchNorm2d (+ residual) (+ ReLU) of mmdet.ResNet in one
  * launch (any shape; the tap-split of under-filled launches is not applied to fused calls).  act: 0 none, 1 ReLU,
  * 3 "gate": Y = (res > 0) ? (X*W) * scale[c] : 0 -- the data-gradient conv of layer i+1 fused with the ReLU / frozen-BN

@@ -364,3 +364,45 @@ def test_hash_tokenizer_and_positive_map():
     assert abs(float(pm.sum()) - 1.0) < 1e-5
     same = tk.batch_encode_plus(texts).input_ids
     assert (same == enc.input_ids).all()
+
+
+def test_checkpoint_tap_order_permutation():
+    """N3 hardening: a checkpoint whose sparse kernels number the 27 (and 8) offsets differently is re-ordered while
+    loading; a synthetic z-fastest / arbitrarily permuted state dict reproduces the original arena bit for bit, and the
+    sparse convolution it drives is unchanged (checked on the CPU oracle)."""
+    import torch
+    from embodiedscan_amd.params import ParamArena, fcaf3d_head_specs, mink_resnet34_specs
+    from oracle import coords as C, sparse as S
+    specs = mink_resnet34_specs() + fcaf3d_head_specs(in_channels=(8, 16), out_channels=8, n_classes=5)
+    a = ParamArena(specs, seed=11)
+    sd = a.state_dict()
+    g = torch.Generator().manual_seed(0)
+    for order in ('z_fastest', {27: torch.randperm(27, generator=g).tolist(), 8: torch.randperm(8, generator=g).tolist()}):
+        p27, p8 = (ParamArena.tap_permutation(order.get(27) if isinstance(order, dict) else order, 3),
+                   ParamArena.tap_permutation(order.get(8) if isinstance(order, dict) else order, 2))
+        foreign = {}
+        for k, v in sd.items():                      # write the checkpoint in the foreign numbering: ck[p[k]] = ours[k]
+            if k.endswith('.kernel') and v.dim() == 3 and v.shape[0] in (27, 8):
+                p = p27 if v.shape[0] == 27 else p8
+                w = torch.empty_like(v)
+                w[torch.tensor(p)] = v
+                foreign[k] = w
+            else:
+                foreign[k] = v
+        b = ParamArena(specs, seed=99)
+        missing, unexpected = b.load_state_dict(foreign, tap_order=order)
+        assert not missing and not unexpected and torch.equal(a.data, b.data)
+        c = ParamArena(specs, seed=99)
+        c.load_state_dict(foreign)                   # without the hook the taps are silently permuted
+        assert not torch.equal(a.data, c.data)
+    assert ParamArena.tap_permutation('z_fastest', 3)[1] == 9 and ParamArena.tap_permutation(None, 2) == list(range(8))
+    # the semantic claim behind the hook: permuting taps AND offsets together leaves the convolution unchanged
+    pts = np.random.default_rng(0).uniform(-1, 1, (300, 3)).astype(np.float32)
+    co, _ = C.voxelize([pts], 0.1)
+    x = torch.randn(co.shape[0], 4, generator=g)
+    w = torch.randn(27, 4, 6, generator=g)
+    y = S.conv(S.SpT(co, x, 1, 1, {}), w, 3).feats
+    nbr = C.kernel_map(co, co, 3, 1)
+    perm = ParamArena.tap_permutation('z_fastest', 3)
+    y2 = S.gather_conv(x, nbr[:, perm], w[torch.tensor(perm)])
+    assert torch.allclose(y, y2, atol=1e-6)
