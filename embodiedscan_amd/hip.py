@@ -51,6 +51,10 @@ for _name, (_ret, _at, _an) in PROTOS.items():
     _fn[_name] = _f
 
 
+if os.environ.get('ES_PINGPONG') is not None:          # A/B switch of the ping-pong LDS conv kernels (default: on)
+    _fn['es_set_option'](1, int(os.environ['ES_PINGPONG']))
+
+
 class HipError(RuntimeError):
     pass
 

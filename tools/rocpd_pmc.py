@@ -3,7 +3,7 @@ import sqlite3
 import sys
 
 
-def main(db_path, out_path=None, top=14):
+def main(db_path, out_path=None, top=60):
     db = sqlite3.connect(db_path)
     rows = db.execute('select kernel_name, counter_name, sum(value), count(*), sum(duration) from counters_collection '
                       'group by kernel_name, counter_name').fetchall()
@@ -16,7 +16,7 @@ def main(db_path, out_path=None, top=14):
     lines = [f'# PMC sums per kernel from {db_path}', 'kernel | calls | dur_ms | ' + ' | '.join(names)]
     for kn in order:
         e = per[kn]
-        lines.append(f"{kn[:48]} | {e['_calls']} | {e['_dur_ms']:.3f} | " + ' | '.join(f'{e.get(c, 0):.4g}' for c in names))
+        lines.append(f"{kn[:64]} | {e['_calls']} | {e['_dur_ms']:.3f} | " + ' | '.join(f'{e.get(c, 0):.4g}' for c in names))
     txt = '\n'.join(lines)
     if out_path:
         open(out_path, 'w').write(txt + '\n')
