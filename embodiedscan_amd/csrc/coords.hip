@@ -404,7 +404,7 @@ __global__ void k_compact_keys(const int64_t* __restrict__ keys, int n, const in
 extern "C" int es_compact_mask(const int64_t* keys, int n, const int* mask, int* scratch, int64_t* out_keys,
                                int* out_src, int* count_host, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  *count_host = 0;
+  if (count_host) *count_host = 0;
   if (n <= 0) return 0;
   int* pos = scratch;
   int* bsum = pos + n;
@@ -413,8 +413,10 @@ extern "C" int es_compact_mask(const int64_t* keys, int n, const int* mask, int*
   if (rc) return rc;
   hipLaunchKernelGGL(k_compact_keys, dim3(es_cdiv(n, 256)), dim3(256), 0, st, keys, n, mask, pos, out_keys, out_src);
   ES_CHECK_LAUNCH();
-  ES_TRY(hipMemcpyAsync(count_host, total, 4, hipMemcpyDeviceToHost, st));
-  ES_TRY(hipStreamSynchronize(st));
+  if (count_host) {                   // NULL: the caller knows the count (top-k pruning keeps min(n_b, k) rows per sample)
+    ES_TRY(hipMemcpyAsync(count_host, total, 4, hipMemcpyDeviceToHost, st));
+    ES_TRY(hipStreamSynchronize(st));
+  }
   return 0;
 }
 

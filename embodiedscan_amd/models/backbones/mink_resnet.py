@@ -38,6 +38,20 @@ class MinkResNet:
             self.blocks.append(layer)
         return self
 
+    def prefetch_coords(self, cs):
+        """every strided coordinate set of the forward pass (each costs one row-count read-back) ahead of the feature
+        kernels; returns the sets of the output levels.  The results are cached on the sets, forward() re-uses them."""
+        cur = cs.strided(2)
+        cur.offsets()                      # per-sample segments of the instance norm behind conv1
+        if self.pool:
+            cur = cur.strided(2)
+        outs = []
+        for _ in self.blocks:
+            cur = cur.strided(2)
+            cur.offsets()
+            outs.append(cur)
+        return outs
+
     def forward(self, x):
         tr = self.training
         cs = x.cs

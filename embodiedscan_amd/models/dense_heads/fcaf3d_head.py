@@ -170,8 +170,25 @@ class FCAF3DHeadRotMat:
         call('es_interp_scores', P(score), P(idx), P(w), x.cs.n, P(s), _stream())
         mask = torch.empty(x.cs.n, dtype=torch.int32, device=x.cs.device)
         call('es_topk_mask', P(s), iarr(off), x.cs.n_batch, int(thr), P(mask), _stream())
-        new_set, src = sparse.compact(x.cs, mask)
+        kept = [0]                                  # top-k keeps min(n_b, thr) rows of sample b: no row-count read-back
+        for b in range(x.cs.n_batch):
+            kept.append(kept[-1] + min(off[b + 1] - off[b], thr))
+        new_set, src = sparse.compact(x.cs, mask, offsets=kept)
         return SparseTensor(new_set, E.gather_rows(x.F, src))
+
+    def prefetch_coords(self, level_sets):
+        """Coordinate work of the top-down pass that does not depend on features -- generative children, unions and their
+        per-sample offsets (each a small device->host read-back) -- done BEFORE the feature kernels are queued, while the
+        image branch keeps the GPU busy.  The forward pass then finds everything cached and issues without host stalls.
+        Stops at the first level whose pruning is live (its output set depends on scores)."""
+        x = level_sets[-1]
+        thr = self.pts_prune_threshold
+        for i in range(len(level_sets) - 2, -1, -1):
+            u, _, _ = sparse.union(level_sets[i], x.children())
+            off = u.offsets()
+            if any(off[b + 1] - off[b] > thr for b in range(u.n_batch)):
+                break
+            x = u
 
     def _levels(self, inputs):
         """Runs the sparse FPN + head.  Returns per level (fine->coarse) a dict with the

@@ -4,6 +4,7 @@ Same registry name, constructor arguments, `forward(inputs, data_samples, mode)`
 embodiedscan/models/detectors/sparse_featfusion_single_stage.py:28-330; `train_step` follows mmengine's
 BaseModel.train_step (preprocess -> forward(mode='loss') -> parse_losses -> optimiser update).
 """
+import os
 import torch
 from ... import hip
 from ... import engine as E
@@ -123,6 +124,14 @@ class SparseFeatureFusionSingleStage3DDetector:
         allp = torch.cat([p[:, :3] for p in pts]) if len(pts) > 1 else pts[0][:, :3].contiguous()
         feats = torch.empty((cs.n, 3), dtype=torch.float32, device=allp.device)
         call('es_row_move', P(feats), 3, P(allp), allp.stride(0), P(src), cs.n, 3, 0, _stream())
+        # all data-dependent row counts of the point branch (strided sets, unions of the head's top-down pass) are read back
+        # here, under the image branch's kernels; the 3-D backbone and the head are then queued without host stalls
+        if os.environ.get('ES_PREFETCH_COORDS', '1') != '0':
+            lv_sets = self.backbone_3d.prefetch_coords(cs)
+            for m in (getattr(self, 'bbox_head', None), getattr(self, 'neck_3d', None)):
+                if m is not None and hasattr(m, 'prefetch_coords'):
+                    m.prefetch_coords(lv_sets)
+                    break
         E.mark('A4 voxelise')
         x = self.backbone_3d(SparseTensor(cs, E.Var(feats, rg=False)))
         E.mark('A5+A6 3-D backbone fwd + maps')

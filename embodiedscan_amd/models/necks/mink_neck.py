@@ -45,8 +45,23 @@ class MinkNeck:
         call('es_interp_scores', P(score), P(idx), P(w), x.cs.n, P(s), hip.stream())
         mask = torch.empty(x.cs.n, dtype=torch.int32, device=x.cs.device)
         call('es_topk_mask', P(s), iarr(off), x.cs.n_batch, int(thr), P(mask), hip.stream())
-        new_set, src = sparse.compact(x.cs, mask)
+        kept = [0]                                  # top-k keeps min(n_b, thr) rows of sample b: no row-count read-back
+        for b in range(x.cs.n_batch):
+            kept.append(kept[-1] + min(off[b + 1] - off[b], thr))
+        new_set, src = sparse.compact(x.cs, mask, offsets=kept)
         return SparseTensor(new_set, E.gather_rows(x.F, src))
+
+    def prefetch_coords(self, level_sets):
+        """feature-independent coordinate work of the top-down pass ahead of the feature kernels (see
+        FCAF3DHeadRotMat.prefetch_coords); stops at the first level whose pruning is live"""
+        x = level_sets[-1]
+        thr = self.pts_prune_threshold
+        for i in range(len(level_sets) - 2, -1, -1):
+            u, _, _ = sparse.union(level_sets[i], x.children())
+            off = u.offsets()
+            if any(off[b + 1] - off[b] > thr for b in range(u.n_batch)):
+                break
+            x = u
 
     def levels(self, inputs):
         """-> per level i (input order: fine .. coarse) dict(cs, out Var (n, out_channels), cls (n, num_classes))"""

@@ -167,7 +167,15 @@ def morton_sorted(cs, src):
 
 
 def union(a, b):
-    """coordinate union for sparse a + b.  Returns (CoordSet, pos_a, pos_b) (int32 rows)."""
+    """coordinate union for sparse a + b.  Returns (CoordSet, pos_a, pos_b) (int32 rows).  Cached on `a` per partner
+    set (like the kernel maps), so a coordinate prefetch pass can pay the row-count read-back early."""
+    key = ('union', id(b))
+    if key not in a.cache:
+        a.cache[key] = _union(a, b) + (b,)         # keep b alive: id() must stay unique
+    return a.cache[key][:3]
+
+
+def _union(a, b):
     dev = a.device
     tk, tv, cap = a.table()
     scratch = torch.empty(3 * b.n + b.n // 2048 + 8, dtype=torch.int32, device=dev)
@@ -181,12 +189,20 @@ def union(a, b):
     return CoordSet(out_keys[:m], m, a.ts, a.n_batch), pos_a[:a.n], pos_b[:b.n]
 
 
-def compact(cs, mask):
-    """rows of `cs` where mask (int32 0/1) is set.  Returns (CoordSet, src rows)."""
+def compact(cs, mask, offsets=None):
+    """rows of `cs` where mask (int32 0/1) is set.  Returns (CoordSet, src rows).
+    offsets: host list of the RESULT's per-sample row offsets when the caller knows them (top-k pruning keeps
+    min(n_b, k) rows of sample b): the launch then stays stream-ordered, no row-count read-back."""
     dev = cs.device
     scratch = torch.empty(cs.n + cs.n // 2048 + 8, dtype=torch.int32, device=dev)
     out_keys = torch.empty(max(cs.n, 1), dtype=torch.int64, device=dev)
     out_src = torch.empty(max(cs.n, 1), dtype=torch.int32, device=dev)
+    if offsets is not None:
+        call('es_compact_mask', P(cs.keys), cs.n, P(mask), P(scratch), P(out_keys), P(out_src), 0, _stream())
+        m = int(offsets[-1])
+        out = CoordSet(out_keys[:m], m, cs.ts, cs.n_batch)
+        out._off_host = [int(v) for v in offsets]
+        return out, out_src[:m]
     cnt = ctypes.c_int(0)
     call('es_compact_mask', P(cs.keys), cs.n, P(mask), P(scratch), P(out_keys), P(out_src), ctypes.byref(cnt),
          _stream())

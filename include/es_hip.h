@@ -58,7 +58,8 @@ int es_union_plan(const int64_t* keys_a, int na, const int64_t* tkeys_a, const i
 /* features_at_coordinates corner indices + trilinear weights.  fcaf3d_head.py:1102-1103 */
 int es_interp_map(const int64_t* query_keys, int n, const int64_t* tkeys, const int* tvals, int cap, int table_ts,
                   int* idx /* (n,8) */, float* w /* (n,8) */, void* stream);
-/* MinkowskiPruning row selection.  fcaf3d_head.py:1113.  scratch: n + n/2048 + 4 ints.  Synchronises. */
+/* MinkowskiPruning row selection.  fcaf3d_head.py:1113.  scratch: n + n/2048 + 4 ints.  Synchronises to report the row count
+ * unless count_host == NULL (callers that know it, e.g. top-k pruning: sum_b min(n_b, k), stay stream-ordered). */
 int es_compact_mask(const int64_t* keys, int n, const int* mask, int* scratch, int64_t* out_keys, int* out_src,
                     int* count_host, void* stream);
 
