@@ -23,7 +23,8 @@ sys.path.insert(0, ROOT)
 
 K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
-ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_affine', 'es_spconv_wgrad', 'es_spconv_wgrad_bf16'}
+ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_wgrad',
+          'es_spconv_wgrad_bf16'}
 SCATTER = {'es_voxel_keys', 'es_unique_first', 'es_morton_sort', 'es_stride_keys', 'es_kernel_map', 'es_inverse_map',
            'es_union_plan', 'es_point_sample_fwd', 'es_point_sample_bwd', 'es_depth_to_points'}
 
@@ -273,13 +274,13 @@ def resolve_pairs(hip, records):
     for name, e0, e1, a in records:
         key = None
         if name in ENGINE:
-            key = a[4] if (name.startswith('es_spconv_wgrad') or name == 'es_spconv_fwd_bf16') else a[3]
+            key = a[4] if (name.startswith('es_spconv_wgrad') or name in ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws')) else a[3]
         out.append((name, e0, e1, a, hip.PAIRS.get(key)))
     return out
 
 
 def engine_args(name, a):
-    if name == 'es_spconv_fwd_bf16':
+    if name in ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws'):
         return a[4], a[5], a[6], a[7], a[8], a[9]
     if not name.startswith('es_spconv_wgrad'):
         return a[3], a[4], a[5], a[6], a[7], a[8]

@@ -205,6 +205,81 @@ __global__ void k_lsa(const double* __restrict__ cost, int Gmax, int Q, const in
   for (int r = 0; r < nr; ++r) if (col4row[r] >= 0) q2g[(size_t)b * Q + col4row[r]] = r;
 }
 
+// The same algorithm with one WAVE per sample and the solver state in LDS: the column scan of every augmenting step runs
+// 64-wide and the argmin is a shuffle reduction that reproduces the sequential tie rule (first column of the minimum
+// value, replaced by the LAST unassigned column among the ties).  The single-thread version above spends ~0.5 ms per
+// decoder layer in dependent global loads; this one a few tens of microseconds.  Q <= LSA_MAXQ.
+#define LSA_MAXQ 1024
+__global__ __launch_bounds__(64) void k_lsa_wave(const double* __restrict__ cost, int Gmax, int Q, const int* __restrict__ gt_off,
+                                                 int* __restrict__ q2g) {
+  __shared__ double u[LSA_MAXQ], v[LSA_MAXQ], sp[LSA_MAXQ];
+  __shared__ int path[LSA_MAXQ], col4row[LSA_MAXQ], row4col[LSA_MAXQ], rem[LSA_MAXQ];
+  __shared__ unsigned char SR[LSA_MAXQ], SC[LSA_MAXQ];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nr = gt_off[b + 1] - gt_off[b], nc = Q;
+  const double* C = cost + (size_t)b * Gmax * Q;
+  for (int j = lane; j < nc; j += 64) { v[j] = 0.0; row4col[j] = -1; }
+  for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+  __syncthreads();
+  for (int cur = 0; cur < nr; ++cur) {
+    for (int it = lane; it < nc; it += 64) { rem[it] = nc - it - 1; SC[it] = 0; sp[it] = INFINITY; }
+    for (int it = lane; it < nr; it += 64) SR[it] = 0;
+    __syncthreads();
+    double minVal = 0.0;
+    int i = cur, num_remaining = nc, sink = -1;
+    while (sink == -1) {
+      if (lane == 0) SR[i] = 1;
+      const double ui = u[i];
+      double lowest = INFINITY;
+      int first = 0x7fffffff, lastU = -1;
+      for (int it = lane; it < num_remaining; it += 64) {
+        int j = rem[it];
+        double r = minVal + C[(size_t)i * Q + j] - ui - v[j];
+        if (r < sp[j]) { path[j] = i; sp[j] = r; }
+        double val = sp[j];
+        bool un = row4col[j] == -1;
+        if (val < lowest) { lowest = val; first = it; lastU = un ? it : -1; }
+        else if (val == lowest && un) lastU = it;           // `it` grows within a lane: a later tie
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        double ol = __shfl_xor(lowest, o, 64);
+        int of = __shfl_xor(first, o, 64), ou = __shfl_xor(lastU, o, 64);
+        if (ol < lowest) { lowest = ol; first = of; lastU = ou; }
+        else if (ol == lowest) { first = min(first, of); lastU = max(lastU, ou); }
+      }
+      minVal = lowest;
+      if (!(minVal < INFINITY)) { sink = -2; break; }
+      const int index = lastU >= 0 ? lastU : first;
+      const int j = rem[index];
+      const int r4 = row4col[j];
+      __syncthreads();                                      // every lane has read rem[] / row4col[] of this step
+      if (r4 == -1) sink = j; else i = r4;
+      if (lane == 0) { SC[j] = 1; rem[index] = rem[num_remaining - 1]; }
+      --num_remaining;
+      __syncthreads();
+    }
+    if (sink < 0) break;
+    if (lane == 0) u[cur] += minVal;
+    for (int r = lane; r < nr; r += 64) if (SR[r] && r != cur) u[r] += minVal - sp[col4row[r]];
+    for (int j = lane; j < nc; j += 64) if (SC[j]) v[j] -= minVal - sp[j];
+    __syncthreads();
+    if (lane == 0) {
+      int j = sink;
+      while (true) {
+        int r = path[j];
+        row4col[j] = r;
+        int t = col4row[r]; col4row[r] = j; j = t;
+        if (r == cur) break;
+      }
+    }
+    __syncthreads();
+  }
+  for (int j = lane; j < nc; j += 64) q2g[(size_t)b * Q + j] = -1;
+  __syncthreads();
+  for (int r = lane; r < nr; r += 64) if (col4row[r] >= 0) q2g[(size_t)b * Q + col4row[r]] = r;
+}
+
 extern "C" int es_ground_match(const float* logits, int Tout, const float* boxes, int B, int Q, const float* gt_boxes,
                                const unsigned char* pos_map, const int* gt_off_dev, int Gmax, const int* tlen_dev, int T,
                                float w_cls, float w_l1, float w_iou, double* cost, double* work, int* iwork, int* q2g,
@@ -215,7 +290,10 @@ extern "C" int es_ground_match(const float* logits, int Tout, const float* boxes
   if (Gmax > 0)
     hipLaunchKernelGGL(k_ground_cost, dim3(es_cdiv((long long)Gmax * Q, 64), B), dim3(64), 0, st, logits, Tout, boxes, Q, gt_boxes,
                        pos_map, gt_off_dev, tlen_dev, T, w_cls, w_l1, w_iou, 0.25f, 2.0f, 1e-12f, cost, Gmax);
-  hipLaunchKernelGGL(k_lsa, dim3(es_cdiv(B, 64)), dim3(64), 0, st, cost, Gmax, Q, gt_off_dev, work, iwork, q2g, B);
+  if (Q <= LSA_MAXQ)
+    hipLaunchKernelGGL(k_lsa_wave, dim3(B), dim3(64), 0, st, cost, Gmax, Q, gt_off_dev, q2g);
+  else
+    hipLaunchKernelGGL(k_lsa, dim3(es_cdiv(B, 64)), dim3(64), 0, st, cost, Gmax, Q, gt_off_dev, work, iwork, q2g, B);
   ES_CHECK_LAUNCH();
   return 0;
 }

@@ -718,7 +718,10 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
           float* p = Y + (size_t)row * ldy + col;
           if (gridDim.z > 1) {
             float v = acc[mf][nf][r] + (bz == 0 ? bv : 0.f);
-            if (nT > tBeg || bz == 0) atomicAdd(p, v);
+            if (ep_act == 7)                                // deterministic tap split: partial sums go to the workspace
+              const_cast<float*>(ep_res)[((size_t)bz * n_out + row) * Cout + col] = v;
+            else if (nT > tBeg || bz == 0)
+              atomicAdd(p, v);
           } else {
             float v = acc[mf][nf][r] + bv;
             if (ep_scale) v = v * sc + sh;
@@ -748,10 +751,35 @@ extern "C" int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cou
          ((long long)K * Cout * Cin < (1ll << 31));
 }
 
+// tap split of under-filled launches: how many workgroups share one output tile's tap list
+static int split_factor(int n_out, int K, int Cout) {
+  int wgs = (Cout % 128 == 0) ? es_cdiv(n_out, BM) * (Cout / 128) : es_cdiv(n_out, BM) * (Cout / 64);
+  int split = 1;
+  while (split < 8 && wgs * split < 192 && split * 3 <= K) split *= 2;
+  return split;
+}
+// Y (+)= sum over the split slices of the partial sums, in slice order (bit-reproducible, unlike f32 atomics)
+__global__ void k_sum_splits(const float* __restrict__ ws, int split, int n_out, int Cout, float* __restrict__ Y, int ldy,
+                             int accumulate) {
+  size_t tot = (size_t)n_out * Cout;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    float s = ws[e];
+    for (int z = 1; z < split; ++z) s += ws[(size_t)z * tot + e];
+    size_t row = e / Cout;
+    float* p = Y + row * ldy + (e - row * Cout);
+    *p = accumulate ? (*p + s) : s;
+  }
+}
+extern "C" size_t es_spconv_split_workspace_floats(int n_out, int K, int Cin, int Cout) {
+  if (K <= 1 || Cin % HBK != 0 || Cout % 64 != 0 || n_out <= 0) return 0;
+  int split = split_factor(n_out, K, Cout);
+  return split > 1 ? (size_t)split * n_out * Cout : 0;
+}
+
 static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out,
                                 int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy,
                                 int accumulate, const float* ep_scale, const float* ep_shift, const float* ep_res,
-                                int ep_ldr, int ep_act, void* stream) {
+                                int ep_ldr, int ep_act, void* stream, float* ws = nullptr, size_t ws_floats = 0) {
   if (n_out <= 0 || Cout <= 0) return 0;
   if (K > MAXK) return -2;
   hipStream_t st = (hipStream_t)stream;
@@ -762,12 +790,16 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
               ((long long)K * Cout * Cin < (1ll << 31)) && (Cout % 64 == 0);
   if (x_is_bf16 && !fast) return -7;            // bf16 input rows are only supported by the fast kernels
   dim3 g128(es_cdiv(n_out, BM), Cout / 128), g64(es_cdiv(n_out, BM), Cout / 64);
+  int det_split = 0;
   if (fast && !(ep_scale || ep_res || ep_act) && K > 1) {
     // too few workgroups for 256 CUs: split the tap list over gridDim.z (partial sums via f32 atomics into zeroed Y)
-    int wgs = (Cout % 128 == 0) ? g128.x * g128.y : g64.x * g64.y;
-    int split = 1;
-    while (split < 8 && wgs * split < 192 && split * 3 <= K) split *= 2;
-    if (split > 1) {
+    int split = split_factor(n_out, K, Cout);
+    if (split > 1 && ws != nullptr && ws_floats >= (size_t)split * n_out * Cout) {
+      det_split = split;                   // deterministic: partial sums to the workspace, fixed-order reduction below
+      ep_res = ws;
+      ep_act = 7;
+      g128.z = g64.z = split;
+    } else if (split > 1) {
       if (!accumulate) {
         if (ldy == Cout) {
           hipError_t e = hipMemsetAsync(Y, 0, (size_t)n_out * Cout * 4, st);
@@ -812,7 +844,20 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
                        nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
   }
   ES_CHECK_LAUNCH();
+  if (det_split) {
+    int g = es_cdiv((long long)n_out * Cout, 256);
+    hipLaunchKernelGGL(k_sum_splits, dim3(g > 4096 ? 4096 : g), dim3(256), 0, st, ws, det_split, n_out, Cout, Y, ldy, accumulate);
+    ES_CHECK_LAUNCH();
+  }
   return 0;
+}
+// the same with a caller-provided workspace (es_spconv_split_workspace_floats): under-filled launches that split their tap
+// list then reduce the partial sums in a fixed order instead of f32 atomics -> bit-reproducible forward / dgrad
+extern "C" int es_spconv_fwd_bf16_ws(const void* Xv, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out,
+                                     int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy,
+                                     int accumulate, float* ws, size_t ws_floats, void* stream) {
+  return spconv_fwd_bf16_impl(Xv, x_is_bf16, ldx, W_bf16, nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate,
+                              nullptr, nullptr, nullptr, 0, 0, stream, ws, ws_floats);
 }
 extern "C" int es_spconv_fwd_bf16(const void* Xv, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out,
                                   int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy,

@@ -250,6 +250,33 @@ def _cast_rows(t):
     return h
 
 
+DET_SPLIT = [os.environ.get('ES_DET_SPLIT', '1') != '0']   # deterministic tap split (workspace + fixed-order reduction)
+
+
+def _split_ws(n_out, K, cin, cout, like):
+    """workspace for the deterministic tap split of an under-filled bf16 conv launch (mirrors split_factor() in
+    csrc/spconv.hip; the C side re-checks the size): (tensor or None, floats)"""
+    if not DET_SPLIT[0] or K <= 1 or cin % 32 or cout % 64 or n_out <= 0:
+        return None, 0
+    wgs = -(-n_out // 128) * (cout // 128 if cout % 128 == 0 else cout // 64)
+    split = 1
+    while split < 8 and wgs * split < 192 and split * 3 <= K:
+        split *= 2
+    if split == 1:
+        return None, 0
+    nf = split * n_out * cout
+    return torch.empty(nf, dtype=torch.float32, device=like.device), nf
+
+
+def _fwd_bf16(X, x_is_bf16, ldx, Wp, nbr, n_out, n_in, K, cin, cout, bias_p, Y, ldy, acc, like):
+    """es_spconv_fwd_bf16 with the deterministic-split workspace when the launch would split its tap list"""
+    ws, nf = _split_ws(n_out, K, cin, cout, like)
+    if ws is not None:
+        call('es_spconv_fwd_bf16_ws', X, x_is_bf16, ldx, Wp, nbr, n_out, n_in, K, cin, cout, bias_p, Y, ldy, acc, P(ws), nf, _stream())
+    else:
+        call('es_spconv_fwd_bf16', X, x_is_bf16, ldx, Wp, nbr, n_out, n_in, K, cin, cout, bias_p, Y, ldy, acc, _stream())
+
+
 def _use_shadow(n_rows, C, K, cin, cout):
     """bf16 shadow pays when the rows are gathered several times (K > 1) and the fast kernel takes the shape"""
     return K > 1 and hip.raw('es_spconv_bf16_is_fast')(n_rows, C, K, cin, cout) == 1
@@ -285,11 +312,11 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
     y = Var(empty((n_out, cout), x.d))
     bf = PRECISION[0] == 'bf16' and cin >= 16
     if bf and SHADOW[0] and _ld(x.d) == cin and _use_shadow(n_in, cin, K, cin, cout):
-        call('es_spconv_fwd_bf16', P(x.shadow()), 1, cin, P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout,
-             P(bias.d) if bias else 0, P(y.d), cout, 0, _stream())
+        _fwd_bf16(P(x.shadow()), 1, cin, P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0, P(y.d),
+                  cout, 0, x.d)
     elif bf:
-        call('es_spconv_fwd_bf16', P(x.d), 0, _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout,
-             P(bias.d) if bias else 0, P(y.d), cout, 0, _stream())
+        _fwd_bf16(P(x.d), 0, _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0, P(y.d),
+                  cout, 0, x.d)
     else:
         call('es_spconv_fwd', P(x.d), _ld(x.d), P(w.d), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0,
              P(y.d), cout, 0, 0, _stream())
@@ -341,11 +368,9 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     elif need_dx and x.rg:
         g, acc = _grad_target(x, x.d)
         if bf and cout >= 16 and SHADOW[0] and _ld(gy) == cout and _use_shadow(n_out, cout, K, cout, cin):
-            call('es_spconv_fwd_bf16', P(y.grad_shadow()), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout,
-                 cin, 0, P(g), _ld(g), acc, s)
+            _fwd_bf16(P(y.grad_shadow()), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc, gy)
         elif bf and cout >= 16:
-            call('es_spconv_fwd_bf16', P(gy), 0, _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0,
-                 P(g), _ld(g), acc, s)
+            _fwd_bf16(P(gy), 0, _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc, gy)
         else:
             call('es_spconv_fwd', P(gy), _ld(gy), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1, acc, s)
 

@@ -118,12 +118,15 @@ class SparseFeatureFusionSingleStage3DDetector:
         E.mark('A7 2-D backbone fwd')
         self._tape_marks = [len(E.TAPE.fns)]                   # end of the 2-D backbone's closures
         points = batch_inputs_dict['points']
-        assert self.use_xyz_feat, 'shipped configs use use_xyz_feat=True'
         pts = [p if (p.dtype == torch.float32 and p.stride(-1) == 1) else p.float().contiguous() for p in points]
         cs, src = sparse.voxelize(pts, self.voxel_size)
-        allp = torch.cat([p[:, :3] for p in pts]) if len(pts) > 1 else pts[0][:, :3].contiguous()
-        feats = torch.empty((cs.n, 3), dtype=torch.float32, device=allp.device)
-        call('es_row_move', P(feats), 3, P(allp), allp.stride(0), P(src), cs.n, 3, 0, _stream())
+        # voxel features (:109-116): the whole point row (xyz + extra columns) with use_xyz_feat, else the columns behind xyz
+        c0 = 0 if self.use_xyz_feat else 3
+        Cf = int(pts[0].shape[1]) - c0
+        assert Cf > 0, 'use_xyz_feat=False needs point columns beyond xyz'
+        allp = torch.cat([p[:, c0:] for p in pts]) if len(pts) > 1 else pts[0][:, c0:].contiguous()
+        feats = torch.empty((cs.n, Cf), dtype=torch.float32, device=allp.device)
+        call('es_row_move', P(feats), Cf, P(allp), allp.stride(0), P(src), cs.n, Cf, 0, _stream())
         # all data-dependent row counts of the point branch (strided sets, unions of the head's top-down pass) are read back
         # here, under the image branch's kernels; the 3-D backbone and the head are then queued without host stalls
         if os.environ.get('ES_PREFETCH_COORDS', '1') != '0':

@@ -73,6 +73,13 @@ int es_spconv_fwd(const float* X, int ldx, const float* W, const int* nbr, int n
  * (reduction index contiguous): the transposed copy for the forward pass, the natural copy for dgrad. */
 int es_spconv_fwd_bf16(const void* X, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in,
                        int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, void* stream);
+/* the same with a caller-provided workspace of es_spconv_split_workspace_floats() floats: launches with too few tiles to
+ * fill the chip split their tap list over several workgroups; with the workspace the partial sums are reduced in a fixed
+ * order (bit-reproducible) instead of f32 atomics into Y */
+size_t es_spconv_split_workspace_floats(int n_out, int K, int Cin, int Cout);
+int es_spconv_fwd_bf16_ws(const void* X, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in,
+                          int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, float* ws,
+                          size_t ws_floats, void* stream);
 /* X may also be a bf16 row matrix (x_is_bf16 = 1, ldx in bf16 elements): the shadow made by es_cast_rows_bf16; only for
  * shapes where es_spconv_bf16_is_fast() returns 1 */
 int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout);

@@ -1,0 +1,68 @@
+"""A7 unit test (the 2-D backbone was only covered end to end): mmdet.ResNet-50 (base 16, and the generic-stem
+path at base 8) on the conv engine -- direct stem kernel, static image-grid maps, 1x1 / 3x3 / strided convs, fused
+conv + frozen-BN (+ residual) (+ ReLU) epilogues and the gated data-gradient launches of the bf16 mode -- against
+torch.nn.functional.conv2d + eval-mode batch_norm on the CPU: the four output feature maps and the gradients of every
+trainable conv kernel.  f32 mode 1e-4 / 1e-3, bf16 mode 2e-2 / 6e-2 (relative L2)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize('base,mode', [(16, 'f32'), (16, 'bf16'), (8, 'f32')])
+def test_resnet50_vs_torch(base, mode):
+    from embodiedscan_amd import engine as E
+    from embodiedscan_amd.models.backbones.resnet2d import ResNet
+    from embodiedscan_amd.params import ParamArena, resnet50_specs
+    from oracle import model as OM
+    dev = torch.device('cuda:0')
+    arena = ParamArena(resnet50_specs(base=base), seed=5)
+    g = torch.Generator().manual_seed(9)
+    for k, v in arena.p.items():                     # non-trivial frozen BN: statistics, scale and shift
+        if k.endswith('running_var'):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif k.endswith('running_mean') or k.endswith('.bias'):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+        elif 'bn' in k and k.endswith('.weight') or 'downsample.1.weight' in k:
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+    names = set(arena.grad_dict().keys())
+    sd = {k: v.clone().requires_grad_(k in names) for k, v in arena.state_dict().items()}
+    arena.to(dev)
+    net = ResNet(depth=50, base_channels=base, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                 norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='pytorch').bind(arena, 'backbone.')
+    n_img, H, W = 3, 96, 64
+    x = torch.randn(n_img, 3, H, W, generator=g)
+    want = OM.resnet50_w16(x, sd)
+    dys = [torch.randn(o.shape, generator=g) for o in want]
+    sum((o * d).sum() for o, d in zip(want, dys)).backward()
+    E.PRECISION[0] = mode
+    try:
+        E.WEIGHT_VERSION[0] += 1
+        E.TAPE.clear()
+        arena.grad.zero_()
+        outs = net(x.permute(0, 2, 3, 1).contiguous().to(dev))
+        tf, tg = (1e-4, 1e-3) if mode == 'f32' else (2e-2, 6e-2)
+        for (o, h, w), r, d in zip(outs, want, dys):
+            assert (h, w) == tuple(r.shape[2:])
+            e = _rel(o.d.cpu(), r.detach().permute(0, 2, 3, 1).reshape(-1, r.shape[1]))
+            print(f'ResNet-50(w{base}) {mode} feature map {h}x{w}x{r.shape[1]}: rel-L2 {e:.2e} (tol {tf:.0e})')
+            assert e < tf
+            o.g = d.permute(0, 2, 3, 1).reshape(-1, d.shape[1]).contiguous().to(dev)
+        E.TAPE.backward()
+        torch.cuda.synchronize()
+    finally:
+        E.PRECISION[0] = 'f32'
+    gd = arena.grad_dict()
+    rel = {k: _rel(v, sd[k].grad) for k, v in gd.items() if sd[k].grad is not None}
+    worst = max(rel, key=rel.get)
+    frozen = [k for k in sd if k.startswith('backbone.layer1.') or k.startswith('backbone.conv1')]
+    assert all(k not in gd for k in frozen), 'frozen_stages=1: stem and layer1 carry no gradient'
+    print(f'ResNet-50(w{base}) {mode}: {len(rel)} conv kernels, gradient rel-L2 median {np.median(list(rel.values())):.2e}, worst '
+          f'{rel[worst]:.2e} at {worst} (tol {tg:.0e})')
+    assert rel[worst] < tg
