@@ -153,7 +153,7 @@ class FCAF3DHeadRotMat:
                               _BN(arena, prefix + p + '.4'))
             p = f'out_block_{i}'
             self.out[i] = (par(p + '.0.kernel'), _BN(arena, prefix + p + '.1'))
-        self.head_w = par('head_out.kernel')             # (1, out_channels, 1 + 12 + num_classes)
+        self.head_w = par('head_out.kernel')             # (1, out_channels, 1 + 12 + num_classes padded to a multiple of 64)
         self.head_b = par('head_out.bias')               # (1 + 12 + num_classes,), only the class part is live
         self.scales = [par(f'scales.{i}.scale') for i in range(n_lvl)]
         return self
@@ -234,7 +234,7 @@ class FCAF3DHeadRotMat:
             sl = [slice(off[b], off[b + 1]) for b in range(lv['cs'].n_batch)]
             cp.append([ho[s, 0:1] for s in sl])
             bp.append([bbox[s] for s in sl])
-            kp.append([ho[s, 13:] for s in sl])
+            kp.append([ho[s, 13:13 + self.num_classes] for s in sl])
             pts.append([points[s] for s in sl])
         return cp, bp, kp, pts
 

@@ -101,9 +101,12 @@ def fcaf3d_head_specs(prefix='bbox_head.', in_channels=(128, 256, 512, 1024), ou
         _mbn(s, p + '.1', out_channels)
     # conv_center (C,1) | conv_reg (C,n_reg) | conv_cls (C,n_classes) fused into ONE row GEMM; exported to the
     # reference names conv_center.kernel / conv_reg.kernel / conv_cls.kernel / conv_cls.bias
+    # columns padded to a multiple of 64 so that the head GEMM, its data gradient and its weight gradient run on the fast
+    # (unchecked) bf16 kernels: 297 -> 320; the padding columns are zero, receive zero gradients and are never read
     nh = 1 + n_reg + n_classes
-    s.append(Spec(prefix + 'head_out.kernel', (1, out_channels, nh), ('normal', .01), ref=('head_out', n_reg, n_classes)))
-    s.append(Spec(prefix + 'head_out.bias', (nh,), ('head_bias', (1 + n_reg, -math.log((1 - .01) / .01))),
+    nhp = (nh + 63) // 64 * 64
+    s.append(Spec(prefix + 'head_out.kernel', (1, out_channels, nhp), ('normal_pad', (.01, nh)), ref=('head_out', n_reg, n_classes)))
+    s.append(Spec(prefix + 'head_out.bias', (nhp,), ('head_bias', (1 + n_reg, -math.log((1 - .01) / .01), nh)),
                   ref=('head_bias', n_reg, n_classes)))
     for i in range(len(in_channels)):
         s.append(Spec(f'{prefix}scales.{i}.scale', (), ('const', 1.)))
@@ -287,9 +290,12 @@ def _fill(t, init, gen):
     elif kind == 'reg_bias':                # GroundingHead.init_weights: last reg layer bias 0, bias[2:] = -2 (grounding_head.py:220-224)
         t.zero_()
         t[2:] = a
+    elif kind == 'normal_pad':              # N(0, std) in the first a[1] columns of the last dim, zero padding behind
+        t.normal_(0, a[0], generator=gen)
+        t[..., a[1]:] = 0
     elif kind == 'head_bias':
         t.zero_()
-        t[a[0]:] = a[1]
+        t[a[0]:(a[2] if len(a) > 2 else None)] = a[1]
     else:
         raise ValueError(kind)
 
@@ -366,10 +372,10 @@ class ParamArena:
             nr = s.ref[1]
             out[pre + 'conv_center.kernel'] = t[0, :, 0:1].clone()
             out[pre + 'conv_reg.kernel'] = t[0, :, 1:1 + nr].clone()
-            out[pre + 'conv_cls.kernel'] = t[0, :, 1 + nr:].clone()
+            out[pre + 'conv_cls.kernel'] = t[0, :, 1 + nr:1 + nr + s.ref[2]].clone()
         elif s.ref[0] == 'head_bias':
             pre = s.name[:-len('head_out.bias')]
-            out[pre + 'conv_cls.bias'] = t[1 + s.ref[1]:].reshape(1, -1).clone()
+            out[pre + 'conv_cls.bias'] = t[1 + s.ref[1]:1 + s.ref[1] + s.ref[2]].reshape(1, -1).clone()
 
     @staticmethod
     def _absorb(s, dst, sd):
@@ -413,12 +419,12 @@ class ParamArena:
             if all(n in sd for n in names):
                 dst[0, :, 0:1].copy_(sd[names[0]])
                 dst[0, :, 1:1 + nr].copy_(sd[names[1]])
-                dst[0, :, 1 + nr:].copy_(sd[names[2]])
+                dst[0, :, 1 + nr:1 + nr + s.ref[2]].copy_(sd[names[2]])
                 return names
         elif s.ref[0] == 'head_bias':
             pre = s.name[:-len('head_out.bias')]
             if pre + 'conv_cls.bias' in sd:
-                dst[1 + s.ref[1]:].copy_(sd[pre + 'conv_cls.bias'].reshape(-1))
+                dst[1 + s.ref[1]:1 + s.ref[1] + s.ref[2]].copy_(sd[pre + 'conv_cls.bias'].reshape(-1))
                 return [pre + 'conv_cls.bias']
         return []
 

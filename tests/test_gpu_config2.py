@@ -179,7 +179,7 @@ def test_losses_and_logits_one_scan(setup, oracle_one_scan, mode):
             print(f'{mode} level {l}: {len(hk)} rows vs oracle {len(okk)}, {frac:.3%} of the oracle rows not kept (tol 0.5 %)')
             assert len(hk) == len(okk) and frac <= (5e-3 if mode == 'bf16' else 1e-4)
         ih, io = torch.from_numpy(ih), torch.from_numpy(io)
-        e_logit = _rel(torch.cat([ho[:, 0:1], ho[:, 13:]], 1)[ih], torch.cat([oc, ok], 1)[io])
+        e_logit = _rel(torch.cat([ho[:, 0:1], ho[:, 13:13 + ok.shape[1]]], 1)[ih], torch.cat([oc, ok], 1)[io])
         e_box = _rel(bb[ih], ob[io])
         print(f'{mode} level {l} ({ho.shape[0]} rows): logits rel-L2 {e_logit:.2e} (tol {tol["logits"]:.0e}), '
               f'decoded bbox rel-L2 {e_box:.2e} (tol {tol["bbox"]:.0e})')
