@@ -291,8 +291,10 @@ def _fill(t, init, gen):
         t.zero_()
         t[2:] = a
     elif kind == 'normal_pad':              # N(0, std) in the first a[1] columns of the last dim, zero padding behind
-        t.normal_(0, a[0], generator=gen)
-        t[..., a[1]:] = 0
+        # (draws exactly the numbers an un-padded tensor would: the random stream of the other parameters is unchanged)
+        live = torch.empty(t.shape[:-1] + (a[1],), dtype=t.dtype).normal_(0, a[0], generator=gen)
+        t.zero_()
+        t[..., :a[1]] = live
     elif kind == 'head_bias':
         t.zero_()
         t[a[0]:(a[2] if len(a) > 2 else None)] = a[1]
