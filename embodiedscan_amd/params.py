@@ -325,7 +325,7 @@ class ParamArena:
         data = torch.zeros(self.total, dtype=torch.float32)
         for s in specs:                     # init in spec order so the stream is layout independent
             o, n = self.offsets[s.name]
-            _fill(data[o:o + n], s.init, gen)
+            _fill(data[o:o + n].view(s.shape), s.init, gen)
         self.data = data.to(device)
         self.grad = torch.zeros(self.n_train, dtype=torch.float32, device=device)
         self._views()
