@@ -5,8 +5,9 @@ from collections import defaultdict
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute('select start, end, name, grid_x, grid_y, grid_z from kernels order by start').fetchall()
 marks = [i for i, r in enumerate(rows) if r[2].startswith('k_adamw')]
-if len(marks) >= 2:
-    rows = rows[marks[-2] + 1: marks[-1] + 1]
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+if len(marks) >= back:
+    rows = rows[marks[-back] + 1: (marks[-back + 1] + 1) if back > 1 else None]
 tot = sum(e - s for s, e, *_ in rows)
 busy, cur_s, cur_e, gaps = 0, None, None, []
 for s, e, *_ in rows:

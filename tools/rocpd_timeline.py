@@ -8,8 +8,9 @@ print('columns:', cols)
 key = 'stream_id' if 'stream_id' in cols else ('queue_id' if 'queue_id' in cols else None)
 rows = db.execute(f'select start, end, name, {key or 0} from kernels order by start').fetchall()
 marks = [i for i, r in enumerate(rows) if r[2].startswith('k_adamw')]
-if len(marks) >= 3:
-    rows = rows[marks[-3] + 1: marks[-2] + 1]
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 3     # which step, counted from the end (k_adamw marks)
+if len(marks) >= back:
+    rows = rows[marks[-back] + 1: marks[-back + 1] + 1]
 t0, t1 = rows[0][0], max(r[1] for r in rows)
 streams = sorted({r[3] for r in rows})
 print(f'step span {(t1 - t0) / 1e6:.2f} ms, streams {streams}')
