@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
 ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_wgrad',
-          'es_spconv_wgrad_bf16'}
+          'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src'}
 SCATTER = {'es_voxel_keys', 'es_unique_first', 'es_morton_sort', 'es_stride_keys', 'es_kernel_map', 'es_inverse_map',
            'es_union_plan', 'es_point_sample_fwd', 'es_point_sample_bwd', 'es_depth_to_points'}
 
@@ -140,11 +140,14 @@ def main():
     # time EXACTLY `steps` steps; the convolution engine launches of the last timed step are bracketed by HIP events
     # recorded on the stream each kernel is launched on (the step runs on four compute streams + the copy stream)
     prof = {'names': ENGINE, 'records': [], 'event': lambda: torch.cuda.Event(enable_timing=True)}
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
     t0 = time.perf_counter()
     for it in range(args.steps):
         # (2 events per launch and one pair counter per kernel map cost ~3 ms of host time, so only the last step)
         hip.PROFILE = prof if it == args.steps - 1 else None
         losses = step()
+        marks[it + 1].record()                                # end of the step's main-stream work (no sync)
     recs = resolve_pairs(hip, prof['records'])
     torch.cuda.synchronize()
     if world > 1:
@@ -259,6 +262,8 @@ def main():
     if world > 1:
         out['replicas_in_sync'] = in_sync
         out['rank_ms_per_step'] = rank_ms
+    # GPU-side duration of each timed step (events on the main stream; the last one carries the launch profiling)
+    out['step_ms'] = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'], out['parity'] = cpu_baseline(scans[0], sd0, det, parity_hip, args)
     print(json.dumps(out))
@@ -273,13 +278,17 @@ def resolve_pairs(hip, records):
     out = []
     for name, e0, e1, a in records:
         key = None
-        if name in ENGINE:
+        if name == 'es_spconv_wgrad_bf16_src':
+            key = a[6]
+        elif name in ENGINE:
             key = a[4] if (name.startswith('es_spconv_wgrad') or name in ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws')) else a[3]
         out.append((name, e0, e1, a, hip.PAIRS.get(key)))
     return out
 
 
 def engine_args(name, a):
+    if name == 'es_spconv_wgrad_bf16_src':      # (X, x_half, ldx, dY, dy_half, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream)
+        return a[6], a[7], a[8], a[9], a[10], a[11]
     if name in ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws'):
         return a[4], a[5], a[6], a[7], a[8], a[9]
     if not name.startswith('es_spconv_wgrad'):
@@ -303,7 +312,13 @@ def engine_totals(records, mfma_peak):
         pb = pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wb
         # compulsory: fwd/dgrad read n_in rows of Cin, write n_out rows of Cout, read the weights once;
         # wgrad reads both row matrices once and read-modify-writes the f32 weight gradient
-        cb = (float(n_in) * cin + float(n_out) * cout) * 4.0 + float(K) * cin * cout * (8.0 if wgrad else wb)
+        # (rows gathered from a bf16 shadow count 2 B per element, the shadow's own cast pass is not an engine launch)
+        bx = by = 4.0
+        if name == 'es_spconv_wgrad_bf16_src':
+            bx, by = (2.0 if a[1] else 4.0), (2.0 if a[4] else 4.0)
+        elif name in ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws') and a[1]:
+            bx = 2.0
+        cb = float(n_in) * cin * bx + float(n_out) * cout * by + float(K) * cin * cout * (8.0 if wgrad else wb)
         tm, th = f / (mfma_peak * 1e12), cb / (K_PEAK_HBM * 1e9)
         flop, pair_b, comp_b = flop + f, pair_b + pb, comp_b + cb
         t_mfma, t_hbm, t_bind = t_mfma + tm, t_hbm + th, t_bind + max(tm, th)

@@ -954,8 +954,36 @@ __device__ __forceinline__ void ring_fill(PairRing& q, const int* __restrict__ n
   while (q.tail - q.head < 2 * GR && q.nextb < rend) ring_refill(q, nbr, sj, koff, rend, n_in);
 }
 
-__global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restrict__ X, int ldx,
-                                                           const float* __restrict__ dY, int ldy,
+// 4 consecutive channels of one row as floats; HALF: the row matrix is a bf16 shadow (exact widening)
+template <int HALF>
+__device__ __forceinline__ void wgrad_load4(const void* __restrict__ base, size_t row, int ld, int c, int C, bool vec,
+                                            float (&o)[4]) {
+  if (HALF) {
+    const unsigned short* p = (const unsigned short*)base + row * ld + c;
+    if (vec && c + 3 < C) {
+      uint2 v = *(const uint2*)p;
+      o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+      o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (c + e < C) ? __uint_as_float((uint32_t)p[e] << 16) : 0.f;
+    }
+  } else {
+    const float* p = (const float*)base + row * ld + c;
+    if (vec && c + 3 < C) {
+      float4 v = *(const float4*)p;
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (c + e < C) ? p[e] : 0.f;
+    }
+  }
+}
+
+// XH / YH: X / dY are bf16 shadows (n, ld) instead of f32 row matrices -- half the gathered bytes
+template <int XH, int YH>
+__global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const void* __restrict__ X, int ldx,
+                                                           const void* __restrict__ dY, int ldy,
                                                            const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                            int Cin, int Cout, int rows_per_split,
                                                            int n_slices, float* __restrict__ dW) {
@@ -989,30 +1017,10 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restri
       int j = -1, idx = -1;
       if (qq < q.tail) { j = q.qj[qq & (QCAP - 1)]; idx = q.qi[qq & (QCAP - 1)]; }
       int c = c0 + l4, n = n0 + l4;
-      if (idx >= 0 && c < Cin) {
-        const float* p = X + (size_t)idx * ldx + c;
-        if (vecA && c + 3 < Cin) {
-          float4 v = *(const float4*)p;
-          xa[h][0] = v.x; xa[h][1] = v.y; xa[h][2] = v.z; xa[h][3] = v.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xa[h][e] = (c + e < Cin) ? p[e] : 0.f;
-        }
-      } else {
-        xa[h][0] = xa[h][1] = xa[h][2] = xa[h][3] = 0.f;
-      }
-      if (idx >= 0 && n < Cout) {
-        const float* p = dY + (size_t)j * ldy + n;
-        if (vecB && n + 3 < Cout) {
-          float4 v = *(const float4*)p;
-          xb[h][0] = v.x; xb[h][1] = v.y; xb[h][2] = v.z; xb[h][3] = v.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xb[h][e] = (n + e < Cout) ? p[e] : 0.f;
-        }
-      } else {
-        xb[h][0] = xb[h][1] = xb[h][2] = xb[h][3] = 0.f;
-      }
+      if (idx >= 0 && c < Cin) wgrad_load4<XH>(X, (size_t)idx, ldx, c, Cin, vecA, xa[h]);
+      else xa[h][0] = xa[h][1] = xa[h][2] = xa[h][3] = 0.f;
+      if (idx >= 0 && n < Cout) wgrad_load4<YH>(dY, (size_t)j, ldy, n, Cout, vecB, xb[h]);
+      else xb[h][0] = xb[h][1] = xb[h][2] = xb[h][3] = 0.f;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1058,8 +1066,9 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const float* __restri
 // (16 MFMAs per 32-pair chunk instead of 4).  For C = 128 layers X[nbr] and dY are then each read exactly once per
 // valid pair.  Fast path only (Cin % 128 == 0, Cout % 128 == 0, aligned, 32-bit offsets); other shapes use
 // k_spconv_wgrad_bf16.
-__global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __restrict__ X, int ldx,
-                                                               const float* __restrict__ dY, int ldy,
+template <int XH, int YH>
+__global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __restrict__ Xv, int ldx,
+                                                               const void* __restrict__ dYv, int ldy,
                                                                const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                                int Cin, int Cout, int rows_per_split,
                                                                int n_slices, float* __restrict__ dW) {
@@ -1086,7 +1095,9 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __re
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 xa[2][2], xb[2][2];
+  // per ring entry h: 8 channels of X and of dY, as 2 float4 (f32 source) or one uint4 of 8 bf16 (shadow source)
+  float4 xa[2][XH ? 1 : 2], xb[2][YH ? 1 : 2];
+  uint4 ha[2], hb[2];
   int va[2];
   auto load_rows = [&]() {
 #pragma unroll
@@ -1095,23 +1106,56 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __re
       va[h] = qq < q.tail;
       int j = va[h] ? q.qj[qq & (QCAP - 1)] : rbeg;       // unconditional loads, masked when packed
       int idx = va[h] ? q.qi[qq & (QCAP - 1)] : 0;
-      const float4* px = (const float4*)(X + idx * ldx + c0 + c8);
-      const float4* py = (const float4*)(dY + j * ldy + n0 + c8);
-      xa[h][0] = px[0]; xa[h][1] = px[1];
-      xb[h][0] = py[0]; xb[h][1] = py[1];
+      if (XH) {
+        ha[h] = *(const uint4*)((const unsigned short*)Xv + idx * ldx + c0 + c8);
+      } else {
+        const float4* px = (const float4*)((const float*)Xv + idx * ldx + c0 + c8);
+        xa[h][0] = px[0]; xa[h][XH ? 0 : 1] = px[1];
+      }
+      if (YH) {
+        hb[h] = *(const uint4*)((const unsigned short*)dYv + j * ldy + n0 + c8);
+      } else {
+        const float4* py = (const float4*)((const float*)dYv + j * ldy + n0 + c8);
+        xb[h][0] = py[0]; xb[h][YH ? 0 : 1] = py[1];
+      }
     }
   };
   auto store_rows = [&]() {
-    float a0[8] = {xa[0][0].x, xa[0][0].y, xa[0][0].z, xa[0][0].w, xa[0][1].x, xa[0][1].y, xa[0][1].z, xa[0][1].w};
-    float a1[8] = {xa[1][0].x, xa[1][0].y, xa[1][0].z, xa[1][0].w, xa[1][1].x, xa[1][1].y, xa[1][1].z, xa[1][1].w};
-    float b0[8] = {xb[0][0].x, xb[0][0].y, xb[0][0].z, xb[0][0].w, xb[0][1].x, xb[0][1].y, xb[0][1].z, xb[0][1].w};
-    float b1[8] = {xb[1][0].x, xb[1][0].y, xb[1][0].z, xb[1][0].w, xb[1][1].x, xb[1][1].y, xb[1][1].z, xb[1][1].w};
+    uint32_t wa[8], wb[8];                                // (entry 2rp, entry 2rp+1) of channel c8+e, packed bf16x2
+    if (XH) {
+      uint32_t m0 = va[0] ? 0xffffffffu : 0u, m1 = va[1] ? 0xffffffffu : 0u;
+      uint32_t u0[4] = {ha[0].x & m0, ha[0].y & m0, ha[0].z & m0, ha[0].w & m0};
+      uint32_t u1[4] = {ha[1].x & m1, ha[1].y & m1, ha[1].z & m1, ha[1].w & m1};
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        wa[e] = (u0[e >> 1] & 0xffffu) | (u1[e >> 1] << 16);
+        wa[e + 1] = (u0[e >> 1] >> 16) | (u1[e >> 1] & 0xffff0000u);
+      }
+    } else {
+      float a0[8] = {xa[0][0].x, xa[0][0].y, xa[0][0].z, xa[0][0].w, xa[0][XH ? 0 : 1].x, xa[0][XH ? 0 : 1].y, xa[0][XH ? 0 : 1].z, xa[0][XH ? 0 : 1].w};
+      float a1[8] = {xa[1][0].x, xa[1][0].y, xa[1][0].z, xa[1][0].w, xa[1][XH ? 0 : 1].x, xa[1][XH ? 0 : 1].y, xa[1][XH ? 0 : 1].z, xa[1][XH ? 0 : 1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wa[e] = pack_bf16(va[0] ? a0[e] : 0.f, va[1] ? a1[e] : 0.f);
+    }
+    if (YH) {
+      uint32_t m0 = va[0] ? 0xffffffffu : 0u, m1 = va[1] ? 0xffffffffu : 0u;
+      uint32_t u0[4] = {hb[0].x & m0, hb[0].y & m0, hb[0].z & m0, hb[0].w & m0};
+      uint32_t u1[4] = {hb[1].x & m1, hb[1].y & m1, hb[1].z & m1, hb[1].w & m1};
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        wb[e] = (u0[e >> 1] & 0xffffu) | (u1[e >> 1] << 16);
+        wb[e + 1] = (u0[e >> 1] >> 16) | (u1[e >> 1] & 0xffff0000u);
+      }
+    } else {
+      float b0[8] = {xb[0][0].x, xb[0][0].y, xb[0][0].z, xb[0][0].w, xb[0][YH ? 0 : 1].x, xb[0][YH ? 0 : 1].y, xb[0][YH ? 0 : 1].z, xb[0][YH ? 0 : 1].w};
+      float b1[8] = {xb[1][0].x, xb[1][0].y, xb[1][0].z, xb[1][0].w, xb[1][YH ? 0 : 1].x, xb[1][YH ? 0 : 1].y, xb[1][YH ? 0 : 1].z, xb[1][YH ? 0 : 1].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wb[e] = pack_bf16(va[0] ? b0[e] : 0.f, va[1] ? b1[e] : 0.f);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float p0 = va[0] ? a0[e] : 0.f, p1 = va[1] ? a1[e] : 0.f;
-      *(uint32_t*)&As[(c8 + e) * GLD + 2 * rp] = pack_bf16(p0, p1);
-      float q0 = va[0] ? b0[e] : 0.f, q1 = va[1] ? b1[e] : 0.f;
-      *(uint32_t*)&Bs[(c8 + e) * GLD + 2 * rp] = pack_bf16(q0, q1);
+      *(uint32_t*)&As[(c8 + e) * GLD + 2 * rp] = wa[e];
+      *(uint32_t*)&Bs[(c8 + e) * GLD + 2 * rp] = wb[e];
     }
   };
   ring_fill(q, nbr, sj, koff, rend, n_in);
@@ -1148,10 +1192,13 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const float* __re
     }
 }
 
-extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out,
-                                    int n_in, int K, int Cin, int Cout, float* dW, void* stream) {
+template <int XH, int YH>
+static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
+                             int Cin, int Cout, float* dW, void* stream) {
   if (n_out <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  bool big = (Cin % 128 == 0) && (Cout % 128 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+  // 16-byte row segments: 4 floats or 8 bf16 per load
+  const int ax = XH ? 8 : 4, ay = YH ? 8 : 4;
+  bool big = (Cin % 128 == 0) && (Cout % 128 == 0) && (ldx % ax == 0) && (ldy % ay == 0) &&
              ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)dY) & 15) == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
              ((long long)n_out * ldy < (1ll << 31)) && n_out >= 512;
   if (big) {
@@ -1163,8 +1210,8 @@ extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, in
     int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
     splits = es_cdiv(n_out, rows_per_split);
     dim3 grid(K * (Cin / 128), Cout / 128, es_cdiv(splits, 8) * 8);
-    hipLaunchKernelGGL(k_spconv_wgrad_bf16_big, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out,
-                       n_in, K, Cin, Cout, rows_per_split, splits, dW);
+    hipLaunchKernelGGL((k_spconv_wgrad_bf16_big<XH, YH>), grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy,
+                       nbr, n_out, n_in, K, Cin, Cout, rows_per_split, splits, dW);
     ES_CHECK_LAUNCH();
     return 0;
   }
@@ -1176,10 +1223,24 @@ extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, in
   int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
   splits = es_cdiv(n_out, rows_per_split);
   dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), es_cdiv(splits, 8) * 8);
-  hipLaunchKernelGGL(k_spconv_wgrad_bf16, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out, n_in,
-                     K, Cin, Cout, rows_per_split, splits, dW);
+  hipLaunchKernelGGL((k_spconv_wgrad_bf16<XH, YH>), grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr,
+                     n_out, n_in, K, Cin, Cout, rows_per_split, splits, dW);
   ES_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out,
+                                    int n_in, int K, int Cin, int Cout, float* dW, void* stream) {
+  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
+}
+
+extern "C" int es_spconv_wgrad_bf16_src(const void* X, int x_half, int ldx, const void* dY, int dy_half, int ldy,
+                                        const int* nbr, int n_out, int n_in, int K, int Cin, int Cout, float* dW,
+                                        void* stream) {
+  if (x_half && dy_half) return wgrad_bf16_launch<1, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
+  if (x_half) return wgrad_bf16_launch<1, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
+  if (dy_half) return wgrad_bf16_launch<0, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
+  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
 }
 
 // f32 row matrix -> contiguous bf16 "shadow" (n, C) used as the gather source of the bf16 kernels

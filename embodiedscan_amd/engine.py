@@ -250,6 +250,7 @@ def _cast_rows(t):
     return h
 
 
+WGRAD_SHADOW = [os.environ.get('ES_WGRAD_SHADOW', '1') != '0']   # weight-gradient launches gather from the bf16 shadows too
 DET_SPLIT = [os.environ.get('ES_DET_SPLIT', '1') != '0']   # deterministic tap split (workspace + fixed-order reduction)
 
 
@@ -351,9 +352,19 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     K, cin, cout = w.d.shape
     n_in = x.d.shape[0]
     s = _stream()
+    # bf16 shadow of the output gradient: gather source of the data-gradient launch and, with the input's shadow from
+    # the forward pass, of the weight-gradient launch (made here, before the weight-gradient stream forks)
+    gh = None
+    if (bf and cout >= 16 and SHADOW[0] and need_dx and x.rg and gate is None and _ld(gy) == cout
+            and _use_shadow(n_out, cout, K, cout, cin)):
+        gh = y.grad_shadow() if gy is y.g else _cast_rows(gy)
     if w.g is not None or (bias is not None and bias.g is not None):
-        sw = _wgrad_stream(gy, x.d)
-    if w.g is not None:
+        sw = _wgrad_stream(gy, x.d, gh, x.dh)
+    if w.g is not None and bf and WGRAD_BF16[0] and SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None):
+        xs, ys = x.dh if x.dh is not None else x.d, gh if gh is not None else gy
+        call('es_spconv_wgrad_bf16_src', P(xs), int(x.dh is not None), _ld(xs), P(ys), int(gh is not None), _ld(ys),
+             P(nbr), n_out, n_in, K, cin, cout, P(w.g), sw)
+    elif w.g is not None:
         call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), P(gy), _ld(gy),
              P(nbr), n_out, n_in, K, cin, cout, P(w.g), sw)
     if bias is not None and bias.g is not None:
@@ -367,8 +378,8 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
              P(x.d), _ld(x.d), 3, P(x.g), _ld(x.g), s)
     elif need_dx and x.rg:
         g, acc = _grad_target(x, x.d)
-        if bf and cout >= 16 and SHADOW[0] and _ld(gy) == cout and _use_shadow(n_out, cout, K, cout, cin):
-            _fwd_bf16(P(y.grad_shadow()), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc, gy)
+        if gh is not None:
+            _fwd_bf16(P(gh), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc, gh)
         elif bf and cout >= 16:
             _fwd_bf16(P(gy), 0, _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc, gy)
         else:

@@ -108,6 +108,12 @@ int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int
  * (atomics), results are reproducible to f32 rounding only. */
 int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
                          int Cin, int Cout, float* dW, void* stream);
+/* Same operator with either operand taken from a bf16 copy ("shadow", es_cast_rows_bf16) of the row matrix: x_half /
+ * dy_half non-zero -> X / dY point at (n, ld) bf16 rows (ld in elements).  Results are bit-identical to
+ * es_spconv_wgrad_bf16 on the f32 originals up to the atomic accumulation order (the f32 path rounds to the same bf16
+ * values while staging); the gathered bytes halve. */
+int es_spconv_wgrad_bf16_src(const void* X, int x_half, int ldx, const void* dY, int dy_half, int ldy, const int* nbr,
+                             int n_out, int n_in, int K, int Cin, int Cout, float* dW, void* stream);
 int es_image_map(int n_img, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int* nbr, void* stream);
 
 /* ---- row operators ----------------------------------------------------------------------------- */

@@ -322,6 +322,20 @@ def test_bf16_kernels_on_large_maps_vs_oracle(dev):
         call('es_spconv_wgrad_bf16', P(xd), cin, P(dyd), cout, P(nbr), n, n, 27, cin, cout, P(d16), st)
         e16 = torch.zeros(1, cin, cout, device=dev)
         call('es_spconv_wgrad_bf16', P(xd), cin, P(dyd), cout, 0, n, n, 1, cin, cout, P(e16), st)
+        # bf16-shadow operands: the same bf16 values reach the MFMAs, only the atomic order differs
+        xh = torch.empty(n, cin, dtype=torch.bfloat16, device=dev)
+        dyh = torch.empty(n, cout, dtype=torch.bfloat16, device=dev)
+        call('es_cast_rows_bf16', P(xd), cin, n, cin, P(xh), st)
+        call('es_cast_rows_bf16', P(dyd), cout, n, cout, P(dyh), st)
+        for xs, ys in ((1, 1), (1, 0), (0, 1)):
+            dh = torch.zeros(27, cin, cout, device=dev)
+            call('es_spconv_wgrad_bf16_src', P(xh if xs else xd), xs, cin, P(dyh if ys else dyd), ys, cout, P(nbr), n, n,
+                 27, cin, cout, P(dh), st)
+            eh = torch.zeros(1, cin, cout, device=dev)
+            call('es_spconv_wgrad_bf16_src', P(xh if xs else xd), xs, cin, P(dyh if ys else dyd), ys, cout, 0, n, n, 1,
+                 cin, cout, P(eh), st)
+            torch.cuda.synchronize()
+            assert rel(dh, d16.double().cpu()) < 2e-6 and rel(eh, e16.double().cpu()) < 2e-6, (cin, cout, xs, ys)
         torch.cuda.synchronize()
         xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
         yo = S.gather_conv(xo, nbr_h, wo)

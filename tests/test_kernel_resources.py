@@ -19,7 +19,7 @@ FLOORS = {
     ('spconv.hip', 'k_spconv_bf16_fastILi128ELb0'): 3,
     ('spconv.hip', 'k_spconv_bf16_fastILi64ELb0'): 4,
     ('spconv.hip', 'k_spconv_wgrad_bf16_big'): 3,
-    ('spconv.hip', '19k_spconv_wgrad_bf16P'): 6,
+    ('spconv.hip', '19k_spconv_wgrad_bf16IL'): 6,
     ('rowops.hip', 'k_norm_stats'): 8,
     ('losses.hip', 'k_pos_losses'): 1,
 }
