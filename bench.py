@@ -140,14 +140,14 @@ def main():
     # time EXACTLY `steps` steps; the convolution engine launches of the last timed step are bracketed by HIP events
     # recorded on the stream each kernel is launched on (the step runs on four compute streams + the copy stream)
     prof = {'names': ENGINE, 'records': [], 'event': lambda: torch.cuda.Event(enable_timing=True)}
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    marks[0].record()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_ev[0].record()
     t0 = time.perf_counter()
     for it in range(args.steps):
         # (2 events per launch and one pair counter per kernel map cost ~3 ms of host time, so only the last step)
         hip.PROFILE = prof if it == args.steps - 1 else None
         losses = step()
-        marks[it + 1].record()                                # end of the step's main-stream work (no sync)
+        step_ev[it + 1].record()                                # end of the step's main-stream work (no sync)
     recs = resolve_pairs(hip, prof['records'])
     torch.cuda.synchronize()
     if world > 1:
@@ -263,7 +263,7 @@ def main():
         out['replicas_in_sync'] = in_sync
         out['rank_ms_per_step'] = rank_ms
     # GPU-side duration of each timed step (events on the main stream; the last one carries the launch profiling)
-    out['step_ms'] = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(args.steps)]
+    out['step_ms'] = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(args.steps)]
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'], out['parity'] = cpu_baseline(scans[0], sd0, det, parity_hip, args)
     print(json.dumps(out))

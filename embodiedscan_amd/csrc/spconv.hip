@@ -1200,7 +1200,8 @@ static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, co
   const int ax = XH ? 8 : 4, ay = YH ? 8 : 4;
   bool big = (Cin % 128 == 0) && (Cout % 128 == 0) && (ldx % ax == 0) && (ldy % ay == 0) &&
              ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)dY) & 15) == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
-             ((long long)n_out * ldy < (1ll << 31)) && n_out >= 512;
+             ((long long)n_out * ldy < (1ll << 31)) &&
+             (n_out >= 512 || (long long)Cin * Cout >= 512ll * 512ll);   // few rows x many channels: dW traffic decides
   if (big) {
     int base = K * (Cin / 128) * (Cout / 128);
     int splits = es_cdiv(8192, base);
