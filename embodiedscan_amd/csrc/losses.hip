@@ -132,122 +132,196 @@ extern "C" int es_reg_decode_bwd(const float* reg, int ldr, const float* bbox, c
   return 0;
 }
 
-// ------------------------------------------------------------------ dual numbers (12 partials)
-// Evaluated in f64: only a few hundred positive locations exist per scan, so the cost is nil, and the
-// atan2/asin/normalise chain of the 6D-rotation coder is ill-conditioned enough that f32 partials were the
-// largest noise source of the whole backward pass (measured: 3e-5 vs 7e-6 for the f32 autograd oracle).
-#define ND 12
+// ------------------------------------------------------------------ dual numbers (forward-mode, N partials)
+// Evaluated in f64: only a few hundred positive locations exist per scan, and the atan2/asin/normalise chain of the
+// 6D-rotation coder is ill-conditioned enough that f32 partials were the largest noise source of the whole backward
+// pass (measured: 3e-5 vs 7e-6 for the f32 autograd oracle).  The derivative is split where the chain is narrow:
+//   6 rotation outputs --Dual<6>--> Euler angles, rotation matrix       (rot_chain)
+//   9 box parameters   --Dual<9>--> corner-Chamfer value and gradient   (corner_cd, nearest target corner chosen on
+//                                                                        plain values first, one dual distance per corner)
+// and the two Jacobians are multiplied by hand (chain_to_outputs) -- a Dual<12> through everything needed 256 VGPRs +
+// 256 AGPRs + scratch and 64 dual distances per corner set.
 typedef double real;
+template <int N>
 struct Dual {
   real v;
-  real d[ND];
+  real d[N];
 };
-__device__ inline Dual dconst(real v) {
-  Dual r; r.v = v;
+template <int N>
+__device__ inline Dual<N> dconst(real v) {
+  Dual<N> r; r.v = v;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = 0;
+  for (int i = 0; i < N; ++i) r.d[i] = 0;
   return r;
 }
-__device__ inline Dual dvar(real v, int i) { Dual r = dconst(v); r.d[i] = 1; return r; }
-__device__ inline Dual operator+(const Dual& a, const Dual& b) {
-  Dual r; r.v = a.v + b.v;
+template <int N>
+__device__ inline Dual<N> dvar(real v, int i) { Dual<N> r = dconst<N>(v); r.d[i] = 1; return r; }
+template <int N>
+__device__ inline Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v + b.v;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] + b.d[i];
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
   return r;
 }
-__device__ inline Dual operator-(const Dual& a, const Dual& b) {
-  Dual r; r.v = a.v - b.v;
+template <int N>
+__device__ inline Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v - b.v;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] - b.d[i];
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
   return r;
 }
-__device__ inline Dual operator-(const Dual& a) {
-  Dual r; r.v = -a.v;
+template <int N>
+__device__ inline Dual<N> operator-(const Dual<N>& a) {
+  Dual<N> r; r.v = -a.v;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = -a.d[i];
+  for (int i = 0; i < N; ++i) r.d[i] = -a.d[i];
   return r;
 }
-__device__ inline Dual operator*(const Dual& a, const Dual& b) {
-  Dual r; r.v = a.v * b.v;
+template <int N>
+__device__ inline Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v * b.v;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
   return r;
 }
-__device__ inline Dual operator*(const Dual& a, real s) {
-  Dual r; r.v = a.v * s;
+template <int N>
+__device__ inline Dual<N> operator*(const Dual<N>& a, real s) {
+  Dual<N> r; r.v = a.v * s;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * s;
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * s;
   return r;
 }
-__device__ inline Dual operator/(const Dual& a, const Dual& b) {
-  Dual r; r.v = a.v / b.v;
+template <int N>
+__device__ inline Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v / b.v;
   real ib = 1.0 / b.v;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+  for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
   return r;
 }
-__device__ inline Dual dchain(const Dual& a, real v, real dv) {   // f(a) with f' = dv
-  Dual r; r.v = v;
+template <int N>
+__device__ inline Dual<N> dchain(const Dual<N>& a, real v, real dv) {   // f(a) with f' = dv
+  Dual<N> r; r.v = v;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * dv;
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * dv;
   return r;
 }
-__device__ inline Dual dsqrt(const Dual& a) { real s = sqrt(a.v); return dchain(a, s, s > 0 ? 0.5 / s : 0.0); }
-__device__ inline Dual dsin(const Dual& a) { return dchain(a, sin(a.v), cos(a.v)); }
-__device__ inline Dual dcos(const Dual& a) { return dchain(a, cos(a.v), -sin(a.v)); }
-__device__ inline Dual dasin(const Dual& a) { return dchain(a, asin(a.v), 1.0 / sqrt(fmax(1.0 - a.v * a.v, 1e-30))); }
-__device__ inline Dual datan2(const Dual& y, const Dual& x) {
-  Dual r; r.v = atan2(y.v, x.v);
+template <int N>
+__device__ inline Dual<N> dsqrt(const Dual<N>& a) { real s = sqrt(a.v); return dchain(a, s, s > 0 ? 0.5 / s : 0.0); }
+template <int N>
+__device__ inline Dual<N> dsin(const Dual<N>& a) { return dchain(a, sin(a.v), cos(a.v)); }
+template <int N>
+__device__ inline Dual<N> dcos(const Dual<N>& a) { return dchain(a, cos(a.v), -sin(a.v)); }
+template <int N>
+__device__ inline Dual<N> dasin(const Dual<N>& a) {
+  return dchain(a, asin(a.v), 1.0 / sqrt(fmax(1.0 - a.v * a.v, 1e-30)));
+}
+template <int N>
+__device__ inline Dual<N> datan2(const Dual<N>& y, const Dual<N>& x) {
+  Dual<N> r; r.v = atan2(y.v, x.v);
   real den = x.v * x.v + y.v * y.v;
   real gy = den > 0 ? x.v / den : 0.0, gx = den > 0 ? -y.v / den : 0.0;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) r.d[i] = y.d[i] * gy + x.d[i] * gx;
+  for (int i = 0; i < N; ++i) r.d[i] = y.d[i] * gy + x.d[i] * gx;
   return r;
 }
-__device__ inline Dual dabs(const Dual& a) { return a.v < 0 ? -a : (a.v > 0 ? a : dconst(0)); }
+template <int N>
+__device__ inline Dual<N> dabs(const Dual<N>& a) { return a.v < 0 ? -a : (a.v > 0 ? a : dconst<N>(0)); }
 
-struct D3 { Dual x, y, z; };
-__device__ inline D3 dcross(const D3& a, const D3& b) {
-  D3 r;
+template <int N>
+struct D3 { Dual<N> x, y, z; };
+template <int N>
+__device__ inline D3<N> dcross(const D3<N>& a, const D3<N>& b) {
+  D3<N> r;
   r.x = a.y * b.z - a.z * b.y;
   r.y = a.z * b.x - a.x * b.z;
   r.z = a.x * b.y - a.y * b.x;
   return r;
 }
-__device__ inline D3 dnormalize(const D3& a) {
-  Dual n = dsqrt(a.x * a.x + a.y * a.y + a.z * a.z) + dconst(1e-8);
-  D3 r; r.x = a.x / n; r.y = a.y / n; r.z = a.z / n;
+template <int N>
+__device__ inline D3<N> dnormalize(const D3<N>& a) {
+  Dual<N> n = dsqrt(a.x * a.x + a.y * a.y + a.z * a.z) + dconst<N>(1e-8);
+  D3<N> r; r.x = a.x / n; r.y = a.y / n; r.z = a.z / n;
   return r;
 }
 // R = Rz(e0) Rx(e1) Ry(e2), row-major 9
-__device__ inline void deuler_to_mat(const Dual* e, Dual* R) {
-  Dual ca = dcos(e[0]), sa = dsin(e[0]), cb = dcos(e[1]), sb = dsin(e[1]), cc = dcos(e[2]), sc = dsin(e[2]);
+template <int N>
+__device__ inline void deuler_to_mat(const Dual<N>* e, Dual<N>* R) {
+  Dual<N> ca = dcos(e[0]), sa = dsin(e[0]), cb = dcos(e[1]), sb = dsin(e[1]), cc = dcos(e[2]), sc = dsin(e[2]);
   R[0] = ca * cc - sa * sb * sc; R[1] = -(sa * cb); R[2] = ca * sc + sa * sb * cc;
   R[3] = sa * cc + ca * sb * sc; R[4] = ca * cb;    R[5] = sa * sc - ca * sb * cc;
   R[6] = -(cb * sc);             R[7] = sb;         R[8] = cb * cc;
 }
-// sum over the 8 source corners of min over target corners of the L1 distance
-__device__ inline Dual corner_cd(const Dual* box, const real* tc) {
-  Dual R[9];
-  deuler_to_mat(box + 6, R);
-  Dual total = dconst(0);
+__device__ inline void euler_to_mat(const real* e, real* R) {
+  real ca = cos(e[0]), sa = sin(e[0]), cb = cos(e[1]), sb = sin(e[1]), cc = cos(e[2]), sc = sin(e[2]);
+  R[0] = ca * cc - sa * sb * sc; R[1] = -(sa * cb); R[2] = ca * sc + sa * sb * cc;
+  R[3] = sa * cc + ca * sb * sc; R[4] = ca * cb;    R[5] = sa * sc - ca * sb * cc;
+  R[6] = -(cb * sc);             R[7] = sb;         R[8] = cb * cc;
+}
+// the 8 corners of a 9-DoF box (plain values): corner a = centre + R * (+-size/2)
+__device__ inline void box_corners(const real* box, real* c) {
+  real R[9];
+  euler_to_mat(box + 6, R);
   const real SX[8] = {1, 1, 1, 1, -1, -1, -1, -1}, SY[8] = {1, 1, -1, -1, 1, 1, -1, -1},
              SZ[8] = {1, -1, 1, -1, 1, -1, 1, -1};
-  Dual hx = box[3] * 0.5, hy = box[4] * 0.5, hz = box[5] * 0.5;
+#pragma unroll
   for (int a = 0; a < 8; ++a) {
-    Dual ex = hx * SX[a], ey = hy * SY[a], ez = hz * SZ[a];
-    Dual cx = box[0] + (ex * R[0] + ey * R[1] + ez * R[2]);
-    Dual cy = box[1] + (ex * R[3] + ey * R[4] + ez * R[5]);
-    Dual cz = box[2] + (ex * R[6] + ey * R[7] + ez * R[8]);
-    Dual best = dconst(0);
-    real bv = INFINITY;
+    real ex = box[3] * 0.5 * SX[a], ey = box[4] * 0.5 * SY[a], ez = box[5] * 0.5 * SZ[a];
+    c[a * 3 + 0] = box[0] + (ex * R[0] + ey * R[1] + ez * R[2]);
+    c[a * 3 + 1] = box[1] + (ex * R[3] + ey * R[4] + ez * R[5]);
+    c[a * 3 + 2] = box[2] + (ex * R[6] + ey * R[7] + ez * R[8]);
+  }
+}
+// sum over the 8 source corners of min over target corners of the L1 distance; value + gradient g[9] w.r.t. the 9 box
+// parameters.  corner_a = centre + R(e) (S_a o size/2): only R needs dual numbers (3 Euler partials); the nearest target
+// corner is the first minimum (as torch.min), |.|' = sign with sign(0) = 0 (as torch.abs).
+__device__ inline real corner_cd(const real* box, const real* tc, real* g) {
+  Dual<3> e[3] = {dvar<3>(box[6], 0), dvar<3>(box[7], 1), dvar<3>(box[8], 2)}, R[9];
+  deuler_to_mat(e, R);
+  const real h[3] = {box[3] * 0.5, box[4] * 0.5, box[5] * 0.5};
+#pragma unroll
+  for (int c = 0; c < 9; ++c) g[c] = 0;
+  real total = 0;
+#pragma unroll 1
+  for (int a = 0; a < 8; ++a) {
+    const real S[3] = {(a & 4) ? -1.0 : 1.0, (a & 2) ? -1.0 : 1.0, (a & 1) ? -1.0 : 1.0};
+    real c[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      c[r] = box[r] + ((h[0] * S[0]) * R[r * 3].v + (h[1] * S[1]) * R[r * 3 + 1].v + (h[2] * S[2]) * R[r * 3 + 2].v);
+    real bv = INFINITY, bt[3] = {0, 0, 0};                // nearest target corner (registers only: static indices)
+#pragma unroll
     for (int b = 0; b < 8; ++b) {
-      Dual dist = dabs(cx - dconst(tc[b * 3])) + dabs(cy - dconst(tc[b * 3 + 1])) + dabs(cz - dconst(tc[b * 3 + 2]));
-      if (dist.v < bv) { bv = dist.v; best = dist; }
+      real dist = fabs(c[0] - tc[b * 3]) + fabs(c[1] - tc[b * 3 + 1]) + fabs(c[2] - tc[b * 3 + 2]);
+      if (dist < bv) { bv = dist; bt[0] = tc[b * 3]; bt[1] = tc[b * 3 + 1]; bt[2] = tc[b * 3 + 2]; }
     }
-    total = total + best;
+    total += bv;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      real df = c[r] - bt[r];
+      real sg = df > 0 ? 1.0 : (df < 0 ? -1.0 : 0.0);
+      g[r] += sg;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g[3 + k] += sg * (0.5 * S[k]) * R[r * 3 + k].v;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        g[6 + j] += sg * ((h[0] * S[0]) * R[r * 3].d[j] + (h[1] * S[1]) * R[r * 3 + 1].d[j] + (h[2] * S[2]) * R[r * 3 + 2].d[j]);
+    }
   }
   return total;
+}
+// decouple group g of the box loss: group 0 takes the predicted centre, 1 the predicted size, 2 the predicted Euler
+// angles (the other components from the target), 3 the whole prediction.  Returns the weighted value; g9 = weighted
+// gradient w.r.t. the PREDICTED box parameters (zero for the components the group takes from the target).
+__device__ inline real decoupled_cd(const real* pred, const real* tgt, const real* tc, int grp, real wg, real* g9) {
+  real v[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) v[c] = (grp == 3 || c / 3 == grp) ? pred[c] : tgt[c];
+  real g[9];
+  real tot = corner_cd(v, tc, g);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) g9[c] = (grp == 3 || c / 3 == grp) ? g[c] * wg : 0.0;
+  return tot * wg;
 }
 
 // one thread per location of ONE sample (all levels, fine -> coarse); rows with cls_t < 0 exit immediately.
@@ -260,7 +334,21 @@ struct PosLevels {
   float* dho[ES_MAX_LEVELS];
   float* dbbox[ES_MAX_LEVELS];
 };
+// rows with a positive class target, appended to list[1..] (list[0] = count; order = arrival order of the waves)
+__global__ void k_pos_compact(const int* __restrict__ cls_t, int n, int* __restrict__ list, int cap) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool v = i < n && cls_t[i] >= 0;
+  unsigned long long m = __ballot(v);
+  if (m == 0) return;
+  int lane = threadIdx.x & 63, base = 0;
+  if (lane == 0) base = atomicAdd(list, __popcll(m));
+  base = __shfl(base, 0, 64);
+  int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+  if (v && pos < cap) list[1 + pos] = i;
+}
+
 __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t, int n,
+                                                   const int* __restrict__ pos_list, int cap,
                                                    const int* __restrict__ n_pos_dev,
                                                    const float* __restrict__ points, PosLevels LV, int ldc,
                                                    const float* __restrict__ center_t,
@@ -271,10 +359,12 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
   // four consecutive lanes share one location: lane q evaluates decouple group q (its corner-Chamfer term carries the
   // f64 dual numbers), the 13 partial results are then summed over the quad with shuffles
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = tid >> 2, grp = tid & 3;
+  const int slot = tid >> 2, grp = tid & 3;
   float lc = 0.f, lb = 0.f;
-  const bool active = (i < n) && (cls_t[i] >= 0);
+  // the launch covers the host's upper bound `cap` on the positives; the compacted list says how many there are
+  const bool active = slot < min(pos_list[0], cap);
   if (active) {
+    const int i = pos_list[1 + slot];
     const int P = n_pos_dev[0];
     int lv = 0;
     for (int l = 1; l < LV.n; ++l) lv += (i >= LV.off[l]);
@@ -291,61 +381,57 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
       float sg = 1.f / (1.f + expf(-x));
       dcenter[0] = (sg - t) * inv_avg * grad_scale;
     }
-    // ---- box coder on dual numbers (the 12 head outputs are the independent variables)
-    Dual bp[12];
+    // ---- box coder: 12 head outputs -> 9-DoF box.  Only the 6 rotation outputs go through a non-trivial chain
+    // (Dual<6>); distances enter linearly and the Jacobian is completed by hand below.
+    real bp[12];
 #pragma unroll
-    for (int c = 0; c < 12; ++c) bp[c] = dvar(bbox_pred[c], c);
-    D3 xr = {bp[6], bp[7], bp[8]}, yr = {bp[9], bp[10], bp[11]};
-    D3 y = dnormalize(yr);
-    D3 z = dnormalize(dcross(xr, y));
-    D3 xo = dcross(y, z);
-    // matrix columns are (x, y, z): M[r][0]=xo_r, M[r][1]=y_r, M[r][2]=z_r
-    Dual eul[3];
-    eul[0] = datan2(-y.x, y.y);          // atan2(-M01, M11)
-    eul[1] = dasin(y.z);                 // asin(M21)
-    eul[2] = datan2(-xo.z, z.z);         // atan2(-M20, M22)
-    Dual R[9];
-    deuler_to_mat(eul, R);
-    Dual s0 = (bp[1] - bp[0]) * 0.5, s1 = (bp[3] - bp[2]) * 0.5, s2 = (bp[5] - bp[4]) * 0.5;
-    Dual dec[9];
-    dec[0] = dconst(points[(size_t)i * 3 + 0]) + (s0 * R[0] + s1 * R[1] + s2 * R[2]);
-    dec[1] = dconst(points[(size_t)i * 3 + 1]) + (s0 * R[3] + s1 * R[4] + s2 * R[5]);
-    dec[2] = dconst(points[(size_t)i * 3 + 2]) + (s0 * R[6] + s1 * R[7] + s2 * R[8]);
-    dec[3] = bp[0] + bp[1]; dec[4] = bp[2] + bp[3]; dec[5] = bp[4] + bp[5];
-    dec[6] = eul[0]; dec[7] = eul[1]; dec[8] = eul[2];
-    // ---- target corners (constants)
-    Dual tb[9];
-    real tc[24];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) tb[c] = dconst(bbox_t[(size_t)i * 9 + c]);
+    for (int c = 0; c < 12; ++c) bp[c] = (real)bbox_pred[c];
+    Dual<6> eul[3], R[9];
     {
-      Dual Rt[9];
-      deuler_to_mat(tb + 6, Rt);
-      const real SX[8] = {1, 1, 1, 1, -1, -1, -1, -1}, SY[8] = {1, 1, -1, -1, 1, 1, -1, -1},
-                 SZ[8] = {1, -1, 1, -1, 1, -1, 1, -1};
-      for (int a = 0; a < 8; ++a) {
-        real ex = tb[3].v * 0.5 * SX[a], ey = tb[4].v * 0.5 * SY[a], ez = tb[5].v * 0.5 * SZ[a];
-        tc[a * 3 + 0] = tb[0].v + (ex * Rt[0].v + ey * Rt[1].v + ez * Rt[2].v);
-        tc[a * 3 + 1] = tb[1].v + (ex * Rt[3].v + ey * Rt[4].v + ez * Rt[5].v);
-        tc[a * 3 + 2] = tb[2].v + (ex * Rt[6].v + ey * Rt[7].v + ez * Rt[8].v);
-      }
+      D3<6> xr = {dvar<6>(bp[6], 0), dvar<6>(bp[7], 1), dvar<6>(bp[8], 2)};
+      D3<6> yr = {dvar<6>(bp[9], 3), dvar<6>(bp[10], 4), dvar<6>(bp[11], 5)};
+      D3<6> y = dnormalize(yr);
+      D3<6> z = dnormalize(dcross(xr, y));
+      D3<6> xo = dcross(y, z);
+      // matrix columns are (x, y, z): M[r][0]=xo_r, M[r][1]=y_r, M[r][2]=z_r
+      eul[0] = datan2(-y.x, y.y);          // atan2(-M01, M11)
+      eul[1] = dasin(y.z);                 // asin(M21)
+      eul[2] = datan2(-xo.z, z.z);         // atan2(-M20, M22)
     }
-    Dual v[9];
-    Dual tot;
+    deuler_to_mat(eul, R);
+    const real sh[3] = {(bp[1] - bp[0]) * 0.5, (bp[3] - bp[2]) * 0.5, (bp[5] - bp[4]) * 0.5};
+    real dec[9], tb[9], tc[24];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      dec[r] = (real)points[(size_t)i * 3 + r] + (sh[0] * R[r * 3].v + sh[1] * R[r * 3 + 1].v + sh[2] * R[r * 3 + 2].v);
+    dec[3] = bp[0] + bp[1]; dec[4] = bp[2] + bp[3]; dec[5] = bp[4] + bp[5];
+    dec[6] = eul[0].v; dec[7] = eul[1].v; dec[8] = eul[2].v;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) tb[c] = (real)bbox_t[(size_t)i * 9 + c];
+    box_corners(tb, tc);
     const real wg = grp == 0 ? (real)w0 : (grp == 1 ? (real)w1 : (grp == 2 ? (real)w2 : (real)w3));
-    if (grp == 3) {
-      tot = corner_cd(dec, tc) * wg;
-    } else {
-      // group 0: predicted centre, 1: predicted size, 2: predicted euler; the other components from the target
-      for (int c = 0; c < 9; ++c) v[c] = (c / 3 == grp) ? dec[c] : tb[c];
-      tot = corner_cd(v, tc) * wg;
+    real g9[9];
+    real red[13];
+    red[0] = decoupled_cd(dec, tb, tc, grp, wg, g9);
+    // ---- chain to the 12 head outputs: d dec / d bp
+    //   centre_r: -+0.5 R[r][k] w.r.t. the distance pair k, sum_k sh_k dR[r][k] w.r.t. rotation output j
+    //   size_k  : 1 w.r.t. both distances of pair k        euler_e: d eul_e w.r.t. rotation output j
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      real gc = g9[0] * R[k].v + g9[1] * R[3 + k].v + g9[2] * R[6 + k].v;
+      red[1 + 2 * k] = g9[3 + k] - 0.5 * gc;
+      red[2 + 2 * k] = g9[3 + k] + 0.5 * gc;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      real acc = g9[6] * eul[0].d[j] + g9[7] * eul[1].d[j] + g9[8] * eul[2].d[j];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        acc += g9[r] * (sh[0] * R[r * 3].d[j] + sh[1] * R[r * 3 + 1].d[j] + sh[2] * R[r * 3 + 2].d[j]);
+      red[7 + j] = acc;
     }
     real inv_mean = 1.0 / ((real)P * 8.0);
     // quad reduction of value + 12 partials (lanes 4j .. 4j+3 are always in the same wave)
-    real red[13];
-    red[0] = tot.v;
-#pragma unroll
-    for (int c = 0; c < 12; ++c) red[c + 1] = tot.d[c];
 #pragma unroll
     for (int c = 0; c < 13; ++c) {
       red[c] += __shfl_xor(red[c], 1, 64);
@@ -364,13 +450,16 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
     atomicAdd(loss_acc + 1, lb);
   }
 }
-extern "C" int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, const float* points, int n_levels,
+extern "C" int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, int max_pos, int* pos_ws,
+                             const float* points, int n_levels,
                              const int* level_off_host, const void* const* ho_host, const void* const* bbox_host,
                              void* const* dho_host, void* const* dbbox_host, int ldh, const float* center_t,
                              const float* bbox_t, const float* avg_factor_dev, float grad_scale, const float* group_w,
                              float* loss_acc, void* stream) {
-  if (n <= 0) return 0;
+  if (n <= 0 || max_pos <= 0) return 0;
   if (n_levels > ES_MAX_LEVELS) return -3;
+  if (!pos_ws) return -2;
+  if (max_pos > n) max_pos = n;
   PosLevels LV;
   LV.n = n_levels;
   for (int l = 0; l <= n_levels; ++l) LV.off[l] = level_off_host[l];
@@ -380,9 +469,14 @@ extern "C" int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, cons
     LV.dho[l] = (float*)dho_host[l];
     LV.dbbox[l] = (float*)dbbox_host[l];
   }
-  hipLaunchKernelGGL(k_pos_losses, dim3(es_cdiv(n * 4, 64)), dim3(64), 0, (hipStream_t)stream, cls_t, n, n_pos_dev,
-                     points, LV, ldh, center_t, bbox_t, avg_factor_dev, grad_scale, group_w[0], group_w[1], group_w[2],
-                     group_w[3], loss_acc);
+  hipStream_t st = (hipStream_t)stream;
+  // the positives are a few hundred rows out of ~1e5: compact them first so that the register-heavy loss kernel (one
+  // wave per SIMD) is launched over the host's bound only
+  if (hipMemsetAsync(pos_ws, 0, sizeof(int), st) != hipSuccess) return -1;
+  hipLaunchKernelGGL(k_pos_compact, dim3(es_cdiv(n, 256)), dim3(256), 0, st, cls_t, n, pos_ws, max_pos);
+  hipLaunchKernelGGL(k_pos_losses, dim3(es_cdiv(max_pos * 4, 64)), dim3(64), 0, st, cls_t, n, pos_ws, max_pos,
+                     n_pos_dev, points, LV, ldh, center_t, bbox_t, avg_factor_dev, grad_scale, group_w[0], group_w[1],
+                     group_w[2], group_w[3], loss_acc);
   ES_CHECK_LAUNCH();
   return 0;
 }
@@ -404,35 +498,13 @@ __global__ __launch_bounds__(64) void k_box_cd_pairs(const float* __restrict__ p
   if (active) {
     const int b = i / Q;
     const float* tgt = gt_boxes + (size_t)(gt_off[b] + q2g[i]) * 9;
-    Dual dec[9], tb[9];
+    real dec[9], tb[9], tc[24];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) { dec[c] = dvar(pred[(size_t)i * 9 + c], c); tb[c] = dconst(tgt[c]); }
-    real tc[24];
-    {
-      Dual Rt[9];
-      deuler_to_mat(tb + 6, Rt);
-      const real SX[8] = {1, 1, 1, 1, -1, -1, -1, -1}, SY[8] = {1, 1, -1, -1, 1, 1, -1, -1},
-                 SZ[8] = {1, -1, 1, -1, 1, -1, 1, -1};
-      for (int a = 0; a < 8; ++a) {
-        real ex = tb[3].v * 0.5 * SX[a], ey = tb[4].v * 0.5 * SY[a], ez = tb[5].v * 0.5 * SZ[a];
-        tc[a * 3 + 0] = tb[0].v + (ex * Rt[0].v + ey * Rt[1].v + ez * Rt[2].v);
-        tc[a * 3 + 1] = tb[1].v + (ex * Rt[3].v + ey * Rt[4].v + ez * Rt[5].v);
-        tc[a * 3 + 2] = tb[2].v + (ex * Rt[6].v + ey * Rt[7].v + ez * Rt[8].v);
-      }
-    }
+    for (int c = 0; c < 9; ++c) { dec[c] = (real)pred[(size_t)i * 9 + c]; tb[c] = (real)tgt[c]; }
+    box_corners(tb, tc);
     const real wg = grp == 0 ? (real)w0 : (grp == 1 ? (real)w1 : (grp == 2 ? (real)w2 : (real)w3));
-    Dual tot;
-    if (grp == 3) {
-      tot = corner_cd(dec, tc) * wg;
-    } else {
-      Dual v[9];
-      for (int c = 0; c < 9; ++c) v[c] = (c / 3 == grp) ? dec[c] : tb[c];
-      tot = corner_cd(v, tc) * wg;
-    }
     real red[10];
-    red[0] = tot.v;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) red[c + 1] = tot.d[c];
+    red[0] = decoupled_cd(dec, tb, tc, grp, wg, red + 1);
 #pragma unroll
     for (int c = 0; c < 10; ++c) {
       red[c] += __shfl_xor(red[c], 1, 64);

@@ -381,8 +381,13 @@ class FCAF3DHeadRotMat:
                     call('es_focal_loss', hos[l] + 4 * 13, ncol, kt.data_ptr() + 4 * lo[l], n, self.num_classes,
                          self.focal_gamma, self.focal_alpha, avg.data_ptr() + 4 * b, gscale, dhos[l] + 4 * 13, ncol,
                          P(partial), loss_cls.data_ptr() + 4 * b, s)
-            call('es_pos_losses', P(kt), lo[-1], P(npos), P(pts), n_lvl, iarr(lo), parr(hos), parr(bbs), parr(dhos),
-                 parr(dbbs), ncol, P(ct), P(bt), avg.data_ptr() + 4 * b, gscale, gwa, loss_acc.data_ptr() + 8 * b, s)
+            # every ground-truth box keeps at most pts_center_threshold locations (fcaf3d_head.py:1640-1650)
+            max_pos = min(lo[-1], self.pts_center_threshold * int(gts[b][0].shape[0]))
+            if max_pos:
+                pos_ws = torch.empty(max_pos + 1, dtype=torch.int32, device=dev)
+                call('es_pos_losses', P(kt), lo[-1], P(npos), max_pos, P(pos_ws), P(pts), n_lvl, iarr(lo), parr(hos),
+                     parr(bbs), parr(dhos), parr(dbbs), ncol, P(ct), P(bt), avg.data_ptr() + 4 * b, gscale, gwa,
+                     loss_acc.data_ptr() + 8 * b, s)
 
         if on_side:
             with E.side_stream():

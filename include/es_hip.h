@@ -190,15 +190,18 @@ int es_focal_loss(const float* logits, int ldl, const int* labels, int N, int C,
 int es_reg_decode_fwd(const float* reg, int ldr, int n, const float* scale, float* bbox /* (n,12) */, void* stream);
 int es_reg_decode_bwd(const float* reg, int ldr, const float* bbox, const float* dbbox, int n, const float* scale,
                       float* dreg, int ldg, float* dscale, void* stream);
-/* One launch per SAMPLE over its n locations of all levels (fine -> coarse, level_off_host = n_levels+1 row offsets inside
- * the per-sample arrays cls_t / points / center_t / bbox_t).  Rows with cls_t < 0 are skipped (no host-side nonzero()).
+/* Per SAMPLE over its n locations of all levels (fine -> coarse, level_off_host = n_levels+1 row offsets inside the
+ * per-sample arrays cls_t / points / center_t / bbox_t).  Rows with cls_t >= 0 are first compacted on the device (no
+ * host-side nonzero()) into pos_ws (int[max_pos + 1], [0] = count); the loss kernel is launched over max_pos, the host's
+ * upper bound on the positives (FCAF3D: pts_center_threshold * n_gt, every box keeps at most that many locations; n is
+ * always valid; 0 = nothing to do).  Positives beyond max_pos would be dropped: the bound must hold.
  * ho_host[l] / dho_host[l]: this sample's first row of level l in the head output / its gradient (leading dim ldh,
  * column 0 = centerness logit); bbox_host[l] / dbbox_host[l]: decoded (.,12) boxes / their gradient.  All four are HOST
  * arrays of device pointers.  group_w: HOST array of the 4 decouple weights.
  * loss_acc[0] += sum BCE, loss_acc[1] += weighted corner loss (mean over n_pos*8). */
 #define ES_MAX_LEVELS 8
-int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, const float* points, int n_levels,
-                  const int* level_off_host, const void* const* ho_host, const void* const* bbox_host,
+int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, int max_pos, int* pos_ws, const float* points,
+                  int n_levels, const int* level_off_host, const void* const* ho_host, const void* const* bbox_host,
                   void* const* dho_host, void* const* dbbox_host, int ldh, const float* center_t, const float* bbox_t,
                   const float* avg_factor_dev, float grad_scale, const float* group_w_host, float* loss_acc, void* stream);
 

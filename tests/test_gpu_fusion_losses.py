@@ -87,7 +87,8 @@ def test_losses_vs_oracle(golden_dir):
     d_pred, d_ct, d_tgt, d_avg = pred.to(dev), center_t.to(dev), tgt.to(dev), avg.to(dev)
     # two "levels" (rows 0..39 and 40..n) to exercise the level table
     n0 = 40
-    call('es_pos_losses', P(d_cls), n, P(d_np), P(d_pts), 2, iarr([0, n0, n]), parr([d_cp.data_ptr(), d_cp.data_ptr() + 4 * n0]),
+    d_ws = torch.empty(n + 1, dtype=torch.int32, device=dev)     # compacted positives (bound: every row)
+    call('es_pos_losses', P(d_cls), n, P(d_np), n, P(d_ws), P(d_pts), 2, iarr([0, n0, n]), parr([d_cp.data_ptr(), d_cp.data_ptr() + 4 * n0]),
          parr([d_pred.data_ptr(), d_pred.data_ptr() + 48 * n0]), parr([dcen.data_ptr(), dcen.data_ptr() + 4 * n0]),
          parr([dbb.data_ptr(), dbb.data_ptr() + 48 * n0]), 1, P(d_ct), P(d_tgt), P(d_avg), 1.0, farr(w), P(acc),
          torch.cuda.current_stream().cuda_stream)

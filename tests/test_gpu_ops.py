@@ -150,6 +150,40 @@ def test_spconv_bf16_mode(dev):
             assert e < 1e-2
 
 
+def test_wgrad_few_rows_many_channels(dev):
+    """the occupancy neck's coarsest level: a few hundred rows, thousands of channels -> the 128x128-tile weight
+    gradient kernel (f32 and bf16-shadow sources) against the exact f32 kernel; tolerance 5e-3 relative L2 (bf16)."""
+    from embodiedscan_amd.hip import call, P
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(11)
+    n, cin, cout, K = 300, 512, 640, 27
+    nbr = torch.randint(-1, n, (n, K), generator=g, dtype=torch.int32)
+    nbr[torch.rand(n, K, generator=g) < 0.3] = -1
+    x, dy = torch.randn(n, cin, generator=g), torch.randn(n, cout, generator=g)
+    xd, dyd, nd = x.to(dev), dy.to(dev), nbr.to(dev)
+    ref = torch.zeros(K, cin, cout, device=dev)
+    call('es_spconv_wgrad', P(xd), cin, P(dyd), cout, P(nd), n, n, K, cin, cout, P(ref), st)
+    a = torch.zeros_like(ref)
+    call('es_spconv_wgrad_bf16', P(xd), cin, P(dyd), cout, P(nd), n, n, K, cin, cout, P(a), st)
+    xh = torch.empty(n, cin, dtype=torch.bfloat16, device=dev)
+    dyh = torch.empty(n, cout, dtype=torch.bfloat16, device=dev)
+    call('es_cast_rows_bf16', P(xd), cin, n, cin, P(xh), st)
+    call('es_cast_rows_bf16', P(dyd), cout, n, cout, P(dyh), st)
+    b = torch.zeros_like(ref)
+    call('es_spconv_wgrad_bf16_src', P(xh), 1, cin, P(dyh), 1, cout, P(nd), n, n, K, cin, cout, P(b), st)
+    torch.cuda.synchronize()
+    # exact reference on the host for one tap
+    k = 5
+    m = nbr[:, k] >= 0
+    want = x[nbr[m, k].long()].t().double() @ dy[m].double()
+    assert float((ref[k].double().cpu() - want).norm() / want.norm()) < 1e-5
+    for t in (a, b):
+        e = float((t.double() - ref.double()).norm() / ref.double().norm())
+        print(f'wgrad n={n} {cin}->{cout}: relative L2 err vs f32 kernel {e:.2e} (tol 5e-3)')
+        assert e < 5e-3
+    assert float((a - b).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
 def test_gen_transpose_norm_pool(dev):
     from embodiedscan_amd import engine as E
     from oracle import coords as C, sparse as S

@@ -21,13 +21,10 @@ FLOORS = {
     ('spconv.hip', 'k_spconv_wgrad_bf16_big'): 3,
     ('spconv.hip', '19k_spconv_wgrad_bf16IL'): 6,
     ('rowops.hip', 'k_norm_stats'): 8,
-    ('losses.hip', 'k_pos_losses'): 1,
 }
 
 # kernels that are KNOWN to use scratch memory today (anything else spilling is a regression)
 KNOWN_SCRATCH = {
-    'k_pos_losses': 'f64 forward-mode dual numbers with 12 partials per lane: 256 VGPRs + 256 AGPRs + 156 B scratch, '
-                    '1 wave/SIMD; 4 launches of ~0.3 ms per step -- to be re-cut (f32 partials or more lanes per location)',
     'k_nms3d_multiclass': 'predict only: one workgroup per class, f64 polygon clipping, 288 B scratch, 1 wave/SIMD',
     'k_box3d_iou': 'f64 polygon clipping of 12 faces: two 16-vertex polygons per lane in scratch (1 KB); a few thousand '
                    '(query, box) pairs per decoder layer, not on the critical path',
