@@ -34,6 +34,28 @@ def build_detector(cfg_or_path, device='cuda:0', seed=0):
     return MODELS.build(cfg['model'], device=device, seed=seed)
 
 
+def build_dataloader(cfg_or_path, split='train', rank=0, world=1, seed=0, num_threads=None, pin=True, **overrides):
+    """`{split}_dataloader` section of a reference config -> (EmbodiedScanDataset, ScanLoader).  `RepeatDataset(times=k)`
+    becomes the loader's `times`; `num_workers` forked CPU pipelines become decode threads (the transforms themselves
+    run on the device); `overrides` replace dataset arguments (data_root, ann_file, metainfo, ...)."""
+    from . import datasets  # noqa: F401  (registers the classes)
+    from .datasets import ScanLoader
+    from .registry import DATASETS
+    cfg = load_config(cfg_or_path) if isinstance(cfg_or_path, str) else cfg_or_path
+    dl = cfg[f'{split}_dataloader']
+    dcfg, times = dict(dl['dataset']), 1
+    if dcfg.get('type', '').split('.')[-1] == 'RepeatDataset':
+        times, dcfg = dcfg.get('times', 1), dict(dcfg['dataset'])
+    dcfg.update(overrides)
+    ds = DATASETS.build(dcfg)
+    sampler = dl.get('sampler') or {}
+    assert sampler.get('type', 'DefaultSampler').split('.')[-1] == 'DefaultSampler', sampler
+    threads = num_threads if num_threads is not None else max(8, 4 * int(dl.get('num_workers', 1)))
+    return ds, ScanLoader(ds, batch_size=dl.get('batch_size', 1), rank=rank, world=world, shuffle=sampler.get('shuffle', False),
+                          seed=seed, times=times, num_threads=threads, prefetch=2 * threads, pin=pin,
+                          drop_last=dl.get('drop_last', split == 'train'))
+
+
 def build_optim_wrapper(cfg):
     from .optim import OptimWrapper
     ow = cfg.get('optim_wrapper', {})

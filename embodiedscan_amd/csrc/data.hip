@@ -82,6 +82,45 @@ extern "C" int es_preprocess_img(const unsigned char* img, int n_img, int H, int
   return 0;
 }
 
+// ------------------------------------------------------------------ N4: Resize(keep_ratio=False) of the decoded frames
+// (V,H,W,3) interleaved u8 -> (V,3,h,w) planar u8, bilinear with OpenCV's 8-bit fixed-point rule (mmcv.imresize ->
+// cv2.resize INTER_LINEAR): 11-bit coefficients from the host tables (xofs/ialpha, yofs/ibeta: first source index and the
+// two weights per output column / row, built once per size pair by pipeline.resize_tables), horizontal pass in int32,
+// vertical pass  ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2 >> 2.  Integer only: bit-exact against oracle/resize.py.
+__global__ void k_resize_u8(const unsigned char* __restrict__ src, int V, int H, int W, const int* __restrict__ xofs,
+                            const short* __restrict__ ialpha, const int* __restrict__ yofs,
+                            const short* __restrict__ ibeta, int h, int w, unsigned char* __restrict__ dst) {
+  size_t hw = (size_t)h * w, tot = (size_t)V * hw;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int v = (int)(e / hw);
+    int px = (int)(e - (size_t)v * hw);
+    int y = px / w, x = px - y * w;
+    int sx0 = xofs[x], sx1 = min(sx0 + 1, W - 1), sy0 = yofs[y], sy1 = min(sy0 + 1, H - 1);
+    int a0 = ialpha[2 * x], a1 = ialpha[2 * x + 1], b0 = ibeta[2 * y], b1 = ibeta[2 * y + 1];
+    const unsigned char* r0 = src + ((size_t)v * H + sy0) * W * 3;
+    const unsigned char* r1 = src + ((size_t)v * H + sy1) * W * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int S0 = r0[sx0 * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+      int S1 = r1[sx0 * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+      int o = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+      dst[((size_t)v * 3 + c) * hw + px] = (unsigned char)min(max(o, 0), 255);
+    }
+  }
+}
+extern "C" int es_resize_u8(const unsigned char* src, int V, int H, int W, const int* xofs, const short* ialpha,
+                            const int* yofs, const short* ibeta, int h, int w, unsigned char* dst, void* stream) {
+  if (V <= 0 || h <= 0 || w <= 0) return 0;
+  if (H <= 0 || W <= 0) return -2;
+  size_t tot = (size_t)V * h * w;
+  int g = (int)((tot + 255) / 256);
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_resize_u8, dim3(g), dim3(256), 0, (hipStream_t)stream, src, V, H, W, xofs, ialpha, yofs, ibeta, h,
+                     w, dst);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------ ResNet stem: 7x7 s2 p3 conv (3 -> Cout<=32) + frozen-BN
 // affine + ReLU in one direct kernel.  The stem is frozen (frozen_stages=1, configs/detection/mv-det3d_...py:29) so only the
 // forward pass exists.  A workgroup computes a 16x16 output tile from a 37x37x3 input patch staged in LDS together with

@@ -1,0 +1,203 @@
+"""Host side of the real-data path: file decode and the random decisions of the reference's train / test
+pipeline.  Everything that touches pixels or points afterwards runs on the device:
+
+  reference CPU transform (configs/detection/mv-det3d_...py:134-160)      here
+  -----------------------------------------------------------------      ---------------------------------------------
+  MultiViewPipeline view choice   (transforms/multiview.py:46-64)         select_views()            host, same draws
+  LoadImageFromFile / LoadDepthFromFile (transforms/loading.py:53-81)     decode_image / decode_depth   host (PIL)
+  ConvertRGBDToPoints + PointSample(n/10) (transforms/points.py:40-53,    sample_pixels(): only the CHOICE of pixels;
+      189-206), AggregateMultiViewPoints, PointSample(n)                  unprojection = es_depth_to_points (A1-A3)
+  Resize((480, 480), keep_ratio=False)                                    es_resize_u8 on the device (pipeline.py)
+  RandomFlip3D + GlobalRotScaleTrans (transforms/augmentation.py:         draw_augmentation(): the draws; points are
+      87-139, 322-447)                                                    transformed inside es_depth_to_points, the
+                                                                          boxes by pipeline.augment_gt_boxes
+
+The draws are taken from one numpy RandomState in the reference's order, so a seeded run of the reference pipeline and of
+this one take the same decisions (pinned for the view choice and PointSample by tests/golden/dataset_parse.pkl)."""
+import numpy as np
+
+
+def decode_image(path):
+    """-> (H, W, 3) uint8 RGB.  (The reference decodes to BGR with cv2 and the data preprocessor swaps to RGB,
+    data_preprocessor.py `bgr_to_rgb=True`; PIL yields RGB directly.)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert('RGB'))
+
+
+def decode_depth(path, depth_shift):
+    """16-bit PNG -> float32 metres: `imfrombytes(flag='unchanged').astype(float32) / depth_shift` (loading.py:68-73)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im)
+    if a.ndim != 2:
+        raise ValueError(f'{path}: depth image must have one channel, got shape {a.shape}')
+    return a.astype(np.float32) / np.float32(depth_shift)
+
+
+def select_views(n_total, n_images, ordered, rng):
+    """ids of the frames MultiViewPipeline keeps (multiview.py:46-64, including the ordered-mode stride rule)"""
+    ids = np.arange(n_total)
+    replace = n_images > len(ids)
+    if ordered:
+        step = (len(ids) - 1) // (n_images - 1)
+        if step > 0:
+            return ids[::step][:n_images]
+        return rng.choice(ids, n_images, replace=replace)
+    return rng.choice(ids, n_images, replace=replace)
+
+
+def sample_pixels(depth, num_points, rng):
+    """PointSample on the points of one frame: the points are the non-zero depth pixels in raster order
+    (points.py:46-53), `choice(range(len), num, replace = len < num)` (points.py:189-206).  Returns pixel indices;
+    an all-zero depth map yields no points (points.py:132-134)."""
+    nz = np.flatnonzero(depth.reshape(-1))
+    if len(nz) == 0:
+        return nz.astype(np.int32)
+    choices = rng.choice(range(len(nz)), num_points, replace=len(nz) < num_points)
+    return nz[choices].astype(np.int32)
+
+
+def draw_augmentation(cfg, rng):
+    """RandomFlip3D then GlobalRotScaleTrans: two rand() for the flips (augmentation.py:114-123), uniform rotation
+    (negated, 377-382), uniform scale (445-446), normal translation (360-361).  -> the `aug` dict of pipeline.py"""
+    hf = bool(rng.rand() < cfg['flip_h']) if cfg.get('flip') else False
+    vf = bool(rng.rand() < cfg['flip_v']) if cfg.get('flip') else False
+    aug = dict(hflip=hf, vflip=vf, rot=np.eye(3, dtype=np.float32), scale=1.0, trans=np.zeros(3, np.float32))
+    meta = dict(transformation_3d_flow=(['HF'] if hf else []) + (['VF'] if vf else []))
+    if cfg.get('flip'):
+        meta.update(pcd_horizontal_flip=hf, pcd_vertical_flip=vf)
+    if cfg.get('rst'):
+        ang = -rng.uniform(cfg['rot_range'][0], cfg['rot_range'][1])
+        scale = float(rng.uniform(cfg['scale_range'][0], cfg['scale_range'][1]))
+        trans = rng.normal(scale=np.array(cfg['trans_std'], dtype=np.float32), size=3).T.astype(np.float32)
+        c, s = np.cos(ang), np.sin(ang)
+        # rotation about z applied as points @ rot_mat_T (base_points.py:198-201, euler_box3d.py rotate)
+        rot_mat_T = np.array([[c, s, 0], [-s, c, 0], [0, 0, 1]], dtype=np.float32)
+        aug.update(rot=rot_mat_T, scale=scale, trans=trans)
+        meta.update(pcd_rotation=rot_mat_T, pcd_rotation_angle=ang, pcd_scale_factor=scale, pcd_trans=trans)
+        meta['transformation_3d_flow'] += ['R', 'S', 'T']
+    return aug, meta
+
+
+class ScanPipeline:
+    """The parameters of a reference pipeline config (list of transform dicts) + the host work it implies."""
+
+    def __init__(self, n_images=20, ordered=False, n_points=100000, view_points=None, img_scale=(480, 480),
+                 flip=False, flip_h=0.5, flip_v=0.5, rst=False, rot_range=(-0.087266, 0.087266), scale_range=(.9, 1.1),
+                 trans_std=(.1, .1, .1), with_occupancy=False, view_masks=False, point_range=None):
+        self.n_images, self.ordered = n_images, ordered
+        self.n_points, self.view_points = n_points, view_points if view_points is not None else n_points // 10
+        self.img_scale = tuple(img_scale)                      # (w, h) as in mmcv Resize
+        self.aug = dict(flip=flip, flip_h=flip_h, flip_v=flip_v, rst=rst, rot_range=tuple(rot_range),
+                        scale_range=tuple(scale_range), trans_std=tuple(trans_std))
+        self.with_occupancy, self.view_masks = with_occupancy, view_masks
+        # PointsRangeFilter (occupancy configs): the reference filters the aggregated cloud on the CPU and THEN samples
+        # n_points among the survivors (transforms/points.py:232-262); here the n_points pixels are chosen first (the
+        # host never sees 3-D coordinates) and the device drops the out-of-range ones when it voxelises -- the cloud is
+        # thinner by the out-of-range fraction.  Kept in the scan so the consumer can apply it.
+        self.point_range = None if point_range is None else tuple(point_range)
+
+    @classmethod
+    def from_cfg(cls, pipeline):
+        """read the knobs out of the reference's transform list; unknown transforms are an error, not a silent skip"""
+        kw = {}
+        if isinstance(pipeline, ScanPipeline):
+            return pipeline
+        for t in pipeline or ():
+            ty = t['type'].split('.')[-1]
+            if ty == 'MultiViewPipeline':
+                kw.update(n_images=t['n_images'], ordered=t.get('ordered', False))
+                for u in t['transforms']:
+                    uy = u['type'].split('.')[-1]
+                    if uy == 'PointSample':
+                        kw['view_points'] = u['num_points']
+                    elif uy == 'Resize':
+                        assert not u.get('keep_ratio', False), 'Resize(keep_ratio=True) is not used by the shipped configs'
+                        kw['img_scale'] = tuple(u['scale'])
+                    elif uy == 'ConvertRGBDToPoints':
+                        assert not u.get('use_color', False), 'coloured points are not part of the device path'
+                    elif uy not in ('LoadImageFromFile', 'LoadDepthFromFile'):
+                        raise NotImplementedError(f'per-view transform {uy}')
+            elif ty == 'PointSample':
+                kw['n_points'] = t['num_points']
+            elif ty == 'RandomFlip3D':
+                kw.update(flip=True, flip_h=t.get('flip_ratio_bev_horizontal', 0.0), flip_v=t.get('flip_ratio_bev_vertical', 0.0))
+            elif ty == 'GlobalRotScaleTrans':
+                std = t.get('translation_std', (0, 0, 0))
+                kw.update(rst=True, rot_range=tuple(t.get('rot_range', (-0.78539816, 0.78539816))),
+                          scale_range=tuple(t.get('scale_ratio_range', (0.95, 1.05))),
+                          trans_std=tuple(std) if isinstance(std, (list, tuple)) else (std,) * 3)
+            elif ty == 'LoadAnnotations3D':
+                kw['with_occupancy'] = bool(t.get('with_occupancy', False))
+            elif ty == 'PointsRangeFilter':
+                kw['point_range'] = tuple(t['point_cloud_range'])
+            elif ty == 'ConstructMultiViewMasks':
+                kw['view_masks'] = True
+            elif ty in ('AggregateMultiViewPoints', 'Pack3DDetInputs'):
+                pass
+            else:
+                raise NotImplementedError(f'pipeline transform {ty}')
+        return cls(**kw)
+
+    def __call__(self, info, rng):
+        """info: one parsed data_info -> raw scan dict (numpy), the exchange format of pipeline.pin_scan/upload_scan:
+        depth (V,H,W) f32 metres, img_raw (V,H,W,3) u8 RGB at the file's resolution (resized on the device),
+        extrinsic / intrinsic (V,4,4), sel_view / sel_pix (n_points,), gt_boxes (G,9) augmented, gt_labels, meta, aug."""
+        ids = select_views(len(info['img_path']), self.n_images, self.ordered, rng)
+        depths, imgs, sel_view, sel_pix = [], [], [], []
+        intr_all, extr = info['depth2img']['intrinsic'], []
+        intr = []
+        dci = info['depth_cam2img']
+        depth_intr = []
+        for j, i in enumerate(ids.tolist()):
+            imgs.append(decode_image(info['img_path'][i]))
+            d = decode_depth(info['depth_img_path'][i], info['depth_shift'])
+            depths.append(d)
+            pix = sample_pixels(d, self.view_points, rng)
+            sel_pix.append(pix)
+            sel_view.append(np.full(len(pix), j, np.int32))
+            intr.append(np.asarray(intr_all[i] if isinstance(intr_all, list) else intr_all, np.float32))
+            depth_intr.append(np.asarray(dci[i] if isinstance(dci, list) else dci, np.float32))
+            extr.append(info['depth2img']['extrinsic'][i])
+        sel_view, sel_pix = np.concatenate(sel_view), np.concatenate(sel_pix)
+        # PointSample(n_points) over the aggregated cloud (points.py:189-206)
+        if len(sel_pix):
+            pick = rng.choice(range(len(sel_pix)), self.n_points, replace=len(sel_pix) < self.n_points)
+            sel_view, sel_pix = sel_view[pick], sel_pix[pick]
+        aug, aug_meta = draw_augmentation(self.aug, rng)
+        shapes = {im.shape[:2] for im in imgs} | {d.shape for d in depths}
+        if len(shapes) != 1:
+            raise ValueError(f"{info['sample_idx']}: frames of one scan must share a resolution, got {sorted(shapes)}")
+        H, W = imgs[0].shape[:2]
+        w_new, h_new = self.img_scale
+        ann = info.get('ann_info') or info.get('eval_ann_info') or {}
+        boxes = np.asarray(ann.get('gt_bboxes_3d', np.zeros((0, 9), np.float32)), np.float32)
+        labels = np.asarray(ann.get('gt_labels_3d', np.zeros((0,), np.int64)), np.int64)
+        from ..pipeline import augment_gt_boxes
+        meta = dict(depth2img=dict(extrinsic=extr, intrinsic=intr, origin=info['depth2img']['origin']),
+                    img_shape=(h_new, w_new), ori_shape=(H, W), scale_factor=(w_new / W, h_new / H),
+                    box_type_3d='euler-depth', scan_id=info['scan_id'], sample_idx=info['sample_idx'],
+                    img_path=[info['img_path'][i] for i in ids.tolist()])
+        meta.update(aug_meta)
+        scan = dict(depth=np.stack(depths), img_raw=np.stack(imgs), extrinsic=np.stack(extr).astype(np.float32),
+                    intrinsic=np.stack(depth_intr), sel_view=sel_view.astype(np.int32), sel_pix=sel_pix.astype(np.int32),
+                    gt_boxes=augment_gt_boxes(boxes, aug).numpy(), gt_labels=labels, meta=meta, aug=aug)
+        if self.with_occupancy and 'gt_occupancy' in ann:
+            scan['gt_occupancy'] = ann['gt_occupancy']
+            vm = ann.get('visible_occupancy_masks')
+            if vm is not None and len(vm) and len(vm[0]):
+                vm = [np.asarray(vm[i]) for i in ids.tolist()]
+                scan['visible_occupancy_masks'] = vm
+                if self.view_masks:
+                    # ConstructMultiViewMasks (multiview.py:253-268): OR over the chosen frames -- the reference's loop
+                    # is `range(1, len(img) - 1)`, i.e. the LAST frame never contributes; kept as is
+                    m = vm[0]
+                    for j in range(1, len(vm) - 1):
+                        m = np.logical_or(m, vm[j])
+                    scan['gt_occupancy_masks'] = m
+        if self.point_range is not None:
+            scan['point_range'] = self.point_range
+        if 'visible_instance_masks' in ann:
+            scan['visible_instance_masks'] = [ann['visible_instance_masks'][i] for i in ids.tolist()]
+        return scan

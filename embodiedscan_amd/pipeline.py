@@ -27,44 +27,109 @@ def scan_matrices(scan):
     return mats, aug
 
 
-def upload_scan(scan, device):
-    """host -> HBM copy of the raw inputs of one scan (done before the timed region in bench.py)."""
+def _axis_table(n_src, n_dst):
+    """first source index + the two 11-bit weights per output index of OpenCV's INTER_LINEAR (imgproc resize.cpp,
+    resizeGeneric_: fx = (float)((d + 0.5) * scale - 0.5), clamped at both ends, cvRound(w * 2048))"""
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (float(n_src) / float(n_dst)) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int32)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    edge = (s < 0) | (s >= n_src - 1)
+    s = np.clip(s, 0, n_src - 1)
+    f[edge] = 0.0
+    c = np.stack([np.float32(1.0) - f, f], 1) * np.float32(2048.0)
+    return torch.from_numpy(s), torch.from_numpy(np.rint(c).astype(np.int16))
+
+
+_RESIZE_TABLES = {}
+
+
+def resize_tables(H, W, h, w, device):
+    """device-resident coefficient tables of es_resize_u8 for (H, W) -> (h, w), built once per size pair and device"""
+    key = (H, W, h, w, str(device))
+    t = _RESIZE_TABLES.get(key)
+    if t is None:
+        xo, xa = _axis_table(W, w)
+        yo, yb = _axis_table(H, h)
+        t = _RESIZE_TABLES[key] = tuple(a.to(device) for a in (xo, xa, yo, yb))
+    return t
+
+
+def resize_frames(img_raw, size_hw, out=None):
+    """Resize(keep_ratio=False) of the decoded frames on the device: (V,H,W,3) u8 RGB -> (V,3,h,w) u8 (es_resize_u8)"""
+    V, H, W, _ = img_raw.shape
+    h, w = size_hw
+    if out is None:
+        out = torch.empty((V, 3, h, w), dtype=torch.uint8, device=img_raw.device)
+    xo, xa, yo, yb = resize_tables(H, W, h, w, img_raw.device)
+    call('es_resize_u8', P(img_raw), V, H, W, P(xo), P(xa), P(yo), P(yb), h, w, P(out),
+         torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+def _host_tensors(scan):
+    """the arrays of one raw scan that go to the device.  A scan from the dataset reader carries `img_raw` (decoded frames
+    at the file resolution, resized on the device); a synthetic scan carries `img` at the network resolution."""
     mats, aug = scan_matrices(scan)
-    return dict(depth=torch.from_numpy(scan['depth']).to(device), img=torch.from_numpy(scan['img']).to(device),
-                sel_view=torch.from_numpy(scan['sel_view']).to(device), sel_pix=torch.from_numpy(scan['sel_pix']).to(device),
-                mats=mats.to(device), aug=aug.to(device), meta=scan['meta'],
-                gt_boxes=torch.from_numpy(scan['gt_boxes']), gt_labels=torch.from_numpy(scan['gt_labels']))
+    host = dict(depth=torch.from_numpy(scan['depth']), sel_view=torch.from_numpy(scan['sel_view']),
+                sel_pix=torch.from_numpy(scan['sel_pix']), mats=mats, aug=aug)
+    if 'img_raw' in scan:
+        host['img_raw'] = torch.from_numpy(scan['img_raw'])
+    else:
+        host['img'] = torch.from_numpy(scan['img'])
+    return host
 
 
-_DEV_KEYS = ('depth', 'img', 'sel_view', 'sel_pix', 'mats', 'aug')
+def _finish(d, scan):
+    d.update(meta=scan['meta'], gt_boxes=torch.as_tensor(scan['gt_boxes']), gt_labels=torch.as_tensor(scan['gt_labels']))
+    for k in ('gt_occupancy', 'gt_occupancy_masks', 'visible_occupancy_masks', 'visible_instance_masks', 'point_range'):
+        if k in scan:
+            d[k] = scan[k]
+    return d
 
 
-def pin_scan(scan):
+def upload_scan(scan, device):
+    """host -> HBM copy of the raw inputs of one scan (blocking; bench.py's timed path uses pin_scan / upload_into)."""
+    d = {k: v.to(device) for k, v in _host_tensors(scan).items()}
+    if 'img_raw' in d:
+        d['img'] = resize_frames(d.pop('img_raw'), scan['meta']['img_shape'])
+    return _finish(d, scan)
+
+
+def pin_scan(scan, pin=True):
     """raw inputs of one scan as PINNED host tensors (what a data-loader worker hands over): source of the per-step
     host->device copy that bench.py keeps inside the timed step"""
-    mats, aug = scan_matrices(scan)
-    host = dict(depth=torch.from_numpy(scan['depth']), img=torch.from_numpy(scan['img']),
-                sel_view=torch.from_numpy(scan['sel_view']), sel_pix=torch.from_numpy(scan['sel_pix']), mats=mats, aug=aug)
-    out = {k: v.contiguous().pin_memory() for k, v in host.items()}
-    out.update(meta=scan['meta'], gt_boxes=torch.from_numpy(scan['gt_boxes']), gt_labels=torch.from_numpy(scan['gt_labels']))
-    return out
+    out = {k: (v.contiguous().pin_memory() if pin else v.contiguous()) for k, v in _host_tensors(scan).items()}
+    return _finish(out, scan)
+
+
+def _dev_keys(pinned):
+    return [k for k in ('depth', 'img', 'img_raw', 'sel_view', 'sel_pix', 'mats', 'aug') if k in pinned]
 
 
 def alloc_slot(pinned, device):
     """preallocated device buffers shaped like one pinned scan (double-buffered by the caller: no allocation and no
     allocator traffic on the copy stream)"""
-    return {k: torch.empty_like(pinned[k], device=device) for k in _DEV_KEYS}
+    slot = {k: torch.empty_like(pinned[k], device=device) for k in _dev_keys(pinned)}
+    if 'img_raw' in slot:
+        h, w = pinned['meta']['img_shape']
+        slot['img'] = torch.empty((pinned['img_raw'].shape[0], 3, h, w), dtype=torch.uint8, device=device)
+    return slot
 
 
 def upload_into(slot, pinned):
-    """async host->device copy of one scan into a slot on the CURRENT stream; returns the dscan dict make_batch takes"""
-    for k in _DEV_KEYS:
+    """async host->device copy of one scan into a slot on the CURRENT stream (+ the device resize of decoded frames, on
+    the same stream); returns the dscan dict make_batch takes"""
+    for k in _dev_keys(pinned):
         slot[k].copy_(pinned[k], non_blocking=True)
-    return dict(slot, meta=pinned['meta'], gt_boxes=pinned['gt_boxes'], gt_labels=pinned['gt_labels'])
+    if 'img_raw' in slot:
+        resize_frames(slot['img_raw'], pinned['meta']['img_shape'], out=slot['img'])
+    d = dict(slot)
+    d.pop('img_raw', None)
+    return _finish(d, {k: pinned[k] for k in pinned if k not in slot})
 
 
 def scan_h2d_bytes(pinned):
-    return sum(pinned[k].numel() * pinned[k].element_size() for k in _DEV_KEYS)
+    return sum(pinned[k].numel() * pinned[k].element_size() for k in _dev_keys(pinned))
 
 
 def depth_to_points(dscan):
@@ -111,10 +176,13 @@ def make_batch(dscans):
     return {'inputs': {'points': points, 'img': imgs}, 'data_samples': samples}
 
 
-def make_occ_batch(dscans, occ_gts):
+def make_occ_batch(dscans, occ_gts=None):
     """`data` dict for DenseFusionOccPredictor.train_step: the detection batch plus `gt_occupancy` (N,4) and
-    `gt_occupancy_masks` (X,Y,Z) on every data sample (Pack3DDetInputs, datasets/transforms/formatting.py:254-264)."""
+    `gt_occupancy_masks` (X,Y,Z) on every data sample (Pack3DDetInputs, datasets/transforms/formatting.py:254-264).
+    occ_gts None: scans from the dataset reader carry both themselves."""
     data = make_batch(dscans)
+    if occ_gts is None:
+        occ_gts = [dict(gt_occupancy=d['gt_occupancy'], gt_occupancy_masks=d.get('gt_occupancy_masks')) for d in dscans]
     for ds, occ in zip(data['data_samples'], occ_gts):
         ds.gt_occupancy = torch.as_tensor(occ['gt_occupancy'])
         m = occ.get('gt_occupancy_masks')

@@ -194,3 +194,71 @@ def make_grounding_sample(scan, seed=0, max_targets=3):
     words += filler[:int(rng.integers(2, len(filler)))]
     return dict(text=' '.join(words), tokens_positive=spans, gt_boxes=scan['gt_boxes'][pick].astype(np.float32),
                 gt_labels=np.zeros(G, np.int64))
+
+
+def write_dataset(root, n_scans=2, n_frames=6, height=60, width=80, n_boxes=6, class_names=None, seed=0,
+                  ann_name='embodiedscan_infos_train.pkl', occupancy=True, n_voxels=(40, 40, 16), jpeg_quality=90,
+                  render_device='cpu'):
+    """Write a small synthetic dataset in the EmbodiedScan on-disk layout: the info `.pkl` the reference's
+    EmbodiedScanDataset reads (embodiedscan_dataset.py:315-375: `metainfo.categories`, `data_list[*]` with
+    sample_idx / axis_align_matrix / cam2img / depth_cam2img / images[*]{img_path, depth_path, cam2global,
+    visible_instance_ids} / instances[*]{bbox_3d, bbox_label_3d, bbox_id}), JPEG colour frames, 16-bit PNG depth in
+    millimetres (depth_shift 1000, :103-107), and per-scan occupancy.npy / visible_occupancy.pkl (:201-244).
+    Geometry comes from make_scan (unaugmented); returns the list of source scans for round-trip checks."""
+    import os
+    import pickle
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    class_names = list(class_names or (_NOUNS + ['object']))
+    categories = {n: 3 * i + 1 for i, n in enumerate(class_names)}            # sparse ids: exercises label_mapping
+    categories['unlabelled thing'] = 3 * len(class_names) + 5                 # a category outside `classes` -> label -1
+    data_list, scans = [], []
+    for s in range(n_scans):
+        scan = make_scan(seed * 1000 + s, n_views=n_frames, height=height, width=width, img_size=(height, width),
+                         n_boxes=n_boxes, n_points=2000, n_classes=len(class_names), augment=False,
+                         render_device=render_device)
+        scans.append(scan)
+        name = f'scene{s:04d}_00'
+        sample_idx = f'scannet/{name}'
+        ang = rng.uniform(-math.pi, math.pi)
+        A = np.eye(4)
+        A[:3, :3] = _euler_zxy([ang, 0, 0])
+        A[:3, 3] = rng.uniform(-1, 1, 3)
+        Ainv = np.linalg.inv(A)
+        frame_dir = os.path.join(root, 'scannet', 'posed_images', name)
+        os.makedirs(frame_dir, exist_ok=True)
+        images = []
+        yy, xx = np.meshgrid(np.arange(height), np.arange(width), indexing='ij')
+        for v in range(n_frames):
+            base = np.stack([(xx * (3 + v) + s * 17) % 256, (yy * (2 + v)) % 256, ((xx + yy) * 2 + 40 * v) % 256], -1)
+            img = np.clip(base + rng.integers(-12, 13, base.shape), 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(frame_dir, f'{v:05d}.jpg'), quality=jpeg_quality)
+            mm = np.clip(np.rint(scan['depth'][v] * 1000.0), 0, 65535).astype(np.uint16)
+            Image.fromarray(mm).save(os.path.join(frame_dir, f'{v:05d}.png'))
+            c2w = np.linalg.inv(scan['extrinsic'][v].astype(np.float64))
+            vis = sorted(rng.choice(n_boxes, rng.integers(1, n_boxes + 1), replace=False).tolist())
+            images.append(dict(img_path=f'scannet/posed_images/{name}/{v:05d}.jpg',
+                               depth_path=f'scannet/posed_images/{name}/{v:05d}.png',
+                               cam2global=Ainv @ c2w, visible_instance_ids=vis))
+        instances = []
+        for b in range(n_boxes):
+            lab = categories['unlabelled thing'] if (b == n_boxes - 1 and s == 0) else categories[class_names[int(scan['gt_labels'][b])]]
+            instances.append(dict(bbox_3d=scan['gt_boxes'][b].astype(np.float64).tolist(), bbox_label_3d=int(lab), bbox_id=b + 1))
+        data_list.append(dict(sample_idx=sample_idx, axis_align_matrix=A, cam2img=scan['intrinsic'][0].astype(np.float64),
+                              depth_cam2img=scan['intrinsic'][0].astype(np.float64), images=images, instances=instances))
+        if occupancy:
+            occ = make_occ_gt(scan, n_voxels=n_voxels, n_classes=len(class_names) + 1, seed=seed + s)
+            g = occ['gt_occupancy'].copy()
+            ids = np.array([categories[n] for n in class_names])
+            g[:, 3] = ids[g[:, 3] - 1]                                        # file stores category ids
+            g[: min(3, len(g)), 3] = categories['unlabelled thing']           # -> 255 (ignored) after mapping
+            occ_dir = os.path.join(root, 'scannet', 'scans', name, 'occupancy')
+            os.makedirs(occ_dir, exist_ok=True)
+            np.save(os.path.join(occ_dir, 'occupancy.npy'), g)
+            masks = [dict(visible_occupancy=(rng.random(n_voxels) < 0.3)) for _ in range(n_frames)]
+            with open(os.path.join(occ_dir, 'visible_occupancy.pkl'), 'wb') as f:
+                pickle.dump(masks, f)
+    meta = dict(categories=categories, DATASET='EmbodiedScan', version='synthetic')
+    with open(os.path.join(root, ann_name), 'wb') as f:
+        pickle.dump(dict(metainfo=meta, data_list=data_list), f)
+    return scans, class_names

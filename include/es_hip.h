@@ -233,6 +233,13 @@ int es_preprocess_img(const unsigned char* img, int n_img, int H, int W, int Hp,
                       const float* mean_host, const float* std_host, float pad_value,
                       float* out /* (n_img,Hp,Wp,3) */, void* stream);
 
+/* ---- N4 real-data path: Resize((w,h), keep_ratio=False) of the decoded frames on the device (configs/detection/
+ * mv-det3d_...py:143; mmcv.imresize -> cv2.resize INTER_LINEAR, 8-bit fixed point).  src (V,H,W,3) interleaved u8 ->
+ * dst (V,3,h,w) planar u8.  xofs (w) / yofs (h): first source column / row; ialpha (w,2) / ibeta (h,2): the two 11-bit
+ * weights (device arrays, built on the host once per size pair). */
+int es_resize_u8(const unsigned char* src, int V, int H, int W, const int* xofs, const short* ialpha, const int* yofs,
+                 const short* ibeta, int h, int w, unsigned char* dst, void* stream);
+
 /* ---- A20 occupancy path (BASELINE config 5).  detectors/dense_fusion_occ.py:120-259, necks/imvoxel_neck.py:34-143,
  * dense_heads/imvoxel_occ_head.py:73-184, losses/occ_loss.py:7-141 ------------------------------------------------------ */
 /* neighbour map of a dense (B,X,Y,Z) grid for nn.Conv3d(k, stride, pad): nbr (B*Xo*Yo*Zo, k^3), row = ((b*X+x)*Y+y)*Z+z,

@@ -155,6 +155,55 @@ def _populate(module):
             def __contains__(self, k):
                 return k in self.__dict__
         module.InstanceData = InstanceData
+    if n in ('mmengine', 'mmengine.fileio'):
+        def load(path, *a, **k):
+            """mmengine.load for the two formats the dataset class reads (.pkl, and .npy through numpy itself)"""
+            import pickle
+            with open(path, 'rb') as f:
+                return pickle.load(f)
+        module.load = load
+    if n == 'mmengine.dataset':
+        import copy
+        import os
+
+        class BaseDataset:
+            """the part of mmengine.dataset.BaseDataset (v0.10, base_dataset.py) the reference's dataset class relies
+            on: metainfo copy, `_join_prefix` (ann_file and every data_prefix entry joined with data_root), eager
+            `full_init` = load_data_list()"""
+
+            def __init__(self, ann_file='', metainfo=None, data_root='', data_prefix=dict(img_path=''), pipeline=(),
+                         test_mode=False, **kw):
+                self.ann_file, self.data_root, self.test_mode = ann_file, data_root, test_mode
+                self._metainfo = copy.deepcopy(dict(metainfo or {}))
+                self.data_prefix = copy.copy(data_prefix)
+                if self.ann_file and not os.path.isabs(self.ann_file) and self.data_root:
+                    self.ann_file = os.path.join(self.data_root, self.ann_file)
+                for k, v in list(self.data_prefix.items()):
+                    if not os.path.isabs(v) and self.data_root:
+                        self.data_prefix[k] = os.path.join(self.data_root, v)
+                self.data_list = self.load_data_list()
+
+            @property
+            def metainfo(self):
+                return self._metainfo
+        module.BaseDataset = BaseDataset
+    if n == 'mmcv.transforms':
+        class BaseTransform:
+            def __call__(self, results):
+                return self.transform(results)
+
+        class Compose:
+            def __init__(self, transforms=()):
+                self.transforms = list(transforms or ())
+
+            def __call__(self, data):
+                for t in self.transforms:
+                    data = t(data)
+                    if data is None:
+                        return None
+                return data
+        module.BaseTransform = BaseTransform
+        module.Compose = Compose
     if n == 'mmdet.models.task_modules':
         class AssignResult:
             def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):

@@ -1,0 +1,240 @@
+"""the `.pkl` annotation reader and the host half of the real-data path against golden vectors made by
+the reference's own EmbodiedScanDataset / MultiViewPipeline / PointSample (oracle/make_golden_dataset.py), plus round
+trips through a freshly written synthetic dataset and the DefaultSampler-style rank sharding."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+FIX_NAMES = None
+
+
+def _names():
+    from embodiedscan_amd.synth import _NOUNS
+    return _NOUNS + ['object']
+
+
+def _same(a, b, path=''):
+    """recursive equality of parsed infos (arrays exact, golden paths carry '<root>')"""
+    if isinstance(b, dict):
+        assert isinstance(a, dict), path
+        kb = set(b)
+        ka = set(a) - {'box_type_3d'}
+        assert ka == kb, (path, sorted(ka ^ kb))
+        for k in kb:
+            _same(a[k], b[k], f'{path}.{k}')
+    elif isinstance(b, (list, tuple)):
+        assert len(a) == len(b), (path, len(a), len(b))
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f'{path}[{i}]')
+    elif isinstance(b, np.ndarray):
+        a = np.asarray(a)
+        assert a.shape == b.shape and a.dtype == b.dtype, (path, a.shape, b.shape, a.dtype, b.dtype)
+        assert np.array_equal(a, b), path
+    elif isinstance(b, str):
+        assert a == b, (path, a, b)
+    else:
+        assert a == b, (path, a, b)
+
+
+def _strip_root(x, root):
+    if isinstance(x, dict):
+        return {k: _strip_root(v, root) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_strip_root(v, root) for v in x]
+    if isinstance(x, str):
+        return x.replace(root, '<root>')
+    return x
+
+
+@pytest.fixture(scope='module')
+def golden(golden_dir):
+    with open(os.path.join(golden_dir, 'dataset_parse.pkl'), 'rb') as f:
+        return pickle.load(f)
+
+
+@pytest.mark.parametrize('tag', ['train', 'test', 'subset_nodontcare', 'default_classes'])
+def test_reader_matches_reference_parse(golden, golden_dir, tag):
+    """every key of every parsed info (paths, extrinsics = inv(axis_align @ cam2global), intrinsics, depth_shift, boxes,
+    mapped labels, visibility masks, occupancy with the 255 rule, eval_ann_info) equals the reference's, bit for bit"""
+    from embodiedscan_amd.datasets import EmbodiedScanDataset
+    names = _names()
+    kw = dict(train=dict(metainfo=dict(classes=names)), test=dict(metainfo=dict(classes=names), test_mode=True),
+              subset_nodontcare=dict(metainfo=dict(classes=names[:5], occ_classes=names[:7]), remove_dontcare=True),
+              default_classes=dict(metainfo=dict(occ_classes=names)))[tag]
+    root = os.path.join(golden_dir, 'fake_dataset')
+    ds = EmbodiedScanDataset(data_root=root, ann_file='embodiedscan_infos_train.pkl', pipeline=[], **kw)
+    g = golden[tag]
+    assert list(ds.metainfo['classes']) == g['classes']
+    assert np.array_equal(ds.label_mapping, g['label_mapping']) and np.array_equal(ds.occ_label_mapping, g['occ_label_mapping'])
+    assert len(ds) == len(g['data_list']) == 2
+    _same(_strip_root(ds.data_list, root), g['data_list'], tag)
+
+
+def test_view_choice_and_point_sample_follow_the_reference_stream(golden):
+    """same seeded numpy stream -> same frames (incl. the ordered-mode stride rule and its fall-back) and same PointSample
+    choices as the reference transforms"""
+    from embodiedscan_amd.datasets.loading import sample_pixels, select_views
+    for v in golden['views']:
+        ids = select_views(v['n_total'], v['n_images'], v['ordered'], np.random.RandomState(v['seed']))
+        assert np.array_equal(ids, v['ids']), v
+    for s in golden['point_sample']:
+        depth = np.ones(s['n'], np.float32)                      # every pixel valid: pixel index == point index
+        pix = sample_pixels(depth, s['num'], np.random.RandomState(s['seed']))
+        assert np.array_equal(pix, s['choices']), (s['seed'], s['n'])
+    # zero-depth pixels are not points; an all-zero frame contributes nothing
+    d = np.zeros((4, 5), np.float32)
+    d[1, 2] = d[3, 4] = 1.0
+    assert set(sample_pixels(d, 10, np.random.RandomState(0)).tolist()) == {7, 19}
+    assert len(sample_pixels(np.zeros((4, 5), np.float32), 10, np.random.RandomState(0))) == 0
+
+
+PIPE = [dict(type='LoadAnnotations3D'),
+        dict(type='MultiViewPipeline', n_images=4,
+             transforms=[dict(type='LoadImageFromFile'), dict(type='LoadDepthFromFile'),
+                         dict(type='ConvertRGBDToPoints', coord_type='CAMERA'), dict(type='PointSample', num_points=300),
+                         dict(type='Resize', scale=(48, 48), keep_ratio=False)]),
+        dict(type='AggregateMultiViewPoints', coord_type='DEPTH'), dict(type='PointSample', num_points=1000),
+        dict(type='RandomFlip3D', sync_2d=False, flip_2d=False, flip_ratio_bev_horizontal=0.5, flip_ratio_bev_vertical=0.5),
+        dict(type='GlobalRotScaleTrans', rot_range=[-0.087266, 0.087266], scale_ratio_range=[.9, 1.1],
+             translation_std=[.1, .1, .1], shift_height=False),
+        dict(type='Pack3DDetInputs', keys=['img', 'points', 'gt_bboxes_3d', 'gt_labels_3d'])]
+
+
+def test_written_dataset_round_trips(tmp_path):
+    """synthetic scan -> files -> reader: depth exact to the PNG's millimetre grid, camera matrices to f32 rounding,
+    JPEG frames within codec error, boxes = augment_gt_boxes(raw), decisions reproducible from the RandomState"""
+    from embodiedscan_amd import synth
+    from embodiedscan_amd.datasets import EmbodiedScanDataset
+    from embodiedscan_amd.pipeline import augment_gt_boxes
+    src, names = synth.write_dataset(str(tmp_path), n_scans=2, n_frames=6, n_voxels=(8, 8, 4), seed=5)
+    ds = EmbodiedScanDataset(str(tmp_path), 'embodiedscan_infos_train.pkl', metainfo=dict(classes=names), pipeline=PIPE)
+    assert ds.pipeline.n_images == 4 and ds.pipeline.view_points == 300 and ds.pipeline.n_points == 1000
+    assert ds.pipeline.img_scale == (48, 48) and ds.pipeline.aug['flip'] and ds.pipeline.aug['rst']
+    a = ds.load_scan(1, np.random.RandomState(3))
+    b = ds.load_scan(1, np.random.RandomState(3))
+    for k in ('depth', 'img_raw', 'sel_view', 'sel_pix', 'gt_boxes', 'extrinsic'):
+        assert np.array_equal(a[k], b[k]), k
+    ids = [int(os.path.basename(p)[:5]) for p in a['meta']['img_path']]
+    s = src[1]
+    assert a['depth'].shape == (4, 60, 80) and a['img_raw'].shape == (4, 60, 80, 3) and a['img_raw'].dtype == np.uint8
+    assert np.array_equal(a['depth'], (np.rint(s['depth'][ids] * 1000.0) / np.float32(1000.0)).astype(np.float32))
+    assert np.abs(a['extrinsic'] - s['extrinsic'][ids]).max() < 2e-6
+    assert np.array_equal(a['intrinsic'], s['intrinsic'][ids])
+    assert a['meta']['img_shape'] == (48, 48) and a['meta']['scale_factor'] == (48 / 80, 48 / 60)
+    assert len(a['sel_pix']) == 1000 and a['sel_view'].max() < 4 and (a['depth'].reshape(4, -1)[a['sel_view'], a['sel_pix']] > 0).all()
+    raw = ds.get_data_info(1)['ann_info']['gt_bboxes_3d']
+    assert np.allclose(raw, s['gt_boxes'], atol=1e-6)
+    assert np.array_equal(a['gt_boxes'], augment_gt_boxes(raw, a['aug']).numpy())
+    flow = a['meta']['transformation_3d_flow']
+    assert flow[-3:] == ['R', 'S', 'T'] and ('HF' in flow) == a['aug']['hflip'] and ('VF' in flow) == a['aug']['vflip']
+    # unknown transforms are refused, not skipped
+    with pytest.raises(NotImplementedError):
+        EmbodiedScanDataset(str(tmp_path), 'embodiedscan_infos_train.pkl', metainfo=dict(classes=names),
+                            pipeline=PIPE + [dict(type='PointShuffle')])
+
+
+def test_rank_sharding_is_default_sampler(tmp_path):
+    """shards: equal length on every rank, union covers the (repeated) dataset, identical to a literal restatement of
+    mmengine's DefaultSampler (seeded randperm, wrap-around padding, rank::world)"""
+    import math
+    import torch
+    from embodiedscan_amd.datasets import shard_indices
+    for n, world, times in ((10, 4, 1), (7, 8, 1), (5, 2, 10), (16, 4, 1)):
+        for epoch in (0, 3):
+            g = torch.Generator()
+            g.manual_seed(11 + epoch)
+            perm = torch.randperm(n * times, generator=g).tolist()
+            size = math.ceil(n * times / world) * world
+            padded = (perm * int(size / len(perm) + 1))[:size]
+            shards = [shard_indices(n, r, world, True, 11, epoch, True, times) for r in range(world)]
+            assert all(s == [i % n for i in padded[r:size:world]] for r, s in enumerate(shards))
+            assert len({len(s) for s in shards}) == 1
+            assert set(sum(shards, [])) == set(range(n))
+    assert shard_indices(5, 1, 2, shuffle=False) == [1, 3, 0]
+
+
+def test_loader_is_ordered_and_thread_count_independent(tmp_path):
+    from embodiedscan_amd import synth
+    from embodiedscan_amd.datasets import EmbodiedScanDataset, ScanLoader
+    _, names = synth.write_dataset(str(tmp_path), n_scans=3, n_frames=5, n_voxels=(8, 8, 4), seed=2)
+    ds = EmbodiedScanDataset(str(tmp_path), 'embodiedscan_infos_train.pkl', metainfo=dict(classes=names), pipeline=PIPE)
+    runs = []
+    for threads in (1, 4):
+        ld = ScanLoader(ds, batch_size=2, rank=1, world=2, seed=4, times=4, num_threads=threads, prefetch=3, pin=False)
+        assert len(ld) == 3
+        runs.append([[(s['meta']['scan_id'], s['sel_pix'].clone(), s['depth'].clone()) for s in b] for b in ld])
+    want = [ds.get_data_info(i)['scan_id'] for i in ScanLoader(ds, 2, 1, 2, seed=4, times=4).indices()]
+    assert [s[0] for b in runs[0] for s in b] == want[:6]
+    for ba, bb in zip(*runs):
+        for (ia, pa, da), (ib, pb, db) in zip(ba, bb):
+            assert ia == ib and bool((pa == pb).all()) and bool((da == db).all())
+    # a failing decode surfaces in the consumer
+    os.remove(ds.get_data_info(0)['depth_img_path'][0])
+    os.remove(ds.get_data_info(1)['depth_img_path'][0])
+    os.remove(ds.get_data_info(2)['depth_img_path'][0])
+    ds.pipeline.n_images = 5                                     # every frame is read -> the missing one is hit
+    with pytest.raises(Exception):
+        list(ScanLoader(ds, batch_size=1, num_threads=2, pin=False))
+
+
+def test_resize_oracle_properties():
+    from oracle.resize import linear_tables, resize_u8
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (2, 30, 40, 3), dtype=np.uint8)
+    assert np.array_equal(resize_u8(img, (30, 40)), img)                          # identity tables: (2048, 0)
+    o, c = linear_tables(640, 480)
+    assert o.min() == 0 and o.max() <= 639 and (c.sum(1) == 2048).all() and c.min() >= 0
+    up = resize_u8(np.full((1, 4, 4, 3), 77, np.uint8), (9, 11))
+    assert up.shape == (1, 9, 11, 3) and (up == 77).all()                          # constants are preserved
+    # product tables == oracle tables
+    from embodiedscan_amd.pipeline import _axis_table
+    for a, b in ((640, 480), (480, 480), (80, 48), (60, 100)):
+        po, pc = _axis_table(a, b)
+        oo, oc = linear_tables(a, b)
+        assert np.array_equal(po.numpy(), oo) and np.array_equal(pc.numpy(), oc)
+
+
+def test_occupancy_pipeline_fields(tmp_path):
+    """occupancy config knobs: LoadAnnotations3D(with_occupancy), PointsRangeFilter, ConstructMultiViewMasks (OR over
+    the chosen frames except the last one, as the reference's loop does)"""
+    from embodiedscan_amd import synth
+    from embodiedscan_amd.datasets import EmbodiedScanDataset
+    _, names = synth.write_dataset(str(tmp_path), n_scans=1, n_frames=6, n_voxels=(8, 8, 4), seed=9)
+    pipe = [dict(type='LoadAnnotations3D', with_occupancy=True, with_visible_occupancy_masks=True)] + PIPE[1:3] + [
+        dict(type='PointsRangeFilter', point_cloud_range=[-3.2, -3.2, -1.28, 3.2, 3.2, 1.28]),
+        dict(type='PointSample', num_points=1000), dict(type='ConstructMultiViewMasks'),
+        dict(type='Pack3DDetInputs', keys=['img', 'points', 'gt_bboxes_3d', 'gt_labels_3d', 'gt_occupancy'])]
+    ds = EmbodiedScanDataset(str(tmp_path), 'embodiedscan_infos_train.pkl', metainfo=dict(classes=names, occ_classes=names),
+                             pipeline=pipe)
+    sc = ds.load_scan(0, np.random.RandomState(1))
+    ann = ds.get_data_info(0)['ann_info']
+    assert np.array_equal(sc['gt_occupancy'], ann['gt_occupancy']) and sc['gt_occupancy'][:, 3].max() == 255
+    ids = [int(os.path.basename(p)[:5]) for p in sc['meta']['img_path']]
+    want = ann['visible_occupancy_masks'][ids[0]]
+    for i in ids[1:-1]:
+        want = np.logical_or(want, ann['visible_occupancy_masks'][i])
+    assert sc['gt_occupancy_masks'].shape == (8, 8, 4) and np.array_equal(sc['gt_occupancy_masks'], want)
+    assert sc['point_range'] == (-3.2, -3.2, -1.28, 3.2, 3.2, 1.28) and not sc['aug']['hflip'] and sc['aug']['scale'] == 1.0
+
+
+def test_build_dataloader_from_config(tmp_path):
+    """the data section of configs/mv_3ddet.py (= the reference config's, :134-200): RepeatDataset -> times,
+    DefaultSampler -> shard, pipeline knobs (20 frames, 100k points, 480x480)"""
+    from embodiedscan_amd import synth
+    from embodiedscan_amd.config import build_dataloader
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _, names = synth.write_dataset(str(tmp_path), n_scans=2, n_frames=5, n_voxels=(8, 8, 4))
+    ds, ld = build_dataloader(os.path.join(root, 'configs', 'mv_3ddet.py'), data_root=str(tmp_path),
+                              metainfo=dict(classes=names), pin=False, rank=1, world=2)
+    p = ds.pipeline
+    assert (p.n_images, p.view_points, p.n_points, p.img_scale, p.ordered) == (20, 10000, 100000, (480, 480), False)
+    assert ld.times == 10 and ld.batch_size == 4 and ld.shuffle and len(ld) == 2          # 20 scans / 2 ranks / 4
+    batch = next(iter(ld))
+    assert len(batch) == 4 and batch[0]['img_raw'].shape == (20, 60, 80, 3) and batch[0]['sel_pix'].numel() == 100000
+    assert batch[0]['meta']['img_shape'] == (480, 480)
+    _, val = build_dataloader(os.path.join(root, 'configs', 'mv_3ddet.py'), split='val', data_root=str(tmp_path),
+                              ann_file='embodiedscan_infos_train.pkl', metainfo=dict(classes=names), pin=False)
+    assert val.dataset.test_mode and val.dataset.pipeline.ordered and val.dataset.pipeline.n_images == 50 and not val.shuffle
+    assert 'eval_ann_info' in val.dataset.get_data_info(0)
