@@ -1,6 +1,11 @@
-"""Feeding the step from files: rank r of W reads its own shard of the scan list, a pool of host threads
-decodes (PIL releases the GIL inside the codecs) and draws the pipeline decisions, and hands over PINNED raw scans; the
-consumer copies them to HBM on its copy stream (pipeline.upload_into) and everything else happens on the device.
+"""Feeding the step from files: rank r of W reads its own shard of the scan list, a pool of host workers
+decodes and draws the pipeline decisions, and hands over PINNED raw scans; the consumer copies them to HBM on its copy
+stream (pipeline.upload_into) and everything else happens on the device.
+
+Two worker kinds: `workers='thread'` (PIL releases the GIL inside the codecs, but numpy's legacy RandomState -- kept so
+that the draws follow the reference's stream -- does not: the permutations of ~3e5 valid pixels per frame serialise, a few
+scans/s at most) and `workers='process'` (forked workers that write the decoded arrays straight into shared-memory slots
+the parent has registered as pinned: no pickling of pixels, no extra copy, scales with the cores).
 
 Sharding follows mmengine's DefaultSampler, which the reference's dataloaders use (`sampler=dict(type='DefaultSampler',
 shuffle=True)`, configs/detection/mv-det3d_...py:186; mmengine/dataset/sampler.py): a seeded permutation per epoch
@@ -41,11 +46,16 @@ class ScanLoader:
     not depend on thread scheduling."""
 
     def __init__(self, dataset, batch_size=4, rank=0, world=1, shuffle=True, seed=0, times=1, num_threads=8, prefetch=16,
-                 pin=True, drop_last=True):
+                 pin=True, drop_last=True, workers='thread'):
+        assert workers in ('thread', 'process')
         self.dataset, self.batch_size = dataset, batch_size
         self.rank, self.world, self.shuffle, self.seed, self.times = rank, world, shuffle, seed, times
         self.num_threads, self.prefetch, self.pin, self.drop_last = max(1, num_threads), max(1, prefetch), pin, drop_last
+        self.workers = workers
         self.epoch = 0
+        self._slabs = None          # process mode: shared (and pinned) slots, allocated on first use, reused across epochs
+        self._busy = {}             # id(batch list) -> slots it occupies, until done(batch)
+        self._pending = []          # (event, slots) released by the consumer, reusable once the event has completed
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -57,11 +67,165 @@ class ScanLoader:
         n = len(self.indices())
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
+    def _rng(self, pos):
+        return np.random.RandomState((self.seed * 1000003 + self.epoch * 7919 + pos * self.world + self.rank) % (2 ** 32))
+
     def _load(self, pos, idx):
-        rng = np.random.RandomState((self.seed * 1000003 + self.epoch * 7919 + pos * self.world + self.rank) % (2 ** 32))
-        return pipeline.pin_scan(self.dataset.load_scan(idx, rng), pin=self.pin)
+        return pipeline.pin_scan(self.dataset.load_scan(idx, self._rng(pos)), pin=self.pin)
+
+    def done(self, batch, event=None):
+        """process mode: the consumer is finished with `batch`'s pinned buffers (event: a CUDA event recorded after the
+        host->device copy was queued; the slots are reused once it has completed).  No-op in thread mode."""
+        slots = self._busy.pop(id(batch), None)
+        if slots is not None:
+            self._pending.append((event, slots))
 
     def __iter__(self):
+        if self.workers == 'process':
+            return self._iter_processes()
+        return self._iter_threads()
+
+    # ------------------------------------------------------------------ forked workers + shared pinned slots
+    @staticmethod
+    def _layout(host):
+        """byte offsets (256-aligned) of the device-bound arrays of one scan inside a slot"""
+        off, lay = 0, {}
+        for k, v in host.items():
+            lay[k] = (off, v.dtype, tuple(v.shape))
+            off = (off + v.numel() * v.element_size() + 255) // 256 * 256
+        return lay, off
+
+    @staticmethod
+    def _views(slab, lay):
+        return {k: slab[o:o + int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()].view(dt).view(shape)
+                for k, (o, dt, shape) in lay.items()}
+
+    def _start_workers(self, first_idx):
+        """allocate the shared slots, fork the PERSISTENT workers (the reference's `persistent_workers=True`), then pin
+        the slots in the parent.  Order matters: the children must inherit the shared mappings, and forking is cheapest
+        before the parent has registered gigabytes of pinned memory."""
+        import multiprocessing as mp
+        probe = pipeline._host_tensors(self.dataset.load_scan(first_idx, self._rng(0)))
+        _, need = self._layout(probe)
+        self._slot_bytes = int(need * 1.25) + 4096           # head-room for scans with more valid pixels / larger frames
+        n_slots = self.prefetch + 2 * self.batch_size
+        self._slabs = [torch.empty(self._slot_bytes, dtype=torch.uint8).share_memory_() for _ in range(n_slots)]
+        ctx = mp.get_context('fork')
+        self._tasks, self._results = ctx.Queue(), ctx.Queue()
+        tasks, results, slabs = self._tasks, self._results, self._slabs
+        ds, layout, views, slot_bytes = self.dataset, self._layout, self._views, self._slot_bytes
+
+        def work():
+            torch.set_num_threads(1)
+            while True:
+                t = tasks.get()
+                if t is None:
+                    return
+                pos, i, slot, seed = t
+                try:
+                    scan = ds.load_scan(i, np.random.RandomState(seed))
+                    host = pipeline._host_tensors(scan)
+                    lay, need = layout(host)
+                    if need > slot_bytes:
+                        results.put((pos, slot, None, f'needs {need} bytes, slots hold {slot_bytes}', None))
+                        continue
+                    dst = views(slabs[slot], lay)
+                    for k, v in host.items():
+                        dst[k].copy_(v)
+                    results.put((pos, slot, lay, None, pipeline._finish({}, scan)))
+                except Exception as e:                        # surfaced in the consumer
+                    results.put((pos, slot, None, repr(e), None))
+
+        self._procs = [ctx.Process(target=work, daemon=True) for _ in range(self.num_threads)]
+        for p in self._procs:
+            p.start()
+        if self.pin and torch.cuda.is_available():
+            for t in self._slabs:
+                err = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel(), 0)
+                if int(err) != 0:
+                    raise RuntimeError(f'cudaHostRegister failed with {int(err)}')
+        self._free = list(range(n_slots))
+
+    def close(self):
+        """stop the persistent workers (process mode)"""
+        procs, self._procs = getattr(self, '_procs', None) or [], None
+        for _ in procs:
+            self._tasks.put(None)
+        for p in procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+        self._slabs = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _reclaim(self):
+        keep = []
+        for ev, sl in self._pending:
+            if ev is None or ev.query():
+                self._free.extend(sl)
+            else:
+                keep.append((ev, sl))
+        self._pending = keep
+
+    def _iter_processes(self):
+        idx = self.indices()
+        n_batches = len(self)
+        idx = idx[:n_batches * self.batch_size] if self.drop_last else idx
+        if not idx:
+            return
+        if self._slabs is None:
+            self._start_workers(idx[0])
+        slabs, free = self._slabs, self._free
+        nxt, got, in_flight = 0, {}, 0
+        try:
+            for b in range(n_batches):
+                lo, hi = b * self.batch_size, min(len(idx), (b + 1) * self.batch_size)
+                while any(pos not in got for pos in range(lo, hi)):
+                    self._reclaim()
+                    while nxt < len(idx) and free and in_flight < self.prefetch:
+                        seed = (self.seed * 1000003 + self.epoch * 7919 + nxt * self.world + self.rank) % (2 ** 32)
+                        self._tasks.put((nxt, idx[nxt], free.pop(), seed))
+                        nxt, in_flight = nxt + 1, in_flight + 1
+                    if in_flight == 0:
+                        if self._pending:                     # every slot waits for a copy to finish
+                            self._pending[0][0].synchronize()
+                            continue
+                        raise RuntimeError('ScanLoader: every pinned slot is held by a batch the consumer has not '
+                                           'released -- call loader.done(batch[, event]) after queueing its copy')
+                    pos, slot, lay, err, small = self._results.get()
+                    in_flight -= 1
+                    if err is not None:
+                        free.append(slot)
+                        raise RuntimeError(f'scan {idx[pos]} (position {pos}): {err}')
+                    got[pos] = (slot, lay, small)
+                batch, slots = [], []
+                for pos in range(lo, hi):
+                    slot, lay, small = got.pop(pos)
+                    d = self._views(slabs[slot], lay)
+                    d.update(small)
+                    batch.append(d)
+                    slots.append(slot)
+                self._busy[id(batch)] = slots
+                yield batch
+        finally:
+            # an abandoned epoch: drain what is still in flight so that the slots come back
+            for slot, _, _ in got.values():
+                free.append(slot)
+            while in_flight > 0:
+                try:
+                    _, slot, _, _, _ = self._results.get(timeout=30)
+                except Exception:
+                    break
+                free.append(slot)
+                in_flight -= 1
+
+    # ------------------------------------------------------------------ threads
+    def _iter_threads(self):
         idx = self.indices()
         n_batches = len(self)
         idx = idx[:n_batches * self.batch_size] if self.drop_last else idx

@@ -54,7 +54,8 @@ def sample_pixels(depth, num_points, rng):
     nz = np.flatnonzero(depth.reshape(-1))
     if len(nz) == 0:
         return nz.astype(np.int32)
-    choices = rng.choice(range(len(nz)), num_points, replace=len(nz) < num_points)
+    # (an int population draws the same stream as the reference's `range(len(points))`, without materialising it)
+    choices = rng.choice(len(nz), num_points, replace=len(nz) < num_points)
     return nz[choices].astype(np.int32)
 
 
@@ -163,7 +164,7 @@ class ScanPipeline:
         sel_view, sel_pix = np.concatenate(sel_view), np.concatenate(sel_pix)
         # PointSample(n_points) over the aggregated cloud (points.py:189-206)
         if len(sel_pix):
-            pick = rng.choice(range(len(sel_pix)), self.n_points, replace=len(sel_pix) < self.n_points)
+            pick = rng.choice(len(sel_pix), self.n_points, replace=len(sel_pix) < self.n_points)
             sel_view, sel_pix = sel_view[pick], sel_pix[pick]
         aug, aug_meta = draw_augmentation(self.aug, rng)
         shapes = {im.shape[:2] for im in imgs} | {d.shape for d in depths}

@@ -238,3 +238,29 @@ def test_build_dataloader_from_config(tmp_path):
                               ann_file='embodiedscan_infos_train.pkl', metainfo=dict(classes=names), pin=False)
     assert val.dataset.test_mode and val.dataset.pipeline.ordered and val.dataset.pipeline.n_images == 50 and not val.shuffle
     assert 'eval_ann_info' in val.dataset.get_data_info(0)
+
+
+def test_process_loader_matches_thread_loader(tmp_path):
+    """forked workers writing into shared slots: same scans, same bytes, same order as the threaded loader; slots are
+    recycled through done(); a consumer that never releases a batch gets a loud error instead of a silent overwrite"""
+    from embodiedscan_amd import synth
+    from embodiedscan_amd.datasets import EmbodiedScanDataset, ScanLoader
+    _, names = synth.write_dataset(str(tmp_path), n_scans=3, n_frames=5, n_voxels=(8, 8, 4), seed=2)
+    ds = EmbodiedScanDataset(str(tmp_path), 'embodiedscan_infos_train.pkl', metainfo=dict(classes=names), pipeline=PIPE)
+    ref = [[{k: (v.clone() if hasattr(v, 'clone') else v) for k, v in s.items()} for s in b]
+           for b in ScanLoader(ds, batch_size=2, seed=4, times=6, num_threads=2, prefetch=3, pin=False)]
+    ld = ScanLoader(ds, batch_size=2, seed=4, times=6, num_threads=3, prefetch=3, pin=False, workers='process')
+    n = 0
+    for got, want in zip(ld, ref):
+        for a, b in zip(got, want):
+            assert a['meta']['scan_id'] == b['meta']['scan_id'] and a['meta']['img_path'] == b['meta']['img_path']
+            for k in ('depth', 'img_raw', 'sel_view', 'sel_pix', 'mats', 'aug', 'gt_boxes', 'gt_labels'):
+                assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and bool((a[k] == b[k]).all()), k
+        ld.done(got)
+        n += 1
+    assert n == len(ref) == 9                                    # 18 scans through 7 slots: recycling works
+    ld2 = ScanLoader(ds, batch_size=2, seed=4, times=6, num_threads=2, prefetch=1, pin=False, workers='process')
+    with pytest.raises(RuntimeError, match='done'):
+        held = []
+        for batch in ld2:
+            held.append(batch)                                   # never released

@@ -19,7 +19,9 @@ def main():
     ap.add_argument('--scans', type=int, default=8)
     ap.add_argument('--frames', type=int, default=24)
     ap.add_argument('--threads', default='1,4,8,16,32,64')
-    ap.add_argument('--repeat', type=int, default=4)
+    ap.add_argument('--repeat', type=int, default=200)
+    ap.add_argument('--seconds', type=float, default=8.0)
+    ap.add_argument('--device-workers', type=int, default=64)
     args = ap.parse_args()
     import torch
     from embodiedscan_amd import pipeline, synth
@@ -42,23 +44,39 @@ def main():
                                 write_s=round(time.time() - t0, 1)),
                    pipeline=dict(n_images=ds.pipeline.n_images, n_points=ds.pipeline.n_points, img_scale=ds.pipeline.img_scale),
                    host_cores=os.cpu_count(), decode=[])
-        for th in [int(t) for t in args.threads.split(',')]:
-            ld = ScanLoader(ds, batch_size=4, shuffle=True, seed=0, times=args.repeat, num_threads=th, prefetch=max(16, 2 * th),
-                            pin=dev is not None)
-            t = time.time()
-            n = sum(len(b) for b in ld)
-            dt = time.time() - t
-            out['decode'].append(dict(threads=th, scans=n, scans_per_s=round(n / dt, 2), ms_per_scan=round(dt / n * 1e3, 1)))
-            print(out['decode'][-1], file=sys.stderr)
+        for kind in ('thread', 'process'):
+            for th in [int(t) for t in args.threads.split(',')]:
+                if kind == 'thread' and th > 16:
+                    continue                                  # GIL-bound: more threads do not help (see loader.py)
+                ld = ScanLoader(ds, batch_size=4, shuffle=True, seed=0, times=args.repeat, num_threads=th,
+                                prefetch=min(max(16, 2 * th), 64), pin=dev is not None, workers=kind)
+                it = iter(ld)
+                ld.done(next(it))                             # untimed: forks the workers, allocates and pins the slots
+                t = time.time()
+                n = 0
+                for b in it:
+                    n += len(b)
+                    ld.done(b)
+                    if time.time() - t >= args.seconds:
+                        break
+                dt = time.time() - t
+                it.close()
+                ld.close()
+                out['decode'].append(dict(workers=kind, n=th, scans=n, scans_per_s=round(n / dt, 2),
+                                          ms_per_scan=round(dt / n * 1e3, 1), pinned=bool(b[0]['depth'].is_pinned())))
+                print(out['decode'][-1], file=sys.stderr)
         if dev is not None:
             # loader -> copy stream (H2D + resize) -> A1-A3 on the compute stream, double-buffered like bench.py
-            th = max(int(t) for t in args.threads.split(','))
-            ld = ScanLoader(ds, batch_size=4, shuffle=True, seed=0, times=args.repeat, num_threads=th, prefetch=2 * th, pin=True)
+            th = args.device_workers
+            ld = ScanLoader(ds, batch_size=4, shuffle=True, seed=0, times=args.repeat * 2, num_threads=th,
+                            prefetch=min(2 * th, 64), pin=True, workers='process')
+            it = iter(ld)
+            ld.done(next(it))
             copy = torch.cuda.Stream()
             slots, ready, n = None, None, 0
             torch.cuda.synchronize()
             t = time.time()
-            for batch in ld:
+            for batch in it:
                 if slots is None:
                     slots = [[pipeline.alloc_slot(s, dev) for s in batch] for _ in range(2)]
                     ready = [torch.cuda.Event() for _ in range(2)]
@@ -69,14 +87,21 @@ def main():
                 with torch.cuda.stream(copy):
                     copy.wait_event(done[k])
                     dscans = [pipeline.upload_into(sl, s) for sl, s in zip(slots[k], batch)]
+                    ev = torch.cuda.Event()
+                    ev.record(copy)
                     ready[k].record(copy)
+                ld.done(batch, ev)                            # pinned slots reusable once the copy has landed
                 torch.cuda.current_stream().wait_event(ready[k])
                 data = pipeline.make_batch(dscans)
                 done[k].record()
                 n += len(batch)
+                if time.time() - t >= args.seconds:
+                    break
             torch.cuda.synchronize()
             dt = time.time() - t
-            out['to_device'] = dict(threads=th, scans=n, scans_per_s=round(n / dt, 2),
+            it.close()
+            ld.close()
+            out['to_device'] = dict(workers='process', n=th, scans=n, scans_per_s=round(n / dt, 2),
                                     h2d_MB_per_scan=round(pipeline.scan_h2d_bytes(batch[0]) / 1e6, 2),
                                     note='decode + pinned hand-over + async H2D + es_resize_u8 + es_depth_to_points')
         print(json.dumps(out))
