@@ -20,6 +20,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: RCCL's peer buffers fail with hipIpcGetMemHandle errors without it
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
