@@ -32,4 +32,24 @@ lr = 5e-4
 optim_wrapper = dict(type='OptimWrapper', optimizer=dict(type='AdamW', lr=lr, weight_decay=0.0005),
                      paramwise_cfg=dict(custom_keys={'text_encoder': dict(lr_mult=0.0), 'decoder': dict(lr_mult=0.1, decay_mult=1.0)}),
                      clip_grad=dict(max_norm=10, norm_type=2))
-train_dataloader = dict(batch_size=12)
+# data section of the reference config (configs/grounding/mv-grounding_8xb12_embodiedscan-vg-9dof.py:95-151)
+n_points = 100000
+train_pipeline = [
+    dict(type='LoadAnnotations3D'),
+    dict(type='MultiViewPipeline', n_images=20,
+         transforms=[dict(type='LoadImageFromFile'), dict(type='LoadDepthFromFile'),
+                     dict(type='ConvertRGBDToPoints', coord_type='CAMERA'),
+                     dict(type='PointSample', num_points=n_points // 10),
+                     dict(type='Resize', scale=(480, 480), keep_ratio=False)]),
+    dict(type='AggregateMultiViewPoints', coord_type='DEPTH'),
+    dict(type='PointSample', num_points=n_points),
+    dict(type='GlobalRotScaleTrans', rot_range=[-0.087266, 0.087266], scale_ratio_range=[.9, 1.1],
+         translation_std=[.1, .1, .1], shift_height=False),
+    dict(type='Pack3DDetInputs', keys=['img', 'points', 'gt_bboxes_3d', 'gt_labels_3d'])]
+train_dataloader = dict(batch_size=12, num_workers=12, sampler=dict(type='DefaultSampler', shuffle=True),
+                        dataset=dict(type='RepeatDataset', times=1,
+                                     dataset=dict(type='MultiView3DGroundingDataset', data_root='data',
+                                                  ann_file='embodiedscan_infos_train.pkl',
+                                                  vg_file='embodiedscan_train_mini_vg.json', metainfo=dict(classes='all'),
+                                                  pipeline=train_pipeline, test_mode=False, filter_empty_gt=True,
+                                                  box_type_3d='Euler-Depth', tokens_positive_rebuild=True)))

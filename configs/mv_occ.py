@@ -18,4 +18,22 @@ model = dict(
     prior_generator=prior_generator, n_voxels=[40, 40, 16], coord_type='DEPTH')
 optim_wrapper = dict(type='OptimWrapper', optimizer=dict(type='AdamW', lr=0.0001, weight_decay=0.01),
                      clip_grad=dict(max_norm=35., norm_type=2))
-train_dataloader = dict(batch_size=1)
+# data section of the reference config (configs/occupancy/mv-occ_8xb1_embodiedscan-occ-80class.py:76-132); `metainfo`
+# (classes = occ_classes = the 80 names, :42-72) is passed by the caller
+n_points = 100000
+train_pipeline = [
+    dict(type='LoadAnnotations3D', with_occupancy=True, with_visible_occupancy_masks=True),
+    dict(type='MultiViewPipeline', n_images=10,
+         transforms=[dict(type='LoadImageFromFile'), dict(type='LoadDepthFromFile'),
+                     dict(type='ConvertRGBDToPoints', coord_type='CAMERA'),
+                     dict(type='PointSample', num_points=n_points // 10),
+                     dict(type='Resize', scale=(480, 480), keep_ratio=False)]),
+    dict(type='AggregateMultiViewPoints', coord_type='DEPTH'),
+    dict(type='PointsRangeFilter', point_cloud_range=[-3.2, -3.2, -0.78, 3.2, 3.2, 1.78]),
+    dict(type='PointSample', num_points=n_points),
+    dict(type='ConstructMultiViewMasks'),
+    dict(type='Pack3DDetInputs', keys=['img', 'points', 'gt_bboxes_3d', 'gt_labels_3d', 'gt_occupancy'])]
+train_dataloader = dict(batch_size=1, num_workers=1, sampler=dict(type='DefaultSampler', shuffle=True),
+                        dataset=dict(type='EmbodiedScanDataset', data_root='data', ann_file='embodiedscan_infos_train.pkl',
+                                     pipeline=train_pipeline, test_mode=False, filter_empty_gt=True,
+                                     box_type_3d='Euler-Depth'))

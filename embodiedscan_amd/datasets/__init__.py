@@ -1,5 +1,6 @@
 from .embodiedscan_dataset import EmbodiedScanDataset
 from .loader import ScanLoader, shard_indices
 from .loading import ScanPipeline
+from .mv_3dvg_dataset import MultiView3DGroundingDataset
 
-__all__ = ['EmbodiedScanDataset', 'ScanLoader', 'ScanPipeline', 'shard_indices']
+__all__ = ['EmbodiedScanDataset', 'MultiView3DGroundingDataset', 'ScanLoader', 'ScanPipeline', 'shard_indices']

@@ -81,7 +81,8 @@ def _host_tensors(scan):
 
 def _finish(d, scan):
     d.update(meta=scan['meta'], gt_boxes=torch.as_tensor(scan['gt_boxes']), gt_labels=torch.as_tensor(scan['gt_labels']))
-    for k in ('gt_occupancy', 'gt_occupancy_masks', 'visible_occupancy_masks', 'visible_instance_masks', 'point_range'):
+    for k in ('gt_occupancy', 'gt_occupancy_masks', 'visible_occupancy_masks', 'visible_instance_masks', 'point_range',
+              'text', 'tokens_positive'):
         if k in scan:
             d[k] = scan[k]
     return d
@@ -190,10 +191,14 @@ def make_occ_batch(dscans, occ_gts=None):
     return data
 
 
-def make_grounding_batch(dscans, anns):
+def make_grounding_batch(dscans, anns=None):
     """`data` dict for SparseFeatureFusion3DGrounder.train_step: the detection batch with the prompt (`text`), the
-    positive character spans (`tokens_positive`) and the TARGET boxes of the prompt as gt_instances_3d."""
+    positive character spans (`tokens_positive`) and the TARGET boxes of the prompt as gt_instances_3d.
+    anns None: scans from MultiView3DGroundingDataset carry text / spans / target boxes themselves."""
     data = make_batch(dscans)
+    if anns is None:
+        anns = [dict(text=d['text'], tokens_positive=d['tokens_positive'], gt_boxes=d['gt_boxes'], gt_labels=d['gt_labels'])
+                for d in dscans]
     for ds, a in zip(data['data_samples'], anns):
         ds.text, ds.tokens_positive = a['text'], a['tokens_positive']
         ds.gt_instances_3d = InstanceData(bboxes_3d=EulerDepthInstance3DBoxes(torch.as_tensor(a['gt_boxes'])),

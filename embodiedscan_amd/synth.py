@@ -261,4 +261,23 @@ def write_dataset(root, n_scans=2, n_frames=6, height=60, width=80, n_boxes=6, c
     meta = dict(categories=categories, DATASET='EmbodiedScan', version='synthetic')
     with open(os.path.join(root, ann_name), 'wb') as f:
         pickle.dump(dict(metainfo=meta, data_list=data_list), f)
+    # visual-grounding annotations (mv_3dvg_dataset.py:301-404): single and multiple targets, a target that does not
+    # exist in its scan (dropped by the reader), a prompt without target_id (all boxes), rebuilt / given token spans
+    import json
+    vg = []
+    for s, d in enumerate(data_list):
+        sid = d['sample_idx']
+        noun = class_names[int(scans[s]['gt_labels'][0])]
+        t1 = f'find the {noun} that is left of the {class_names[int(scans[s]["gt_labels"][1])]}'
+        vg.append(dict(scan_id=sid, text=t1, target_id=1, target=noun, distractor_ids=[2, 3, 4, 5],
+                       tokens_positive=[[9, 9 + len(noun)]], anchors=[class_names[int(scans[s]['gt_labels'][1])]], anchor_ids=[2]))
+        vg.append(dict(scan_id=sid, text='all the things near the window', target_id=[2, 3], target=['thing', 'thing'],
+                       distractor_ids=[], tokens_positive=[[8, 14], [8, 14]]))
+        vg.append(dict(scan_id=sid, text='the object that is not there', target_id=n_boxes + 40, target='object',
+                       distractor_ids=[], tokens_positive=[[4, 10]]))
+        vg.append(dict(scan_id=sid, text='everything in the room'))
+        vg.append(dict(scan_id=sid, text='two of them , one missing', target_id=[1, n_boxes + 41], target=['a', 'b'],
+                       distractor_ids=[1], tokens_positive=[[0, 3], [15, 18]]))
+    with open(os.path.join(root, 'embodiedscan_train_vg.json'), 'w') as f:
+        json.dump(vg, f)
     return scans, class_names

@@ -158,10 +158,15 @@ def _populate(module):
     if n in ('mmengine', 'mmengine.fileio'):
         def load(path, *a, **k):
             """mmengine.load for the two formats the dataset class reads (.pkl, and .npy through numpy itself)"""
+            import json
             import pickle
+            if str(path).endswith('.json'):
+                with open(path) as f:
+                    return json.load(f)
             with open(path, 'rb') as f:
                 return pickle.load(f)
         module.load = load
+        module.track_iter_progress = lambda it, *a, **k: it
     if n == 'mmengine.dataset':
         import copy
         import os
@@ -186,6 +191,9 @@ def _populate(module):
             @property
             def metainfo(self):
                 return self._metainfo
+
+            def _serialize_data(self):
+                return None, None
         module.BaseDataset = BaseDataset
     if n == 'mmcv.transforms':
         class BaseTransform:

@@ -58,6 +58,12 @@ def main():
         ds = Ref(data_root=FIX, ann_file='embodiedscan_infos_train.pkl', pipeline=[], **kw)
         out[tag] = dict(data_list=plain(ds.data_list), label_mapping=ds.label_mapping, occ_label_mapping=ds.occ_label_mapping,
                         classes=list(ds.metainfo['classes']))
+    # visual grounding reader
+    from embodiedscan.datasets.mv_3dvg_dataset import MultiView3DGroundingDataset as RefVG
+    for tag, kw in dict(vg_train=dict(metainfo=dict(classes=names), tokens_positive_rebuild=True),
+                        vg_test=dict(metainfo=dict(classes=names), test_mode=True, tokens_positive_rebuild=False)).items():
+        ds = RefVG(data_root=FIX, ann_file='embodiedscan_infos_train.pkl', vg_file='embodiedscan_train_vg.json', pipeline=[], **kw)
+        out[tag] = dict(data_list=plain(ds.data_list), label_mapping=ds.label_mapping)
     # view choice: extrinsic i is tagged with its index so the chosen ids can be read back
     views = []
     for seed, n_total, n_images, ordered in ((0, 30, 20, False), (1, 12, 20, False), (2, 300, 50, True), (3, 40, 50, True),

@@ -264,3 +264,40 @@ def test_process_loader_matches_thread_loader(tmp_path):
         held = []
         for batch in ld2:
             held.append(batch)                                   # never released
+
+
+@pytest.mark.parametrize('tag', ['vg_train', 'vg_test'])
+def test_grounding_reader_matches_reference(golden, golden_dir, tag):
+    """MultiView3DGroundingDataset: one sample per language annotation -- targets looked up by bbox_id (single, list,
+    missing -> dropped, none -> all boxes), tokens_positive given or rebuilt from the target phrase, hard / unique /
+    view-dependent flags -- equal to the reference's class key for key"""
+    from embodiedscan_amd.datasets import MultiView3DGroundingDataset
+    names = _names()
+    kw = dict(vg_train=dict(metainfo=dict(classes=names), tokens_positive_rebuild=True),
+              vg_test=dict(metainfo=dict(classes=names), test_mode=True, tokens_positive_rebuild=False))[tag]
+    root = os.path.join(golden_dir, 'fake_dataset')
+    ds = MultiView3DGroundingDataset(data_root=root, ann_file='embodiedscan_infos_train.pkl',
+                                     vg_file='embodiedscan_train_vg.json', pipeline=[], **kw)
+    g = golden[tag]
+    assert np.array_equal(ds.label_mapping, g['label_mapping']) and len(ds) == len(g['data_list']) == 6
+    _same(_strip_root(ds.data_list, root), g['data_list'], tag)
+
+
+def test_grounding_scan_from_files(tmp_path):
+    from embodiedscan_amd import synth
+    from embodiedscan_amd.datasets import MultiView3DGroundingDataset
+    from embodiedscan_amd.pipeline import augment_gt_boxes
+    src, names = synth.write_dataset(str(tmp_path), n_scans=1, n_frames=5, n_voxels=(8, 8, 4), seed=7)
+    pipe = PIPE[:4] + [PIPE[5], PIPE[6]]                       # the grounding config has no RandomFlip3D
+    ds = MultiView3DGroundingDataset(str(tmp_path), 'embodiedscan_infos_train.pkl', 'embodiedscan_train_vg.json',
+                                     metainfo=dict(classes='all'), pipeline=pipe, tokens_positive_rebuild=True)
+    assert len(ds) == 3 and not ds.pipeline.aug['flip'] and ds.pipeline.aug['rst']
+    sc = ds.load_scan(0, np.random.RandomState(0))
+    noun = sc['text'].split()[2]
+    assert sc['text'].startswith('find the') and sc['tokens_positive'] == [[[9, 9 + len(noun)]]]
+    assert sc['gt_boxes'].shape == (1, 9) and not sc['aug']['hflip'] and sc['meta']['is_view_dep'] and sc['meta']['is_hard']
+    assert np.allclose(sc['gt_boxes'], augment_gt_boxes(src[0]['gt_boxes'][:1], sc['aug']).numpy(), atol=1e-6)
+    multi = ds.load_scan(1, np.random.RandomState(0))
+    assert multi['gt_boxes'].shape == (2, 9) and multi['tokens_positive'] == [[[8, 14]], [[8, 14]]] and multi['meta']['is_unique']
+    every = ds.load_scan(2, np.random.RandomState(0))
+    assert every['gt_boxes'].shape == (6, 9) and 'tokens_positive' not in every
