@@ -67,6 +67,8 @@ def main():
     from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
     from embodiedscan_amd.synth import make_scan
 
+    # (Measured and rejected: running the step's dependent chain on a high-priority stream -- 42-45 ms/step against 30.7 on
+    # the same box; the weight-gradient / side streams starve behind it and the joins at the end of backward wait longer.)
     E.PRECISION[0] = args.precision
     cfg = load_config(os.path.join(ROOT, 'configs', 'mv_3ddet.py'))
     det = build_detector(cfg, device=dev, seed=0).to(dev)          # same initial weights on every rank
