@@ -740,8 +740,10 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
 
 // run-time tuning switches (A/B measurements without a rebuild): key 1 = ping-pong LDS in the fast bf16 kernels
 static int ES_OPT_PINGPONG = 1;
+static int ES_OPT_WGRAD_HUGE = 1;      // 256 x 256 weight-gradient tile for wide layers (both operands bf16 shadows)
 extern "C" int es_set_option(int key, int value) {
   if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
+  if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }
   return -2;
 }
 
@@ -1192,6 +1194,125 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
     }
 }
 
+// 256 x 256 tile of dW[k] per workgroup of 8 waves (each a 64 x 128 slab: 32 MFMAs per 32-pair chunk), both operands
+// from bf16 shadows.  The 128 x 128 tile moves (128 + 128) * 2 B per pair and 16 k outputs = 64 flop/B through L2 -> LDS,
+// which is what bounds the weight gradients of the wide (768 .. 3072 channel) dense layers; this tile doubles that.
+#define QCAP2 1024            // ring capacity (max live: 63 left over + 512 appended)
+__device__ __forceinline__ void ring_refill512(PairRing& q, const int* __restrict__ nbr, long long sj, long long koff,
+                                               int rend, int n_in) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int j = q.nextb + t, idx = -1;
+  if (j < rend) idx = nbr ? nbr[j * sj + koff] : (j < n_in ? j : -1);
+  bool v = idx >= 0;
+  unsigned long long m = __ballot(v);
+  int pre = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) q.wcnt[wv] = __popcll(m);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    int c = q.wcnt[w];
+    off += (w < wv) ? c : 0;
+    tot += c;
+  }
+  if (v) {
+    int pos = (q.tail + off + pre) & (QCAP2 - 1);
+    q.qj[pos] = j; q.qi[pos] = idx;
+  }
+  q.tail += tot;
+  q.nextb += 512;
+  __syncthreads();
+}
+__global__ __launch_bounds__(512) void k_spconv_wgrad_bf16_huge(const unsigned short* __restrict__ X, int ldx,
+                                                                const unsigned short* __restrict__ dY, int ldy,
+                                                                const int* __restrict__ nbr, int n_out, int n_in, int K,
+                                                                int Cin, int Cout, int rows_per_split, int n_slices,
+                                                                float* __restrict__ dW) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[256 * GLD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[256 * GLD];
+  __shared__ int s_qj[QCAP2], s_qi[QCAP2], s_wc[8];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+  const int nCt = Cin / 256;
+  int bx, by, bz;
+  if (!xcd_slice_order(n_slices, bx, by, bz)) return;
+  const int k = bx / nCt, c0 = (bx % nCt) * 256;
+  const int n0 = by * 256;
+  const int rbeg = bz * rows_per_split;
+  const int rend = min(n_out, rbeg + rows_per_split);
+  // staging: thread = (pair-of-pairs rp 0..15, channel group 0..31 of 8 channels)
+  const int rp = t & 15, c8 = (t >> 4) * 8;
+  const int li = lane & 15, kq = lane >> 4;
+  PairRing q{s_qj, s_qi, s_wc, 0, 0, rbeg};
+  const long long sj = K, koff = k;
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 ha[2], hb[2];
+  int va[2];
+  auto fill = [&]() {
+    while (q.tail - q.head < 2 * GR && q.nextb < rend) ring_refill512(q, nbr, sj, koff, rend, n_in);
+  };
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int qq = q.head + 2 * rp + h;
+      va[h] = qq < q.tail;
+      int j = va[h] ? q.qj[qq & (QCAP2 - 1)] : rbeg;      // unconditional loads, masked when packed
+      int idx = va[h] ? q.qi[qq & (QCAP2 - 1)] : 0;
+      ha[h] = *(const uint4*)(X + idx * ldx + c0 + c8);
+      hb[h] = *(const uint4*)(dY + j * ldy + n0 + c8);
+    }
+  };
+  auto store_rows = [&]() {
+    uint32_t m0 = va[0] ? 0xffffffffu : 0u, m1 = va[1] ? 0xffffffffu : 0u;
+    uint32_t a0[4] = {ha[0].x & m0, ha[0].y & m0, ha[0].z & m0, ha[0].w & m0};
+    uint32_t a1[4] = {ha[1].x & m1, ha[1].y & m1, ha[1].z & m1, ha[1].w & m1};
+    uint32_t b0[4] = {hb[0].x & m0, hb[0].y & m0, hb[0].z & m0, hb[0].w & m0};
+    uint32_t b1[4] = {hb[1].x & m1, hb[1].y & m1, hb[1].z & m1, hb[1].w & m1};
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      *(uint32_t*)&As[(c8 + e) * GLD + 2 * rp] = (a0[e >> 1] & 0xffffu) | (a1[e >> 1] << 16);
+      *(uint32_t*)&As[(c8 + e + 1) * GLD + 2 * rp] = (a0[e >> 1] >> 16) | (a1[e >> 1] & 0xffff0000u);
+      *(uint32_t*)&Bs[(c8 + e) * GLD + 2 * rp] = (b0[e >> 1] & 0xffffu) | (b1[e >> 1] << 16);
+      *(uint32_t*)&Bs[(c8 + e + 1) * GLD + 2 * rp] = (b0[e >> 1] >> 16) | (b1[e >> 1] & 0xffff0000u);
+    }
+  };
+  fill();
+  load_rows();
+  while (q.head < q.tail) {
+    store_rows();
+    __syncthreads();
+    q.head += GR;
+    fill();
+    load_rows();                                          // entries past the tail are masked (and clamped) inside
+    bf16x8_t a[4], b[8];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) a[mf] = *(const bf16x8_t*)&As[(wm * 64 + mf * 16 + li) * GLD + kq * 8];
+#pragma unroll
+    for (int nf = 0; nf < 8; ++nf) b[nf] = *(const bf16x8_t*)&Bs[(wn * 128 + nf * 16 + li) * GLD + kq * 8];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 8; ++nf)
+        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+    __syncthreads();
+  }
+  if (q.tail == 0) return;
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < 8; ++nf) {
+      int col = n0 + wn * 128 + nf * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int c = c0 + wm * 64 + mf * 16 + kq * 4 + r;
+        atomicAdd(dW + ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r]);
+      }
+    }
+}
+
 template <int XH, int YH>
 static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
                              int Cin, int Cout, float* dW, void* stream) {
@@ -1202,6 +1323,20 @@ static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, co
              ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)dY) & 15) == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
              ((long long)n_out * ldy < (1ll << 31)) &&
              (n_out >= 512 || (long long)Cin * Cout >= 512ll * 512ll);   // few rows x many channels: dW traffic decides
+  if (big && XH && YH && ES_OPT_WGRAD_HUGE && (Cin % 256 == 0) && (Cout % 256 == 0) && (ldx % 8 == 0) && (ldy % 8 == 0)) {
+    int base = K * (Cin / 256) * (Cout / 256);
+    int splits = es_cdiv(2048, base);
+    int max_splits = es_cdiv(n_out, 1024);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
+    splits = es_cdiv(n_out, rows_per_split);
+    dim3 grid(K * (Cin / 256), Cout / 256, es_cdiv(splits, 8) * 8);
+    hipLaunchKernelGGL(k_spconv_wgrad_bf16_huge, grid, dim3(512), 0, (hipStream_t)stream, (const unsigned short*)X, ldx,
+                       (const unsigned short*)dY, ldy, nbr, n_out, n_in, K, Cin, Cout, rows_per_split, splits, dW);
+    ES_CHECK_LAUNCH();
+    return 0;
+  }
   if (big) {
     int base = K * (Cin / 128) * (Cout / 128);
     int splits = es_cdiv(8192, base);

@@ -53,6 +53,8 @@ for _name, (_ret, _at, _an) in PROTOS.items():
 
 if os.environ.get('ES_PINGPONG') is not None:          # A/B switch of the ping-pong LDS conv kernels (default: on)
     _fn['es_set_option'](1, int(os.environ['ES_PINGPONG']))
+if os.environ.get('ES_WGRAD_HUGE') is not None:        # A/B switch of the 256x256 weight-gradient tile (default: on)
+    _fn['es_set_option'](2, int(os.environ['ES_WGRAD_HUGE']))
 
 
 class HipError(RuntimeError):

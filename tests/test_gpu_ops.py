@@ -156,7 +156,13 @@ def test_wgrad_few_rows_many_channels(dev):
     from embodiedscan_amd.hip import call, P
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(11)
-    n, cin, cout, K = 300, 512, 640, 27
+    for n, cin, cout, K in ((300, 512, 640, 27), (1500, 512, 768, 27)):   # 2nd: the 256x256 tile (both dims % 256, shadows)
+        _wgrad_case(dev, g, n, cin, cout, K)
+
+
+def _wgrad_case(dev, g, n, cin, cout, K):
+    from embodiedscan_amd.hip import call, P
+    st = torch.cuda.current_stream().cuda_stream
     nbr = torch.randint(-1, n, (n, K), generator=g, dtype=torch.int32)
     nbr[torch.rand(n, K, generator=g) < 0.3] = -1
     x, dy = torch.randn(n, cin, generator=g), torch.randn(n, cout, generator=g)
