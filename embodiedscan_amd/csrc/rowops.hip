@@ -149,6 +149,39 @@ __global__ void k_norm_apply(const float* __restrict__ x, int ldx, int n, int C,
   }
 }
 
+// float4 version of k_norm_apply (same arithmetic per element).  Two independent row pieces per loop trip: these passes
+// are latency-bound unless every thread keeps several 16-B loads in flight.
+__global__ __launch_bounds__(256) void k_norm_apply4(const float* __restrict__ x, int ldx, int n, int C, Segs segs,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     const float* __restrict__ res, int ldr, int act,
+                                                     float* __restrict__ y, int ldy) {
+  const int C4 = C >> 2;
+  const size_t tot = (size_t)n * C4, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < tot; e0 += 2 * stride) {
+    size_t e1 = e0 + stride;
+    bool v1 = e1 < tot;
+    int r0 = (int)(e0 / C4), c0 = (int)(e0 - (size_t)r0 * C4) * 4;
+    int r1 = v1 ? (int)(e1 / C4) : r0, c1 = v1 ? (int)(e1 - (size_t)r1 * C4) * 4 : c0;
+    float4 x0 = *(const float4*)(x + (size_t)r0 * ldx + c0), x1 = *(const float4*)(x + (size_t)r1 * ldx + c1);
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0;
+    if (res) { q0 = *(const float4*)(res + (size_t)r0 * ldr + c0); q1 = *(const float4*)(res + (size_t)r1 * ldr + c1); }
+#define NA_ONE(xv, qv, r, c)                                                                                   \
+    {                                                                                                          \
+      int sg = seg_of(segs, r);                                                                                \
+      float4 m = *(const float4*)(mean + sg * C + c), is = *(const float4*)(invstd + sg * C + c);             \
+      float4 ww = *(const float4*)(w + c), bb = *(const float4*)(b + c);                                       \
+      float z0 = (xv.x - m.x) * is.x * ww.x + bb.x, z1 = (xv.y - m.y) * is.y * ww.y + bb.y;                    \
+      float z2 = (xv.z - m.z) * is.z * ww.z + bb.z, z3 = (xv.w - m.w) * is.w * ww.w + bb.w;                    \
+      if (res) { z0 += qv.x; z1 += qv.y; z2 += qv.z; z3 += qv.w; }                                             \
+      *(float4*)(y + (size_t)r * ldy + c) = make_float4(act_fwd(z0, act), act_fwd(z1, act), act_fwd(z2, act), act_fwd(z3, act)); \
+    }
+    NA_ONE(x0, q0, r0, c0)
+    if (v1) NA_ONE(x1, q1, r1, c1)
+#undef NA_ONE
+  }
+}
+
 // workspace floats: nseg * cdiv(max_seg_rows, 64) * 2 * C
 extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg_off, int nseg, float eps,
                            const float* weight, const float* bias, const float* res, int ldr, int act,
@@ -163,10 +196,20 @@ extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg
                      workspace);
   hipLaunchKernelGGL(k_norm_finalize, dim3(es_cdiv(C, 64), nseg), dim3(64 * FST), 0, st, workspace, C, s, nchunk, eps,
                      mean, invstd, running_mean, running_var, momentum);
-  int g = es_cdiv((long long)n * C, 256);
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(k_norm_apply, dim3(g), dim3(256), 0, st, x, ldx, n, C, s, mean, invstd, weight, bias, res,
-                     ldr, act, y, ldy);
+  const bool vec = ((C & 3) == 0) && ((ldx & 3) == 0) && ((ldy & 3) == 0) && (!res || (ldr & 3) == 0) &&
+                   (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)weight) | ((uintptr_t)bias) |
+                      ((uintptr_t)mean) | ((uintptr_t)invstd)) & 15) == 0);
+  if (vec) {
+    int g = es_cdiv((long long)n * (C >> 2), 512);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_norm_apply4, dim3(g < 1 ? 1 : g), dim3(256), 0, st, x, ldx, n, C, s, mean, invstd, weight, bias,
+                       res, ldr, act, y, ldy);
+  } else {
+    int g = es_cdiv((long long)n * C, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_norm_apply, dim3(g), dim3(256), 0, st, x, ldx, n, C, s, mean, invstd, weight, bias, res,
+                       ldr, act, y, ldy);
+  }
   ES_CHECK_LAUNCH();
   return 0;
 }
@@ -217,23 +260,41 @@ __global__ __launch_bounds__(256) void k_norm_bwd_stats(float* __restrict__ dy, 
     float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
     if (c4 < C4 && ty < TY) {
       float4 m = *(const float4*)(mean + seg * C + c4 * 4), is = *(const float4*)(invstd + seg * C + c4 * 4);
-      for (int r = r0 + ty; r < r1; r += TY) {
-        float4 g = *(const float4*)(dy + (size_t)r * ldd + c4 * 4);
-        if (act) {
-          float4 yv = *(const float4*)(y + (size_t)r * ldy + c4 * 4);
-          if (act == 1) {
-            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
-            g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
-          } else {
-            g.x = yv.x > 0.f ? g.x : g.x * (yv.x + 1.f); g.y = yv.y > 0.f ? g.y : g.y * (yv.y + 1.f);
-            g.z = yv.z > 0.f ? g.z : g.z * (yv.z + 1.f); g.w = yv.w > 0.f ? g.w : g.w * (yv.w + 1.f);
-          }
-          *(float4*)(dy + (size_t)r * ldd + c4 * 4) = g;
+      // four rows per trip, all loads first: the in-place store of dz would otherwise order every row's loads behind
+      // the previous row's store (same pointer), leaving one 16-B load in flight per thread
+      for (int rb = r0 + ty; rb < r1; rb += 4 * TY) {
+        float4 g[4], yv[4], xv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int r = rb + u * TY;
+          ok[u] = r < r1;
+          int rc = ok[u] ? r : rb;
+          g[u] = *(const float4*)(dy + (size_t)rc * ldd + c4 * 4);
+          if (act) yv[u] = *(const float4*)(y + (size_t)rc * ldy + c4 * 4);
+          xv[u] = *(const float4*)(x + (size_t)rc * ldx + c4 * 4);
         }
-        float4 xv = *(const float4*)(x + (size_t)r * ldx + c4 * 4);
-        s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
-        q.x += g.x * ((xv.x - m.x) * is.x); q.y += g.y * ((xv.y - m.y) * is.y);
-        q.z += g.z * ((xv.z - m.z) * is.z); q.w += g.w * ((xv.w - m.w) * is.w);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!ok[u]) continue;
+          int r = rb + u * TY;
+          float4 gg = g[u];
+          if (act) {
+            float4 yy = yv[u];
+            if (act == 1) {
+              gg.x = yy.x > 0.f ? gg.x : 0.f; gg.y = yy.y > 0.f ? gg.y : 0.f;
+              gg.z = yy.z > 0.f ? gg.z : 0.f; gg.w = yy.w > 0.f ? gg.w : 0.f;
+            } else {
+              gg.x = yy.x > 0.f ? gg.x : gg.x * (yy.x + 1.f); gg.y = yy.y > 0.f ? gg.y : gg.y * (yy.y + 1.f);
+              gg.z = yy.z > 0.f ? gg.z : gg.z * (yy.z + 1.f); gg.w = yy.w > 0.f ? gg.w : gg.w * (yy.w + 1.f);
+            }
+            *(float4*)(dy + (size_t)r * ldd + c4 * 4) = gg;
+          }
+          float4 xx = xv[u];
+          s.x += gg.x; s.y += gg.y; s.z += gg.z; s.w += gg.w;
+          q.x += gg.x * ((xx.x - m.x) * is.x); q.y += gg.y * ((xx.y - m.y) * is.y);
+          q.z += gg.z * ((xx.z - m.z) * is.z); q.w += gg.w * ((xx.w - m.w) * is.w);
+        }
       }
     }
     red[0][threadIdx.x] = s;
@@ -303,6 +364,43 @@ __global__ void k_norm_bwd_apply(const float* __restrict__ dz, int ldd, const fl
     *p = accumulate ? (*p + g) : g;
   }
 }
+__global__ __launch_bounds__(256) void k_norm_bwd_apply4(const float* __restrict__ dz, int ldd,
+                                                         const float* __restrict__ x, int ldx, int n, int C, Segs segs,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ w,
+                                                         const float* __restrict__ sum_dz,
+                                                         const float* __restrict__ sum_dzx, float* __restrict__ dx,
+                                                         int ldo, int accumulate) {
+  const int C4 = C >> 2;
+  const size_t tot = (size_t)n * C4, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < tot; e0 += 2 * stride) {
+    size_t e1 = e0 + stride;
+    bool v1 = e1 < tot;
+    int r0 = (int)(e0 / C4), c0 = (int)(e0 - (size_t)r0 * C4) * 4;
+    int r1 = v1 ? (int)(e1 / C4) : r0, c1 = v1 ? (int)(e1 - (size_t)r1 * C4) * 4 : c0;
+    float4 x0 = *(const float4*)(x + (size_t)r0 * ldx + c0), x1 = *(const float4*)(x + (size_t)r1 * ldx + c1);
+    float4 g0 = *(const float4*)(dz + (size_t)r0 * ldd + c0), g1 = *(const float4*)(dz + (size_t)r1 * ldd + c1);
+    float4 o0 = make_float4(0, 0, 0, 0), o1 = o0;
+    if (accumulate) { o0 = *(const float4*)(dx + (size_t)r0 * ldo + c0); o1 = *(const float4*)(dx + (size_t)r1 * ldo + c1); }
+#define NB_ELT(xe, ge, oe, me, ie, we, se, qe) \
+    { float xh = ((xe) - (me)) * (ie); float gg = (we) * (ie) * ((ge) - (se) * inv_n - xh * (qe) * inv_n); oe = accumulate ? ((oe) + gg) : gg; }
+#define NB_ONE(xv, gv, ov, r, c)                                                                               \
+    {                                                                                                          \
+      int sg = seg_of(segs, r);                                                                                \
+      float inv_n = 1.f / (float)(segs.off[sg + 1] - segs.off[sg]);                                            \
+      float4 m = *(const float4*)(mean + sg * C + c), is = *(const float4*)(invstd + sg * C + c);             \
+      float4 ww = *(const float4*)(w + c), sd = *(const float4*)(sum_dz + sg * C + c);                         \
+      float4 sq = *(const float4*)(sum_dzx + sg * C + c);                                                      \
+      NB_ELT(xv.x, gv.x, ov.x, m.x, is.x, ww.x, sd.x, sq.x) NB_ELT(xv.y, gv.y, ov.y, m.y, is.y, ww.y, sd.y, sq.y) \
+      NB_ELT(xv.z, gv.z, ov.z, m.z, is.z, ww.z, sd.z, sq.z) NB_ELT(xv.w, gv.w, ov.w, m.w, is.w, ww.w, sd.w, sq.w) \
+      *(float4*)(dx + (size_t)r * ldo + c) = ov;                                                               \
+    }
+    NB_ONE(x0, g0, o0, r0, c0)
+    if (v1) NB_ONE(x1, g1, o1, r1, c1)
+#undef NB_ONE
+#undef NB_ELT
+  }
+}
 // dy is overwritten with dz (= gradient w.r.t. the pre-activation, which is also the
 // gradient of the residual input).  workspace as in es_norm_fwd plus 2*nseg*C floats.
 extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const float* x, int ldx, int n, int C,
@@ -319,10 +417,20 @@ extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const fl
                      ldx, C, s, nchunk, mean, invstd, act, workspace);
   hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(es_cdiv(C, 64)), dim3(64 * FST), 0, st, workspace, C, s, nchunk, sums,
                      sums + (size_t)nseg * C, dweight, dbias);
-  int g = es_cdiv((long long)n * C, 256);
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(k_norm_bwd_apply, dim3(g), dim3(256), 0, st, dy, ldd, x, ldx, n, C, s, mean, invstd, weight,
-                     sums, sums + (size_t)nseg * C, dx, ldo, accumulate);
+  const bool vec = ((C & 3) == 0) && ((ldx & 3) == 0) && ((ldd & 3) == 0) && ((ldo & 3) == 0) &&
+                   (((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)weight) | ((uintptr_t)mean) |
+                      ((uintptr_t)invstd) | ((uintptr_t)sums)) & 15) == 0) && ((((size_t)nseg * C) & 3) == 0);
+  if (vec && dx != dy) {
+    int g = es_cdiv((long long)n * (C >> 2), 512);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_norm_bwd_apply4, dim3(g < 1 ? 1 : g), dim3(256), 0, st, dy, ldd, x, ldx, n, C, s, mean, invstd,
+                       weight, sums, sums + (size_t)nseg * C, dx, ldo, accumulate);
+  } else {
+    int g = es_cdiv((long long)n * C, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_norm_bwd_apply, dim3(g), dim3(256), 0, st, dy, ldd, x, ldx, n, C, s, mean, invstd, weight,
+                       sums, sums + (size_t)nseg * C, dx, ldo, accumulate);
+  }
   ES_CHECK_LAUNCH();
   return 0;
 }

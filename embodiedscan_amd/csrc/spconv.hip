@@ -738,12 +738,145 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
     }
 }
 
+// ------------------------------------------------------------------ K = 1 on the identity map: a streaming row GEMM
+// Y[r, :] = epilogue(X[r, :] @ W): every 1x1 convolution of the 2-D backbone (with its frozen-BN / residual / ReLU or
+// gated-dgrad epilogue), the head's output GEMMs, the 1x1 shortcuts of MinkResNet, every Linear layer and all of their data
+// gradients.  These launches are bound by the f32 rows they stream (C_in + C_out (+ residual) floats per row, a few flops per
+// byte), so the kernel is built around memory transactions instead of the gather machinery of k_spconv_bf16_fast:
+//   * A fragments come straight from global memory in MFMA layout (lane = row, 8 consecutive channels: 32-B pieces, four lanes
+//     complete a 128-B line), converted to bf16 in registers, register double-buffered -- no LDS, no map, no tap lists;
+//   * the weight slab (NT x 32 bf16) is ping-ponged through LDS: one barrier per k-step;
+//   * the epilogue goes through LDS so that global traffic is whole rows: the accumulator layout (lane = column) would
+//     write 64-B pieces; staged, every half-wave reads / writes 512 contiguous bytes of Y (and of the residual).
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_rowgemm_bf16(const float* __restrict__ X, int ldx,
+                                                      const unsigned short* __restrict__ W, int n_out, int n_in, int Cin,
+                                                      int Cout, const float* __restrict__ bias, float* __restrict__ Y,
+                                                      int ldy, int accumulate, const float* __restrict__ ep_scale,
+                                                      const float* __restrict__ ep_shift,
+                                                      const float* __restrict__ ep_res, int ep_ldr, int ep_act) {
+  constexpr int NF = NT / 16, SLD = NT + 4;
+  constexpr int B_BYTES = 2 * NT * HLD * 2, S_BYTES = 4 * 16 * SLD * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES > S_BYTES ? B_BYTES : S_BYTES];
+  unsigned short* Bs = (unsigned short*)smem;             // [2][NT][HLD]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * BM + wv * 32, n0 = blockIdx.y * NT;
+  const int n_rows = min(n_out, n_in);                    // identity map: rows past the input are empty
+  f32x4 acc[2][NF];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int ns = Cin / HBK;
+  // (scalars, not arrays: arrays captured by the loader lambdas ended up in scratch memory)
+  float4 a00, a01, a10, a11;
+  uint4 bg0, bg1;
+  const int rowA0 = row0 + li, rowA1 = row0 + 16 + li;
+  const float* pa0 = X + (size_t)min(rowA0, n_rows - 1) * ldx + kq * 8;
+  const float* pa1 = X + (size_t)min(rowA1, n_rows - 1) * ldx + kq * 8;
+  const bool va0 = rowA0 < n_rows, va1 = rowA1 < n_rows;
+  const int bc0 = t >> 2, bq = t & 3;                     // weight slab: NT x 32 bf16 = NT*4 16-byte granules
+  const unsigned short* pb0 = W + (size_t)(n0 + bc0) * Cin + bq * 8;
+  const unsigned short* pb1 = W + (size_t)(n0 + (NT > 64 ? 64 : 0) + bc0) * Cin + bq * 8;
+#define RG_LOAD(s_)                                                                    \
+  do {                                                                                 \
+    const float4* q0_ = (const float4*)(pa0 + (s_) * HBK);                             \
+    const float4* q1_ = (const float4*)(pa1 + (s_) * HBK);                             \
+    a00 = q0_[0]; a01 = q0_[1]; a10 = q1_[0]; a11 = q1_[1];   /* clamped addresses */ \
+    if (!va0) { a00 = make_float4(0.f, 0.f, 0.f, 0.f); a01 = a00; }                    \
+    if (!va1) { a10 = make_float4(0.f, 0.f, 0.f, 0.f); a11 = a10; }                    \
+    bg0 = *(const uint4*)(pb0 + (s_) * HBK);                                           \
+    if (NT > 64) bg1 = *(const uint4*)(pb1 + (s_) * HBK);                              \
+  } while (0)
+#define RG_STORE_B(buf_)                                                               \
+  do {                                                                                 \
+    *(uint4*)&Bs[((buf_) * NT + bc0) * HLD + bq * 8] = bg0;                            \
+    if (NT > 64) *(uint4*)&Bs[((buf_) * NT + 64 + bc0) * HLD + bq * 8] = bg1;          \
+  } while (0)
+  if (n_rows <= 0) return;
+  // The epilogue's second operand (residual / gate rows, or Y itself when accumulating) is requested NOW, in the layout the
+  // final stores use: these launches move a few hundred bytes per row and are latency-bound unless every thread keeps
+  // many 16-B loads in flight (Little: 8 TB/s x ~2 us = 64 KB per CU).
+  constexpr int NI = (16 * NT / 4) / 64;
+  const float* pre = ep_res ? ep_res : (accumulate ? Y : nullptr);
+  const int pre_ld = ep_res ? ep_ldr : ldy;
+  float4 pf[2][NI];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int f = i * 64 + lane, rr = f / (NT / 4), c4 = f - rr * (NT / 4);
+      int row = row0 + mf * 16 + rr;
+      pf[mf][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pre && row < n_out) pf[mf][i] = *(const float4*)(pre + (size_t)row * pre_ld + n0 + c4 * 4);
+    }
+  RG_LOAD(0);
+  RG_STORE_B(0);
+  __syncthreads();
+  for (int s = 0; s < ns; ++s) {
+    uint4 pk0 = make_uint4(pack_bf16(a00.x, a00.y), pack_bf16(a00.z, a00.w), pack_bf16(a01.x, a01.y), pack_bf16(a01.z, a01.w));
+    uint4 pk1 = make_uint4(pack_bf16(a10.x, a10.y), pack_bf16(a10.z, a10.w), pack_bf16(a11.x, a11.y), pack_bf16(a11.z, a11.w));
+    bf16x8_t fa0 = __builtin_bit_cast(bf16x8_t, pk0), fa1 = __builtin_bit_cast(bf16x8_t, pk1);
+    if (s + 1 < ns) RG_LOAD(s + 1);
+    const unsigned short* Bc = Bs + (s & 1) * NT * HLD;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      bf16x8_t b = *(const bf16x8_t*)&Bc[(nf * 16 + li) * HLD + kq * 8];
+      acc[0][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, b, acc[0][nf], 0, 0, 0);
+      acc[1][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, b, acc[1][nf], 0, 0, 0);
+    }
+    if (s + 1 < ns) RG_STORE_B((s + 1) & 1);
+    __syncthreads();
+  }
+#undef RG_LOAD
+#undef RG_STORE_B
+  // epilogue through LDS: 16 rows x NT columns per wave and pass
+  float* stage = (float*)smem + wv * 16 * SLD;
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    if (mf) __syncthreads();
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stage[(kq * 4 + r) * SLD + nf * 16 + li] = acc[mf][nf][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (16 * NT / 4) / 64; ++i) {
+      int f = i * 64 + lane, rr = f / (NT / 4), c4 = f - rr * (NT / 4);
+      int row = row0 + mf * 16 + rr, col = n0 + c4 * 4;
+      if (row >= n_out) continue;
+      float4 v = *(const float4*)&stage[rr * SLD + c4 * 4];
+      const float4 q = pf[mf][i];
+      auto ep1 = [&](float x, float r, int c) -> float {
+        x += bias ? bias[c] : 0.f;
+        if (ep_scale) x = x * ep_scale[c] + (ep_shift ? ep_shift[c] : 0.f);
+        if (ep_act == 3) {                                // gate: pass x only where the residual operand is > 0
+          if (!(r > 0.f)) x = 0.f;
+        } else {
+          if (ep_res) x += r;
+          if (ep_act) x = fmaxf(x, 0.f);
+        }
+        return x;
+      };
+      float o0 = ep1(v.x, q.x, col), o1 = ep1(v.y, q.y, col + 1), o2 = ep1(v.z, q.z, col + 2), o3 = ep1(v.w, q.w, col + 3);
+      float4* py = (float4*)(Y + (size_t)row * ldy + col);
+      if (accumulate) {
+        float4 y0 = ep_res ? *py : q;                     // (residual AND accumulation: Y was not prefetched)
+        o0 += y0.x; o1 += y0.y; o2 += y0.z; o3 += y0.w;
+      }
+      *py = make_float4(o0, o1, o2, o3);
+    }
+  }
+}
+
 // run-time tuning switches (A/B measurements without a rebuild): key 1 = ping-pong LDS in the fast bf16 kernels
 static int ES_OPT_PINGPONG = 1;
 static int ES_OPT_WGRAD_HUGE = 1;      // 256 x 256 weight-gradient tile for wide layers (both operands bf16 shadows)
+static int ES_OPT_ROWGEMM = 1;         // streaming row GEMM for K = 1 on the identity map
 extern "C" int es_set_option(int key, int value) {
   if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
   if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }
+  if (key == 3) { ES_OPT_ROWGEMM = value; return 0; }
   return -2;
 }
 
@@ -792,6 +925,17 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
               ((long long)K * Cout * Cin < (1ll << 31)) && (Cout % 64 == 0);
   if (x_is_bf16 && !fast) return -7;            // bf16 input rows are only supported by the fast kernels
   dim3 g128(es_cdiv(n_out, BM), Cout / 128), g64(es_cdiv(n_out, BM), Cout / 64);
+  if (fast && ES_OPT_ROWGEMM && K == 1 && nbr == nullptr && !x_is_bf16 && ep_act != 7 && n_in >= n_out && (ldy % 4 == 0) &&
+      ((((uintptr_t)Y) & 15) == 0) && (!ep_res || ((ep_ldr % 4 == 0) && ((((uintptr_t)ep_res) & 15) == 0)))) {
+    if (Cout % 128 == 0)
+      hipLaunchKernelGGL(k_rowgemm_bf16<128>, g128, dim3(256), 0, st, X, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy,
+                         accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+    else
+      hipLaunchKernelGGL(k_rowgemm_bf16<64>, g64, dim3(256), 0, st, X, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy,
+                         accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+    ES_CHECK_LAUNCH();
+    return 0;
+  }
   int det_split = 0;
   if (fast && !(ep_scale || ep_res || ep_act) && K > 1) {
     // too few workgroups for 256 CUs: split the tap list over gridDim.z (partial sums via f32 atomics into zeroed Y)

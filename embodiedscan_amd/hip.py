@@ -55,6 +55,8 @@ if os.environ.get('ES_PINGPONG') is not None:          # A/B switch of the ping-
     _fn['es_set_option'](1, int(os.environ['ES_PINGPONG']))
 if os.environ.get('ES_WGRAD_HUGE') is not None:        # A/B switch of the 256x256 weight-gradient tile (default: on)
     _fn['es_set_option'](2, int(os.environ['ES_WGRAD_HUGE']))
+if os.environ.get('ES_ROWGEMM') is not None:           # A/B switch of the K = 1 streaming row-GEMM kernel (default: on)
+    _fn['es_set_option'](3, int(os.environ['ES_ROWGEMM']))
 
 
 class HipError(RuntimeError):

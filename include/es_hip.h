@@ -84,7 +84,8 @@ int es_spconv_fwd_bf16_ws(const void* X, int x_is_bf16, int ldx, const void* W_b
  * shapes where es_spconv_bf16_is_fast() returns 1 */
 int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout);
 /* run-time tuning switches for A/B measurements: key 1 = ping-pong LDS buffers in the fast bf16 kernels (default 1),
- * key 2 = 256x256 weight-gradient tile for layers with C_in, C_out multiples of 256 and bf16-shadow operands (default 1) */
+ * key 2 = 256x256 weight-gradient tile for layers with C_in, C_out multiples of 256 and bf16-shadow operands (default 1),
+ * key 3 = streaming row-GEMM kernel for K = 1 launches on the identity map (default 1) */
 int es_set_option(int key, int value);
 /* Y = act((X*W) * scale[c] + shift[c] (+ res)): conv2d + frozen BatchNorm2d (+ residual) (+ ReLU) of mmdet.ResNet in one
  * launch (any shape; the tap-split of under-filled launches is not applied to fused calls).  act: 0 none, 1 ReLU,
