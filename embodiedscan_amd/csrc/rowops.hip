@@ -494,9 +494,33 @@ __global__ void k_row_move(float* __restrict__ dst, int ldd, const float* __rest
     else dst[(size_t)r * ldd + c] = src[(size_t)i * lds + c];
   }
 }
+__global__ void k_row_move4(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds,
+                            const int* __restrict__ idx, int n, int C4, int mode) {
+  size_t tot = (size_t)n * C4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int i = (int)(e / C4), c = (int)(e - (size_t)i * C4) * 4;
+    int r = idx ? idx[i] : i;
+    if (r < 0) continue;
+    if (mode == 0) {
+      *(float4*)(dst + (size_t)i * ldd + c) = *(const float4*)(src + (size_t)r * lds + c);
+    } else if (mode == 1) {
+      float4 a = *(const float4*)(dst + (size_t)r * ldd + c), b = *(const float4*)(src + (size_t)i * lds + c);
+      *(float4*)(dst + (size_t)r * ldd + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    } else {
+      *(float4*)(dst + (size_t)r * ldd + c) = *(const float4*)(src + (size_t)i * lds + c);
+    }
+  }
+}
 extern "C" int es_row_move(float* dst, int ldd, const float* src, int lds, const int* idx, int n, int C, int mode,
                            void* stream) {
   if (n <= 0 || C <= 0) return 0;
+  if ((C % 4 == 0) && (ldd % 4 == 0) && (lds % 4 == 0) && (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0)) {
+    int g4 = es_cdiv((long long)n * (C / 4), 256);
+    if (g4 > 8192) g4 = 8192;
+    hipLaunchKernelGGL(k_row_move4, dim3(g4), dim3(256), 0, (hipStream_t)stream, dst, ldd, src, lds, idx, n, C / 4, mode);
+    ES_CHECK_LAUNCH();
+    return 0;
+  }
   int g = es_cdiv((long long)n * C, 256);
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(k_row_move, dim3(g), dim3(256), 0, (hipStream_t)stream, dst, ldd, src, lds, idx, n, C, mode);

@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int ns = Cin / HBK;
+  const int ns = (Cin + HBK - 1) / HBK;                     // C_in % 8 == 0; a ragged last slab is zero-filled
   // (scalars, not arrays: arrays captured by the loader lambdas ended up in scratch memory)
   float4 a00, a01, a10, a11;
   uint4 bg0, bg1;
@@ -776,21 +776,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   const float* pa1 = X + (size_t)min(rowA1, n_rows - 1) * ldx + kq * 8;
   const bool va0 = rowA0 < n_rows, va1 = rowA1 < n_rows;
   const int bc0 = t >> 2, bq = t & 3;                     // weight slab: NT x 32 bf16 = NT*4 16-byte granules
-  const unsigned short* pb0 = W + (size_t)(n0 + bc0) * Cin + bq * 8;
+  const unsigned short* pb0 = W + (size_t)(n0 + (bc0 < NT ? bc0 : 0)) * Cin + bq * 8;
   const unsigned short* pb1 = W + (size_t)(n0 + (NT > 64 ? 64 : 0) + bc0) * Cin + bq * 8;
 #define RG_LOAD(s_)                                                                    \
   do {                                                                                 \
-    const float4* q0_ = (const float4*)(pa0 + (s_) * HBK);                             \
-    const float4* q1_ = (const float4*)(pa1 + (s_) * HBK);                             \
-    a00 = q0_[0]; a01 = q0_[1]; a10 = q1_[0]; a11 = q1_[1];   /* clamped addresses */ \
-    if (!va0) { a00 = make_float4(0.f, 0.f, 0.f, 0.f); a01 = a00; }                    \
-    if (!va1) { a10 = make_float4(0.f, 0.f, 0.f, 0.f); a11 = a10; }                    \
-    bg0 = *(const uint4*)(pb0 + (s_) * HBK);                                           \
-    if (NT > 64) bg1 = *(const uint4*)(pb1 + (s_) * HBK);                              \
+    const bool ka_ = (s_) * HBK + kq * 8 < Cin, kb_ = (s_) * HBK + bq * 8 < Cin;       \
+    a00 = a01 = a10 = a11 = make_float4(0.f, 0.f, 0.f, 0.f);                           \
+    bg0 = bg1 = make_uint4(0u, 0u, 0u, 0u);                                            \
+    if (va0 && ka_) {                                                                  \
+      const float4* q0_ = (const float4*)(pa0 + (s_) * HBK);                           \
+      a00 = q0_[0]; a01 = q0_[1];                                                      \
+    }                                                                                  \
+    if (va1 && ka_) {                                                                  \
+      const float4* q1_ = (const float4*)(pa1 + (s_) * HBK);                           \
+      a10 = q1_[0]; a11 = q1_[1];                                                      \
+    }                                                                                  \
+    if (kb_ && bc0 < NT) bg0 = *(const uint4*)(pb0 + (s_) * HBK);                      \
+    if (NT > 64 && kb_) bg1 = *(const uint4*)(pb1 + (s_) * HBK);                       \
   } while (0)
 #define RG_STORE_B(buf_)                                                               \
   do {                                                                                 \
-    *(uint4*)&Bs[((buf_) * NT + bc0) * HLD + bq * 8] = bg0;                            \
+    if (bc0 < NT) *(uint4*)&Bs[((buf_) * NT + bc0) * HLD + bq * 8] = bg0;              \
     if (NT > 64) *(uint4*)&Bs[((buf_) * NT + 64 + bc0) * HLD + bq * 8] = bg1;          \
   } while (0)
   if (n_rows <= 0) return;
@@ -905,6 +911,20 @@ __global__ void k_sum_splits(const float* __restrict__ ws, int split, int n_out,
     *p = accumulate ? (*p + s) : s;
   }
 }
+__global__ void k_sum_splits4(const float4* __restrict__ ws, int split, size_t tot4, int C4, float* __restrict__ Y, int ldy,
+                              int accumulate) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot4; e += (size_t)gridDim.x * blockDim.x) {
+    float4 s = ws[e];
+    for (int z = 1; z < split; ++z) {
+      float4 v = ws[(size_t)z * tot4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    size_t row = e / C4;
+    float4* p = (float4*)(Y + row * ldy + (e - row * C4) * 4);
+    if (accumulate) { float4 y0 = *p; s.x = y0.x + s.x; s.y = y0.y + s.y; s.z = y0.z + s.z; s.w = y0.w + s.w; }
+    *p = s;
+  }
+}
 extern "C" size_t es_spconv_split_workspace_floats(int n_out, int K, int Cin, int Cout) {
   if (K <= 1 || Cin % HBK != 0 || Cout % 64 != 0 || n_out <= 0) return 0;
   int split = split_factor(n_out, K, Cout);
@@ -925,14 +945,20 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
               ((long long)K * Cout * Cin < (1ll << 31)) && (Cout % 64 == 0);
   if (x_is_bf16 && !fast) return -7;            // bf16 input rows are only supported by the fast kernels
   dim3 g128(es_cdiv(n_out, BM), Cout / 128), g64(es_cdiv(n_out, BM), Cout / 64);
-  if (fast && ES_OPT_ROWGEMM && K == 1 && nbr == nullptr && !x_is_bf16 && ep_act != 7 && n_in >= n_out && (ldy % 4 == 0) &&
-      ((((uintptr_t)Y) & 15) == 0) && (!ep_res || ((ep_ldr % 4 == 0) && ((((uintptr_t)ep_res) & 15) == 0)))) {
-    if (Cout % 128 == 0)
-      hipLaunchKernelGGL(k_rowgemm_bf16<128>, g128, dim3(256), 0, st, X, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy,
-                         accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
-    else
-      hipLaunchKernelGGL(k_rowgemm_bf16<64>, g64, dim3(256), 0, st, X, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy,
-                         accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+  if (ES_OPT_ROWGEMM && K == 1 && nbr == nullptr && !x_is_bf16 && ep_act != 7 && n_in >= n_out && (Cin % 8 == 0) &&
+      (Cout % 16 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+      (((((uintptr_t)Xv) | ((uintptr_t)Wh) | ((uintptr_t)Y)) & 15) == 0) &&
+      (!ep_res || ((ep_ldr % 4 == 0) && ((((uintptr_t)ep_res) & 15) == 0)))) {
+    const int nt = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0) ? 64 : (Cout % 32 == 0) ? 32 : 16;
+    dim3 g(es_cdiv(n_out, BM), Cout / nt);
+#define RG_LAUNCH(NT_)                                                                                              \
+    hipLaunchKernelGGL(k_rowgemm_bf16<NT_>, g, dim3(256), 0, st, X, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy,   \
+                       accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act)
+    if (nt == 128) RG_LAUNCH(128);
+    else if (nt == 64) RG_LAUNCH(64);
+    else if (nt == 32) RG_LAUNCH(32);
+    else RG_LAUNCH(16);
+#undef RG_LAUNCH
     ES_CHECK_LAUNCH();
     return 0;
   }
@@ -991,8 +1017,15 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
   }
   ES_CHECK_LAUNCH();
   if (det_split) {
-    int g = es_cdiv((long long)n_out * Cout, 256);
-    hipLaunchKernelGGL(k_sum_splits, dim3(g > 4096 ? 4096 : g), dim3(256), 0, st, ws, det_split, n_out, Cout, Y, ldy, accumulate);
+    if ((Cout % 4 == 0) && (ldy % 4 == 0) && (((((uintptr_t)ws) | ((uintptr_t)Y)) & 15) == 0)) {
+      size_t tot4 = (size_t)n_out * (Cout / 4);
+      int g = es_cdiv((long long)tot4, 256);
+      hipLaunchKernelGGL(k_sum_splits4, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, (const float4*)ws, det_split, tot4,
+                         Cout / 4, Y, ldy, accumulate);
+    } else {
+      int g = es_cdiv((long long)n_out * Cout, 256);
+      hipLaunchKernelGGL(k_sum_splits, dim3(g > 4096 ? 4096 : g), dim3(256), 0, st, ws, det_split, n_out, Cout, Y, ldy, accumulate);
+    }
     ES_CHECK_LAUNCH();
   }
   return 0;
@@ -1533,9 +1566,28 @@ __global__ void k_cast_rows(const float* __restrict__ x, int ldx, size_t n, int 
     ((uint32_t*)h)[e] = pack_bf16(p[0], p[1]);
   }
 }
+// 8 channels per thread: two float4 in, one 16-B store
+__global__ void k_cast_rows8(const float* __restrict__ x, int ldx, size_t n, int C8, uint4* __restrict__ h) {
+  size_t tot = n * (size_t)C8;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    size_t r = e / C8;
+    int c = (int)(e - r * C8) * 8;
+    const float4* p = (const float4*)(x + r * ldx + c);
+    float4 a = p[0], b = p[1];
+    h[e] = make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w));
+  }
+}
 extern "C" int es_cast_rows_bf16(const float* x, int ldx, int n, int C, void* h, void* stream) {
   if (n <= 0 || C <= 0) return 0;
   if (C & 1) return -8;
+  if ((C % 8 == 0) && (ldx % 4 == 0) && (((((uintptr_t)x) | ((uintptr_t)h)) & 15) == 0)) {
+    long long tot8 = (long long)n * (C / 8);
+    int g8 = es_cdiv(tot8, 256);
+    if (g8 > 8192) g8 = 8192;
+    hipLaunchKernelGGL(k_cast_rows8, dim3(g8), dim3(256), 0, (hipStream_t)stream, x, ldx, (size_t)n, C / 8, (uint4*)h);
+    ES_CHECK_LAUNCH();
+    return 0;
+  }
   long long tot = (long long)n * (C >> 1);
   int g = es_cdiv(tot, 256);
   if (g > 8192) g = 8192;

@@ -200,7 +200,8 @@ def test_rowgemm_matches_general_kernel(dev):
     g = torch.Generator().manual_seed(21)
     opt = hip.raw('es_set_option')
     try:
-        for n, cin, cout in ((1000, 32, 128), (5000, 64, 256), (777, 128, 64), (300, 512, 192), (129, 96, 320)):
+        for n, cin, cout in ((1000, 32, 128), (5000, 64, 256), (777, 128, 64), (300, 512, 192), (129, 96, 320),
+                             (1000, 16, 64), (2000, 64, 16), (500, 48, 32), (640, 128, 32), (333, 24, 48)):
             x = torch.randn(n, cin, generator=g).to(dev)
             w = (torch.randn(1, cin, cout, generator=g) / cin ** 0.5).to(dev)
             wt = torch.empty((1, cout, cin), dtype=torch.bfloat16, device=dev)
@@ -231,11 +232,15 @@ def test_rowgemm_matches_general_kernel(dev):
                 torch.cuda.synchronize()
                 outs[on] = o
             for a, b in zip(outs[1], outs[0]):
-                assert torch.equal(a, b), (n, cin, cout, float((a - b).abs().max()))
+                # same bf16 products and accumulation order: identical (a last-bit difference is tolerated for the ragged
+                # shapes, where the general kernel pads its K chunk differently)
+                exact = cin % 32 == 0 and cout % 64 == 0
+                d = float((a - b).abs().max())
+                assert torch.equal(a, b) if exact else d <= 2e-6 * float(b.abs().max()), (n, cin, cout, d)
             xb, wb = x.bfloat16().double(), w[0].bfloat16().double()
             want = xb @ wb + bias.double()
             err = float((outs[1][0].double() - want).abs().max() / want.abs().max())
-            print(f'rowgemm n={n} {cin}->{cout}: identical to the general kernel in 7 modes; vs f64 GEMM on bf16 operands {err:.1e}')
+            print(f'rowgemm n={n} {cin}->{cout}: equal to the general kernel in 7 modes; vs f64 GEMM on bf16 operands {err:.1e}')
             assert err < 1e-6
     finally:
         opt(3, 1)
