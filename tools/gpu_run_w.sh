@@ -15,8 +15,6 @@ prof fetch --pmc FETCH_SIZE TCC_HIT_sum
 python tools/rocpd_pmc.py $DB gpurun_out/w_pmc_fetch.txt > /dev/null 2>&1
 prof write --pmc WRITE_SIZE TCC_MISS_sum
 python tools/rocpd_pmc.py $DB gpurun_out/w_pmc_write.txt > /dev/null 2>&1
-prof sq --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY
-python tools/rocpd_pmc.py $DB gpurun_out/w_pmc_sq.txt > /dev/null 2>&1
 cp gpurun_out/w_pmc_fetch.txt profiles/r2_pmc_fetch.txt; cp gpurun_out/w_pmc_write.txt profiles/r2_pmc_write.txt
 python tools/pmc_traffic.py > gpurun_out/w_pmc_traffic.log 2>&1; cp profiles/r2_pmc_traffic.json gpurun_out/w_pmc_traffic.json
 prof default --stats
@@ -27,8 +25,8 @@ timeout 900 python bench.py > gpurun_out/w_bench.json 2> gpurun_out/w_bench.err
 timeout 600 python bench.py --no-cpu-baseline --precision f32 > gpurun_out/w_bench_f32.json 2>> gpurun_out/w_bench.err
 timeout 600 python tools/bench_occ.py > gpurun_out/w_bench_occ.json 2> gpurun_out/w_bench_occ.err
 timeout 900 python tools/bench_grounding.py > gpurun_out/w_bench_ground.json 2> gpurun_out/w_bench_ground.err
-python -m pytest tests -m gpu -q -s > gpurun_out/w_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/w_pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/w_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/w_smoke.log
+python -m pytest tests -m gpu -q -s > gpurun_out/w_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/w_pytest.log
 set +x
 grep -E "passed|failed|rc=" gpurun_out/w_pytest.log; tail -2 gpurun_out/w_smoke.log
 cat gpurun_out/w_pmc_traffic.log

@@ -18,7 +18,7 @@ def table(path):
 
 def main(steps=7):
     f, w = table(os.path.join(ROOT, 'profiles', 'r2_pmc_fetch.txt')), table(os.path.join(ROOT, 'profiles', 'r2_pmc_write.txt'))
-    fam = [k for k in f if 'k_spconv' in k]
+    fam = [k for k in f if 'k_spconv' in k or 'k_rowgemm' in k]      # every kernel behind the es_spconv_* entry points
     fetch = sum(f[k]['FETCH_SIZE'] for k in fam) * 1024 * 2
     write = sum(w[k]['WRITE_SIZE'] for k in fam if k in w) * 1024
     launches = int(sum(f[k]['calls'] for k in fam))
