@@ -230,7 +230,7 @@ def main():
         roof = dict(bound='hbm', achieved=eng['comp_GBps'], peak=K_PEAK_HBM, unit='GB/s',
                     frac=round(eng['comp_GBps'] / K_PEAK_HBM, 4))
     roofline = dict(roof, traffic=traffic,
-                    kernel='convolution engine: k_spconv_bf16* (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
+                    kernel='convolution engine: k_spconv_bf16* / k_rowgemm_bf16 (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
                     else 'convolution engine: k_spconv / k_spconv_wgrad (exact-f32 MFMA)',
                     launches_per_step=eng['launches'], kernel_ms_per_step=eng['ms'],
                     frac_of_binding_roof=eng['frac_binding'],
