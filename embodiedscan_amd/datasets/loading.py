@@ -180,6 +180,11 @@ class ScanPipeline:
                     img_shape=(h_new, w_new), ori_shape=(H, W), scale_factor=(w_new / W, h_new / H),
                     box_type_3d='euler-depth', scan_id=info['scan_id'], sample_idx=info['sample_idx'],
                     img_path=[info['img_path'][i] for i in ids.tolist()])
+        # the remaining keys Pack3DDetInputs copies into the data sample when the pipeline produced them
+        # (transforms/formatting.py:66-79)
+        for k in ('axis_align_matrix', 'cam2img'):
+            if k in info:
+                meta[k] = info[k]
         meta.update(aug_meta)
         scan = dict(depth=np.stack(depths), img_raw=np.stack(imgs), extrinsic=np.stack(extr).astype(np.float32),
                     intrinsic=np.stack(depth_intr), sel_view=sel_view.astype(np.int32), sel_pix=sel_pix.astype(np.int32),

@@ -127,6 +127,10 @@ def test_written_dataset_round_trips(tmp_path):
     raw = ds.get_data_info(1)['ann_info']['gt_bboxes_3d']
     assert np.allclose(raw, s['gt_boxes'], atol=1e-6)
     assert np.array_equal(a['gt_boxes'], augment_gt_boxes(raw, a['aug']).numpy())
+    # meta keys of the data sample (the subset of Pack3DDetInputs.meta_keys this pipeline produces)
+    assert {'img_path', 'ori_shape', 'img_shape', 'depth2img', 'scale_factor', 'pcd_horizontal_flip', 'pcd_vertical_flip',
+            'box_type_3d', 'pcd_trans', 'sample_idx', 'pcd_scale_factor', 'pcd_rotation', 'pcd_rotation_angle',
+            'transformation_3d_flow', 'axis_align_matrix', 'cam2img', 'scan_id'} <= set(a['meta'])
     flow = a['meta']['transformation_3d_flow']
     assert flow[-3:] == ['R', 'S', 'T'] and ('HF' in flow) == a['aug']['hflip'] and ('VF' in flow) == a['aug']['vflip']
     # unknown transforms are refused, not skipped
