@@ -143,6 +143,30 @@ def _dp_worker():
     dist.all_gather(gathered, mine)
     assert torch.allclose(big.grad, torch.stack(gathered).mean(0), atol=1e-7)
     assert not red.finish()                                      # nothing pending any more
+    # N4 / 8e: every rank reads ITS shard of the scan list from files -- same number of batches on both ranks, the shards
+    # are the two halves of one seeded permutation (no collective in the data path; this gather is the test's own)
+    from embodiedscan_amd.datasets import EmbodiedScanDataset, ScanLoader
+    from embodiedscan_amd.synth import _NOUNS
+    fix = os.path.join(ROOT, 'tests', 'golden', 'fake_dataset')
+    pipe = [dict(type='LoadAnnotations3D'),
+            dict(type='MultiViewPipeline', n_images=3,
+                 transforms=[dict(type='LoadImageFromFile'), dict(type='LoadDepthFromFile'),
+                             dict(type='ConvertRGBDToPoints', coord_type='CAMERA'), dict(type='PointSample', num_points=200),
+                             dict(type='Resize', scale=(48, 48), keep_ratio=False)]),
+            dict(type='AggregateMultiViewPoints', coord_type='DEPTH'), dict(type='PointSample', num_points=500),
+            dict(type='Pack3DDetInputs', keys=['img', 'points', 'gt_bboxes_3d', 'gt_labels_3d'])]
+    ds = EmbodiedScanDataset(fix, 'embodiedscan_infos_train.pkl', metainfo=dict(classes=_NOUNS + ['object']), pipeline=pipe)
+    loader = ScanLoader(ds, batch_size=2, rank=rank, world=world, shuffle=True, seed=5, times=6, num_threads=2, pin=False)
+    mine_ids = [s['meta']['scan_id'] for b in loader for s in b]
+    both = [None] * world
+    dist.all_gather_object(both, (len(loader), loader.indices(), mine_ids))
+    assert both[0][0] == both[1][0] == 3 and len(mine_ids) == 6
+    import torch as _t
+    g3 = _t.Generator()
+    g3.manual_seed(5)
+    perm = [i % len(ds) for i in _t.randperm(len(ds) * 6, generator=g3).tolist()]
+    assert both[0][1] == perm[0::2] and both[1][1] == perm[1::2]
+    assert mine_ids == [ds.get_data_info(i)['scan_id'] for i in loader.indices()[:6]]
     dist.destroy_process_group()
     print(f'rank {rank} ok')
 
