@@ -1500,12 +1500,20 @@ static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, co
              ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)dY) & 15) == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
              ((long long)n_out * ldy < (1ll << 31)) &&
              (n_out >= 512 || (long long)Cin * Cout >= 512ll * 512ll);   // few rows x many channels: dW traffic decides
-  if (big && XH && YH && ES_OPT_WGRAD_HUGE && (Cin % 256 == 0) && (Cout % 256 == 0) && (ldx % 8 == 0) && (ldy % 8 == 0)) {
+  bool huge = big && XH && YH && ES_OPT_WGRAD_HUGE && (Cin % 256 == 0) && (Cout % 256 == 0) && (ldx % 8 == 0) && (ldy % 8 == 0);
+  int huge_splits = 1;
+  if (huge) {
     int base = K * (Cin / 256) * (Cout / 256);
-    int splits = es_cdiv(2048, base);
+    huge_splits = es_cdiv(2048, base);
     int max_splits = es_cdiv(n_out, 1024);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
+    if (huge_splits > max_splits) huge_splits = max_splits;
+    if (huge_splits < 1) huge_splits = 1;
+    // one 512-thread workgroup per CU: below ~4 workgroups per CU the 128 x 128 tile fills the chip better (measured: the
+    // 256 .. 1024-channel levels of mv-3ddet have 190 .. 12 k rows -> 200 .. 400 workgroups, +0.9 ms per step)
+    huge = (long long)base * huge_splits >= 1024;
+  }
+  if (huge) {
+    int splits = huge_splits;
     int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
     splits = es_cdiv(n_out, rows_per_split);
     dim3 grid(K * (Cin / 256), Cout / 256, es_cdiv(splits, 8) * 8);

@@ -156,7 +156,8 @@ def test_wgrad_few_rows_many_channels(dev):
     from embodiedscan_amd.hip import call, P
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(11)
-    for n, cin, cout, K in ((300, 512, 640, 27), (1500, 512, 768, 27)):   # 2nd: the 256x256 tile (both dims % 256, shadows)
+    for n, cin, cout, K in ((300, 512, 640, 27), (4096, 1024, 768, 27)):  # 2nd: the 256x256 tile (both dims % 256, shadows,
+                                                                         # >= 1024 workgroups)
         _wgrad_case(dev, g, n, cin, cout, K)
 
 
