@@ -263,11 +263,13 @@ def test_process_loader_matches_thread_loader(tmp_path):
         ld.done(got)
         n += 1
     assert n == len(ref) == 9                                    # 18 scans through 7 slots: recycling works
+    ld.close()
     ld2 = ScanLoader(ds, batch_size=2, seed=4, times=6, num_threads=2, prefetch=1, pin=False, workers='process')
     with pytest.raises(RuntimeError, match='done'):
         held = []
         for batch in ld2:
             held.append(batch)                                   # never released
+    ld2.close()
 
 
 @pytest.mark.parametrize('tag', ['vg_train', 'vg_test'])
