@@ -38,6 +38,11 @@ def shard_indices(n, rank=0, world=1, shuffle=True, seed=0, epoch=0, round_up=Tr
     return [i % n for i in idx[rank::world]]
 
 
+class _Batch(list):
+    """a batch of pinned raw scans + the shared slots they live in (process mode), until ScanLoader.done()"""
+    slots = None
+
+
 class ScanLoader:
     """iterator over batches (lists of `batch_size` pinned raw scans) of this rank's shard.
 
@@ -54,7 +59,6 @@ class ScanLoader:
         self.workers = workers
         self.epoch = 0
         self._slabs = None          # process mode: shared (and pinned) slots, allocated on first use, reused across epochs
-        self._busy = {}             # id(batch list) -> slots it occupies, until done(batch)
         self._pending = []          # (event, slots) released by the consumer, reusable once the event has completed
 
     def set_epoch(self, epoch):
@@ -76,8 +80,9 @@ class ScanLoader:
     def done(self, batch, event=None):
         """process mode: the consumer is finished with `batch`'s pinned buffers (event: a CUDA event recorded after the
         host->device copy was queued; the slots are reused once it has completed).  No-op in thread mode."""
-        slots = self._busy.pop(id(batch), None)
-        if slots is not None:
+        slots = getattr(batch, 'slots', None)
+        if slots:
+            batch.slots = None
             self._pending.append((event, slots))
 
     def __iter__(self):
@@ -203,14 +208,14 @@ class ScanLoader:
                         free.append(slot)
                         raise RuntimeError(f'scan {idx[pos]} (position {pos}): {err}')
                     got[pos] = (slot, lay, small)
-                batch, slots = [], []
+                batch, slots = _Batch(), []
                 for pos in range(lo, hi):
                     slot, lay, small = got.pop(pos)
                     d = self._views(slabs[slot], lay)
                     d.update(small)
                     batch.append(d)
                     slots.append(slot)
-                self._busy[id(batch)] = slots
+                batch.slots = slots
                 yield batch
         finally:
             # an abandoned epoch: drain what is still in flight so that the slots come back
