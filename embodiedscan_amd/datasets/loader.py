@@ -144,13 +144,11 @@ class ScanLoader:
         self._procs = [ctx.Process(target=work, daemon=True) for _ in range(self.num_threads)]
         for p in self._procs:
             p.start()
-        self._registered = False
         if self.pin and torch.cuda.is_available():
             for t in self._slabs:
                 err = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel(), 0)
                 if int(err) != 0:
                     raise RuntimeError(f'cudaHostRegister failed with {int(err)}')
-            self._registered = True
         self._free = list(range(n_slots))
 
     def close(self):
@@ -162,13 +160,6 @@ class ScanLoader:
             p.join(timeout=5)
             if p.is_alive():
                 p.terminate()
-        if getattr(self, '_registered', False):
-            for t in self._slabs or ():
-                try:                                          # best effort: the mapping goes away with the tensor anyway
-                    torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
-                except Exception:
-                    pass
-            self._registered = False
         self._slabs = None
 
     def __del__(self):
