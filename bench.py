@@ -31,6 +31,52 @@ SCATTER = {'es_voxel_keys', 'es_unique_first', 'es_morton_sort', 'es_stride_keys
            'es_union_plan', 'es_point_sample_fwd', 'es_point_sample_bwd', 'es_depth_to_points'}
 
 
+class Feeder:
+    """Host->device feed of whole batches: every batch is ONE pinned slab (pipeline.pin_batch), the device side two byte
+    slabs; the copy of step i+1 is queued on a copy stream under the kernels of step i (one hipMemcpyAsync per batch),
+    the step waits for its own batch and the slot is recycled when the step that read it has been queued completely."""
+
+    def __init__(self, batches, dev, resident=False):
+        import torch
+        from embodiedscan_amd import pipeline
+        self.torch, self.pipeline = torch, pipeline
+        self.batches, self.dev, self.resident = batches, dev, resident
+        self.h2d_bytes = batches[0].nbytes
+        cap = max(b.nbytes for b in batches)
+        self.slots = [pipeline.alloc_batch_slot(cap, dev) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream()
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]     # slot s holds its batch
+        self.freed = [torch.cuda.Event(), torch.cuda.Event()]     # the step that read slot s has been queued completely
+        self.i = 0
+        self.dscans = [None, None]
+
+    def _prefetch(self, i):
+        s = i % 2
+        with self.torch.cuda.stream(self.copy_stream):
+            if i >= 2:
+                self.copy_stream.wait_event(self.freed[s])        # step i-2 (last reader of this slot) is done
+            self.dscans[s] = self.pipeline.upload_batch(self.slots[s], self.batches[i % len(self.batches)])
+            self.ready[s].record(self.copy_stream)
+
+    def next(self):
+        """dscans of this step's batch (the current stream is made to wait for its copy; the next copy is queued)"""
+        i, s = self.i, self.i % 2
+        if self.resident:
+            if self.dscans[0] is None:
+                self.dscans[0] = self.pipeline.upload_batch(self.slots[0], self.batches[0])
+            return self.dscans[0]
+        if i == 0:
+            self._prefetch(0)
+        self.torch.cuda.current_stream().wait_event(self.ready[s])
+        self._prefetch(i + 1)
+        return self.dscans[s]
+
+    def done(self):
+        if not self.resident:
+            self.freed[self.i % 2].record(self.torch.cuda.current_stream())
+        self.i += 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -43,6 +89,12 @@ def main():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'],
                     help='conv fwd/dgrad matrix-core type: bf16 MFMA with f32 accumulate (BASELINE config) or exact-f32 MFMA')
     ap.add_argument('--resident', action='store_true', help='skip the per-step host->device copy (inputs resident in HBM)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip BASELINE configs 4 (mv-grounding) and 5 (occupancy), which the default 1-GPU run appends as `other_configs`')
+    ap.add_argument('--only', default=None, choices=['grounding', 'occupancy'],
+                    help='run ONLY that configuration and print its object as the JSON line (profiling passes)')
+    ap.add_argument('--grounding-batch', type=int, default=12, help='scans per GPU per step of config 4 (reference: 8xb12)')
+    ap.add_argument('--other-steps', type=int, default=10, help='timed steps of the other configs (capped by --steps)')
     args = ap.parse_args()
 
     import torch
@@ -67,6 +119,15 @@ def main():
     from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
     from embodiedscan_amd.synth import make_scan
 
+    if args.only:
+        assert world == 1
+        E.PRECISION[0] = args.precision
+        res = run_other_config(args.only, args, dev)
+        print(json.dumps(res))
+        if res.get('parity') and not res['parity']['ok']:
+            raise SystemExit(f'parity check of config {args.only} FAILED: ' + json.dumps(res['parity']))
+        return
+
     # (Measured and rejected: running the step's dependent chain on a high-priority stream -- 42-45 ms/step against 30.7 on
     # the same box; the weight-gradient / side streams starve behind it and the joins at the end of backward wait longer.)
     E.PRECISION[0] = args.precision
@@ -79,23 +140,9 @@ def main():
     n_rot = max(1, args.rotate)
     scans = [make_scan(1234 + rank * 10007 + i, n_views=args.views, render_device=str(dev))
              for i in range(args.batch * n_rot)]
-    pinned = [pipeline.pin_scan(s) for s in scans]
-    batches = [pinned[r * args.batch:(r + 1) * args.batch] for r in range(n_rot)]
-    h2d_bytes = sum(pipeline.scan_h2d_bytes(p) for p in batches[0])
-    slots = [[pipeline.alloc_slot(p, dev) for p in batches[0]] for _ in range(2)]
-    copy_stream = torch.cuda.Stream()
-    ready = [torch.cuda.Event(), torch.cuda.Event()]          # slot s holds its batch
-    freed = [torch.cuda.Event(), torch.cuda.Event()]          # the step that read slot s has been queued completely
-    state = dict(i=0, dscans=[None, None])
-
-    def prefetch(i):
-        """queue the host->device copy of step i's batch into slot i%2 on the copy stream"""
-        s = i % 2
-        with torch.cuda.stream(copy_stream):
-            if i >= 2:
-                copy_stream.wait_event(freed[s])              # step i-2 (last reader of this slot) is done
-            state['dscans'][s] = [pipeline.upload_into(sl, p) for sl, p in zip(slots[s], batches[i % n_rot])]
-            ready[s].record(copy_stream)
+    feeder = Feeder([pipeline.pin_batch(scans[r * args.batch:(r + 1) * args.batch]) for r in range(n_rot)], dev,
+                    resident=args.resident)
+    h2d_bytes = feeder.h2d_bytes
 
     # ---- parity at the benchmarked configuration, part 1 (untimed): losses of scans[0] alone from the PRE-training
     # weights on the HIP path; cpu_baseline() below runs the oracle on the same scan / weights and asserts agreement
@@ -115,24 +162,11 @@ def main():
         del d0, b0, data, l0
 
     def step():
-        i = state['i']
-        s = i % 2
-        if args.resident:
-            if state['dscans'][0] is None:
-                state['dscans'][0] = [pipeline.upload_scan(sc, dev) for sc in scans[:args.batch]]
-            dscans = state['dscans'][0]
-        else:
-            if i == 0:
-                prefetch(0)
-            torch.cuda.current_stream().wait_event(ready[s])  # this step's batch has landed in HBM
-            prefetch(i + 1)                                   # next step's copy runs under this step's kernels
-            dscans = state['dscans'][s]
+        dscans = feeder.next()                                # this step's batch has landed in HBM; next copy queued
         E.mark('_begin')
         batch = pipeline.make_batch(dscans)                   # A1-A3 on device
         out = det.train_step(batch, optim)
-        if not args.resident:
-            freed[s].record(torch.cuda.current_stream())
-        state['i'] = i + 1
+        feeder.done()
         return out
 
     for _ in range(args.warmup):
@@ -187,7 +221,7 @@ def main():
 
     # ---- one extra UNTIMED step on the single-stream schedule: stand-alone duration of every engine launch, the
     # scatter-path kernels (north_star: "achieved HBM GB/s for the scatter path") and per-stage times
-    single = scatter = stages = None
+    single = scatter = stages = classes = None
     if world == 1:
         saved = (E.TWO_STREAMS[0], E.WGRAD_ASYNC[0])
         E.TWO_STREAMS[0] = E.WGRAD_ASYNC[0] = False
@@ -206,6 +240,7 @@ def main():
                       note='same launches, one extra untimed step with ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0 (stand-alone '
                            'durations); rocprofv3 summary of this schedule: profiles/r2_single_stream_kernel_stats.txt')
         scatter = scatter_totals([r for r in r1 if r[0] in SCATTER])
+        classes = launch_classes(r1, mfma_peak)
         stages = {}
         for (n0, ev0), (n1, ev1) in zip(marks[:-1], marks[1:]):
             stages[n1] = round(stages.get(n1, 0.0) + ev0.elapsed_time(ev1), 3)
@@ -239,14 +274,15 @@ def main():
                                         bytes_per_step=eng['comp_bytes']),
                     hbm_pair_bytes=dict(achieved_GBps=eng['pair_GBps'], frac=round(eng['pair_GBps'] / K_PEAK_HBM, 4),
                                         bytes_per_step=eng['pair_bytes']),
-                    single_stream=single,
+                    single_stream=single, classes=classes,
                     note='per launch: algorithmic flops = 2*P*Cin*Cout (P = valid (output,tap) pairs), compulsory bytes = '
                          'every input row, output row and weight once, pair bytes = SURVEY 8(d) P*(Cin+Cout)*4 + weights; '
                          'binding roof per launch = max(flops/MFMA peak, compulsory bytes/HBM peak); frac_of_binding_roof = '
                          'sum of binding-roof times / sum of HIP-event launch durations; bound/achieved/peak/frac = the '
                          'roof that binds the family in total; durations are HIP-event times on the launch stream under the '
                          'concurrent 4-stream schedule (kernels of different streams share the chip, so the sum exceeds wall '
-                         'time); ' + traffic_note)
+                         'time); classes = the top engine launch classes of the single-stream step (stand-alone durations); '
+                         + traffic_note)
 
     out = dict(metric='scans/sec (train step) mv-3ddet, 20x(480x640) RGB-D views', value=round(world * args.batch * args.steps / dt, 4),
                unit='scans/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -258,7 +294,7 @@ def main():
                            scans_per_gpu_per_step=args.batch, views=args.views, parallelism=f'dp{world}',
                            distinct_batches=n_rot,
                            h2d='resident (no per-step copy)' if args.resident else
-                           f'{h2d_bytes / 1e6:.0f} MB per step from pinned host memory on a copy stream, double-buffered'),
+                           f'{h2d_bytes / 1e6:.0f} MB per step as ONE copy from a pinned slab on a copy stream, double-buffered'),
                losses={k: round(float(v), 6) for k, v in losses.items()}, roofline=roofline)
     if scatter is not None:
         out['scatter_path'] = scatter
@@ -270,11 +306,268 @@ def main():
     out['step_ms'] = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(args.steps)]
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'], out['parity'] = cpu_baseline(scans[0], sd0, det, parity_hip, args)
+    # ---- BASELINE configs 4 and 5 on the same GPU, same rules (H2D in the step, rotating batches, parity vs the oracle)
+    bad = []
+    if world == 1 and not args.no_other_configs:
+        del det, optim, feeder, scans, losses
+        E.TAPE.clear()
+        torch.cuda.empty_cache()
+        out['other_configs'] = {}
+        for kind in ('grounding', 'occupancy'):
+            try:
+                r = run_other_config(kind, args, dev)
+            except Exception as e:                              # the primary line must survive a failure here
+                import traceback
+                r = dict(error=f'{type(e).__name__}: {e}', traceback=traceback.format_exc()[-1500:])
+            out['other_configs'][kind] = r
+            if r.get('error') or (r.get('parity') and not r['parity']['ok']):
+                bad.append(kind)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
     if out.get('parity') and not out['parity']['ok']:
         raise SystemExit('parity check at the benchmarked configuration FAILED: ' + json.dumps(out['parity']))
+    if bad:
+        raise SystemExit(f'other_configs {bad}: error or parity failure (see the JSON line)')
+
+
+OTHER = {
+    'grounding': dict(cfg='mv_grounding.py', views=20, rotate=2, seed=777,
+                      metric='scans/sec (train step) mv-grounding, 20x(480x640) RGB-D views',
+                      workload='SparseFeatureFusion3DGrounder: ResNet-50(w16) + MinkResNet34 + MinkNeck + 6-layer decoder (256 queries, '
+                               '8 heads, FFN 2048) + GroundingHead with device-side Hungarian; frozen random-init RoBERTa-base-shaped '
+                               'text encoder; full train step incl. H2D of the batch and paramwise AdamW'),
+    'occupancy': dict(cfg='mv_occ.py', views=10, rotate=3, seed=4321,
+                      metric='scans/sec (train step) occupancy, 10x(480x640) RGB-D views, 40x40x16 volume',
+                      workload='DenseFusionOccPredictor: ResNet-50 + FPN, MinkResNet34, IndoorImVoxelNeck 768-1536-3072, ImVoxelOccHead '
+                               '81 classes, batch 1 (reference 8xb1), 751 M parameters; full train step incl. H2D of the batch and AdamW'),
+}
+ATTN = {'es_attn_fwd', 'es_attn_bwd'}
+
+
+def run_other_config(kind, args, dev):
+    """BASELINE config 4 (mv-grounding, `--grounding-batch` scans per step, reference 8xb12) or 5 (occupancy, batch 1) under
+    the same rules as the primary line: host->device copy of every batch inside the step (one pinned slab, copy stream,
+    double-buffered), rotating distinct batches, parity of the losses against the CPU oracle from the pre-training weights,
+    roofline of the kernel family north_star names for it (attention MFMA / dense-neck MFMA), single-stream stage times."""
+    import torch
+    from embodiedscan_amd import engine as E, hip, pipeline
+    from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
+    from embodiedscan_amd.synth import make_grounding_sample, make_occ_gt, make_scan
+    o = OTHER[kind]
+    hip.PAIRS.clear()                     # map pointers of the previous detector may be recycled
+    batch = args.grounding_batch if kind == 'grounding' else 1
+    steps, warmup = max(1, min(args.steps, args.other_steps)), max(1, min(args.warmup, 3))
+    cfg = load_config(os.path.join(ROOT, 'configs', o['cfg']))
+    det = build_detector(cfg, device=dev, seed=0).to(dev)
+    optim = build_optim_wrapper(cfg)
+    scans = []
+    for i in range(batch * o['rotate']):
+        sc = make_scan(o['seed'] + i, n_views=o['views'], augment=(kind == 'grounding'), render_device=str(dev))
+        if kind == 'grounding':
+            a = make_grounding_sample(sc, seed=i)
+            sc = dict(sc, text=a['text'], tokens_positive=a['tokens_positive'], gt_boxes=a['gt_boxes'], gt_labels=a['gt_labels'])
+        else:
+            oc = make_occ_gt(sc, seed=i)
+            sc = dict(sc, gt_occupancy=oc['gt_occupancy'], gt_occupancy_masks=oc['gt_occupancy_masks'])
+        scans.append(sc)
+    make = pipeline.make_grounding_batch if kind == 'grounding' else pipeline.make_occ_batch
+
+    # ---- parity (untimed): losses of scans[0] alone, pre-training weights, HIP path vs the CPU oracle's forward
+    parity = base = None
+    if not args.no_cpu_baseline:
+        parity, base = other_parity(kind, cfg, det, scans[0], make, dev, args)
+
+    feeder = Feeder([pipeline.pin_batch(scans[r * batch:(r + 1) * batch]) for r in range(o['rotate'])], dev)
+
+    def step():
+        dscans = feeder.next()
+        E.mark('_begin')
+        out = det.train_step(make(dscans), optim)
+        feeder.done()
+        return out
+
+    for _ in range(warmup):
+        losses = step()
+    torch.cuda.synchronize()
+    prof = {'names': ENGINE | ATTN | {'es_ground_match'}, 'records': [], 'event': lambda: torch.cuda.Event(enable_timing=True)}
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    step_ev[0].record()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        hip.PROFILE = prof if it == steps - 1 else None
+        losses = step()
+        step_ev[it + 1].record()
+    recs = resolve_pairs(hip, prof['records'])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hip.PROFILE = None
+    peak = K_PEAK_MFMA[args.precision]
+    eng = engine_totals([r for r in recs if r[0] in ENGINE], peak)
+    # one extra untimed step on the single-stream schedule: stage times (SURVEY 8d) and stand-alone launch durations
+    saved = (E.TWO_STREAMS[0], E.WGRAD_ASYNC[0])
+    E.TWO_STREAMS[0] = E.WGRAD_ASYNC[0] = False
+    prof1 = dict(prof, records=[])
+    hip.PROFILE = prof1
+    E.MARKS = []
+    step()
+    marks, E.MARKS = E.MARKS, None
+    hip.PROFILE = None
+    E.TWO_STREAMS[0], E.WGRAD_ASYNC[0] = saved
+    r1 = resolve_pairs(hip, prof1['records'])
+    torch.cuda.synchronize()
+    stages = {}
+    for (n0, ev0), (n1, ev1) in zip(marks[:-1], marks[1:]):
+        stages[n1] = round(stages.get(n1, 0.0) + ev0.elapsed_time(ev1), 3)
+    stages['_note'] = 'single-stream schedule (ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0), HIP-event time between stage boundaries of ONE untimed step'
+    e1 = engine_totals([r for r in r1 if r[0] in ENGINE], peak)
+
+    traffic, tnote = None, 'traffic: null (no PMC summary committed for this configuration)'
+    pmc_file = os.path.join(ROOT, 'profiles', f'r3_pmc_traffic_{kind}.json')
+    if args.precision == 'bf16' and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        traffic = pmc['bytes_per_launch']
+        tnote = (f"traffic is STATIC: HBM bytes per launch of the named family from the committed PMC passes of `bench.py --only {kind}` "
+                 f"(profiles/r3_pmc_traffic_{kind}.json), not re-measured by this run")
+    if kind == 'grounding':
+        klen = det.last_queries['klen'].cpu().tolist()
+        tl = det.last_text['mask'].sum(1).cpu().tolist()
+        Lmax = det.neck_3d.last['Lmax']
+        att = attention_totals(r1, klen, tl, Lmax)              # stand-alone durations (single-stream step)
+        att_c = attention_totals(recs, klen, tl, Lmax)          # under the concurrent schedule of the timed step
+        tfl = att['tflops']
+        roofline = dict(bound='mfma', achieved=tfl, peak=peak, unit='TFLOP/s', frac=round(tfl / peak, 5), traffic=traffic,
+                        kernel='attention: k_attn_fwd + k_attn_bwd_dq + k_attn_bwd_dkv (+ k_attn_delta), head_dim 32, 8 heads',
+                        launches_per_step=att['launches'], kernel_ms_per_step=att['ms'], fwd=att['fwd'], bwd=att['bwd'],
+                        concurrent_schedule=dict(kernel_ms_per_step=att_c['ms'], tflops=att_c['tflops']),
+                        note='algorithmic flops per call: forward 4*H*Lq*Lk_valid*32, backward 10*H*Lq*Lk_valid*32 summed over the '
+                             'samples (valid keys only); durations = HIP events on the launch stream, stand-alone (single-stream '
+                             'step); ' + tnote)
+        extra = dict(point_tokens=klen, text_tokens=tl,
+                     hungarian_ms=round(sum(e0.elapsed_time(e1_) for n, e0, e1_, a, _ in r1 if n == 'es_ground_match'), 3))
+    else:
+        neck = [r for r in r1 if max(engine_args(r[0], r[3])[4:6]) >= 768]
+        nk = engine_totals(neck, peak)
+        neck_c = engine_totals([r for r in recs if r[0] in ENGINE and max(engine_args(r[0], r[3])[4:6]) >= 768], peak)
+        roofline = dict(bound='mfma', achieved=nk['tflops'], peak=peak, unit='TFLOP/s', frac=round(nk['tflops'] / peak, 4),
+                        traffic=traffic, kernel='convolution engine on the dense 3-D neck (launches with >= 768 channels on a side)',
+                        launches_per_step=nk['launches'], kernel_ms_per_step=nk['ms'], frac_of_binding_roof=nk['frac_binding'],
+                        concurrent_schedule=dict(kernel_ms_per_step=neck_c['ms'], tflops=neck_c['tflops']),
+                        note='algorithmic flops = 2*P*Cin*Cout per launch (P = valid (output, tap) pairs of the dense 3x3x3 maps); '
+                             'durations = HIP events on the launch stream, stand-alone (single-stream step); ' + tnote)
+        extra = {}
+    res = dict(metric=o['metric'], value=round(batch * steps / dt, 4), unit='scans/s', n_gpus=1, steps=steps, warmup=warmup,
+               ms_per_step=round(dt / steps * 1e3, 3), higher_is_better=True, dtype=args.precision, data='synthetic',
+               config=dict(workload=o['workload'], scans_per_gpu_per_step=batch, views=o['views'], distinct_batches=o['rotate'],
+                           h2d=f'{feeder.h2d_bytes / 1e6:.0f} MB per step as ONE copy from a pinned slab on a copy stream, double-buffered'),
+               losses={k: round(float(v), 6) for k, v in losses.items()}, roofline=roofline,
+               engine_all=dict(launches_per_step=eng['launches'], kernel_ms_per_step=eng['ms'], tflops=eng['tflops'],
+                               frac_of_binding_roof=eng['frac_binding'], compulsory_GBps=eng['comp_GBps'],
+                               single_stream=dict(kernel_ms_per_step=e1['ms'], tflops=e1['tflops'], frac_of_binding_roof=e1['frac_binding'])),
+               classes=launch_classes(r1, peak), stage_ms=stages,
+               step_ms=[round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(steps)], **extra)
+    if parity is not None:
+        res['parity'], res['cpu_baseline'] = parity, base
+    del det, optim, feeder
+    E.TAPE.clear()
+    torch.cuda.empty_cache()
+    return res
+
+
+def attention_totals(records, klen, tl, Lmax):
+    att = dict(fwd=[0.0, 0.0, 0], bwd=[0.0, 0.0, 0])
+    for name, e0, e1, a, _ in records:
+        if name not in ATTN:
+            continue
+        t = e0.elapsed_time(e1)
+        if name == 'es_attn_fwd':
+            Bn, H, Lq, Lk, kl = a[6], a[7], a[8], a[9], a[10]
+        else:
+            Bn, H, Lq, Lk, kl = a[11], a[12], a[13], a[14], a[15]
+        valid = sum(klen) if (kl and Lk == Lmax) else (sum(tl) if kl else Bn * Lk)
+        d = att['fwd' if name == 'es_attn_fwd' else 'bwd']
+        d[0] += t
+        d[1] += (4.0 if name == 'es_attn_fwd' else 10.0) * H * Lq * valid * 32
+        d[2] += 1
+    ms, fl = att['fwd'][0] + att['bwd'][0], att['fwd'][1] + att['bwd'][1]
+    one = lambda d: dict(ms=round(d[0], 3), launches=d[2], tflops=round(d[1] / max(d[0], 1e-9) / 1e9, 3))
+    return dict(ms=round(ms, 3), launches=att['fwd'][2] + att['bwd'][2], tflops=round(fl / max(ms, 1e-9) / 1e9, 3),
+                fwd=one(att['fwd']), bwd=one(att['bwd']))
+
+
+def launch_classes(records, mfma_peak, top=6):
+    """the engine launches of one step grouped into launch classes (entry point x tap count x channel widths): launches, ms,
+    algorithmic TFLOP, compulsory GB and the fraction of the binding roof of each -- the dominant kernels' fractions
+    without arithmetic"""
+    groups = {}
+    for r in records:
+        name, a = r[0], r[3]
+        if name not in ENGINE:
+            continue
+        nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
+        kind = 'wgrad' if name.startswith('es_spconv_wgrad') else 'fwd/dgrad'
+        key = f'{kind} K={K} {cin}->{cout}'
+        groups.setdefault(key, []).append(r)
+    rows = []
+    for key, rs in groups.items():
+        t = engine_totals(rs, mfma_peak)
+        rows.append(dict(cls=key, launches=t['launches'], ms=t['ms'], tflop=round(t['tflops'] * t['ms'] * 1e-3, 4),
+                         compulsory_GB=round(t['comp_bytes'] / 1e9, 3), tflops=t['tflops'], compulsory_GBps=t['comp_GBps'],
+                         frac_of_binding_roof=t['frac_binding']))
+    rows.sort(key=lambda d: -d['ms'])
+    return rows[:top]
+
+
+def other_parity(kind, cfg, det, scan, make, dev, args):
+    """losses of ONE scan from the pre-training weights: HIP path vs the CPU oracle's forward (no gradients; the oracle's
+    forward+backward is what the primary line's cpu_baseline times).  Tolerance: bf16 5e-2 (grounding: 12 losses over 6
+    decoder layers) / 2e-2 (occupancy), exact-f32 mode 1e-3."""
+    import torch
+    from embodiedscan_amd import engine as E, pipeline
+    from oracle import model as OM
+    sd0 = {k: v.cpu() for k, v in det.state_dict().items()}
+    d0 = pipeline.upload_scan(scan, dev)
+    d0.update({k: scan[k] for k in ('text', 'tokens_positive', 'gt_occupancy', 'gt_occupancy_masks') if k in scan})
+    b0 = make([d0])
+    points = [p.cpu() for p in b0['inputs']['points']]
+    E.TAPE.clear()
+    data = det.data_preprocessor(b0, True)
+    det._bind()
+    l0 = det.forward(data['inputs'], data['data_samples'], mode='loss')
+    torch.cuda.synchronize()
+    hipl = {k: float(v) for k, v in l0.items()}
+    E.TAPE.clear()
+    E.join_wgrad_streams()
+    imgs = OM.preprocess_img(torch.from_numpy(scan['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])[None]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        if kind == 'grounding':
+            from oracle import grounding as OG
+            th, tm = det.last_text['hidden'].float().cpu(), det.last_text['mask'].cpu()
+            pms = [ds.gt_instances_3d.positive_maps.cpu() for ds in data['data_samples']]
+            ol = OG.grounder_loss(sd0, points, imgs, [scan['meta']], th, tm, [torch.as_tensor(scan['gt_boxes'])], pms,
+                                  num_queries=det.num_queries, num_layers=det.decoder.num_layers,
+                                  thr=cfg['model']['neck_3d']['pts_prune_threshold'])
+            tol = 5e-2
+        else:
+            from oracle import occ as OO
+            m = cfg['model']
+            ol = OO.detector_loss(sd0, points, imgs, [scan['meta']], [torch.from_numpy(scan['gt_occupancy'])],
+                                  [torch.from_numpy(scan['gt_occupancy_masks'])], m['n_voxels'], m['point_cloud_range'],
+                                  cfg['prior_generator']['ranges'][0], tuple(m['neck_3d']['n_blocks']))
+            tol = 2e-2
+    dt = time.perf_counter() - t0
+    if args.precision != 'bf16':
+        tol = 1e-3
+    rel = {k: abs(hipl[k] - float(ol[k])) / max(abs(float(ol[k])), 1e-6) for k in ol}
+    parity = dict(what=f'{len(ol)} losses of scans[0] alone, pre-training weights, HIP path vs CPU oracle (f32)',
+                  hip={k: round(v, 6) for k, v in hipl.items()}, oracle={k: round(float(v), 6) for k, v in ol.items()},
+                  rel_err={k: float(f'{v:.3e}') for k, v in rel.items()}, tol=tol, ok=bool(max(rel.values()) < tol))
+    base = dict(value=round(1.0 / dt, 5), unit='scans/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'1 scan x {scan["depth"].shape[0]} views 480x640, 100k points, ONE FORWARD (no backward, no optimiser) of the '
+                       f'PyTorch-f32 CPU oracle, {dt:.1f} s')
+    del d0, b0, data, l0
+    return parity, base
 
 
 def resolve_pairs(hip, records):

@@ -137,9 +137,14 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
     def loss(self, batch_inputs_dict, batch_data_samples, **kwargs):
         self._bind()
         self.extract_feat(batch_inputs_dict, batch_data_samples)
+        E.mark('A19 MinkNeck (+ pruning, token padding)')
         text, mask, tlen, T = self.encode_text(batch_data_samples)
+        E.mark('A19 frozen text encoder + text_feat_map')
         hidden, boxes = self.forward_transformer(text, tlen, T, batch_data_samples)
-        return self.bbox_head.loss(hidden, boxes, text, mask, batch_data_samples, tlen=tlen)
+        E.mark('A19 query selection + 6-layer decoder')
+        out = self.bbox_head.loss(hidden, boxes, text, mask, batch_data_samples, tlen=tlen)
+        E.mark('A19/N2 head: token logits + Hungarian + focal + corner-Chamfer')
+        return out
 
     def predict(self, batch_inputs_dict, batch_data_samples, **kwargs):
         was = self.training

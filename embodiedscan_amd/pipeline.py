@@ -171,7 +171,8 @@ def augment_gt_boxes(boxes, aug):
 def make_batch(dscans):
     """-> the `data` dict of mmengine's train_step: {'inputs': {'points', 'img'}, 'data_samples'}."""
     points = [depth_to_points(d) for d in dscans]
-    imgs = torch.stack([d['img'] for d in dscans])
+    st = dscans[0].get('_img_stack') if dscans else None       # upload_batch: the frames already are one (B, V, 3, h, w) block
+    imgs = st if (st is not None and st.shape[0] == len(dscans)) else torch.stack([d['img'] for d in dscans])
     samples = [Det3DDataSample(d['meta'], InstanceData(bboxes_3d=EulerDepthInstance3DBoxes(d['gt_boxes']),
                                                        labels_3d=d['gt_labels'])) for d in dscans]
     return {'inputs': {'points': points, 'img': imgs}, 'data_samples': samples}
@@ -204,3 +205,97 @@ def make_grounding_batch(dscans, anns=None):
         ds.gt_instances_3d = InstanceData(bboxes_3d=EulerDepthInstance3DBoxes(torch.as_tensor(a['gt_boxes'])),
                                           labels_3d=torch.as_tensor(a['gt_labels']))
     return data
+
+
+# ------------------------------------------------------------------ one slab per batch (bench.py, loader hand-over)
+# A batch of B scans used to go up as 7 tensors per scan (28+ hipMemcpyAsync per step, most of them a few hundred bytes).
+# Here every array of every scan of the batch lives in ONE pinned byte slab (256-byte aligned pieces, arrays of one kind
+# adjacent so that equal-shaped frames are also one (B, V, 3, h, w) view) and the device side is one byte slab of the same
+# layout: the host->device copy of a batch is a single hipMemcpyAsync.
+_SLAB_ALIGN = 256
+
+
+class BatchSlab:
+    """views[i][key] -> tensor of scan i inside `slab` (uint8, pinned host or device memory); `layout` = [(scan, key,
+    offset, shape, dtype)]; `extras[i]` = the host-side fields of scan i (meta, ground truth, prompt ...)."""
+
+    def __init__(self, slab, layout, extras):
+        self.slab, self.layout, self.extras = slab, layout, extras
+        self.views = [dict() for _ in extras]
+        for i, k, off, shape, dtype in layout:
+            n = 1
+            for s in shape:
+                n *= int(s)
+            nb = n * torch.empty((), dtype=dtype).element_size()
+            self.views[i][k] = slab[off:off + nb].view(dtype).view(shape)
+
+    @property
+    def nbytes(self):
+        return int(self.slab.numel())
+
+    def stacked(self, key):
+        """(B, ...) view over the `key` arrays of all scans when they are equal-shaped and adjacent, else None"""
+        ent = [e for e in self.layout if e[1] == key]
+        if not ent or any(e[3] != ent[0][3] for e in ent):
+            return None
+        n = 1
+        for s in ent[0][3]:
+            n *= int(s)
+        nb = n * torch.empty((), dtype=ent[0][4]).element_size()
+        stride = ent[1][2] - ent[0][2] if len(ent) > 1 else nb
+        if stride != nb or any(b[2] - a[2] != stride for a, b in zip(ent[:-1], ent[1:])):
+            return None
+        return self.slab[ent[0][2]:ent[0][2] + nb * len(ent)].view(ent[0][4]).view((len(ent),) + tuple(ent[0][3]))
+
+
+def pin_batch(scans, pin=True):
+    """the raw inputs of a batch of scans in ONE pinned host slab (-> BatchSlab)"""
+    hosts = [_host_tensors(s) for s in scans]
+    keys = [k for k in ('img', 'img_raw', 'depth', 'sel_view', 'sel_pix', 'mats', 'aug') if any(k in h for h in hosts)]
+    layout, off = [], 0
+    for k in keys:                       # arrays of one kind adjacent; a kind starts on an aligned offset
+        off = -(-off // _SLAB_ALIGN) * _SLAB_ALIGN
+        for i, h in enumerate(hosts):
+            if k not in h:
+                continue
+            t = h[k]
+            layout.append((i, k, off, tuple(t.shape), t.dtype))
+            nb = t.numel() * t.element_size()
+            # equal-shaped arrays stay adjacent (stackable) when their size keeps the alignment, else pad each piece
+            off += nb if nb % 16 == 0 else -(-nb // _SLAB_ALIGN) * _SLAB_ALIGN
+    total = -(-off // _SLAB_ALIGN) * _SLAB_ALIGN
+    slab = torch.empty(max(total, _SLAB_ALIGN), dtype=torch.uint8)
+    if pin:
+        slab = slab.pin_memory()
+    extras = [_finish({}, s) for s in scans]
+    out = BatchSlab(slab, layout, extras)
+    for i, h in enumerate(hosts):
+        for k, t in h.items():
+            out.views[i][k].copy_(t)
+    return out
+
+
+def alloc_batch_slot(nbytes, device):
+    """device byte slab able to hold any batch of up to `nbytes` (+ the resized frames of file-backed scans are allocated
+    per upload by resize_frames)"""
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def upload_batch(slot, pinned):
+    """ONE async host->device copy of a whole batch on the current stream -> list of dscan dicts (make_batch's input);
+    equal-shaped frames additionally come back as one stacked (B, V, 3, h, w) tensor under '_img_stack' of scan 0"""
+    assert slot.numel() >= pinned.nbytes, 'device slot smaller than the batch slab'
+    dst = slot[:pinned.nbytes]
+    dst.copy_(pinned.slab, non_blocking=True)
+    dev = BatchSlab(dst, pinned.layout, pinned.extras)
+    out = []
+    for i, v in enumerate(dev.views):
+        d = dict(v)
+        if 'img_raw' in d:
+            d['img'] = resize_frames(d.pop('img_raw'), pinned.extras[i]['meta']['img_shape'])
+        d.update(pinned.extras[i])
+        out.append(d)
+    st = dev.stacked('img')
+    if st is not None and out:
+        out[0]['_img_stack'] = st
+    return out

@@ -1,0 +1,107 @@
+"""Parity AT BASELINE config 5 (occupancy): DenseFusionOccPredictor at the reference's shapes -- 1 scan x 10 views
+480x640, 100 k points, ResNet-50 (base 64) + FPN 256, MinkResNet34, 40x40x16 volume, IndoorImVoxelNeck 768 -> 1536 ->
+3072 (751 M parameters), ImVoxelOccHead with 81 classes -- HIP path vs the CPU oracle (oracle/occ.py) on the same points /
+images / weights, forward AND backward.
+Reference shapes: /root/reference/configs/occupancy/mv-occ_8xb1_embodiedscan-occ-80class.py:41-50,81,121.
+
+Supervision targets of the three levels bit exact; f32 (exact-f32 matrix cores): logits and losses within 1e-4, the weight
+gradients of the dense neck (incl. the 3072 x 3072 x 27 kernels of the coarsest level, 400 voxels -- the launches that run
+on the 128^2 / 256^2 weight-gradient tiles) within 1e-3 rel-L2 of the oracle's autograd; bf16: losses 2e-2, logits 8e-2
+(coarsest level: train-mode BatchNorm over 400 rows after 3072-wide bf16 reductions), neck weight gradients against the
+f32 oracle reported with a stated bound of 1e-1 rel-L2 per tensor (bf16 operands, f32 accumulation).
+The oracle's forward + backward of the 751 M-parameter net takes minutes on the host cores: slow, and worth it."""
+import os
+import time
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MEAN, STD = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _rows(t):
+    return t[0].permute(1, 2, 3, 0).reshape(-1, t.shape[1]).contiguous()
+
+
+def test_config5_train_step_vs_oracle():
+    from embodiedscan_amd import engine as E, pipeline
+    from embodiedscan_amd.config import build_detector, load_config
+    from embodiedscan_amd.synth import make_occ_gt, make_scan
+    from oracle import model as OM, occ as OO
+    dev = torch.device('cuda:0')
+    cfg = load_config(os.path.join(ROOT, 'configs', 'mv_occ.py'))
+    m = cfg['model']
+    assert m['n_voxels'] == [40, 40, 16] and m['neck_3d']['in_channels'] == 768
+    det = build_detector(cfg, device=dev, seed=0).to(dev)
+    assert det.arena.n_train > 700e6
+    scan = make_scan(5100, n_views=10, augment=False, render_device='cuda:0')
+    occ = make_occ_gt(scan, seed=51)
+    dscan = pipeline.upload_scan(scan, dev)
+    sd = {k: v.cpu() for k, v in det.state_dict().items()}
+    neck_keys = [k for k in det.arena.grad_dict() if k.startswith('neck_3d.') and k.endswith('.weight') and sd[k].dim() == 5]
+    watch = neck_keys + [k for k in det.arena.grad_dict() if k.startswith('bbox_head.')]
+    res = {}
+    try:
+        for mode in ('f32', 'bf16'):
+            E.PRECISION[0] = mode
+            E.WEIGHT_VERSION[0] += 1
+            E.TAPE.clear()
+            batch = pipeline.make_occ_batch([dscan], [occ])
+            points_host = [p.cpu() for p in batch['inputs']['points']]
+            data = det.data_preprocessor(batch, True)
+            det._bind()
+            det.arena.grad.zero_()
+            losses = det.forward(data['inputs'], data['data_samples'], mode='loss')
+            E.TAPE.backward()
+            torch.cuda.synchronize()
+            gd = det.arena.grad_dict()
+            res[mode] = dict(losses={k: float(v) for k, v in losses.items()},
+                             logits=[l['logits'].d.cpu() for l in det.bbox_head.last],
+                             gt=[l['gt'].cpu() for l in det.bbox_head.last],
+                             grads={k: gd[k].cpu() for k in watch},
+                             finite=bool(torch.isfinite(det.arena.grad).all()))
+    finally:
+        E.PRECISION[0] = 'f32'
+    del det
+    torch.cuda.empty_cache()
+    # ---- oracle: forward + backward, gradients only for the watched tensors (the 2-D / 3-D backbones are checked at
+    # config-2 scale and in test_gpu_occ.py; restricting autograd keeps the host memory at ~10 GB)
+    osd = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
+    imgs = OM.preprocess_img(torch.from_numpy(scan['img']), MEAN, STD)[None]
+    t0 = time.perf_counter()
+    ol, aux = OO.detector_loss(osd, points_host, imgs, [scan['meta']], [torch.from_numpy(occ['gt_occupancy'])],
+                               [torch.from_numpy(occ['gt_occupancy_masks'])], m['n_voxels'], m['point_cloud_range'],
+                               cfg['prior_generator']['ranges'][0], tuple(m['neck_3d']['n_blocks']), return_aux=True)
+    t1 = time.perf_counter()
+    sum(ol.values()).backward()
+    print(f'oracle at config-5 scale: forward {t1 - t0:.1f} s, backward {time.perf_counter() - t1:.1f} s on {torch.get_num_threads()} threads')
+    for i in range(3):
+        np.testing.assert_array_equal(res['f32']['gt'][i].numpy(), aux['parts'][i][3].reshape(-1).numpy())
+        np.testing.assert_array_equal(res['bf16']['gt'][i].numpy(), aux['parts'][i][3].reshape(-1).numpy())
+    print('supervision targets of the 20x20x8 / 10x10x4 / 5x5x2 levels: bit exact')
+    for mode, tl, tg in (('f32', 1e-4, 1e-4), ('bf16', 2e-2, 8e-2)):
+        for i in range(3):
+            e = _rel(res[mode]['logits'][i], _rows(aux['preds'][i].detach()))
+            print(f'{mode} occ logits level {i} ({res[mode]["logits"][i].shape[0]} voxels): rel-L2 {e:.2e} (tol {tg:.0e})')
+            assert e < tg
+        for k in ol:
+            e = abs(res[mode]['losses'][k] - float(ol[k])) / abs(float(ol[k]))
+            print(f'{mode} {k}: hip {res[mode]["losses"][k]:.6f} oracle {float(ol[k]):.6f} rel err {e:.2e} (tol {tl:.0e})')
+            assert e < tl
+        assert res[mode]['finite']
+    for mode, tol in (('f32', 1e-3), ('bf16', 1e-1)):
+        rel = {k: _rel(res[mode]['grads'][k], osd[k].grad) for k in watch if osd[k].grad is not None and float(osd[k].grad.norm()) > 1e-12}
+        for k in neck_keys:
+            print(f'{mode} weight gradient {k} {tuple(sd[k].shape)}: rel-L2 {rel[k]:.2e} (tol {tol:.0e})')
+        worst = max(rel, key=rel.get)
+        print(f'{mode}: {len(rel)} neck / head gradient tensors, median {float(np.median(list(rel.values()))):.2e}, worst {rel[worst]:.2e} at {worst}')
+        assert all(v < tol for v in rel.values()), {k: v for k, v in rel.items() if v >= tol}
+        big = [k for k in neck_keys if sd[k].shape[0] == 3072 and sd[k].shape[1] == 3072]
+        assert big, 'the 3072 x 3072 level is missing from the watched tensors'
