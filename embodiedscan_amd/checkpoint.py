@@ -15,7 +15,9 @@ def _arena(model):
 
 def save_checkpoint(model, path, optim=None, meta=None, schedulers=None):
     arena = _arena(model)
-    sd = {k: v.cpu() for k, v in arena.state_dict().items()}
+    # a detector's own state_dict() may carry more than the arena (the grounder's frozen `text_encoder.*`)
+    src = model.state_dict() if (model is not arena and hasattr(model, 'state_dict')) else arena.state_dict()
+    sd = {k: v.cpu() for k, v in src.items()}
     steps = int(optim.step) if optim is not None else 0
     for k in list(sd):                       # nn.BatchNorm buffers a strict reference-side load expects
         if k.endswith('.running_var'):

@@ -34,10 +34,13 @@ def build_detector(cfg_or_path, device='cuda:0', seed=0):
     return MODELS.build(cfg['model'], device=device, seed=seed)
 
 
-def build_dataloader(cfg_or_path, split='train', rank=0, world=1, seed=0, num_threads=None, pin=True, **overrides):
+def build_dataloader(cfg_or_path, split='train', rank=0, world=1, seed=0, num_threads=None, pin=True, workers='thread',
+                     **overrides):
     """`{split}_dataloader` section of a reference config -> (EmbodiedScanDataset, ScanLoader).  `RepeatDataset(times=k)`
-    becomes the loader's `times`; `num_workers` forked CPU pipelines become decode threads (the transforms themselves
-    run on the device); `overrides` replace dataset arguments (data_root, ann_file, metainfo, ...)."""
+    becomes the loader's `times`; `num_workers` forked CPU pipelines become decode workers (`workers='thread'` or
+    'process': forked workers writing into shared pinned slots; the transforms themselves run on the device);
+    `overrides` replace dataset arguments (data_root, ann_file, metainfo, ...).  Defaults follow the reference stack:
+    mmengine's DefaultSampler shuffles unless told otherwise and torch's DataLoader keeps the last partial batch."""
     from . import datasets  # noqa: F401  (registers the classes)
     from .datasets import ScanLoader
     from .registry import DATASETS
@@ -51,9 +54,9 @@ def build_dataloader(cfg_or_path, split='train', rank=0, world=1, seed=0, num_th
     sampler = dl.get('sampler') or {}
     assert sampler.get('type', 'DefaultSampler').split('.')[-1] == 'DefaultSampler', sampler
     threads = num_threads if num_threads is not None else max(8, 4 * int(dl.get('num_workers', 1)))
-    return ds, ScanLoader(ds, batch_size=dl.get('batch_size', 1), rank=rank, world=world, shuffle=sampler.get('shuffle', False),
+    return ds, ScanLoader(ds, batch_size=dl.get('batch_size', 1), rank=rank, world=world, shuffle=sampler.get('shuffle', True),
                           seed=seed, times=times, num_threads=threads, prefetch=2 * threads, pin=pin,
-                          drop_last=dl.get('drop_last', split == 'train'))
+                          drop_last=dl.get('drop_last', False), workers=workers)
 
 
 def build_optim_wrapper(cfg):

@@ -51,12 +51,18 @@ class ScanLoader:
     not depend on thread scheduling."""
 
     def __init__(self, dataset, batch_size=4, rank=0, world=1, shuffle=True, seed=0, times=1, num_threads=8, prefetch=16,
-                 pin=True, drop_last=True, workers='thread'):
+                 pin=True, drop_last=True, workers='thread', slot_bytes=None, worker_timeout=120.0):
+        """slot_bytes: size of one shared pinned slot in process mode (None: estimated from the frame headers of every
+        source of the dataset -- EmbodiedScan mixes ScanNet / 3RScan / Matterport3D resolutions); a scan that still does
+        not fit is decoded by the parent instead of aborting the epoch.  worker_timeout: seconds without any result
+        after which the workers' liveness is checked (a worker killed by the OOM killer or a signal raises instead of
+        hanging the training loop)."""
         assert workers in ('thread', 'process')
         self.dataset, self.batch_size = dataset, batch_size
         self.rank, self.world, self.shuffle, self.seed, self.times = rank, world, shuffle, seed, times
         self.num_threads, self.prefetch, self.pin, self.drop_last = max(1, num_threads), max(1, prefetch), pin, drop_last
         self.workers = workers
+        self.slot_bytes, self.worker_timeout = slot_bytes, float(worker_timeout)
         self.epoch = 0
         self._slabs = None          # process mode: shared (and pinned) slots, allocated on first use, reused across epochs
         self._pending = []          # (event, slots) released by the consumer, reusable once the event has completed
@@ -105,14 +111,39 @@ class ScanLoader:
         return {k: slab[o:o + int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()].view(dt).view(shape)
                 for k, (o, dt, shape) in lay.items()}
 
+    def _estimate_slot_bytes(self, first_idx):
+        """upper bound of a scan's device-bound bytes over the dataset: one scan is decoded (exact layout), and for every
+        SOURCE of the dataset (first path component of sample_idx: scannet / 3rscan / matterport3d ...) the headers of one
+        colour frame and one depth map give that source's frame sizes -- the slots are sized for the largest."""
+        probe = pipeline._host_tensors(self.dataset.load_scan(first_idx, self._rng(0)))
+        _, need = self._layout(probe)
+        V = int(probe['depth'].shape[0])
+        fixed = need - int(probe['depth'].numel()) * 4 - int(probe['img_raw'].numel() if 'img_raw' in probe else probe['img'].numel())
+        best = need
+        try:
+            from PIL import Image
+            seen = set()
+            for i in range(len(self.dataset)):
+                info = self.dataset.get_data_info(i)
+                src = str(info.get('sample_idx', '')).split('/')[0]
+                if src in seen or not info.get('img_path'):
+                    continue
+                seen.add(src)
+                with Image.open(info['img_path'][0]) as im:
+                    w, h = im.size
+                with Image.open(info['depth_img_path'][0]) as im:
+                    wd, hd = im.size
+                best = max(best, fixed + V * (h * w * 3 + hd * wd * 4) + 512 * V)
+        except Exception:                                     # header probing is an optimisation: fall back to head-room
+            best = max(best, int(need * 1.5))
+        return int(best * 1.05) + 65536
+
     def _start_workers(self, first_idx):
         """allocate the shared slots, fork the PERSISTENT workers (the reference's `persistent_workers=True`), then pin
         the slots in the parent.  Order matters: the children must inherit the shared mappings, and forking is cheapest
         before the parent has registered gigabytes of pinned memory."""
         import multiprocessing as mp
-        probe = pipeline._host_tensors(self.dataset.load_scan(first_idx, self._rng(0)))
-        _, need = self._layout(probe)
-        self._slot_bytes = int(need * 1.25) + 4096           # head-room for scans with more valid pixels / larger frames
+        self._slot_bytes = int(self.slot_bytes) if self.slot_bytes else self._estimate_slot_bytes(first_idx)
         n_slots = self.prefetch + 2 * self.batch_size
         self._slabs = [torch.empty(self._slot_bytes, dtype=torch.uint8).share_memory_() for _ in range(n_slots)]
         ctx = mp.get_context('fork')
@@ -131,8 +162,8 @@ class ScanLoader:
                     scan = ds.load_scan(i, np.random.RandomState(seed))
                     host = pipeline._host_tensors(scan)
                     lay, need = layout(host)
-                    if need > slot_bytes:
-                        results.put((pos, slot, None, f'needs {need} bytes, slots hold {slot_bytes}', None))
+                    if need > slot_bytes:                     # the parent decodes this one itself (slow path, no abort)
+                        results.put((pos, slot, None, 'overflow', (i, seed, need)))
                         continue
                     dst = views(slabs[slot], lay)
                     for k, v in host.items():
@@ -152,7 +183,8 @@ class ScanLoader:
         self._free = list(range(n_slots))
 
     def close(self):
-        """stop the persistent workers (process mode)"""
+        """stop the persistent workers (process mode), wait for every copy that still reads a slot, forget the slot
+        bookkeeping and un-register the pinned slabs before their shared mappings go away"""
         procs, self._procs = getattr(self, '_procs', None) or [], None
         for _ in procs:
             self._tasks.put(None)
@@ -160,13 +192,40 @@ class ScanLoader:
             p.join(timeout=5)
             if p.is_alive():
                 p.terminate()
-        self._slabs = None
+        for ev, _ in self._pending:                           # copies out of the slots must have finished
+            if ev is not None:
+                try:
+                    ev.synchronize()
+                except Exception:
+                    pass
+        self._pending = []                                    # stale slot ids must not leak into a later epoch's free list
+        self._free = []
+        slabs, self._slabs = self._slabs, None
+        if slabs and self.pin and torch.cuda.is_available():
+            try:
+                torch.cuda.synchronize()
+                rt = torch.cuda.cudart()
+                for t in slabs:                               # the registration must not outlive the mapping
+                    rt.cudaHostUnregister(t.data_ptr())
+            except Exception:
+                pass
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+    def _get_result(self):
+        """next worker result; every `worker_timeout` seconds of silence the workers' liveness is checked"""
+        while True:
+            try:
+                return self._results.get(timeout=self.worker_timeout)
+            except queue.Empty:
+                dead = [p.pid for p in (self._procs or []) if not p.is_alive()]
+                if dead or not self._procs:
+                    raise RuntimeError(f'ScanLoader: worker process(es) {dead} died (killed by the OOM killer or a signal?); '
+                                       'no result for %.0f s' % self.worker_timeout)
 
     def _reclaim(self):
         keep = []
@@ -202,8 +261,14 @@ class ScanLoader:
                             continue
                         raise RuntimeError('ScanLoader: every pinned slot is held by a batch the consumer has not '
                                            'released -- call loader.done(batch[, event]) after queueing its copy')
-                    pos, slot, lay, err, small = self._results.get()
+                    pos, slot, lay, err, small = self._get_result()
                     in_flight -= 1
+                    if err == 'overflow':                     # larger than a slot: decode here into its own pinned buffers
+                        free.append(slot)
+                        i, seed, need = small
+                        got[pos] = (None, None, pipeline.pin_scan(self.dataset.load_scan(i, np.random.RandomState(seed)),
+                                                                  pin=self.pin))
+                        continue
                     if err is not None:
                         free.append(slot)
                         raise RuntimeError(f'scan {idx[pos]} (position {pos}): {err}')
@@ -211,6 +276,9 @@ class ScanLoader:
                 batch, slots = _Batch(), []
                 for pos in range(lo, hi):
                     slot, lay, small = got.pop(pos)
+                    if slot is None:
+                        batch.append(small)
+                        continue
                     d = self._views(slabs[slot], lay)
                     d.update(small)
                     batch.append(d)
@@ -220,7 +288,8 @@ class ScanLoader:
         finally:
             # an abandoned epoch: drain what is still in flight so that the slots come back
             for slot, _, _ in got.values():
-                free.append(slot)
+                if slot is not None:
+                    free.append(slot)
             while in_flight > 0:
                 try:
                     _, slot, _, _, _ = self._results.get(timeout=30)

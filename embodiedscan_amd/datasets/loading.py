@@ -59,6 +59,33 @@ def sample_pixels(depth, num_points, rng):
     return nz[choices].astype(np.int32)
 
 
+def points_in_range(depths, depth_intr, extr, sel_view, sel_pix, point_range):
+    """mask over the chosen pixels: is the aggregated GLOBAL point inside `point_range` (BasePoints.in_range_3d: strict
+    inequalities on all six faces)?  Same f32 arithmetic as ConvertRGBDToPoints + AggregateMultiViewPoints
+    (points.py:46-53, structures/bbox_3d/utils.py:357-366, multiview.py:151-153): (u d, v d, d, 1) inv(pad4(K))^T, then the
+    camera->global transform; only the chosen pixels are un-projected."""
+    keep = np.zeros(len(sel_pix), bool)
+    lo, hi = np.asarray(point_range[:3], np.float32), np.asarray(point_range[3:], np.float32)
+    for v in range(len(depths)):
+        m = np.flatnonzero(sel_view == v)
+        if len(m) == 0:
+            continue
+        d = depths[v]
+        W = d.shape[1]
+        pix = sel_pix[m]
+        dd = d.reshape(-1)[pix].astype(np.float32)
+        u, w_ = (pix % W).astype(np.float32), (pix // W).astype(np.float32)
+        K = np.eye(4, dtype=np.float32)
+        k = np.asarray(depth_intr[v], np.float32)
+        K[:k.shape[0], :k.shape[1]] = k
+        homo = np.stack([u * dd, w_ * dd, dd, np.ones_like(dd)], 1)
+        cam = (homo @ np.linalg.inv(K).T.astype(np.float32))[:, :3]
+        E = np.linalg.inv(np.asarray(extr[v], np.float32)).astype(np.float32)
+        g = cam @ E[:3, :3].T + E[:3, 3]
+        keep[m] = np.all((g > lo) & (g < hi), axis=1)
+    return keep
+
+
 def draw_augmentation(cfg, rng):
     """RandomFlip3D then GlobalRotScaleTrans: two rand() for the flips (augmentation.py:114-123), uniform rotation
     (negated, 377-382), uniform scale (445-446), normal translation (360-361).  -> the `aug` dict of pipeline.py"""
@@ -162,14 +189,26 @@ class ScanPipeline:
             depth_intr.append(np.asarray(dci[i] if isinstance(dci, list) else dci, np.float32))
             extr.append(info['depth2img']['extrinsic'][i])
         sel_view, sel_pix = np.concatenate(sel_view), np.concatenate(sel_pix)
+        # colour frames and depth maps come at their own native resolutions (e.g. ScanNet 1296x968 jpg, 640x480 png: the
+        # reference keeps a separate depth_cam2img for that reason); each kind must be uniform inside a scan because the
+        # frames of a kind are stacked, but the two kinds are independent -- depth_to_points uses the depth size, the frame
+        # resize the colour size
+        ishapes, dshapes = {im.shape[:2] for im in imgs}, {d.shape for d in depths}
+        if len(ishapes) != 1 or len(dshapes) != 1:
+            raise ValueError(f"{info['sample_idx']}: the colour frames of one scan must share a resolution and so must its "
+                             f"depth maps, got colour {sorted(ishapes)} depth {sorted(dshapes)}")
+        # PointsRangeFilter sits BETWEEN the aggregation and PointSample(n_points) in the occupancy pipeline
+        # (configs/occupancy/mv-occ_...py:121-123, transforms/points.py:246-263): drop the aggregated points outside the
+        # range (unless fewer than 100 survive), THEN draw -- so the draw's population is the filtered cloud
+        if self.point_range is not None and len(sel_pix):
+            keep = points_in_range(depths, depth_intr, extr, sel_view, sel_pix, self.point_range)
+            if int(keep.sum()) >= 100:
+                sel_view, sel_pix = sel_view[keep], sel_pix[keep]
         # PointSample(n_points) over the aggregated cloud (points.py:189-206)
         if len(sel_pix):
             pick = rng.choice(len(sel_pix), self.n_points, replace=len(sel_pix) < self.n_points)
             sel_view, sel_pix = sel_view[pick], sel_pix[pick]
         aug, aug_meta = draw_augmentation(self.aug, rng)
-        shapes = {im.shape[:2] for im in imgs} | {d.shape for d in depths}
-        if len(shapes) != 1:
-            raise ValueError(f"{info['sample_idx']}: frames of one scan must share a resolution, got {sorted(shapes)}")
         H, W = imgs[0].shape[:2]
         w_new, h_new = self.img_scale
         ann = info.get('ann_info') or info.get('eval_ann_info') or {}

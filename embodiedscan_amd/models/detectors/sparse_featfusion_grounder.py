@@ -70,6 +70,35 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
                 E.end_bind()
             self._bound = True
 
+    # The frozen RoBERTa is a submodule of the reference detector, so its weights are part of the reference's state dict
+    # (`text_encoder.*`, sparse_featfusion_grounder.py:104-116): a checkpoint written here must carry them and a reference
+    # grounding checkpoint must load them -- otherwise the prompts would be encoded by random weights (round-2 advisor).
+    def state_dict(self):
+        sd = self.arena.state_dict()
+        for k, v in self.text_encoder.state_dict().items():
+            sd['text_encoder.' + k] = v
+        return sd
+
+    def load_state_dict(self, sd, strict=False, tap_order=None):
+        pre = 'text_encoder.'
+        text = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        rest = {k: v for k, v in sd.items() if not k.startswith(pre)}
+        missing, unexpected = super().load_state_dict(rest, strict=False, tap_order=tap_order)
+        own = self.text_encoder.state_dict()
+        dev = next(self.text_encoder.parameters()).device
+        with torch.no_grad():
+            for k, v in text.items():
+                if k in own and tuple(own[k].shape) == tuple(v.shape):
+                    own[k].copy_(v.to(dev))
+                else:
+                    unexpected.append(pre + k)
+        # (buffers such as embeddings.position_ids exist or not depending on the transformers version: never "missing")
+        params = {k for k, _ in self.text_encoder.named_parameters()}
+        missing = list(missing) + [pre + k for k in own if k not in text and k in params]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'load_state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...')
+        return missing, unexpected
+
     def train(self, mode=True):
         self.training = mode
         for m in (self.backbone_3d, self.neck_3d, self.decoder, self.bbox_head):

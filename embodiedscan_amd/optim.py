@@ -105,7 +105,9 @@ class MultiStepLR:
         self.epoch = 0
 
     def lr_at(self, epoch):
-        e = min(max(epoch, self.begin), self.end)
+        """mmengine counts a scheduler's steps from its `begin` (_ParamScheduler.step only runs inside [begin, end) and
+        `last_step` starts at 0 there): a milestone m is passed after m epochs SINCE begin"""
+        e = min(max(epoch, self.begin), self.end) - self.begin
         return self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= e)
 
     def step(self):

@@ -198,13 +198,15 @@ def make_grounding_sample(scan, seed=0, max_targets=3):
 
 def write_dataset(root, n_scans=2, n_frames=6, height=60, width=80, n_boxes=6, class_names=None, seed=0,
                   ann_name='embodiedscan_infos_train.pkl', occupancy=True, n_voxels=(40, 40, 16), jpeg_quality=90,
-                  render_device='cpu'):
+                  render_device='cpu', depth_div=1):
     """Write a small synthetic dataset in the EmbodiedScan on-disk layout: the info `.pkl` the reference's
     EmbodiedScanDataset reads (embodiedscan_dataset.py:315-375: `metainfo.categories`, `data_list[*]` with
     sample_idx / axis_align_matrix / cam2img / depth_cam2img / images[*]{img_path, depth_path, cam2global,
     visible_instance_ids} / instances[*]{bbox_3d, bbox_label_3d, bbox_id}), JPEG colour frames, 16-bit PNG depth in
     millimetres (depth_shift 1000, :103-107), and per-scan occupancy.npy / visible_occupancy.pkl (:201-244).
-    Geometry comes from make_scan (unaugmented); returns the list of source scans for round-trip checks."""
+    Geometry comes from make_scan (unaugmented); returns the list of source scans for round-trip checks.
+    depth_div > 1: the depth PNGs are written at 1/depth_div of the colour resolution with their own `depth_cam2img`
+    (real scans: ScanNet colour 1296x968, depth 640x480)."""
     import os
     import pickle
     from PIL import Image
@@ -233,8 +235,8 @@ def write_dataset(root, n_scans=2, n_frames=6, height=60, width=80, n_boxes=6, c
             base = np.stack([(xx * (3 + v) + s * 17) % 256, (yy * (2 + v)) % 256, ((xx + yy) * 2 + 40 * v) % 256], -1)
             img = np.clip(base + rng.integers(-12, 13, base.shape), 0, 255).astype(np.uint8)
             Image.fromarray(img).save(os.path.join(frame_dir, f'{v:05d}.jpg'), quality=jpeg_quality)
-            mm = np.clip(np.rint(scan['depth'][v] * 1000.0), 0, 65535).astype(np.uint16)
-            Image.fromarray(mm).save(os.path.join(frame_dir, f'{v:05d}.png'))
+            mm = np.clip(np.rint(scan['depth'][v] * 1000.0), 0, 65535).astype(np.uint16)[::depth_div, ::depth_div]
+            Image.fromarray(np.ascontiguousarray(mm)).save(os.path.join(frame_dir, f'{v:05d}.png'))
             c2w = np.linalg.inv(scan['extrinsic'][v].astype(np.float64))
             vis = sorted(rng.choice(n_boxes, rng.integers(1, n_boxes + 1), replace=False).tolist())
             images.append(dict(img_path=f'scannet/posed_images/{name}/{v:05d}.jpg',
@@ -244,8 +246,10 @@ def write_dataset(root, n_scans=2, n_frames=6, height=60, width=80, n_boxes=6, c
         for b in range(n_boxes):
             lab = categories['unlabelled thing'] if (b == n_boxes - 1 and s == 0) else categories[class_names[int(scan['gt_labels'][b])]]
             instances.append(dict(bbox_3d=scan['gt_boxes'][b].astype(np.float64).tolist(), bbox_label_3d=int(lab), bbox_id=b + 1))
+        dK = scan['intrinsic'][0].astype(np.float64).copy()
+        dK[:2, :3] /= depth_div                 # pixel (u, v) of the decimated map is pixel (u, v) * depth_div of the full one
         data_list.append(dict(sample_idx=sample_idx, axis_align_matrix=A, cam2img=scan['intrinsic'][0].astype(np.float64),
-                              depth_cam2img=scan['intrinsic'][0].astype(np.float64), images=images, instances=instances))
+                              depth_cam2img=dK, images=images, instances=instances))
         if occupancy:
             occ = make_occ_gt(scan, n_voxels=n_voxels, n_classes=len(class_names) + 1, seed=seed + s)
             g = occ['gt_occupancy'].copy()

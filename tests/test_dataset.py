@@ -234,7 +234,7 @@ def test_build_dataloader_from_config(tmp_path):
                               metainfo=dict(classes=names), pin=False, rank=1, world=2)
     p = ds.pipeline
     assert (p.n_images, p.view_points, p.n_points, p.img_scale, p.ordered) == (20, 10000, 100000, (480, 480), False)
-    assert ld.times == 10 and ld.batch_size == 4 and ld.shuffle and len(ld) == 2          # 20 scans / 2 ranks / 4
+    assert ld.times == 10 and ld.batch_size == 4 and ld.shuffle and not ld.drop_last and len(ld) == 3   # ceil(20 scans / 2 ranks / 4)
     batch = next(iter(ld))
     assert len(batch) == 4 and batch[0]['img_raw'].shape == (20, 60, 80, 3) and batch[0]['sel_pix'].numel() == 100000
     assert batch[0]['meta']['img_shape'] == (480, 480)
@@ -270,6 +270,74 @@ def test_process_loader_matches_thread_loader(tmp_path):
         for batch in ld2:
             held.append(batch)                                   # never released
     ld2.close()
+    assert ld2._pending == [] and ld2._free == [] and ld2._slabs is None
+    # a re-iteration after close() starts from a clean slot table (no stale ids from the abandoned epoch)
+    first = next(iter(ld2))
+    assert first[0]['meta']['scan_id'] == ref[0][0]['meta']['scan_id'] and sorted(ld2._free + first.slots) == list(range(len(ld2._slabs)))
+    ld2.close()
+
+
+def test_process_loader_mixed_resolutions_and_dead_workers(tmp_path):
+    """EmbodiedScan mixes ScanNet / 3RScan / Matterport3D frame sizes: the shared slots are sized from the frame headers of
+    every source; a scan that still does not fit (slot_bytes forced small here) is decoded by the parent instead of
+    aborting the epoch; a worker that dies raises instead of hanging the consumer (round-2 advisor findings)"""
+    import os as _os
+    import pickle
+    import signal
+    from embodiedscan_amd import synth
+    from embodiedscan_amd.datasets import EmbodiedScanDataset, ScanLoader
+    _, names = synth.write_dataset(str(tmp_path), n_scans=2, n_frames=5, height=60, width=80, n_voxels=(8, 8, 4), seed=2)
+    big = tmp_path / 'big'
+    synth.write_dataset(str(big), n_scans=1, n_frames=5, height=120, width=160, n_voxels=(8, 8, 4), seed=3)
+    # graft the larger scan into the first dataset as a second "source"
+    with open(tmp_path / 'embodiedscan_infos_train.pkl', 'rb') as f:
+        a = pickle.load(f)
+    with open(big / 'embodiedscan_infos_train.pkl', 'rb') as f:
+        b = pickle.load(f)
+    e = b['data_list'][0]
+    import shutil
+    name = e['sample_idx'].split('/')[1]
+    e['sample_idx'] = '3rscan/' + name
+    shutil.copytree(str(big / 'scannet' / 'scans' / name / 'occupancy'), str(tmp_path / '3rscan' / name / 'occupancy'))
+    for im in e['images']:
+        im['img_path'] = _os.path.join('big', im['img_path'])
+        im['depth_path'] = _os.path.join('big', im['depth_path'])
+    a['data_list'].append(e)
+    with open(tmp_path / 'mixed.pkl', 'wb') as f:
+        pickle.dump(a, f)
+    ds = EmbodiedScanDataset(str(tmp_path), 'mixed.pkl', metainfo=dict(classes=names), pipeline=PIPE)
+    want = [ds.get_data_info(i)['sample_idx'] for i in range(len(ds))]
+    if not any(w.startswith('3rscan') for w in want):
+        pytest.skip('the reader dropped the grafted scan')
+    ld = ScanLoader(ds, batch_size=1, shuffle=False, num_threads=2, prefetch=2, pin=False, workers='process')
+    shapes = []
+    for batch in ld:
+        shapes.append(tuple(batch[0]['img_raw'].shape[1:3]))
+        ld.done(batch)
+    assert (120, 160) in shapes and (60, 80) in shapes           # the header probe sized the slots for the large source
+    small_need = ld._slot_bytes
+    ld.close()
+    # forced-small slots: the large scan takes the parent's slow path, same bytes
+    ld = ScanLoader(ds, batch_size=1, shuffle=False, num_threads=2, prefetch=2, pin=False, workers='process',
+                    slot_bytes=small_need // 3)
+    got = []
+    for batch in ld:
+        got.append((tuple(batch[0]['img_raw'].shape[1:3]), int(batch[0]['img_raw'].long().sum())))
+        ld.done(batch)
+    ld.close()
+    ref = [(tuple(b[0]['img_raw'].shape[1:3]), int(b[0]['img_raw'].long().sum()))
+           for b in ScanLoader(ds, batch_size=1, shuffle=False, num_threads=1, pin=False)]
+    assert got == ref
+    # a dead worker is noticed
+    ld = ScanLoader(ds, batch_size=1, shuffle=False, times=50, num_threads=1, prefetch=1, pin=False, workers='process',
+                    worker_timeout=1.0)
+    it = iter(ld)
+    ld.done(next(it))
+    _os.kill(ld._procs[0].pid, signal.SIGKILL)
+    with pytest.raises(RuntimeError, match='died'):
+        for _ in range(20):
+            ld.done(next(it))
+    ld.close()
 
 
 @pytest.mark.parametrize('tag', ['vg_train', 'vg_test'])
@@ -307,3 +375,64 @@ def test_grounding_scan_from_files(tmp_path):
     assert multi['gt_boxes'].shape == (2, 9) and multi['tokens_positive'] == [[[8, 14]], [[8, 14]]] and multi['meta']['is_unique']
     every = ds.load_scan(2, np.random.RandomState(0))
     assert every['gt_boxes'].shape == (6, 9) and 'tokens_positive' not in every
+
+
+def test_depth_and_colour_resolutions_are_independent(tmp_path):
+    """real scans store colour and depth at different native sizes (ScanNet 1296x968 jpg vs 640x480 png, hence the
+    reference's separate depth_cam2img): the file-backed path must load them, un-project with the DEPTH size / intrinsics and
+    keep ori_shape / scale_factor from the COLOUR frames (round-2 advisor finding: it raised)"""
+    import torch
+    from embodiedscan_amd import synth
+    from embodiedscan_amd.datasets import EmbodiedScanDataset
+    from oracle import pipeline as OP
+    srcs, names = synth.write_dataset(str(tmp_path), n_scans=1, n_frames=4, height=60, width=80, seed=3, depth_div=2)
+    ds = EmbodiedScanDataset(str(tmp_path), 'embodiedscan_infos_train.pkl', metainfo=dict(classes=names), pipeline=PIPE)
+    sc = ds.load_scan(0, np.random.RandomState(0))
+    assert sc['img_raw'].shape[1:3] == (60, 80) and sc['depth'].shape[1:] == (30, 40)
+    assert sc['meta']['ori_shape'] == (60, 80)
+    assert int(sc['sel_pix'].max()) < 30 * 40
+    # the un-projected cloud lies on the source scan's surfaces: every point reproduces a pixel of the FULL-resolution depth
+    pts = OP.scan_to_points(dict(sc, aug=dict(hflip=False, vflip=False, rot=np.eye(3, dtype=np.float32), scale=1.0,
+                                              trans=np.zeros(3, np.float32))))
+    assert torch.isfinite(pts).all() and pts.shape == (len(sc['sel_pix']), 3)
+    full = srcs[0]['depth']
+    v, p = sc['sel_view'], sc['sel_pix']
+    ids = [int(os.path.basename(q)[:5]) for q in sc['meta']['img_path']]
+    want = np.array([full[ids[a], 2 * (b // 40), 2 * (b % 40)] for a, b in zip(v.tolist(), p.tolist())])
+    got = sc['depth'].reshape(len(ids), -1)[v, p]
+    assert np.abs(got - want).max() < 1e-3          # millimetre PNG quantisation
+    # mixed sizes inside one kind are still refused
+    from PIL import Image
+    f = os.path.join(str(tmp_path), sc['meta']['img_path'][0].replace('.jpg', '.png')) if not os.path.isabs(sc['meta']['img_path'][0]) \
+        else sc['meta']['img_path'][0].replace('.jpg', '.png')
+    Image.fromarray(np.zeros((10, 10), np.uint16)).save(f)
+    with pytest.raises(ValueError, match='share a resolution'):
+        ds.load_scan(0, np.random.RandomState(0))
+
+
+def test_points_range_filter_precedes_point_sample(tmp_path):
+    """occupancy pipeline order (configs/occupancy/mv-occ_...py:121-123): aggregate -> PointsRangeFilter -> PointSample.
+    Every point the loader hands over lies strictly inside the range, and the draw runs over the FILTERED population: with
+    a range that keeps only part of the cloud, PointSample(n) still returns n points, all of them inside."""
+    import torch
+    from embodiedscan_amd import synth
+    from embodiedscan_amd.datasets import EmbodiedScanDataset
+    from oracle import pipeline as OP
+    _, names = synth.write_dataset(str(tmp_path), n_scans=1, n_frames=6, n_voxels=(8, 8, 4), seed=9)
+    rng_box = [-2.0, -1.5, -0.5, 3.2, 1.5, 2.0]
+    pipe = [dict(type='LoadAnnotations3D', with_occupancy=True, with_visible_occupancy_masks=True)] + PIPE[1:3] + [
+        dict(type='PointsRangeFilter', point_cloud_range=rng_box),
+        dict(type='PointSample', num_points=1000), dict(type='ConstructMultiViewMasks'),
+        dict(type='Pack3DDetInputs', keys=['img', 'points', 'gt_bboxes_3d', 'gt_labels_3d', 'gt_occupancy'])]
+    ds = EmbodiedScanDataset(str(tmp_path), 'embodiedscan_infos_train.pkl', metainfo=dict(classes=names, occ_classes=names),
+                             pipeline=pipe)
+    sc = ds.load_scan(0, np.random.RandomState(1))
+    pts = OP.scan_to_points(sc).numpy()
+    assert pts.shape == (1000, 3)
+    lo, hi = np.array(rng_box[:3], np.float32), np.array(rng_box[3:], np.float32)
+    assert ((pts > lo) & (pts < hi)).all()
+    # without the filter the same scan has points outside that box (the filter did something)
+    ds2 = EmbodiedScanDataset(str(tmp_path), 'embodiedscan_infos_train.pkl', metainfo=dict(classes=names, occ_classes=names),
+                              pipeline=[pipe[0]] + PIPE[1:3] + pipe[4:])
+    p2 = OP.scan_to_points(ds2.load_scan(0, np.random.RandomState(1))).numpy()
+    assert not ((p2 > lo) & (p2 < hi)).all()
