@@ -647,8 +647,9 @@ def scatter_totals(records):
             b = (a[1] + a[6]) * (8 + 12 + 4 + 8)
         elif name == 'es_point_sample_fwd':    # (coords, n, vs, meta, ms, V, feats, Hf, Wf, C, out, ldo, pix, cnt)
             b = a[1] * (16 + a[5] * a[9] * 4 + a[9] * 4 + a[5] * 4 + 4)
-        elif name == 'es_point_sample_bwd':    # (coords, n, V, dout, ldo, pix, cnt, Hf, Wf, C, dfeats)
-            b = a[1] * (a[9] * 4 + a[2] * 4 + 4 + a[2] * a[9] * 8)
+        elif name == 'es_point_sample_bwd':    # (coords, n, V, dout, ldo, pix, cnt, Hf, Wf, C, dfeats, n_img, head, next, acc)
+            npix = a[11] * a[7] * a[8]             # compulsory: pix + link words, one read of every dout row, every pixel written
+            b = a[1] * (a[2] * 8 + 4 + a[9] * 4) + npix * (4 + a[9] * 4)
         elif name == 'es_depth_to_points':     # (depth, H, W, sel_view, sel_pix, n, ...)
             b = a[5] * (4 + 4 + 4 + 12)
         else:

@@ -124,28 +124,87 @@ extern "C" int es_point_sample_fwd_pts(const int* coords, const float* points, i
   return 0;
 }
 
-__global__ __launch_bounds__(256) void k_point_sample_bwd(const int* __restrict__ coords, int n, int V,
-                                                          const float* __restrict__ dout, int ldo,
-                                                          const int* __restrict__ pix, const int* __restrict__ cnt,
-                                                          int Hf, int Wf, int C, float* __restrict__ dfeats) {
-  int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= n) return;
-  int nv = cnt[i];
-  if (nv <= 0) return;
-  int b = coords[(size_t)i * 4];
-  float inv = __fdiv_rn(1.f, (float)nv);
-  for (int v = 0; v < V; ++v) {
-    int p = pix[(size_t)i * V + v];
+// Backward of the projection fusion, deterministic (round 3; rounds 1-2 scattered with f32 atomics): the feature-map
+// gradient is GATHERED.  (1) every hit (voxel i, view v -> pixel p) is linked into the list of its feature-map pixel
+// (integer atomicExch: the list CONTENT is deterministic, its order is not); (2) one wave per feature-map pixel walks its
+// list and adds the rows dout[i] / cnt[i] in ASCENDING voxel order (64 smallest remaining hits at a time, extracted by
+// wave-min), so the sum order is fixed whatever the link order was.  Every pixel is written (zeros when nothing projects
+// to it): the caller needs no memset and no float atomics are left on the path.
+__global__ void k_ps_link(const int* __restrict__ coords, int n, int V, const int* __restrict__ pix, int HW,
+                          int* __restrict__ head, int* __restrict__ next) {
+  size_t tot = (size_t)n * V;
+  for (size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x; h < tot; h += (size_t)gridDim.x * blockDim.x) {
+    int p = pix[h];
     if (p < 0) continue;
-    float* f = dfeats + (((size_t)b * V + v) * Hf * Wf + p) * C;
-    for (int ch = lane; ch < C; ch += 64) atomicAdd(f + ch, dout[(size_t)i * ldo + ch] * inv);
+    int i = (int)(h / V), v = (int)(h - (size_t)i * V);
+    int b = coords[(size_t)i * 4];
+    next[h] = atomicExch(&head[((size_t)b * V + v) * HW + p], (int)h);
+  }
+}
+#define PS_MAXC 8
+__global__ __launch_bounds__(256) void k_ps_gather(const int* __restrict__ head, const int* __restrict__ next, int n_pix,
+                                                   int V, const float* __restrict__ dout, int ldo,
+                                                   const int* __restrict__ cnt, int C, float* __restrict__ dfeats,
+                                                   int accumulate) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= n_pix) return;
+  float acc[PS_MAXC];
+#pragma unroll
+  for (int q = 0; q < PS_MAXC; ++q) acc[q] = 0.f;
+  const int h0 = head[g];
+  if (h0 >= 0) {
+    int last = -1;
+    while (true) {
+      int mine = 0x7fffffff, got = 0;                     // got is wave-uniform
+      for (int h = h0; h >= 0; h = next[h]) {             // wave-uniform walk
+        if (h <= last) continue;
+        if (got < 64) {
+          if (lane == got) mine = h;
+          ++got;
+        } else {                                          // keep the 64 smallest: replace the current maximum
+          int mx = es_wave_max_i(mine);
+          if (h < mx && mine == mx) mine = h;
+        }
+      }
+      if (got == 0) break;
+      for (int r = 0; r < got; ++r) {
+        const int m = es_wave_min_i(mine);
+        const int i = m / V;
+        const float inv = __fdiv_rn(1.f, (float)cnt[i]);
+        const float* row = dout + (size_t)i * ldo;
+#pragma unroll
+        for (int q = 0; q < PS_MAXC; ++q) {
+          int ch = lane + q * 64;
+          if (ch < C) acc[q] += row[ch] * inv;
+        }
+        if (mine == m) mine = 0x7fffffff;
+        last = m;
+      }
+      if (got < 64) break;                                // the walk has seen every remaining hit
+    }
+  }
+  float* f = dfeats + (size_t)g * C;
+#pragma unroll
+  for (int q = 0; q < PS_MAXC; ++q) {
+    int ch = lane + q * 64;
+    if (ch < C) f[ch] = accumulate ? (f[ch] + acc[q]) : acc[q];
   }
 }
 extern "C" int es_point_sample_bwd(const int* coords, int n, int V, const float* dout, int ldo, const int* pix,
-                                   const int* cnt, int Hf, int Wf, int C, float* dfeats, void* stream) {
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_point_sample_bwd, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords, n, V, dout,
-                     ldo, pix, cnt, Hf, Wf, C, dfeats);
+                                   const int* cnt, int Hf, int Wf, int C, float* dfeats, int n_img, int* head, int* next,
+                                   int accumulate, void* stream) {
+  if (C > 64 * PS_MAXC) return -4;
+  const long long n_pix = (long long)n_img * Hf * Wf;
+  if (n_pix <= 0 || n_pix >= (1ll << 31) || (long long)n * V >= (1ll << 31)) return n_pix <= 0 ? 0 : -6;
+  hipStream_t st = (hipStream_t)stream;
+  ES_TRY(hipMemsetAsync(head, 0xff, (size_t)n_pix * sizeof(int), st));
+  if (n > 0) {
+    int g = es_cdiv((long long)n * V, 256);
+    hipLaunchKernelGGL(k_ps_link, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, coords, n, V, pix, Hf * Wf, head, next);
+    ES_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_ps_gather, dim3(es_cdiv(n_pix, 4)), dim3(256), 0, st, head, next, (int)n_pix, V, dout, ldo, cnt, C,
+                     dfeats, accumulate);
   ES_CHECK_LAUNCH();
   return 0;
 }

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_ground_focal(const float* __restrict__ 
     }
   }
   acc = es_wave_sum_d(acc);
-  if (lane == 0 && acc != 0.0) atomicAdd(loss_sum, acc);
+  if (lane == 0 && acc != 0.0) unsafeAtomicAdd(loss_sum, acc);
 }
 extern "C" int es_ground_focal(const float* logits, int Tout, int B, int Q, const int* q2g, const unsigned char* pos_map,
                                const int* gt_off_dev, const int* tlen_dev, int T, float alpha, float gamma,

@@ -101,33 +101,50 @@ extern "C" int es_reg_decode_fwd(const float* reg, int ldr, int n, const float* 
   ES_CHECK_LAUNCH();
   return 0;
 }
-// dreg = dbbox * d(decode)/dreg ; dscale += sum dbbox * bbox * reg  (where not clamped)
-__global__ void k_reg_decode_bwd(const float* __restrict__ reg, int ldr, const float* __restrict__ bbox,
+// dreg = dbbox * d(decode)/dreg ; dscale += sum dbbox * bbox * reg  (where not clamped).
+// The Scale gradient is reduced deterministically (round 3): a fixed grid of grid-striding blocks, wave sums in a fixed
+// shuffle tree, the four wave partials of a block added in wave order, the block partials added in block order by a second
+// one-wave launch -- no float atomics.
+#define RD_BLOCKS 512
+__global__ __launch_bounds__(256) void k_reg_decode_bwd(const float* __restrict__ reg, int ldr, const float* __restrict__ bbox,
                                  const float* __restrict__ dbbox, int n, const float* __restrict__ scale,
-                                 float* __restrict__ dreg, int ldg, float* __restrict__ dscale) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+                                 float* __restrict__ dreg, int ldg, float* __restrict__ partial) {
+  __shared__ float wsum[4];
   float ds = 0.f;
-  if (e < n * 12) {
-    int i = e / 12, c = e - i * 12;
+  const size_t tot = (size_t)n * 12;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    size_t i = e / 12;
+    int c = (int)(e - i * 12);
     float g = dbbox[e];
     if (c < 6) {
       float b = bbox[e];
       bool live = b > 1e-3f;                     // clamp passes gradient only above the floor
       float gb = live ? g * b : 0.f;
-      dreg[(size_t)i * ldg + c] = gb * scale[0];
-      ds = gb * reg[(size_t)i * ldr + c];
+      dreg[i * ldg + c] = gb * scale[0];
+      ds += gb * reg[i * ldr + c];
     } else {
-      dreg[(size_t)i * ldg + c] = g;
+      dreg[i * ldg + c] = g;
     }
   }
   ds = es_wave_sum(ds);
-  if ((threadIdx.x & 63) == 0 && ds != 0.f) atomicAdd(dscale, ds);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ds;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+__global__ void k_sum_partials_add(const float* __restrict__ partial, int nb, float* __restrict__ dst) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 64) s += partial[i];
+  s = es_wave_sum(s);
+  if (threadIdx.x == 0) dst[0] += s;
 }
 extern "C" int es_reg_decode_bwd(const float* reg, int ldr, const float* bbox, const float* dbbox, int n,
-                                 const float* scale, float* dreg, int ldg, float* dscale, void* stream) {
+                                 const float* scale, float* dreg, int ldg, float* dscale, float* partial, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_reg_decode_bwd, dim3(es_cdiv(n * 12, 256)), dim3(256), 0, (hipStream_t)stream, reg, ldr, bbox,
-                     dbbox, n, scale, dreg, ldg, dscale);
+  int g = es_cdiv((long long)n * 12, 256);
+  if (g > RD_BLOCKS) g = RD_BLOCKS;
+  hipLaunchKernelGGL(k_reg_decode_bwd, dim3(g), dim3(256), 0, (hipStream_t)stream, reg, ldr, bbox, dbbox, n, scale, dreg, ldg,
+                     partial);
+  hipLaunchKernelGGL(k_sum_partials_add, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, g, dscale);
   ES_CHECK_LAUNCH();
   return 0;
 }
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
                                                    const float* __restrict__ bbox_t,
                                                    const float* __restrict__ avg_factor, float grad_scale,
                                                    float w0, float w1, float w2, float w3,
-                                                   float* __restrict__ loss_acc /* [0]=center sum, [1]=bbox sum */) {
+                                                   double* __restrict__ loss_acc /* [0]=center sum, [1]=bbox sum */) {
   // four consecutive lanes share one location: lane q evaluates decouple group q (its corner-Chamfer term carries the
   // f64 dual numbers), the 13 partial results are then summed over the quad with shuffles
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,11 +460,12 @@ __global__ __launch_bounds__(64) void k_pos_losses(const int* __restrict__ cls_t
       for (int c = 0; c < 12; ++c) dbbox[c] = (float)(red[c + 1] * inv_mean * (real)grad_scale);
     }
   }
-  lc = es_wave_sum(lc);
-  lb = es_wave_sum(lb);
+  // loss VALUES: the positives were compacted in slot-grab order, so the sums are taken in f64 (every f32 term is exact in
+  // f64 and the f64 rounding is far below the final f32 rounding: the reported losses do not depend on that order)
+  double lcd = es_wave_sum_d((double)lc), lbd = es_wave_sum_d((double)lb);
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(loss_acc + 0, lc);
-    atomicAdd(loss_acc + 1, lb);
+    unsafeAtomicAdd(loss_acc + 0, lcd);
+    unsafeAtomicAdd(loss_acc + 1, lbd);
   }
 }
 extern "C" int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, int max_pos, int* pos_ws,
@@ -455,7 +473,7 @@ extern "C" int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, int 
                              const int* level_off_host, const void* const* ho_host, const void* const* bbox_host,
                              void* const* dho_host, void* const* dbbox_host, int ldh, const float* center_t,
                              const float* bbox_t, const float* avg_factor_dev, float grad_scale, const float* group_w,
-                             float* loss_acc, void* stream) {
+                             double* loss_acc, void* stream) {
   if (n <= 0 || max_pos <= 0) return 0;
   if (n_levels > ES_MAX_LEVELS) return -3;
   if (!pos_ws) return -2;
@@ -519,7 +537,7 @@ __global__ __launch_bounds__(64) void k_box_cd_pairs(const float* __restrict__ p
     }
   }
   lb = es_wave_sum(lb);
-  if ((threadIdx.x & 63) == 0 && lb != 0.f) atomicAdd(loss_acc, lb);
+  if ((threadIdx.x & 63) == 0 && lb != 0.f) unsafeAtomicAdd(loss_acc, lb);    // loss VALUE only (gradients are per row)
 }
 extern "C" int es_box_cd_pairs(const float* pred, const int* q2g, int B, int Q, const float* gt_boxes, const int* gt_off_dev,
                                int n_pairs, float grad_scale, const float* group_w, float* dpred, float* loss_acc,

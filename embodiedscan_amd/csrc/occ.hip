@@ -109,14 +109,14 @@ __global__ __launch_bounds__(256) void k_occ_stats(const float* __restrict__ log
   for (int q = 0; q < OCC_PER; ++q) {
     int c = lane + q * 64;
     if (c < C) {
-      if (A[q] != 0.0) atomicAdd(&stats[c], A[q]);
-      if (Bc[q] != 0.0) atomicAdd(&stats[C + c], Bc[q]);
-      if (N[q] != 0.0) atomicAdd(&stats[2 * C + c], N[q]);
+      if (A[q] != 0.0) unsafeAtomicAdd(&stats[c], A[q]);
+      if (Bc[q] != 0.0) unsafeAtomicAdd(&stats[C + c], Bc[q]);
+      if (N[q] != 0.0) unsafeAtomicAdd(&stats[2 * C + c], N[q]);
     }
   }
   if (lane == 0 && nm != 0.0) {
-    atomicAdd(&stats[3 * C], nm);
-    atomicAdd(&stats[3 * C + 1], ce);
+    unsafeAtomicAdd(&stats[3 * C], nm);
+    unsafeAtomicAdd(&stats[3 * C + 1], ce);
   }
 }
 

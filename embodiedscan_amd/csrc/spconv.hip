@@ -203,6 +203,13 @@ extern "C" int es_spconv_fwd(const float* X, int ldx, const float* W, const int*
 }
 
 // ------------------------------------------------------------------------------------ wgrad
+// where a weight-gradient workgroup puts one element of its partial tile: slice `bz` of the workspace (plain store), or --
+// without a workspace the launch has ONE row slice -- straight into dW (this workgroup is the element's only writer)
+__device__ __forceinline__ void wgrad_emit(float* __restrict__ dW, float* __restrict__ ws, int bz, size_t dw_floats,
+                                           size_t off, float v) {
+  if (ws) ws[(size_t)bz * dw_floats + off] = v;
+  else dW[off] += v;
+}
 // dW[k][c][n] += sum_{j in row slice} X[nbr[j,k]][c] * dY[j][n]
 #define WM 64
 #define WN 64
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
                                                       const float* __restrict__ dY, int ldy,
                                                       const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                       int Cin, int Cout, int rows_per_split,
-                                                      float* __restrict__ dW) {
+                                                      float* __restrict__ dW, float* __restrict__ ws) {
   __shared__ float As[WR * LDW];
   __shared__ float Bs[WR * LDW];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -287,26 +294,76 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int c = c0 + wv * 16 + kq * 4 + r;
-      if (c < Cin) atomicAdd(dW + ((size_t)k * Cin + c) * Cout + col, acc[nf][r]);
+      if (c < Cin) wgrad_emit(dW, ws, blockIdx.z, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[nf][r]);
     }
   }
 }
 
-extern "C" int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out,
-                               int n_in, int K, int Cin, int Cout, float* dW, void* stream) {
-  if (n_out <= 0 || Cin <= 0 || Cout <= 0) return 0;
+// ---- deterministic split over rows (round 3): every (tap, channel tile, row slice) workgroup owns its partial tile.
+// splits == 1: the tile is added straight into dW (sole owner, plain read-modify-write); splits > 1: the partial tiles go to
+// a caller-provided workspace laid out [slice][K][Cin][Cout] and k_wgrad_reduce adds them to dW in slice order.  No float
+// atomics anywhere: two runs give bit-identical weight gradients (rounds 1-2 used f32 atomics, 1e-6 run-to-run).
+#define WGRAD_WS_CAP_FLOATS (64ll << 20)     // 256 MB of partial tiles per launch at most (write + read back ~ 65 us)
+struct WgradPlan { int kind, splits, rows_per_split; };   // kind: 0 exact-f32 64x64, 1 bf16 64x64, 2 bf16 128x128, 3 bf16 256x256
+static int cap_splits(int splits, long long dw_floats, bool have_ws) {
+  if (!have_ws) return 1;
+  long long cap = WGRAD_WS_CAP_FLOATS / (dw_floats > 0 ? dw_floats : 1);
+  if (cap < 1) cap = 1;
+  if (splits > cap) splits = (int)cap;
+  return splits < 1 ? 1 : splits;
+}
+static WgradPlan wgrad_plan_f32(int n_out, int K, int Cin, int Cout, bool have_ws) {
   int base = K * es_cdiv(Cin, WM) * es_cdiv(Cout, WN);
   int splits = es_cdiv(2048, base);
   int max_splits = es_cdiv(n_out, 128);
   if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  splits = cap_splits(splits, (long long)K * Cin * Cout, have_ws);
   int rows_per_split = es_cdiv(es_cdiv(n_out, splits), WR) * WR;
   splits = es_cdiv(n_out, rows_per_split);
-  dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), splits);
-  hipLaunchKernelGGL(k_spconv_wgrad, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out, n_in, K,
-                     Cin, Cout, rows_per_split, dW);
+  return WgradPlan{0, splits, rows_per_split};
+}
+__global__ void k_wgrad_reduce(const float* __restrict__ ws, int splits, size_t n, float* __restrict__ dW) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    float s = ws[e];
+    for (int z = 1; z < splits; ++z) s += ws[(size_t)z * n + e];
+    dW[e] += s;
+  }
+}
+__global__ void k_wgrad_reduce4(const float4* __restrict__ ws, int splits, size_t n4, float4* __restrict__ dW) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+    float4 s = ws[e];
+    for (int z = 1; z < splits; ++z) {
+      float4 v = ws[(size_t)z * n4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4 d = dW[e];
+    dW[e] = make_float4(d.x + s.x, d.y + s.y, d.z + s.z, d.w + s.w);
+  }
+}
+static int wgrad_reduce(const float* ws, int splits, size_t n, float* dW, hipStream_t st) {
+  if (splits <= 1 || n == 0) return 0;
+  if ((n % 4 == 0) && (((((uintptr_t)ws) | ((uintptr_t)dW)) & 15) == 0)) {
+    int g = es_cdiv((long long)(n / 4), 256);
+    hipLaunchKernelGGL(k_wgrad_reduce4, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, (const float4*)ws, splits, n / 4, (float4*)dW);
+  } else {
+    int g = es_cdiv((long long)n, 256);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, ws, splits, n, dW);
+  }
   ES_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out,
+                               int n_in, int K, int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream) {
+  if (n_out <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  WgradPlan p = wgrad_plan_f32(n_out, K, Cin, Cout, ws != nullptr);
+  const size_t nw = (size_t)K * Cin * Cout;
+  if (p.splits > 1 && ws_floats < (size_t)p.splits * nw) return -5;
+  dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), p.splits);
+  hipLaunchKernelGGL(k_spconv_wgrad, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out, n_in, K,
+                     Cin, Cout, p.rows_per_split, dW, p.splits > 1 ? ws : nullptr);
+  ES_CHECK_LAUNCH();
+  return wgrad_reduce(ws, p.splits, nw, dW, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ bf16 MFMA path
@@ -554,7 +611,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
   }
   __syncthreads();
   // tap split (gridDim.z > 1): launches with too few tiles to fill the chip share the tap list among gridDim.z
-  // workgroups which add their partial sums into a pre-zeroed Y with f32 atomics
+  // workgroups which write their partial sums to a workspace (k_sum_splits adds them in slice order)
   const int nTall = nTaps;
   const int tBeg = (int)(((long long)nTall * bz) / gridDim.z);
   const int nT = (int)(((long long)nTall * (bz + 1)) / gridDim.z);
@@ -718,10 +775,8 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
           float* p = Y + (size_t)row * ldy + col;
           if (gridDim.z > 1) {
             float v = acc[mf][nf][r] + (bz == 0 ? bv : 0.f);
-            if (ep_act == 7)                                // deterministic tap split: partial sums go to the workspace
-              const_cast<float*>(ep_res)[((size_t)bz * n_out + row) * Cout + col] = v;
-            else if (nT > tBeg || bz == 0)
-              atomicAdd(p, v);
+            // deterministic tap split (the only kind since round 3): partial sums go to the workspace
+            const_cast<float*>(ep_res)[((size_t)bz * n_out + row) * Cout + col] = v;
           } else {
             float v = acc[mf][nf][r] + bv;
             if (ep_scale) v = v * sc + sh;
@@ -964,24 +1019,14 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
   }
   int det_split = 0;
   if (fast && !(ep_scale || ep_res || ep_act) && K > 1) {
-    // too few workgroups for 256 CUs: split the tap list over gridDim.z (partial sums via f32 atomics into zeroed Y)
+    // too few workgroups for 256 CUs: split the tap list over gridDim.z (partial sums through the caller's workspace)
     int split = split_factor(n_out, K, Cout);
     if (split > 1 && ws != nullptr && ws_floats >= (size_t)split * n_out * Cout) {
       det_split = split;                   // deterministic: partial sums to the workspace, fixed-order reduction below
       ep_res = ws;
       ep_act = 7;
       g128.z = g64.z = split;
-    } else if (split > 1) {
-      if (!accumulate) {
-        if (ldy == Cout) {
-          hipError_t e = hipMemsetAsync(Y, 0, (size_t)n_out * Cout * 4, st);
-          if (e != hipSuccess) return (int)e;
-        } else {
-          split = 1;                       // strided outputs are not zero-filled here
-        }
-      }
-      g128.z = g64.z = split;
-    }
+    }                                      // (without a workspace the launch keeps one workgroup per tile: no f32 atomics)
   }
   if (fast && ES_OPT_PINGPONG) {
     if (x_is_bf16 && Cout % 128 == 0)
@@ -1165,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const void* __restric
                                                            const void* __restrict__ dY, int ldy,
                                                            const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                            int Cin, int Cout, int rows_per_split,
-                                                           int n_slices, float* __restrict__ dW) {
+                                                           int n_slices, float* __restrict__ dW, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) unsigned short As[WM * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[WN * GLD];
   __shared__ int s_qj[QCAP], s_qi[QCAP], s_wc[4];
@@ -1228,7 +1273,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const void* __restric
     }
     __syncthreads();
   }
-  if (q.tail == 0) return;                                // tap absent from this slice: nothing to add
+  if (q.tail == 0 && !ws) return;                         // tap absent from the (only) slice: nothing to add
 #pragma unroll
   for (int nf = 0; nf < 4; ++nf) {
     int col = n0 + nf * 16 + li;
@@ -1236,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const void* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int c = c0 + wv * 16 + kq * 4 + r;
-      if (c < Cin) atomicAdd(dW + ((size_t)k * Cin + c) * Cout + col, acc[nf][r]);
+      if (c < Cin) wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[nf][r]);
     }
   }
 }
@@ -1250,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
                                                                const void* __restrict__ dYv, int ldy,
                                                                const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                                int Cin, int Cout, int rows_per_split,
-                                                               int n_slices, float* __restrict__ dW) {
+                                                               int n_slices, float* __restrict__ dW, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) unsigned short As[128 * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[128 * GLD];
   __shared__ int s_qj[QCAP], s_qi[QCAP], s_wc[4];
@@ -1357,7 +1402,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
         acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
     __syncthreads();
   }
-  if (q.tail == 0) return;
+  if (q.tail == 0 && !ws) return;
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
@@ -1366,7 +1411,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int c = c0 + wv * 32 + mf * 16 + kq * 4 + r;
-        atomicAdd(dW + ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r]);
+        wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r]);
       }
     }
 }
@@ -1404,7 +1449,7 @@ __global__ __launch_bounds__(512) void k_spconv_wgrad_bf16_huge(const unsigned s
                                                                 const unsigned short* __restrict__ dY, int ldy,
                                                                 const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                                 int Cin, int Cout, int rows_per_split, int n_slices,
-                                                                float* __restrict__ dW) {
+                                                                float* __restrict__ dW, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) unsigned short As[256 * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[256 * GLD];
   __shared__ int s_qj[QCAP2], s_qi[QCAP2], s_wc[8];
@@ -1476,7 +1521,7 @@ __global__ __launch_bounds__(512) void k_spconv_wgrad_bf16_huge(const unsigned s
         acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
     __syncthreads();
   }
-  if (q.tail == 0) return;
+  if (q.tail == 0 && !ws) return;
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
@@ -1485,15 +1530,15 @@ __global__ __launch_bounds__(512) void k_spconv_wgrad_bf16_huge(const unsigned s
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int c = c0 + wm * 64 + mf * 16 + kq * 4 + r;
-        atomicAdd(dW + ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r]);
+        wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r]);
       }
     }
 }
 
-template <int XH, int YH>
-static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
-                             int Cin, int Cout, float* dW, void* stream) {
-  if (n_out <= 0 || Cin <= 0 || Cout <= 0) return 0;
+// which tile and how many row slices a bf16 weight-gradient launch uses (shared by the launch and the workspace query)
+static WgradPlan wgrad_plan_bf16(int XH, int YH, const void* X, int ldx, const void* dY, int ldy, int n_out, int n_in, int K,
+                                 int Cin, int Cout, bool have_ws) {
+  const long long nw = (long long)K * Cin * Cout;
   // 16-byte row segments: 4 floats or 8 bf16 per load
   const int ax = XH ? 8 : 4, ay = YH ? 8 : 4;
   bool big = (Cin % 128 == 0) && (Cout % 128 == 0) && (ldx % ax == 0) && (ldy % ay == 0) &&
@@ -1501,67 +1546,87 @@ static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, co
              ((long long)n_out * ldy < (1ll << 31)) &&
              (n_out >= 512 || (long long)Cin * Cout >= 512ll * 512ll);   // few rows x many channels: dW traffic decides
   bool huge = big && XH && YH && ES_OPT_WGRAD_HUGE && (Cin % 256 == 0) && (Cout % 256 == 0) && (ldx % 8 == 0) && (ldy % 8 == 0);
-  int huge_splits = 1;
   if (huge) {
     int base = K * (Cin / 256) * (Cout / 256);
-    huge_splits = es_cdiv(2048, base);
+    int splits = es_cdiv(2048, base);
     int max_splits = es_cdiv(n_out, 1024);
-    if (huge_splits > max_splits) huge_splits = max_splits;
-    if (huge_splits < 1) huge_splits = 1;
+    if (splits > max_splits) splits = max_splits;
+    splits = cap_splits(splits, nw, have_ws);
     // one 512-thread workgroup per CU: below ~4 workgroups per CU the 128 x 128 tile fills the chip better (measured: the
     // 256 .. 1024-channel levels of mv-3ddet have 190 .. 12 k rows -> 200 .. 400 workgroups, +0.9 ms per step)
-    huge = (long long)base * huge_splits >= 1024;
-  }
-  if (huge) {
-    int splits = huge_splits;
-    int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
-    splits = es_cdiv(n_out, rows_per_split);
-    dim3 grid(K * (Cin / 256), Cout / 256, es_cdiv(splits, 8) * 8);
-    hipLaunchKernelGGL(k_spconv_wgrad_bf16_huge, grid, dim3(512), 0, (hipStream_t)stream, (const unsigned short*)X, ldx,
-                       (const unsigned short*)dY, ldy, nbr, n_out, n_in, K, Cin, Cout, rows_per_split, splits, dW);
-    ES_CHECK_LAUNCH();
-    return 0;
+    if ((long long)base * splits >= 960) {
+      int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
+      return WgradPlan{3, es_cdiv(n_out, rows_per_split), rows_per_split};
+    }
   }
   if (big) {
     int base = K * (Cin / 128) * (Cout / 128);
     int splits = es_cdiv(8192, base);
     int max_splits = es_cdiv(n_out, 512);
     if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
+    splits = cap_splits(splits, nw, have_ws);
     int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
-    splits = es_cdiv(n_out, rows_per_split);
-    dim3 grid(K * (Cin / 128), Cout / 128, es_cdiv(splits, 8) * 8);
-    hipLaunchKernelGGL((k_spconv_wgrad_bf16_big<XH, YH>), grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy,
-                       nbr, n_out, n_in, K, Cin, Cout, rows_per_split, splits, dW);
-    ES_CHECK_LAUNCH();
-    return 0;
+    return WgradPlan{2, es_cdiv(n_out, rows_per_split), rows_per_split};
   }
   int base = K * es_cdiv(Cin, WM) * es_cdiv(Cout, WN);
   int splits = es_cdiv(4096, base);
   int max_splits = es_cdiv(n_out, 256);
   if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  splits = cap_splits(splits, nw, have_ws);
   int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
-  splits = es_cdiv(n_out, rows_per_split);
-  dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), es_cdiv(splits, 8) * 8);
-  hipLaunchKernelGGL((k_spconv_wgrad_bf16<XH, YH>), grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr,
-                     n_out, n_in, K, Cin, Cout, rows_per_split, splits, dW);
+  return WgradPlan{1, es_cdiv(n_out, rows_per_split), rows_per_split};
+}
+
+template <int XH, int YH>
+static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
+                             int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream) {
+  if (n_out <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const WgradPlan p = wgrad_plan_bf16(XH, YH, X, ldx, dY, ldy, n_out, n_in, K, Cin, Cout, ws != nullptr);
+  const size_t nw = (size_t)K * Cin * Cout;
+  if (p.splits > 1 && ws_floats < (size_t)p.splits * nw) return -5;
+  float* wsk = p.splits > 1 ? ws : nullptr;
+  const int gz = es_cdiv(p.splits, 8) * 8;                // XCD-aware slice order: slices >= p.splits exit
+  hipStream_t st = (hipStream_t)stream;
+  if (p.kind == 3) {
+    dim3 grid(K * (Cin / 256), Cout / 256, gz);
+    hipLaunchKernelGGL(k_spconv_wgrad_bf16_huge, grid, dim3(512), 0, st, (const unsigned short*)X, ldx,
+                       (const unsigned short*)dY, ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk);
+  } else if (p.kind == 2) {
+    dim3 grid(K * (Cin / 128), Cout / 128, gz);
+    hipLaunchKernelGGL((k_spconv_wgrad_bf16_big<XH, YH>), grid, dim3(256), 0, st, X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin,
+                       Cout, p.rows_per_split, p.splits, dW, wsk);
+  } else {
+    dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), gz);
+    hipLaunchKernelGGL((k_spconv_wgrad_bf16<XH, YH>), grid, dim3(256), 0, st, X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin,
+                       Cout, p.rows_per_split, p.splits, dW, wsk);
+  }
   ES_CHECK_LAUNCH();
-  return 0;
+  return wgrad_reduce(ws, p.splits, nw, dW, st);
 }
 
 extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out,
-                                    int n_in, int K, int Cin, int Cout, float* dW, void* stream) {
-  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
+                                    int n_in, int K, int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream) {
+  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
 }
 
 extern "C" int es_spconv_wgrad_bf16_src(const void* X, int x_half, int ldx, const void* dY, int dy_half, int ldy,
                                         const int* nbr, int n_out, int n_in, int K, int Cin, int Cout, float* dW,
-                                        void* stream) {
-  if (x_half && dy_half) return wgrad_bf16_launch<1, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
-  if (x_half) return wgrad_bf16_launch<1, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
-  if (dy_half) return wgrad_bf16_launch<0, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
-  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream);
+                                        float* ws, size_t ws_floats, void* stream) {
+  if (x_half && dy_half) return wgrad_bf16_launch<1, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
+  if (x_half) return wgrad_bf16_launch<1, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
+  if (dy_half) return wgrad_bf16_launch<0, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
+  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
+}
+
+// floats of workspace the weight-gradient launch of this shape wants for its row split (0: a single slice, none needed).
+// bf16 = 0: es_spconv_wgrad (exact f32); 1: es_spconv_wgrad_bf16[_src] with the given operand kinds / strides / pointers
+// (alignment decides the tile).  Without a workspace the launches run ONE row slice: still deterministic, under-filled.
+extern "C" size_t es_spconv_wgrad_workspace_floats(int bf16, const void* X, int x_half, int ldx, const void* dY, int dy_half,
+                                                   int ldy, int n_out, int n_in, int K, int Cin, int Cout) {
+  if (n_out <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  WgradPlan p = bf16 ? wgrad_plan_bf16(x_half, dy_half, X, ldx, dY, ldy, n_out, n_in, K, Cin, Cout, true)
+                     : wgrad_plan_f32(n_out, K, Cin, Cout, true);
+  return p.splits > 1 ? (size_t)p.splits * K * Cin * Cout : 0;
 }
 
 // f32 row matrix -> contiguous bf16 "shadow" (n, C) used as the gather source of the bf16 kernels

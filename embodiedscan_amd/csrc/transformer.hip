@@ -450,8 +450,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float a = sw[0][c] + sw[1][c] + sw[2][c] + sw[3][c], bsum = sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c];
-    if (dw) atomicAdd(dw + c, a);
-    if (db) atomicAdd(db + c, bsum);
+    if (dw) unsafeAtomicAdd(dw + c, a);
+    if (db) unsafeAtomicAdd(db + c, bsum);
   }
 }
 extern "C" int es_layernorm_bwd(const float* dy, const float* z, int n, int C, const float* w, const float* mean,
@@ -578,8 +578,8 @@ __global__ __launch_bounds__(256) void k_contrastive_bwd(const float* __restrict
   }
   __syncthreads();
   if (dtext)
-    for (int e = threadIdx.x; e < tl * C; e += 256) if (dts[e] != 0.f) atomicAdd(dtext + (size_t)b * T * C + e, dts[e]);
-  if (dbias && lane == 0 && bsum != 0.f) atomicAdd(dbias, bsum);
+    for (int e = threadIdx.x; e < tl * C; e += 256) if (dts[e] != 0.f) unsafeAtomicAdd(dtext + (size_t)b * T * C + e, dts[e]);
+  if (dbias && lane == 0 && bsum != 0.f) unsafeAtomicAdd(dbias, bsum);
 }
 extern "C" int es_contrastive_bwd(const float* dlogits, int Tout, const float* v, int B, int L, const float* text, int T, int C,
                                   const int* tlen_dev, float* dv, int acc_v, float* dtext, float* dbias, void* stream) {

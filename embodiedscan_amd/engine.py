@@ -218,6 +218,30 @@ def _wgrad_stream(*keep):
     return ws['h']
 
 
+_WGRAD_WS = {}          # stream handle -> persistent workspace of the deterministic weight-gradient row split
+
+
+def _wgrad(name, sw, dW, *args):
+    """launch a weight-gradient entry point (`args` = everything between the function name and dW) on stream `sw` with the
+    workspace its row split asks for.  One buffer per stream, grown on demand and reused by every launch of that stream:
+    the launches of a stream (partial tiles -> fixed-order reduction into dW) are ordered, so the reuse is race free."""
+    if name == 'es_spconv_wgrad_bf16_src':
+        X, xh, ldx, dY, yh, ldy, nbr, n_out, n_in, K, cin, cout = args
+        need = hip.raw('es_spconv_wgrad_workspace_floats')(1, X, xh, ldx, dY, yh, ldy, n_out, n_in, K, cin, cout)
+    else:
+        X, ldx, dY, ldy, nbr, n_out, n_in, K, cin, cout = args
+        need = hip.raw('es_spconv_wgrad_workspace_floats')(int(name == 'es_spconv_wgrad_bf16'), X, 0, ldx, dY, 0, ldy, n_out, n_in,
+                                                           K, cin, cout)
+    ws = None
+    if need:
+        ws = _WGRAD_WS.get(sw)
+        if ws is None or ws.numel() < need:
+            if ws is not None:
+                _KEEP.append(ws)                 # launches already queued on `sw` may still use the old buffer
+            ws = _WGRAD_WS[sw] = torch.empty(max(int(need), 1 << 22), dtype=torch.float32, device=torch.device('cuda', torch.cuda.current_device()))
+    call(name, *args, dW, P(ws), ws.numel() if ws is not None else 0, sw)
+
+
 def join_wgrad_streams(final=True):
     """make the current stream wait for every queued weight-gradient launch (before the gradients are reduced or
     consumed by the optimiser)"""
@@ -362,15 +386,15 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         sw = _wgrad_stream(gy, x.d, gh, x.dh)
     if w.g is not None and bf and WGRAD_BF16[0] and SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None):
         xs, ys = x.dh if x.dh is not None else x.d, gh if gh is not None else gy
-        call('es_spconv_wgrad_bf16_src', P(xs), int(x.dh is not None), _ld(xs), P(ys), int(gh is not None), _ld(ys),
-             P(nbr), n_out, n_in, K, cin, cout, P(w.g), sw)
+        _wgrad('es_spconv_wgrad_bf16_src', sw, P(w.g), P(xs), int(x.dh is not None), _ld(xs), P(ys), int(gh is not None), _ld(ys),
+               P(nbr), n_out, n_in, K, cin, cout)
     elif w.g is not None:
-        call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), P(gy), _ld(gy),
-             P(nbr), n_out, n_in, K, cin, cout, P(w.g), sw)
+        _wgrad('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', sw, P(w.g), P(x.d), _ld(x.d), P(gy),
+               _ld(gy), P(nbr), n_out, n_in, K, cin, cout)
     if bias is not None and bias.g is not None:
         ones = _ones(n_out, x.d.device)
-        call('es_spconv_wgrad', P(ones), 1, gy.data_ptr() + 4 * bias_from, _ld(gy), 0, n_out, n_out, 1, 1,
-             cout - bias_from, bias.g.data_ptr() + 4 * bias_from, sw)
+        _wgrad('es_spconv_wgrad', sw, bias.g.data_ptr() + 4 * bias_from, P(ones), 1, gy.data_ptr() + 4 * bias_from, _ld(gy), 0,
+               n_out, n_out, 1, 1, cout - bias_from)
     if need_dx and x.rg and gate is not None:
         assert x.g is None and bf, 'gated dgrad: x must have exactly one consumer'
         x.g, x.gated = torch.empty_like(x.d), True
@@ -447,8 +471,8 @@ def gen_conv_transpose(x, w):
         for k in range(8):
             gy = y.g.data_ptr() + 4 * k * cout
             if w.g is not None:
-                call('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', P(x.d), _ld(x.d), gy,
-                     8 * cout, 0, n, n, 1, cin, cout, w.g.data_ptr() + 4 * k * cin * cout, sw)
+                _wgrad('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', sw,
+                       w.g.data_ptr() + 4 * k * cin * cout, P(x.d), _ld(x.d), gy, 8 * cout, 0, n, n, 1, cin, cout)
             if g is not None and bf:
                 call('es_spconv_fwd_bf16', gy, 0, 8 * cout, w.bf16()[0].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cout,
                      cin, 0, P(g), _ld(g), 1 if (acc or k > 0) else 0, s)

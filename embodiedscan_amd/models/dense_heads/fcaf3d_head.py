@@ -355,7 +355,7 @@ class FCAF3DHeadRotMat:
         avg = reduce_mean(n_pos_all.float()).clamp(min=1.0).contiguous()
         # phase 3: losses + gradients, per (sample, level) slice, no host sync
         loss_cls = torch.zeros(B, dtype=torch.float32, device=dev)
-        loss_acc = torch.zeros((B, 2), dtype=torch.float32, device=dev)
+        loss_acc = torch.zeros((B, 2), dtype=torch.float64, device=dev)       # f64 sums (order-independent after rounding)
         partials = [torch.empty(2048, dtype=torch.float64, device=dev) for _ in range(2)]   # one scratch per stream
         gw = [w * self.bbox_loss_weight for w in self.decouple_weights]
         if not self.decouple_bbox_loss:
@@ -387,7 +387,7 @@ class FCAF3DHeadRotMat:
                 pos_ws = torch.empty(max_pos + 1, dtype=torch.int32, device=dev)
                 call('es_pos_losses', P(kt), lo[-1], P(npos), max_pos, P(pos_ws), P(pts), n_lvl, iarr(lo), parr(hos),
                      parr(bbs), parr(dhos), parr(dbbs), ncol, P(ct), P(bt), avg.data_ptr() + 4 * b, gscale, gwa,
-                     loss_acc.data_ptr() + 8 * b, s)
+                     loss_acc.data_ptr() + 16 * b, s)
 
         if on_side:
             with E.side_stream():
@@ -403,9 +403,10 @@ class FCAF3DHeadRotMat:
             n = lv['cs'].n
             ncol = lv['ho'].d.shape[1]
             call('es_reg_decode_bwd', lv['ho'].d.data_ptr() + 4, ncol, P(lv['bbox']), P(lv['dbbox']), n,
-                 P(lv['scale'].d), lv['dho'].data_ptr() + 4, ncol, P(lv['scale'].g), s)
+                 P(lv['scale'].d), lv['dho'].data_ptr() + 4, ncol, P(lv['scale'].g), P(partials[0]), s)
             lv['ho'].g = lv['dho']
         eps = float(torch.finfo(torch.float32).eps)
+        loss_acc = loss_acc.float()
         losses = dict(loss_center=(loss_acc[:, 0] / (avg + eps)).mean(), loss_bbox=loss_acc[:, 1].mean(),
                       loss_cls=loss_cls.mean())
         self.last_targets = [(p[2], p[3], p[4]) for p in per]

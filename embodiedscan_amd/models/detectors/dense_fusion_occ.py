@@ -123,10 +123,13 @@ class DenseFusionOccPredictor(DetectorBase):
             else:
                 E.add_into(x3.F.g, g3)
             if f2d.rg:
+                acc = 1
                 if f2d.g is None:
-                    f2d.g = torch.zeros_like(f2d.d)
+                    f2d.g, acc = torch.empty_like(f2d.d), 0         # the gather writes every pixel
+                head = torch.empty(f2d.d.shape[0], dtype=torch.int32, device=self.device)
+                nxt = torch.empty(B * nvox * V, dtype=torch.int32, device=self.device)
                 call('es_point_sample_bwd', P(bidx), B * nvox, V, P(v.g), C2 + C3, P(pix), P(cnt), Hf, Wf, C2, P(f2d.g),
-                     hip.stream())
+                     B * V, P(head), P(nxt), acc, hip.stream())
         E.TAPE.add(bwd)
         outs = self.neck_3d(v, (X, Y, Z), B)
         E.mark('IndoorImVoxelNeck')

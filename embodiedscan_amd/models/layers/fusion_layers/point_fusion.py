@@ -51,7 +51,7 @@ def build_fusion_meta(metas, coord_type, img_pad_shape, n_views):
 
 def batch_point_sample_level(cs, voxel_size, meta_dev, n_views, feat, Hf, Wf, out, col0):
     """Writes the sampled image features of every voxel of `cs` into out[:, col0:col0+C] and registers the
-    backward (atomic scatter-add into the feature-map gradient).  feat: Var ((B*V*Hf*Wf), C)."""
+    backward (deterministic gather into the feature-map gradient).  feat: Var ((B*V*Hf*Wf), C)."""
     C = feat.d.shape[1]
     n = cs.n
     pix = torch.empty((n, n_views), dtype=torch.int32, device=out.device)
@@ -65,7 +65,11 @@ def batch_point_sample_level_bwd(cs, n_views, dout, col0, pix, cnt, feat, Hf, Wf
     C = feat.d.shape[1]
     if not feat.rg:
         return
+    acc = 1
     if feat.g is None:
-        feat.g = torch.zeros_like(feat.d)
+        feat.g, acc = torch.empty_like(feat.d), 0           # the gather writes every pixel
+    n_pix = feat.d.shape[0]
+    head = torch.empty(n_pix, dtype=torch.int32, device=feat.d.device)
+    nxt = torch.empty(max(cs.n * n_views, 1), dtype=torch.int32, device=feat.d.device)
     call('es_point_sample_bwd', P(cs.coords), cs.n, n_views, dout.data_ptr() + 4 * col0, dout.stride(0), P(pix), P(cnt),
-         Hf, Wf, C, P(feat.g), _stream())
+         Hf, Wf, C, P(feat.g), n_pix // (Hf * Wf), P(head), P(nxt), acc, _stream())

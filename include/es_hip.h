@@ -101,21 +101,29 @@ int es_cast_weight_bf16(const float* w, int K, int A, int B, void* natural, void
  * {src f32 ptr, natural bf16 ptr, transposed bf16 ptr, K, A, B, first_tile}; one workgroup per 64x64 tile of a tap,
  * first_tile = exclusive prefix sum of K*ceil(A/64)*ceil(B/64) */
 int es_cast_weights_table(const void* table_dev, int n_entries, int total_tiles, void* stream);
-/* dW[k] += X[nbr[:,k]]^T . dY */
+/* dW[k] += X[nbr[:,k]]^T . dY.  Deterministic (round 3): the rows are split into slices, every (tap, channel tile, slice)
+ * workgroup owns its partial tile; with one slice the tile is added straight into dW, with several the partial tiles go to
+ * the caller's workspace `ws` ([slice][K][Cin][Cout], es_spconv_wgrad_workspace_floats) and are added to dW in slice order
+ * by a second launch.  No float atomics: bit-identical gradients run to run.  ws NULL: ONE slice (correct, under-filled).
+ * Replaces the backward of MinkowskiConvolution / nn.Conv2d / nn.Linear (mink_resnet.py:58-62, fcaf3d_head.py:907-984). */
 int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
-                    int Cin, int Cout, float* dW, void* stream);
-/* bf16-MFMA variant of es_spconv_wgrad (operands rounded to bf16 while staged, f32 accumulate / atomics into dW, which
- * the caller zeroes once per step).  Each (tap, row slice) workgroup compacts the valid (row, neighbour) pairs of its
- * slice before the GEMM, so absent neighbours cost one map read; the accumulation order across slices is not fixed
- * (atomics), results are reproducible to f32 rounding only. */
+                    int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream);
+/* bf16-MFMA variant of es_spconv_wgrad (operands rounded to bf16 while staged, f32 accumulate into dW, which the caller
+ * zeroes once per step).  Each (tap, row slice) workgroup compacts the valid (row, neighbour) pairs of its slice before
+ * the GEMM, so absent neighbours cost one map read.  Same deterministic slice scheme as es_spconv_wgrad. */
 int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
-                         int Cin, int Cout, float* dW, void* stream);
+                         int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream);
 /* Same operator with either operand taken from a bf16 copy ("shadow", es_cast_rows_bf16) of the row matrix: x_half /
  * dy_half non-zero -> X / dY point at (n, ld) bf16 rows (ld in elements).  Results are bit-identical to
- * es_spconv_wgrad_bf16 on the f32 originals up to the atomic accumulation order (the f32 path rounds to the same bf16
- * values while staging); the gathered bytes halve. */
+ * es_spconv_wgrad_bf16 on the f32 originals when both launches use the same tile and slices (the f32 path rounds to the
+ * same bf16 values while staging); the gathered bytes halve. */
 int es_spconv_wgrad_bf16_src(const void* X, int x_half, int ldx, const void* dY, int dy_half, int ldy, const int* nbr,
-                             int n_out, int n_in, int K, int Cin, int Cout, float* dW, void* stream);
+                             int n_out, int n_in, int K, int Cin, int Cout, float* dW, float* ws, size_t ws_floats,
+                             void* stream);
+/* floats of workspace the weight-gradient launch of this shape asks for (0: one slice).  bf16 = 0: es_spconv_wgrad;
+ * 1: es_spconv_wgrad_bf16[_src] with these operand kinds, strides and pointers (their alignment selects the tile). */
+size_t es_spconv_wgrad_workspace_floats(int bf16, const void* X, int x_half, int ldx, const void* dY, int dy_half, int ldy,
+                                        int n_out, int n_in, int K, int Cin, int Cout);
 int es_image_map(int n_img, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int* nbr, void* stream);
 
 /* ---- row operators ----------------------------------------------------------------------------- */
@@ -174,8 +182,12 @@ int es_point_sample_fwd(const int* coords, int n, float voxel_size, const float*
 int es_point_sample_fwd_pts(const int* coords, const float* points, int n, const float* meta, int meta_stride, int V,
                             const float* feats, int Hf, int Wf, int C, float* out, int ldo, int* pix, int* cnt,
                             void* stream);
+/* backward of the projection fusion (point_fusion.py:86-107 through autograd of grid_sample / the hit average):
+ * dfeats ((n_img*Hf*Wf), C) (+)= for every feature-map pixel the sum over the voxels that sampled it of dout[i]/cnt[i], added
+ * in ascending voxel order (deterministic gather: no float atomics; EVERY pixel is written, so with accumulate = 0 the
+ * caller needs no memset).  n_img = samples * V; head: n_img*Hf*Wf ints, next: n*V ints of scratch. */
 int es_point_sample_bwd(const int* coords, int n, int V, const float* dout, int ldo, const int* pix, const int* cnt,
-                        int Hf, int Wf, int C, float* dfeats, void* stream);
+                        int Hf, int Wf, int C, float* dfeats, int n_img, int* head, int* next, int accumulate, void* stream);
 
 /* ---- A12 target assignment.  fcaf3d_head.py:1578-1664 --------------------------------------------- */
 /* level_off: HOST array n_levels+1.  rot_neg: (G,9) row-major R(-euler) (ZXY) computed on the host.
@@ -190,8 +202,9 @@ int es_focal_loss(const float* logits, int ldl, const int* labels, int N, int C,
                   float* loss_out /* accumulated */, void* stream);
 /* bbox[:, :6] = clamp(exp(scale * reg[:, :6]), 1e-3), bbox[:, 6:] = reg[:, 6:]  (fcaf3d_head.py:1135-1137) */
 int es_reg_decode_fwd(const float* reg, int ldr, int n, const float* scale, float* bbox /* (n,12) */, void* stream);
+/* partial: >= 512 floats of scratch (the Scale gradient is reduced in a fixed order, no atomics) */
 int es_reg_decode_bwd(const float* reg, int ldr, const float* bbox, const float* dbbox, int n, const float* scale,
-                      float* dreg, int ldg, float* dscale, void* stream);
+                      float* dreg, int ldg, float* dscale, float* partial, void* stream);
 /* Per SAMPLE over its n locations of all levels (fine -> coarse, level_off_host = n_levels+1 row offsets inside the
  * per-sample arrays cls_t / points / center_t / bbox_t).  Rows with cls_t >= 0 are first compacted on the device (no
  * host-side nonzero()) into pos_ws (int[max_pos + 1], [0] = count); the loss kernel is launched over max_pos, the host's
@@ -200,12 +213,14 @@ int es_reg_decode_bwd(const float* reg, int ldr, const float* bbox, const float*
  * ho_host[l] / dho_host[l]: this sample's first row of level l in the head output / its gradient (leading dim ldh,
  * column 0 = centerness logit); bbox_host[l] / dbbox_host[l]: decoded (.,12) boxes / their gradient.  All four are HOST
  * arrays of device pointers.  group_w: HOST array of the 4 decouple weights.
- * loss_acc[0] += sum BCE, loss_acc[1] += weighted corner loss (mean over n_pos*8). */
+ * loss_acc[0] += sum BCE, loss_acc[1] += weighted corner loss (mean over n_pos*8); f64 accumulators: the positives are
+ * compacted in slot-grab order and f64 sums of f32 terms do not depend on it after rounding back to f32. */
 #define ES_MAX_LEVELS 8
 int es_pos_losses(const int* cls_t, int n, const int* n_pos_dev, int max_pos, int* pos_ws, const float* points,
                   int n_levels, const int* level_off_host, const void* const* ho_host, const void* const* bbox_host,
                   void* const* dho_host, void* const* dbbox_host, int ldh, const float* center_t, const float* bbox_t,
-                  const float* avg_factor_dev, float grad_scale, const float* group_w_host, float* loss_acc, void* stream);
+                  const float* avg_factor_dev, float grad_scale, const float* group_w_host, double* loss_acc /* f64 sums */,
+                  void* stream);
 
 /* ---- N1 inference post-processing.  fcaf3d_head.py:1352-1399,1666-1725 + mmcv.ops.nms3d ------------------------- */
 /* scores[i,c] = sigmoid(cls[i,c]) * sigmoid(centerness[i]) from the head output rows (col 0 centerness, 13.. classes) */

@@ -81,7 +81,7 @@ def test_losses_vs_oracle(golden_dir):
     (lb + lc).backward()
     dcen = torch.zeros(n, device=dev)
     dbb = torch.zeros((n, 12), device=dev)
-    acc = torch.zeros(2, device=dev)
+    acc = torch.zeros(2, dtype=torch.float64, device=dev)          # f64 loss sums
     # keep every device tensor alive in a variable: P() only takes the pointer
     d_cls, d_np, d_pts, d_cp = cls_t.to(dev), torch.tensor([npos], dtype=torch.int32, device=dev), pts.to(dev), center_p.to(dev)
     d_pred, d_ct, d_tgt, d_avg = pred.to(dev), center_t.to(dev), tgt.to(dev), avg.to(dev)

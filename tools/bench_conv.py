@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 from embodiedscan_amd import sparse, hip
 from embodiedscan_amd.hip import P, call
+from embodiedscan_amd.engine import _wgrad as WG
 from embodiedscan_amd.synth import make_scan
 from embodiedscan_amd import pipeline
 
@@ -54,9 +55,9 @@ for (S, cin, cout) in cases:
         t = timeit(lambda: call('es_spconv_fwd_bf16', P(xh), 1, cin, P(wb_t), P(m), n, n, 27, cin, cout, 0, P(y), cout, 0, st))
         tag = tag + ', bf16 rows'
         print(f'  bf16 fwd [{tag}]: {t:.3f} ms  {2 * p_ * cin * cout / t / 1e9:.1f} TF/s alg  gather {p_ * cin * 4 / t / 1e6:.0f} GB/s')
-        t = timeit(lambda: call('es_spconv_wgrad', P(x), cin, P(y), cout, P(m), n, n, 27, cin, cout, P(dw), st))
+        t = timeit(lambda: WG('es_spconv_wgrad', st, P(dw), P(x), cin, P(y), cout, P(m), n, n, 27, cin, cout))
         print(f'  f32 wgrad[{tag}]: {t:.3f} ms  {2 * p_ * cin * cout / t / 1e9:.1f} TF/s alg')
-        t = timeit(lambda: call('es_spconv_wgrad_bf16', P(x), cin, P(y), cout, P(m), n, n, 27, cin, cout, P(dw), st))
+        t = timeit(lambda: WG('es_spconv_wgrad_bf16', st, P(dw), P(x), cin, P(y), cout, P(m), n, n, 27, cin, cout))
         print(f'  bf16 wgrad[{tag}]: {t:.3f} ms  {2 * p_ * cin * cout / t / 1e9:.1f} TF/s alg')
     t = timeit(lambda: call('es_spconv_fwd_bf16', P(x), 0, cin, P(wb_t), 0, n, n, 1, cin, cout, 0, P(y), cout, 0, st))
     print(f'  bf16 k1 GEMM: {t:.3f} ms  {2 * n * cin * cout / t / 1e9:.1f} TF/s  read {n * cin * 4 / t / 1e6:.0f} GB/s')
