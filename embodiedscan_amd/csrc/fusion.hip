@@ -130,13 +130,14 @@ extern "C" int es_point_sample_fwd_pts(const int* coords, const float* points, i
 // list and adds the rows dout[i] / cnt[i] in ASCENDING voxel order (64 smallest remaining hits at a time, extracted by
 // wave-min), so the sum order is fixed whatever the link order was.  Every pixel is written (zeros when nothing projects
 // to it): the caller needs no memset and no float atomics are left on the path.
-__global__ void k_ps_link(const int* __restrict__ coords, int n, int V, const int* __restrict__ pix, int HW,
-                          int* __restrict__ head, int* __restrict__ next) {
+__global__ void k_ps_link(const int* __restrict__ coords, int n, int V, const int* __restrict__ pix,
+                          const int* __restrict__ cnt, int HW, int* __restrict__ head, int* __restrict__ next) {
   size_t tot = (size_t)n * V;
   for (size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x; h < tot; h += (size_t)gridDim.x * blockDim.x) {
     int p = pix[h];
     if (p < 0) continue;
     int i = (int)(h / V), v = (int)(h - (size_t)i * V);
+    if (cnt[i] <= 0) continue;       // no valid view: the forward output of this voxel is 0 whatever was sampled
     int b = coords[(size_t)i * 4];
     next[h] = atomicExch(&head[((size_t)b * V + v) * HW + p], (int)h);
   }
@@ -200,7 +201,7 @@ extern "C" int es_point_sample_bwd(const int* coords, int n, int V, const float*
   ES_TRY(hipMemsetAsync(head, 0xff, (size_t)n_pix * sizeof(int), st));
   if (n > 0) {
     int g = es_cdiv((long long)n * V, 256);
-    hipLaunchKernelGGL(k_ps_link, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, coords, n, V, pix, Hf * Wf, head, next);
+    hipLaunchKernelGGL(k_ps_link, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, coords, n, V, pix, cnt, Hf * Wf, head, next);
     ES_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_ps_gather, dim3(es_cdiv(n_pix, 4)), dim3(256), 0, st, head, next, (int)n_pix, V, dout, ldo, cnt, C,

@@ -340,9 +340,37 @@ __global__ void k_wgrad_reduce4(const float4* __restrict__ ws, int splits, size_
     dW[e] = make_float4(d.x + s.x, d.y + s.y, d.z + s.z, d.w + s.w);
   }
 }
+// Many slices of a SMALL weight (the 1x1 convolutions of the image backbone: a few thousand weights, > 1e6 rows -> thousands of
+// slices): one thread per element would walk thousands of slices serially (measured: 1.3 ms for a 64 x 32 weight).  Here
+// a 256-thread block owns EB = 256 / R elements and R slice ranges: thread (el, rr) adds its contiguous range of slices in
+// order, the R range sums are then added in range order through LDS -- a fixed tree, so still bit-reproducible.
+template <int R>
+__global__ __launch_bounds__(256) void k_wgrad_reduce_ranges(const float* __restrict__ ws, int splits, size_t n,
+                                                             float* __restrict__ dW) {
+  constexpr int EB = 256 / R;
+  __shared__ float part[R][EB];
+  const int el = threadIdx.x % EB, rr = threadIdx.x / EB;
+  const size_t e = (size_t)blockIdx.x * EB + el;
+  const int per = (splits + R - 1) / R;
+  const int z0 = rr * per, z1 = min(splits, z0 + per);
+  float s = 0.f;
+  if (e < n)
+    for (int z = z0; z < z1; ++z) s += ws[(size_t)z * n + e];
+  part[rr][el] = s;
+  __syncthreads();
+  if (rr == 0 && e < n) {
+    float t = part[0][el];
+#pragma unroll
+    for (int r = 1; r < R; ++r) t += part[r][el];
+    dW[e] += t;
+  }
+}
 static int wgrad_reduce(const float* ws, int splits, size_t n, float* dW, hipStream_t st) {
   if (splits <= 1 || n == 0) return 0;
-  if ((n % 4 == 0) && (((((uintptr_t)ws) | ((uintptr_t)dW)) & 15) == 0)) {
+  if (splits >= 64) {                      // (the choice depends on the slice count only: same launch -> same summation tree)
+    if (splits >= 512) hipLaunchKernelGGL(k_wgrad_reduce_ranges<64>, dim3(es_cdiv((long long)n, 4)), dim3(256), 0, st, ws, splits, n, dW);
+    else hipLaunchKernelGGL(k_wgrad_reduce_ranges<16>, dim3(es_cdiv((long long)n, 16)), dim3(256), 0, st, ws, splits, n, dW);
+  } else if ((n % 4 == 0) && (((((uintptr_t)ws) | ((uintptr_t)dW)) & 15) == 0)) {
     int g = es_cdiv((long long)(n / 4), 256);
     hipLaunchKernelGGL(k_wgrad_reduce4, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, (const float4*)ws, splits, n / 4, (float4*)dW);
   } else {

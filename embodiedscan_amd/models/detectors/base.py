@@ -4,6 +4,7 @@ state dicts, `forward(inputs, data_samples, mode)` dispatch and `train_step(data
 import torch
 from ... import engine as E
 from ... import hip
+from ...parallel import BucketedGradReducer, is_dist
 from ...params import ParamArena
 
 
@@ -92,6 +93,37 @@ class DetectorBase:
                 det.train(self.was)
         return _G()
 
+    # data-parallel gradient buckets (parallel.BucketedGradReducer): name-prefix groups + the implicit last part; a
+    # detector's forward records (tape index, part) pairs in `_tape_parts`: when the reverse replay of the tape has passed
+    # the index, every gradient of that part is complete and its all-reduce starts under the rest of the backward pass
+    _bucket_groups = (('backbone.',), ('backbone_3d.',))
+
+    def tape_part(self, part):
+        """called in forward: everything recorded on the tape from here on belongs to gradient part `part` (or later ones)"""
+        if getattr(self, '_tape_parts', None) is not None:
+            self._tape_parts.append((len(E.TAPE.fns), part))
+
+    def _backward(self, red):
+        fns = E.TAPE.fns
+        hi = len(fns)
+        done = set()
+        for idx, part in sorted(getattr(self, '_tape_parts', None) or [], reverse=True):
+            for fn in reversed(fns[idx:hi]):
+                fn()
+            hi = idx
+            if red is not None:
+                E.join_wgrad_streams(final=False)
+                red.launch(part)
+                done.add(part)
+        for fn in reversed(fns[:hi]):
+            fn()
+        E.join_wgrad_streams()
+        if red is not None:
+            for part in range(len(red.parts)):
+                if part not in done:
+                    red.launch(part)
+        E.TAPE.fns = []
+
     def train_step(self, data, optim_wrapper):
         E.TAPE.clear()
         hip.refresh_stream()
@@ -100,9 +132,15 @@ class DetectorBase:
             data = self.data_preprocessor(data, True)
         self._bind()
         self.arena.grad.zero_()
+        self._tape_parts = []
         losses = self.forward(data['inputs'], data['data_samples'], mode='loss')
         E.mark('forward + losses')
-        E.TAPE.backward()
+        red = None
+        if is_dist():
+            if getattr(self.arena, 'reducer', None) is None:
+                self.arena.reducer = BucketedGradReducer(self.arena, groups=self._bucket_groups)
+            red = self.arena.reducer
+        self._backward(red)
         E.mark('backward')
         optim_wrapper.update_params(self.arena)
         E.mark('all-reduce + clip + AdamW')

@@ -51,6 +51,12 @@ class DenseFusionOccPredictor(DetectorBase):
         self._init_base(specs, device, seed, data_preprocessor)
         self._prior = None
 
+    # gradient buckets: part 0 = the image branch (ResNet-50 + FPN: complete last), 1 = MinkResNet34, 2 = the fine half of
+    # the dense neck (down_layer_0/1: 0.3 GB), implicit part 3 = the coarse half + head (down_layer_2, up / out blocks: 2.6 GB of
+    # the 2.9 GB of gradients) -- its all-reduce starts when the reverse replay leaves down_layer_2, in 256 MB chunks, under
+    # the backward of the fine neck levels and both backbones instead of as one 2.9 GB call at the end
+    _bucket_groups = (('backbone.', 'neck.'), ('backbone_3d.',), ('neck_3d.down_layer_0', 'neck_3d.down_layer_1'))
+
     def _children(self):
         return [(self.backbone, 'backbone.'), (self.neck, 'neck.'), (self.backbone_3d, 'backbone_3d.'),
                 (self.neck_3d, 'neck_3d.'), (self.bbox_head, 'bbox_head.')]
@@ -81,6 +87,7 @@ class DenseFusionOccPredictor(DetectorBase):
         E.refresh_weight_copies()
         f2d, Hf, Wf = self.neck(self.backbone(nhwc), B * V, levels=[0])[0]
         E.mark('2-D backbone + FPN')
+        self.tape_part(1)                       # behind this point: 3-D backbone, then the neck parts
         metas = [ds.metainfo for ds in batch_data_samples]
         X, Y, Z = self.n_voxels
         nvox = X * Y * Z
@@ -105,6 +112,7 @@ class DenseFusionOccPredictor(DetectorBase):
         feats = torch.empty((cs.n, 3), dtype=torch.float32, device=self.device)
         call('es_row_move', P(feats), 3, P(allp), allp.stride(0), P(src), cs.n, 3, 0, hip.stream())
         x3 = self.backbone_3d(SparseTensor(cs, E.Var(feats, rg=False)))[-1]
+        self.tape_part(2)
         assert x3.F.d.shape[1] == C3 and x3.cs.ts == self.voxel_stride
         didx = torch.empty(x3.cs.n, dtype=torch.int32, device=self.device)
         call('es_dense_index', P(x3.cs.coords), x3.cs.n, x3.cs.ts, X, Y, Z, P(didx), hip.stream())
@@ -131,7 +139,7 @@ class DenseFusionOccPredictor(DetectorBase):
                 call('es_point_sample_bwd', P(bidx), B * nvox, V, P(v.g), C2 + C3, P(pix), P(cnt), Hf, Wf, C2, P(f2d.g),
                      B * V, P(head), P(nxt), acc, hip.stream())
         E.TAPE.add(bwd)
-        outs = self.neck_3d(v, (X, Y, Z), B)
+        outs = self.neck_3d(v, (X, Y, Z), B, on_coarse=lambda: self.tape_part(3))
         E.mark('IndoorImVoxelNeck')
         return outs
 

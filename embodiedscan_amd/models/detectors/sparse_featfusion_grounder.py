@@ -46,6 +46,10 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         self.training = True
         self._bound = False
 
+    # gradient buckets (data parallel): the backbones, the MinkNeck, and -- implicit last part -- decoder + head +
+    # text_feat_map, whose gradients are complete first: four all-reduces, each under the backward of what precedes it
+    _bucket_groups = (('backbone.',), ('backbone_3d.',), ('neck_3d.',))
+
     # ------------------------------------------------------------------ parameters
     def to(self, device):
         super().to(device)
@@ -134,7 +138,11 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
     def extract_feat(self, batch_inputs_dict, batch_data_samples):
         """:176-310: fused sparse levels (inherited) -> MinkNeck -> (feats, scores, coords) per-sample lists"""
         x = super().extract_feat(batch_inputs_dict, batch_data_samples)
-        return self.neck_3d(x, len(batch_data_samples))
+        out = self.neck_3d(x, len(batch_data_samples))
+        # everything recorded from here on (text map, decoder, head) belongs to the last gradient part (3); once the reverse
+        # replay is back here only fusion + neck closures remain before the 3-D backbone's: part 2 (neck_3d.) is theirs
+        self._tape_marks = self._tape_marks[:2] + [(len(E.TAPE.fns), 3)]
+        return out
 
     def forward_transformer(self, text, tlen, T, batch_data_samples):
         """pre_decoder + forward_decoder (:312-447) on the padded buffers of the neck"""

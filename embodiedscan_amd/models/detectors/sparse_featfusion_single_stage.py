@@ -214,7 +214,7 @@ class SparseFeatureFusionSingleStage3DDetector:
             # bucketed gradient all-reduce overlapped with backward: markers fire when the tape (run in reverse) has
             # finished the head (+ fusion) closures, then the 3-D backbone's, then everything
             if getattr(self.arena, 'reducer', None) is None:
-                self.arena.reducer = BucketedGradReducer(self.arena)
+                self.arena.reducer = BucketedGradReducer(self.arena, groups=self._bucket_groups)
             red = self.arena.reducer
             self._backward(red)
         else:
@@ -224,17 +224,27 @@ class SparseFeatureFusionSingleStage3DDetector:
         E.mark('all-reduce wait + clip + AdamW')
         return losses
 
+    # gradient buckets of the data-parallel exchange (parallel.BucketedGradReducer): parts 0 / 1 = the backbones, the
+    # implicit last part = everything else (head); subclasses add parts and tape marks for what sits behind the fusion
+    _bucket_groups = (('backbone.',), ('backbone_3d.',))
+
     def _backward(self, red):
         """Run the tape in reverse: head + fusion, then the 3-D backbone on the main stream while the 2-D backbone's
         backward runs on the side stream (they share nothing but the fusion gradients).  `red` (data parallel only)
-        all-reduces each part of the gradient arena as soon as it is complete."""
+        all-reduces each part of the gradient arena as soon as it is complete.  `_tape_marks` = [end of the 2-D
+        backbone's closures, end of the 3-D backbone's, *(tape index, part) pairs a subclass recorded behind them*]: when
+        the reverse replay has passed a pair's index, that part's gradients are complete."""
         fns = E.TAPE.fns
-        m2d, m3d = self._tape_marks
-        for fn in reversed(fns[m3d:]):
-            fn()
-        if red is not None:
-            E.join_wgrad_streams(final=False)
-            red.launch(2)                                      # head gradients complete
+        m2d, m3d = self._tape_marks[:2]
+        extra = sorted(self._tape_marks[2:], reverse=True) + [(m3d, 2)]     # part 2: what sits between the 3-D backbone and the marks
+        hi = len(fns)
+        for idx, part in extra:                                # (the last pair: everything behind the backbones)
+            for fn in reversed(fns[idx:hi]):
+                fn()
+            hi = idx
+            if red is not None:
+                E.join_wgrad_streams(final=False)
+                red.launch(part)                               # e.g. head gradients complete
         img, pts = fns[:m2d][::-1], fns[m2d:m3d][::-1]
         if E.TWO_STREAMS[0] and img and pts:
             # issue the two branches in alternating chunks so that neither queue runs dry while the host is busy

@@ -127,13 +127,15 @@ class IndoorImVoxelNeck:
         o = self._conv3(o, blk['conv2'], g_out)
         return blk['norm2'](o, act=1, res=idt, training=tr), g_out          # relu(bn(conv2) + identity)
 
-    def forward(self, x, dims, B=1):
+    def forward(self, x, dims, B=1, on_coarse=None):
         """x: Var (B*X*Y*Z, C_in) channels-last, dims = (X, Y, Z).  Returns [(Var (B*Xi*Yi*Zi, out_channels), (Xi,Yi,Zi))]
         fine -> coarse (imvoxel_neck.py:34-58)."""
         tr = self.training
         g = self._grid(B, dims, x.d.device)
         down = []
-        for layer in self.down:
+        for li, layer in enumerate(self.down):
+            if on_coarse is not None and li == self.n_scales - 1:
+                on_coarse()                     # tape position: everything recorded from here on is the coarse half of the neck
             for blk in layer:
                 x, g = self._res(x, blk, g, B)
             down.append((x, g))

@@ -22,7 +22,7 @@ class OptimWrapper:
         n = arena.n_train
         self.m = torch.zeros(n, dtype=torch.float32, device=arena.data.device)
         self.v = torch.zeros(n, dtype=torch.float32, device=arena.data.device)
-        self.partial = torch.empty(2048, dtype=torch.float64, device=arena.data.device)
+        self.partial = torch.empty(2048 * 64, dtype=torch.float64, device=arena.data.device)     # 2048 per reduced chunk
         self.norm = torch.zeros(1, dtype=torch.float32, device=arena.data.device)
 
     def _build_groups(self, arena):
@@ -69,15 +69,33 @@ class OptimWrapper:
             self.state_init(arena)
         s = torch.cuda.current_stream().cuda_stream
         reducer = getattr(arena, 'reducer', None)
-        if reducer is None or not reducer.finish():           # buckets launched during backward (parallel.py) ...
-            allreduce_mean_(arena.grad)                       # ... else one flat 346 MB all-reduce (RCCL over xGMI)
         n = arena.n_train
         self.step += 1
-        call('es_grad_norm', P(arena.grad), n, P(self.partial), P(self.norm), s)
+        gscale = 1.0
+        if reducer is not None and reducer.sumsq is None and arena.grad.is_cuda:
+            # clip norm under the bucket all-reduces: every reduced chunk's sum of squares is taken on the reducer's side
+            # stream right behind its collective (takes effect from the next step's launches on)
+            grad, partial = arena.grad, self.partial
+            reducer.sumsq = lambda a, b, slot: call('es_sumsq_partial', grad.data_ptr() + 4 * a, b - a,
+                                                    partial.data_ptr() + 8 * 2048 * slot, torch.cuda.current_stream().cuda_stream)
+            fresh = True
+        else:
+            fresh = False
+        chunks = reducer.finish() if reducer is not None else 0   # buckets launched during backward (parallel.py) ...
+        if chunks and not fresh and reducer.sumsq is not None and chunks <= 64:
+            import torch.distributed as dist
+            gscale = 1.0 / dist.get_world_size()              # the arena holds the SUM over ranks: mean folded into AdamW
+            call('es_norm_from_partials', P(self.partial), 2048 * chunks, gscale, P(self.norm), s)
+        else:
+            if chunks:
+                reducer.scale_()
+            else:
+                allreduce_mean_(arena.grad)                   # ... else one flat all-reduce (RCCL over xGMI)
+            call('es_grad_norm', P(arena.grad), n, P(self.partial), P(self.norm), s)
         if not self.paramwise:
             call('es_adamw_step', P(arena.data), P(arena.grad), P(self.m), P(self.v), n, float(self.lr),
                  float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step,
-                 float(self.max_norm if self.max_norm else 0.0), P(self.norm), s)
+                 float(self.max_norm if self.max_norm else 0.0), P(self.norm), gscale, s)
         else:
             if self.groups is None:
                 self._build_groups(arena)
@@ -85,7 +103,7 @@ class OptimWrapper:
                 call('es_adamw_step', arena.data.data_ptr() + 4 * a, arena.grad.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
                      self.v.data_ptr() + 4 * a, b - a, float(self.lr * lm), float(self.betas[0]), float(self.betas[1]),
                      float(self.eps), float(self.wd * dm), self.step, float(self.max_norm if self.max_norm else 0.0),
-                     P(self.norm), s)
+                     P(self.norm), gscale, s)
         self.last_norm = self.norm
         from . import engine
         engine.WEIGHT_VERSION[0] += 1          # bf16 weight copies are stale now

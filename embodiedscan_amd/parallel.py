@@ -1,8 +1,11 @@
 """Data-parallel exchange steps of the train step: scans are independent units, every rank
-processes its own scans end to end; the only collectives are ONE all-reduce of the flat gradient arena per step and
-ONE all-reduce of the per-sample positive counts (the reference issues `reduce_mean` once per sample inside a Python
-loop, embodiedscan/utils/dist_utils.py:4-10 called from dense_heads/fcaf3d_head.py:1183).
-Backend: "nccl" (== RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests."""
+processes its own scans end to end; the only collectives are the all-reduce of the flat gradient arena (in buckets, launched
+from markers on the backward tape so that they travel under the rest of the backward pass) and ONE all-reduce of the
+per-sample positive counts (the reference issues `reduce_mean` once per sample inside a Python loop,
+embodiedscan/utils/dist_utils.py:4-10 called from dense_heads/fcaf3d_head.py:1183).
+Backend: "nccl" (== RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests.  No RCCL run of this code exists yet (the
+driver's scaling bench is the first); it is covered by 2-rank gloo tests."""
+import torch
 import torch.distributed as dist
 
 
@@ -27,45 +30,106 @@ def reduce_mean(t):
     return t
 
 
+# upper bound of one all-reduce call: a 2.9 GB bucket (the occupancy neck) is issued as several calls so that the ring
+# pipeline of the first chunk starts while later chunks are still being queued and the exposed tail is one chunk, not 3 GB
+MAX_BUCKET_FLOATS = 64 << 20          # 256 MB
+
+
 class BucketedGradReducer:
     """Overlaps the gradient all-reduce with the backward pass.
 
-    The gradient arena is laid out [2-D backbone | 3-D backbone | everything else]; backward finishes those parts in the opposite
-    order, so each part is all-reduced asynchronously (torch.distributed `async_op=True`: RCCL runs it on its own
-    stream after an event on the compute stream) as soon as the tape has passed the marker behind it: the 86 MB head
-    bucket travels over xGMI under the 3-D backbone's backward, the 254 MB 3-D bucket under the 2-D backbone's.
-    The reference gets the same effect from DDP's bucketed reducer (mmengine MMDistributedDataParallel)."""
+    groups: ordered list of tuples of parameter-name prefixes.  Part k = the trainable tensors whose name starts with
+    one of groups[k]'s prefixes (first match wins); the LAST part = everything no group claims.  The arena packs
+    trainable tensors in spec order, so a part is a handful of contiguous ranges; the parts tile [0, n_train) exactly
+    (asserted).  `launch(k)` -- called from a marker on the backward tape when every gradient of part k is complete --
+    all-reduces the part's ranges asynchronously (torch.distributed `async_op=True`: RCCL runs on its own stream after
+    an event on the compute stream), in chunks of at most MAX_BUCKET_FLOATS.  mv-3ddet: the 86 MB head bucket travels
+    over xGMI under the 3-D backbone's backward, the 254 MB 3-D bucket under the 2-D backbone's.  The reference gets the
+    same effect from DDP's bucketed reducer (mmengine MMDistributedDataParallel).
 
-    def __init__(self, arena, prefixes=('backbone.', 'backbone_3d.')):
-        """parts 0..len(prefixes)-1 = the trainable tensors under each prefix; the LAST part = everything else (heads,
-        necks, decoders: whatever the detector defines after its backbones).  The arena packs trainable tensors in spec
-        order, so every part is one contiguous range and the parts tile [0, n_train)."""
+    The clip norm rides along: when `sumsq` is given (OptimWrapper on a GPU), the sum of squares of every reduced range is
+    taken on a side stream right behind its all-reduce, so the optimiser only combines a few partial scalars after the last
+    bucket instead of reading the whole arena again; the 1/world scaling is folded into the optimiser kernel."""
+
+    def __init__(self, arena, prefixes=('backbone.', 'backbone_3d.'), groups=None):
         self.arena = arena
+        groups = [tuple(g) if isinstance(g, (tuple, list)) else (g,) for g in (groups if groups is not None else prefixes)]
         names = arena.trainable_names()
-        spans = []
-        for pre in prefixes:
-            offs = [arena.offsets[n] for n in names if n.startswith(pre)]
-            spans.append((min(o for o, _ in offs), max(o + ((n + 3) // 4) * 4 for o, n in offs)) if offs else None)
-        rest = [arena.offsets[n] for n in names if not any(n.startswith(p) for p in prefixes)]
-        spans.append((min(o for o, _ in rest), max(o + ((n + 3) // 4) * 4 for o, n in rest)) if rest else None)
-        self.ranges = [sp if sp is not None else (0, 0) for sp in spans]
-        real = sorted(sp for sp in spans if sp is not None)
-        assert real and real[0][0] == 0 and real[-1][1] == arena.n_train and \
-            all(a[1] == b[0] for a, b in zip(real[:-1], real[1:])), f'gradient buckets do not tile the arena: {real}'
-        self.work = []
+        member = {}
+        for n in names:
+            member[n] = next((k for k, g in enumerate(groups) if any(n.startswith(p) for p in g)), len(groups))
+        self.parts = []                      # part -> [(a, b)] merged contiguous ranges, ascending
+        for k in range(len(groups) + 1):
+            spans = sorted((arena.offsets[n][0], arena.offsets[n][0] + (arena.offsets[n][1] + 3) // 4 * 4)
+                           for n in names if member[n] == k)
+            merged = []
+            for a, b in spans:
+                if merged and merged[-1][1] == a:
+                    merged[-1] = (merged[-1][0], b)
+                else:
+                    merged.append((a, b))
+            self.parts.append(merged)
+        # compatibility view (one span per part when the part is contiguous): used by tests and DESIGN
+        self.ranges = [(p[0][0], p[-1][1]) if len(p) == 1 else ((0, 0) if not p else (p[0][0], p[-1][1])) for p in self.parts]
+        allr = sorted(r for p in self.parts for r in p)
+        assert allr and allr[0][0] == 0 and allr[-1][1] == arena.n_train and \
+            all(a[1] == b[0] for a, b in zip(allr[:-1], allr[1:])), f'gradient buckets do not tile the arena: {allr}'
+        self.work = []                       # (work handle, a, b)
+        self.sumsq = None                    # callable(a, b, slot) queued behind a range's all-reduce (set by OptimWrapper)
+        self.n_chunks = 0
+        self.profile = None                  # bench.py: list that receives (part, floats, exposed_ms) per waited chunk
+        self._side = None
+
+    def chunks(self, part):
+        out = []
+        for a, b in self.parts[part]:
+            while b - a > MAX_BUCKET_FLOATS:
+                out.append((a, a + MAX_BUCKET_FLOATS))
+                a += MAX_BUCKET_FLOATS
+            if b > a:
+                out.append((a, b))
+        return out
 
     def launch(self, part):
         """all-reduce (sum) part `part` of the gradient arena without blocking the compute stream"""
-        a, b = self.ranges[part]
-        if is_dist() and b > a:
-            self.work.append(dist.all_reduce(self.arena.grad[a:b], async_op=True))
+        if not is_dist():
+            return
+        for a, b in self.chunks(part):
+            w = dist.all_reduce(self.arena.grad[a:b], async_op=True)
+            slot = self.n_chunks
+            self.n_chunks += 1
+            if self.sumsq is not None and self.arena.grad.is_cuda:
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                with torch.cuda.stream(self._side):
+                    w.wait()                         # orders the side stream behind the collective (no host block)
+                    self.sumsq(a, b, slot)
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                self.work.append((w, a, b, part, ev))
+            else:
+                self.work.append((w, a, b, part, None))
 
     def finish(self):
-        """wait for every launched bucket and turn the sums into means; returns True if anything was reduced"""
+        """wait for every launched chunk; returns the number of chunks reduced (0: nothing was launched).  The sums are
+        NOT scaled here: the caller folds 1/world into its next pass over the gradients (OptimWrapper) or calls scale_()."""
         if not self.work:
-            return False
-        for w in self.work:
-            w.wait()
+            return 0
+        n = len(self.work)
+        for w, a, b, part, ev in self.work:
+            if self.profile is not None and self.arena.grad.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                w.wait()
+                e1.record()
+                self.profile.append((part, b - a, e0, e1))
+            else:
+                w.wait()
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
         self.work = []
+        self.n_chunks = 0
+        return n
+
+    def scale_(self):
         self.arena.grad.mul_(1.0 / dist.get_world_size())
-        return True

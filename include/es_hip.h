@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ES_MAX_SEG 8 /* max samples per batch for segmented (per-sample) operators */
+#define ES_MAX_SEG 32 /* max samples per batch for segmented (per-sample) operators */
 
 /* ---- coordinate manager (replaces ME.SparseTensor / CoordinateManager) ------------------- */
 /* A4: keys[i] = pack(batch, trunc(p_i / voxel_size)).  sparse_featfusion_single_stage.py:109-116 */
@@ -233,9 +233,15 @@ int es_nms3d_multiclass(const float* boxes, const float* scores, int M, int C, f
 
 /* ---- optimiser.  configs/detection/mv-det3d_...py:219-223 ------------------------------------------ */
 int es_grad_norm(const float* grad, size_t n, double* partial /* 2048 */, float* norm_out, void* stream);
+/* grad_scale multiplies every gradient element after clipping (1 / world when grad still holds the SUM over the ranks:
+ * the data-parallel mean is folded into this pass; grad_norm_dev must then be the norm of the MEAN gradient) */
 int es_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float max_norm, const float* grad_norm_dev,
-                  void* stream);
+                  float grad_scale, void* stream);
+/* data parallel (parallel.py): sum of squares of one reduced gradient bucket -> 2048 doubles; the clip norm of the mean
+ * gradient from all buckets' partials (scale = 1 / world) */
+int es_sumsq_partial(const float* grad, size_t n, double* partial /* 2048 */, void* stream);
+int es_norm_from_partials(const double* partial, int n_partials, float scale, float* norm_out, void* stream);
 
 /* ---- A1-A3, A18 data side ---------------------------------------------------------------------------- */
 int es_depth_to_points(const float* depth, int H, int W, const int* sel_view, const int* sel_pix, int n,

@@ -83,7 +83,12 @@ def occ_multiscale_supervision(gt_occ, ratio, gt_shape, gt_occupancy_masks=None)
     gt = torch.zeros([gt_shape[0], gt_shape[2], gt_shape[3], gt_shape[4]], dtype=torch.long)
     for i in range(gt.shape[0]):
         coords = torch.div(gt_occ[i][:, :3].long(), ratio, rounding_mode='trunc')
-        gt[i, coords[:, 0], coords[:, 1], coords[:, 2]] = gt_occ[i][:, 3].long()       # last write wins (CPU index_put)
+        # duplicate voxels: LAST row wins (our stated convention).  torch's CPU index_put_ only behaves like
+        # that while it runs sequentially (small inputs: the golden vectors of the reference's own function); on thousands of
+        # rows it is parallelised and the winner is unspecified -- numpy's fancy assignment is sequential by definition
+        g = gt[i].numpy()
+        c = coords.numpy()
+        g[c[:, 0], c[:, 1], c[:, 2]] = gt_occ[i][:, 3].long().numpy()
         if gt_occupancy_masks is not None:
             gt[i][~gt_occupancy_masks[i]] = 255
     return gt

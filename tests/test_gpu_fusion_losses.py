@@ -142,3 +142,48 @@ def test_optimizer_step():
     err = float((pd.cpu() - pt.detach()).abs().max())
     print(f'AdamW 3 steps max abs err {err:.2e} (tol 1e-6)')
     assert err < 1e-6
+
+
+def test_point_sample_bwd_is_an_ordered_gather():
+    """es_point_sample_bwd (round 3: linked hit lists + one wave per feature-map pixel adding its hits in ascending voxel
+    order) against index_add_ in f64: pixels with > 64 and > 128 hits (the multi-round extraction), voxels WITHOUT a valid
+    view whose pix entries are >= 0 all the same (the forward samples unmasked, SURVEY Q3: they must not contribute),
+    empty pixels written as zeros, accumulate on / off; two runs bit-identical."""
+    from embodiedscan_amd.hip import P, call
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    B, V, Hf, Wf, C, n = 2, 3, 6, 5, 96, 4000
+    HW = Hf * Wf
+    coords = torch.zeros((n, 4), dtype=torch.int32)
+    coords[:, 0] = (torch.arange(n) >= n // 2).int()
+    pix = torch.randint(-1, HW, (n, V), generator=g, dtype=torch.int32)
+    pix[:600, 0] = 7                                         # 600 hits on one pixel of (sample 0, view 0)
+    pix[torch.rand(n, V, generator=g) < 0.3] = -1
+    cnt = (pix >= 0).sum(1).int()
+    dead = torch.rand(n, generator=g) < 0.1                  # sampled somewhere, but no VALID view
+    cnt[dead] = 0
+    dout = torch.randn(n, C + 8, generator=g)                # strided rows (columns 8.. are the image part)
+    want = torch.zeros(B * V * HW, C, dtype=torch.float64)
+    for v in range(V):
+        m = (pix[:, v] >= 0) & (cnt > 0)
+        rows = (coords[m, 0].long() * V + v) * HW + pix[m, v].long()
+        want.index_add_(0, rows, dout[m, 8:].double() / cnt[m, None].double())
+    d = dict(coords=coords.to(dev), pix=pix.to(dev), cnt=cnt.to(dev), dout=dout.to(dev))
+    head = torch.empty(B * V * HW, dtype=torch.int32, device=dev)
+    nxt = torch.empty(n * V, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for _ in range(2):
+        f = torch.full((B * V * HW, C), float('nan'), device=dev)        # accumulate = 0 must overwrite everything
+        call('es_point_sample_bwd', P(d['coords']), n, V, d['dout'].data_ptr() + 32, C + 8, P(d['pix']), P(d['cnt']), Hf, Wf, C,
+             P(f), B * V, P(head), P(nxt), 0, st)
+        outs.append(f.clone())
+    assert torch.equal(outs[0], outs[1])
+    e = float((outs[0].double().cpu() - want).norm() / want.norm())
+    print(f'point_sample_bwd vs f64 index_add: rel-L2 {e:.2e} (tol 1e-6); busiest pixel {int((pix[:, 0] == 7).sum())} hits')
+    assert e < 1e-6 and torch.isfinite(outs[0]).all()
+    base = torch.randn(B * V * HW, C, generator=g)
+    f = base.to(dev)
+    call('es_point_sample_bwd', P(d['coords']), n, V, d['dout'].data_ptr() + 32, C + 8, P(d['pix']), P(d['cnt']), Hf, Wf, C,
+         P(f), B * V, P(head), P(nxt), 1, st)
+    assert float((f.double().cpu() - (want + base.double())).norm() / want.norm()) < 1e-6

@@ -139,11 +139,43 @@ def _dp_worker():
     mine = big.grad.clone()
     for part in (2, 1, 0):
         red.launch(part)
-    assert red.finish()
+    assert red.finish() == 3
+    red.scale_()                                                 # (on a GPU the 1/world is folded into the AdamW pass)
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
     assert torch.allclose(big.grad, torch.stack(gathered).mean(0), atol=1e-7)
     assert not red.finish()                                      # nothing pending any more
+    # the grounder's four parts (backbones, MinkNeck, decoder + head + text map) and the occupancy detector's (image branch,
+    # MinkResNet, fine neck, coarse neck + head) with the 256 MB chunking forced down to 1 MB: every element is reduced
+    # exactly once whatever the launch order of the parts, and no single call carries more than the chunk bound
+    import embodiedscan_amd.parallel as PAR
+    from embodiedscan_amd.models.detectors.dense_fusion_occ import DenseFusionOccPredictor
+    from embodiedscan_amd.models.detectors.sparse_featfusion_grounder import SparseFeatureFusion3DGrounder
+    from embodiedscan_amd.params import grounder_specs, occ_detector_specs
+    PAR.MAX_BUCKET_FLOATS = 1 << 18
+    cases = (('grounder', grounder_specs(text_dim=32, E=64, num_layers=1, ffn=64), SparseFeatureFusion3DGrounder._bucket_groups, (3, 2, 1, 0)),
+             ('occupancy', occ_detector_specs(base_channels=8, fpn_out=16, neck_in=16 + 512, neck_out=16, n_blocks=[1, 1, 1], num_classes=5,
+                                              head_in=[16, 16, 16]), DenseFusionOccPredictor._bucket_groups, (3, 2, 1, 0)))
+    for name, specs, groups, order in cases:
+        ar = ParamArena(specs, seed=0)
+        red = BucketedGradReducer(ar, groups=groups)
+        assert len(red.parts) == len(groups) + 1 and all(red.parts), (name, [len(p) for p in red.parts])
+        sizes = [sum(b - a for a, b in red.chunks(k)) for k in range(len(red.parts))]
+        assert sum(sizes) == ar.n_train and max(b - a for k in range(len(red.parts)) for a, b in red.chunks(k)) <= PAR.MAX_BUCKET_FLOATS
+        gk = torch.Generator().manual_seed(31 + rank)
+        ar.grad.copy_(torch.randn(ar.n_train, generator=gk))
+        mine = ar.grad.clone()
+        n_calls = 0
+        for part in order:
+            n_calls += len(red.chunks(part))
+            red.launch(part)
+        assert red.finish() == n_calls
+        red.scale_()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        assert torch.allclose(ar.grad, torch.stack(gathered).mean(0), atol=1e-6), name
+        if rank == 0:
+            print(f'{name}: parts {[s * 4 // 2 ** 20 for s in sizes]} MiB in {n_calls} all-reduce calls')
     # N4 / 8e: every rank reads ITS shard of the scan list from files -- same number of batches on both ranks, the shards
     # are the two halves of one seeded permutation (no collective in the data path; this gather is the test's own)
     from embodiedscan_amd.datasets import EmbodiedScanDataset, ScanLoader
@@ -329,14 +361,24 @@ def test_gradient_buckets_tile_every_full_detector():
                 if s.trainable:
                     self.n_train = off
             self.total = off
-    for name, specs in (('mv-3ddet', detector_specs(284)), ('grounder', grounder_specs()), ('occupancy', occ_detector_specs())):
+    from embodiedscan_amd.models.detectors.dense_fusion_occ import DenseFusionOccPredictor
+    from embodiedscan_amd.models.detectors.sparse_featfusion_grounder import SparseFeatureFusion3DGrounder
+    from embodiedscan_amd.models.detectors.sparse_featfusion_single_stage import SparseFeatureFusionSingleStage3DDetector
+    from embodiedscan_amd.parallel import MAX_BUCKET_FLOATS
+    for name, specs, cls in (('mv-3ddet', detector_specs(284), SparseFeatureFusionSingleStage3DDetector),
+                             ('grounder', grounder_specs(), SparseFeatureFusion3DGrounder),
+                             ('occupancy', occ_detector_specs(), DenseFusionOccPredictor)):
         a = Lazy(specs)
-        red = BucketedGradReducer(a)
-        spans = sorted(r for r in red.ranges if r[1] > r[0])
+        red = BucketedGradReducer(a, groups=cls._bucket_groups)
+        assert len(red.parts) == len(cls._bucket_groups) + 1 and all(red.parts), name
+        spans = sorted(r for k in range(len(red.parts)) for r in red.chunks(k))
         assert spans[0][0] == 0 and spans[-1][1] == a.n_train and all(x[1] == y[0] for x, y in zip(spans[:-1], spans[1:])), name
         covered = sum(b - a_ for a_, b in spans)
-        assert covered == a.n_train, (name, covered, a.n_train)
-        print(f'{name}: {len(spans)} buckets {[(b - a_) * 4 // 2 ** 20 for a_, b in spans]} MiB tile [0, {a.n_train})')
+        assert covered == a.n_train and max(b - a_ for a_, b in spans) <= MAX_BUCKET_FLOATS, (name, covered, a.n_train)
+        part_mib = [sum(b - a_ for a_, b in red.chunks(k)) * 4 // 2 ** 20 for k in range(len(red.parts))]
+        print(f'{name}: parts {part_mib} MiB in {len(spans)} all-reduce calls of <= {MAX_BUCKET_FLOATS * 4 // 2 ** 20} MiB tile [0, {a.n_train})')
+        if name == 'occupancy':                 # the 2.9 GB of neck gradients are NOT one call at the end of backward
+            assert part_mib[-1] > 2000 and len(red.chunks(len(red.parts) - 1)) >= 8 and part_mib[0] < 200
 
 
 def test_reduce_mean_called_once_per_step(monkeypatch):
