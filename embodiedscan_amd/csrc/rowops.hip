@@ -9,8 +9,13 @@
 #include "common.h"
 #include "../../include/es_hip.h"
 
-#define NCH 128  // rows per statistics chunk
-#define FST 16   // chunk stripes per channel in the finalize kernels (block = 64 channels x FST)
+// Rows per statistics chunk: 128 for small levels (enough chunks to fill the chip), up to 512 for the 1e5..1e6-row levels so
+// that the finalize kernels do not walk thousands of partials (round 2: 2969 partials per channel on the finest level,
+// finalize kernels at 15-18 us for a few-hundred-float reduction).
+static int norm_chunk_rows(int max_rows) { return max_rows <= (1 << 17) ? 128 : (max_rows <= (1 << 18) ? 256 : 512); }
+// finalize kernels: a block owns FCH channels x FST chunk stripes (round 2: 64 x 16 -> ONE block for a 64-channel level)
+#define FCH 16
+#define FST 64
 
 struct Segs { int n; int off[ES_MAX_SEG + 1]; };
 __device__ inline int seg_of(const Segs& s, int row) {
@@ -35,7 +40,7 @@ static int max_seg_rows(const Segs& s) {
 // first row (a shift that is itself a sample), M2 = q - s^2/n.  256 threads = (C/4 column lanes) x (row lanes), float4
 // loads, LDS reduction over the row lanes.
 __global__ __launch_bounds__(256) void k_norm_stats(const float* __restrict__ x, int ldx, int C, Segs segs, int nchunk,
-                                                    float* __restrict__ partial) {
+                                                    int NCH, float* __restrict__ partial) {
   __shared__ float4 red[2][256];
   int seg = blockIdx.y, chunk = blockIdx.x;
   int r0 = segs.off[seg] + chunk * NCH, r1 = min(segs.off[seg + 1], r0 + NCH);
@@ -88,13 +93,13 @@ __global__ __launch_bounds__(256) void k_norm_stats(const float* __restrict__ x,
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(64 * FST) void k_norm_finalize(const float* __restrict__ partial, int C, Segs segs,
-                                                            int nchunk, float eps, float* __restrict__ mean,
+__global__ __launch_bounds__(FCH * FST) void k_norm_finalize(const float* __restrict__ partial, int C, Segs segs,
+                                                            int nchunk, int NCH, float eps, float* __restrict__ mean,
                                                             float* __restrict__ invstd, float* running_mean,
                                                             float* running_var, float momentum) {
-  __shared__ double red[FST][64];
-  int seg = blockIdx.y, cl = threadIdx.x & 63, st = threadIdx.x >> 6;
-  int c = blockIdx.x * 64 + cl;
+  __shared__ double red[FST][FCH];
+  int seg = blockIdx.y, cl = threadIdx.x % FCH, st = threadIdx.x / FCH;
+  int c = blockIdx.x * FCH + cl;
   int r0 = segs.off[seg], n = segs.off[seg + 1] - r0;
   int used = (n + NCH - 1) / NCH;
   // pass 1: total sum -> mean
@@ -190,11 +195,12 @@ extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0 || nseg > ES_MAX_SEG) return nseg > ES_MAX_SEG ? -3 : 0;
   Segs s = make_segs(seg_off, nseg);
+  const int NCH = norm_chunk_rows(max_seg_rows(s));
   int nchunk = es_cdiv(max_seg_rows(s), NCH);
   if (nchunk < 1) nchunk = 1;
-  hipLaunchKernelGGL(k_norm_stats, dim3(nchunk, nseg), dim3(256), 0, st, x, ldx, C, s, nchunk,
+  hipLaunchKernelGGL(k_norm_stats, dim3(nchunk, nseg), dim3(256), 0, st, x, ldx, C, s, nchunk, NCH,
                      workspace);
-  hipLaunchKernelGGL(k_norm_finalize, dim3(es_cdiv(C, 64), nseg), dim3(64 * FST), 0, st, workspace, C, s, nchunk, eps,
+  hipLaunchKernelGGL(k_norm_finalize, dim3(es_cdiv(C, FCH), nseg), dim3(FCH * FST), 0, st, workspace, C, s, nchunk, NCH, eps,
                      mean, invstd, running_mean, running_var, momentum);
   const bool vec = ((C & 3) == 0) && ((ldx & 3) == 0) && ((ldy & 3) == 0) && (!res || (ldr & 3) == 0) &&
                    (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)weight) | ((uintptr_t)bias) |
@@ -216,7 +222,7 @@ extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg
 extern "C" size_t es_norm_workspace_floats(int n, int C, const int* seg_off, int nseg) {
   int m = 0;
   for (int i = 0; i < nseg; ++i) m = max(m, seg_off[i + 1] - seg_off[i]);
-  int nchunk = es_cdiv(m, NCH);
+  int nchunk = es_cdiv(m, norm_chunk_rows(m));
   if (nchunk < 1) nchunk = 1;
   return (size_t)nseg * nchunk * 2 * C;
 }
@@ -225,7 +231,7 @@ extern "C" size_t es_norm_workspace_floats(int n, int C, const int* seg_off, int
 // (same 2-D thread layout / float4 accesses as k_norm_stats)
 __global__ __launch_bounds__(256) void k_norm_bwd_stats(float* __restrict__ dy, int ldd, const float* __restrict__ y,
                                                         int ldy, const float* __restrict__ x, int ldx, int C, Segs segs,
-                                                        int nchunk, const float* __restrict__ mean,
+                                                        int nchunk, int NCH, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, int act,
                                                         float* __restrict__ partial) {
   __shared__ float4 red[2][256];
@@ -312,13 +318,13 @@ __global__ __launch_bounds__(256) void k_norm_bwd_stats(float* __restrict__ dy, 
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(64 * FST) void k_norm_bwd_finalize(const float* __restrict__ partial, int C, Segs segs,
-                                                                int nchunk, float* __restrict__ sum_dz,
+__global__ __launch_bounds__(FCH * FST) void k_norm_bwd_finalize(const float* __restrict__ partial, int C, Segs segs,
+                                                                int nchunk, int NCH, float* __restrict__ sum_dz,
                                                                 float* __restrict__ sum_dzx, float* dweight,
                                                                 float* dbias) {
-  __shared__ double red[2][FST][64];
-  int cl = threadIdx.x & 63, st = threadIdx.x >> 6;
-  int c = blockIdx.x * 64 + cl;
+  __shared__ double red[2][FST][FCH];
+  int cl = threadIdx.x % FCH, st = threadIdx.x / FCH;
+  int c = blockIdx.x * FCH + cl;
   double tw = 0, tb = 0;
   for (int seg = 0; seg < segs.n; ++seg) {
     int n = segs.off[seg + 1] - segs.off[seg];
@@ -410,12 +416,13 @@ extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const fl
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0 || nseg > ES_MAX_SEG) return nseg > ES_MAX_SEG ? -3 : 0;
   Segs s = make_segs(seg_off, nseg);
+  const int NCH = norm_chunk_rows(max_seg_rows(s));
   int nchunk = es_cdiv(max_seg_rows(s), NCH);
   if (nchunk < 1) nchunk = 1;
   float* sums = workspace + (size_t)nseg * nchunk * 2 * C;
   hipLaunchKernelGGL(k_norm_bwd_stats, dim3(nchunk, nseg), dim3(256), 0, st, dy, ldd, y, ldy, x,
-                     ldx, C, s, nchunk, mean, invstd, act, workspace);
-  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(es_cdiv(C, 64)), dim3(64 * FST), 0, st, workspace, C, s, nchunk, sums,
+                     ldx, C, s, nchunk, NCH, mean, invstd, act, workspace);
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(es_cdiv(C, FCH)), dim3(FCH * FST), 0, st, workspace, C, s, nchunk, NCH, sums,
                      sums + (size_t)nseg * C, dweight, dbias);
   const bool vec = ((C & 3) == 0) && ((ldx & 3) == 0) && ((ldd & 3) == 0) && ((ldo & 3) == 0) &&
                    (((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)weight) | ((uintptr_t)mean) |

@@ -206,9 +206,10 @@ extern "C" int es_spconv_fwd(const float* X, int ldx, const float* W, const int*
 // where a weight-gradient workgroup puts one element of its partial tile: slice `bz` of the workspace (plain store), or --
 // without a workspace the launch has ONE row slice -- straight into dW (this workgroup is the element's only writer)
 __device__ __forceinline__ void wgrad_emit(float* __restrict__ dW, float* __restrict__ ws, int bz, size_t dw_floats,
-                                           size_t off, float v) {
+                                           size_t off, float v, int accumulate) {
   if (ws) ws[(size_t)bz * dw_floats + off] = v;
-  else dW[off] += v;
+  else if (accumulate) dW[off] += v;
+  else dW[off] = v;                     // first gradient of the step for this weight: a plain store (no read, no wait)
 }
 // dW[k][c][n] += sum_{j in row slice} X[nbr[j,k]][c] * dY[j][n]
 #define WM 64
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
                                                       const float* __restrict__ dY, int ldy,
                                                       const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                       int Cin, int Cout, int rows_per_split,
-                                                      float* __restrict__ dW, float* __restrict__ ws) {
+                                                      float* __restrict__ dW, float* __restrict__ ws, int accumulate) {
   __shared__ float As[WR * LDW];
   __shared__ float Bs[WR * LDW];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int c = c0 + wv * 16 + kq * 4 + r;
-      if (c < Cin) wgrad_emit(dW, ws, blockIdx.z, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[nf][r]);
+      if (c < Cin) wgrad_emit(dW, ws, blockIdx.z, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[nf][r], accumulate);
     }
   }
 }
@@ -322,22 +323,25 @@ static WgradPlan wgrad_plan_f32(int n_out, int K, int Cin, int Cout, bool have_w
   splits = es_cdiv(n_out, rows_per_split);
   return WgradPlan{0, splits, rows_per_split};
 }
-__global__ void k_wgrad_reduce(const float* __restrict__ ws, int splits, size_t n, float* __restrict__ dW) {
+__global__ void k_wgrad_reduce(const float* __restrict__ ws, int splits, size_t n, float* __restrict__ dW, int accumulate) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
     float s = ws[e];
     for (int z = 1; z < splits; ++z) s += ws[(size_t)z * n + e];
-    dW[e] += s;
+    dW[e] = accumulate ? dW[e] + s : s;
   }
 }
-__global__ void k_wgrad_reduce4(const float4* __restrict__ ws, int splits, size_t n4, float4* __restrict__ dW) {
+__global__ void k_wgrad_reduce4(const float4* __restrict__ ws, int splits, size_t n4, float4* __restrict__ dW, int accumulate) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
     float4 s = ws[e];
     for (int z = 1; z < splits; ++z) {
       float4 v = ws[(size_t)z * n4 + e];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    float4 d = dW[e];
-    dW[e] = make_float4(d.x + s.x, d.y + s.y, d.z + s.z, d.w + s.w);
+    if (accumulate) {
+      float4 d = dW[e];
+      s = make_float4(d.x + s.x, d.y + s.y, d.z + s.z, d.w + s.w);
+    }
+    dW[e] = s;
   }
 }
 // Many slices of a SMALL weight (the 1x1 convolutions of the image backbone: a few thousand weights, > 1e6 rows -> thousands of
@@ -346,7 +350,7 @@ __global__ void k_wgrad_reduce4(const float4* __restrict__ ws, int splits, size_
 // order, the R range sums are then added in range order through LDS -- a fixed tree, so still bit-reproducible.
 template <int R>
 __global__ __launch_bounds__(256) void k_wgrad_reduce_ranges(const float* __restrict__ ws, int splits, size_t n,
-                                                             float* __restrict__ dW) {
+                                                             float* __restrict__ dW, int accumulate) {
   constexpr int EB = 256 / R;
   __shared__ float part[R][EB];
   const int el = threadIdx.x % EB, rr = threadIdx.x / EB;
@@ -362,36 +366,37 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_ranges(const float* __rest
     float t = part[0][el];
 #pragma unroll
     for (int r = 1; r < R; ++r) t += part[r][el];
-    dW[e] += t;
+    dW[e] = accumulate ? dW[e] + t : t;
   }
 }
-static int wgrad_reduce(const float* ws, int splits, size_t n, float* dW, hipStream_t st) {
+static int wgrad_reduce(const float* ws, int splits, size_t n, float* dW, int accumulate, hipStream_t st) {
   if (splits <= 1 || n == 0) return 0;
   if (splits >= 64) {                      // (the choice depends on the slice count only: same launch -> same summation tree)
-    if (splits >= 512) hipLaunchKernelGGL(k_wgrad_reduce_ranges<64>, dim3(es_cdiv((long long)n, 4)), dim3(256), 0, st, ws, splits, n, dW);
-    else hipLaunchKernelGGL(k_wgrad_reduce_ranges<16>, dim3(es_cdiv((long long)n, 16)), dim3(256), 0, st, ws, splits, n, dW);
+    if (splits >= 512) hipLaunchKernelGGL(k_wgrad_reduce_ranges<64>, dim3(es_cdiv((long long)n, 4)), dim3(256), 0, st, ws, splits, n, dW, accumulate);
+    else hipLaunchKernelGGL(k_wgrad_reduce_ranges<16>, dim3(es_cdiv((long long)n, 16)), dim3(256), 0, st, ws, splits, n, dW, accumulate);
   } else if ((n % 4 == 0) && (((((uintptr_t)ws) | ((uintptr_t)dW)) & 15) == 0)) {
     int g = es_cdiv((long long)(n / 4), 256);
-    hipLaunchKernelGGL(k_wgrad_reduce4, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, (const float4*)ws, splits, n / 4, (float4*)dW);
+    hipLaunchKernelGGL(k_wgrad_reduce4, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, (const float4*)ws, splits, n / 4, (float4*)dW, accumulate);
   } else {
     int g = es_cdiv((long long)n, 256);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, ws, splits, n, dW);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, ws, splits, n, dW, accumulate);
   }
   ES_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out,
-                               int n_in, int K, int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream) {
+                               int n_in, int K, int Cin, int Cout, float* dW, int accumulate, float* ws, size_t ws_floats,
+                               void* stream) {
   if (n_out <= 0 || Cin <= 0 || Cout <= 0) return 0;
   WgradPlan p = wgrad_plan_f32(n_out, K, Cin, Cout, ws != nullptr);
   const size_t nw = (size_t)K * Cin * Cout;
   if (p.splits > 1 && ws_floats < (size_t)p.splits * nw) return -5;
   dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), p.splits);
   hipLaunchKernelGGL(k_spconv_wgrad, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out, n_in, K,
-                     Cin, Cout, p.rows_per_split, dW, p.splits > 1 ? ws : nullptr);
+                     Cin, Cout, p.rows_per_split, dW, p.splits > 1 ? ws : nullptr, accumulate);
   ES_CHECK_LAUNCH();
-  return wgrad_reduce(ws, p.splits, nw, dW, (hipStream_t)stream);
+  return wgrad_reduce(ws, p.splits, nw, dW, accumulate, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ bf16 MFMA path
@@ -1238,7 +1243,8 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const void* __restric
                                                            const void* __restrict__ dY, int ldy,
                                                            const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                            int Cin, int Cout, int rows_per_split,
-                                                           int n_slices, float* __restrict__ dW, float* __restrict__ ws) {
+                                                           int n_slices, float* __restrict__ dW, float* __restrict__ ws,
+                                                           int accumulate) {
   __shared__ __attribute__((aligned(16))) unsigned short As[WM * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[WN * GLD];
   __shared__ int s_qj[QCAP], s_qi[QCAP], s_wc[4];
@@ -1301,7 +1307,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const void* __restric
     }
     __syncthreads();
   }
-  if (q.tail == 0 && !ws) return;                         // tap absent from the (only) slice: nothing to add
+  if (q.tail == 0 && !ws && accumulate) return;           // tap absent from the (only) slice: nothing to add
 #pragma unroll
   for (int nf = 0; nf < 4; ++nf) {
     int col = n0 + nf * 16 + li;
@@ -1309,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16(const void* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int c = c0 + wv * 16 + kq * 4 + r;
-      if (c < Cin) wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[nf][r]);
+      if (c < Cin) wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[nf][r], accumulate);
     }
   }
 }
@@ -1323,7 +1329,8 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
                                                                const void* __restrict__ dYv, int ldy,
                                                                const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                                int Cin, int Cout, int rows_per_split,
-                                                               int n_slices, float* __restrict__ dW, float* __restrict__ ws) {
+                                                               int n_slices, float* __restrict__ dW, float* __restrict__ ws,
+                                                               int accumulate) {
   __shared__ __attribute__((aligned(16))) unsigned short As[128 * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[128 * GLD];
   __shared__ int s_qj[QCAP], s_qi[QCAP], s_wc[4];
@@ -1430,7 +1437,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
         acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
     __syncthreads();
   }
-  if (q.tail == 0 && !ws) return;
+  if (q.tail == 0 && !ws && accumulate) return;
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
@@ -1439,7 +1446,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int c = c0 + wv * 32 + mf * 16 + kq * 4 + r;
-        wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r]);
+        wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r], accumulate);
       }
     }
 }
@@ -1477,7 +1484,7 @@ __global__ __launch_bounds__(512) void k_spconv_wgrad_bf16_huge(const unsigned s
                                                                 const unsigned short* __restrict__ dY, int ldy,
                                                                 const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                                 int Cin, int Cout, int rows_per_split, int n_slices,
-                                                                float* __restrict__ dW, float* __restrict__ ws) {
+                                                                float* __restrict__ dW, float* __restrict__ ws, int accumulate) {
   __shared__ __attribute__((aligned(16))) unsigned short As[256 * GLD];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[256 * GLD];
   __shared__ int s_qj[QCAP2], s_qi[QCAP2], s_wc[8];
@@ -1549,7 +1556,7 @@ __global__ __launch_bounds__(512) void k_spconv_wgrad_bf16_huge(const unsigned s
         acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
     __syncthreads();
   }
-  if (q.tail == 0 && !ws) return;
+  if (q.tail == 0 && !ws && accumulate) return;
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
@@ -1558,7 +1565,7 @@ __global__ __launch_bounds__(512) void k_spconv_wgrad_bf16_huge(const unsigned s
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int c = c0 + wm * 64 + mf * 16 + kq * 4 + r;
-        wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r]);
+        wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r], accumulate);
       }
     }
 }
@@ -1607,7 +1614,7 @@ static WgradPlan wgrad_plan_bf16(int XH, int YH, const void* X, int ldx, const v
 
 template <int XH, int YH>
 static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
-                             int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream) {
+                             int Cin, int Cout, float* dW, int accumulate, float* ws, size_t ws_floats, void* stream) {
   if (n_out <= 0 || Cin <= 0 || Cout <= 0) return 0;
   const WgradPlan p = wgrad_plan_bf16(XH, YH, X, ldx, dY, ldy, n_out, n_in, K, Cin, Cout, ws != nullptr);
   const size_t nw = (size_t)K * Cin * Cout;
@@ -1618,32 +1625,33 @@ static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, co
   if (p.kind == 3) {
     dim3 grid(K * (Cin / 256), Cout / 256, gz);
     hipLaunchKernelGGL(k_spconv_wgrad_bf16_huge, grid, dim3(512), 0, st, (const unsigned short*)X, ldx,
-                       (const unsigned short*)dY, ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk);
+                       (const unsigned short*)dY, ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);
   } else if (p.kind == 2) {
     dim3 grid(K * (Cin / 128), Cout / 128, gz);
     hipLaunchKernelGGL((k_spconv_wgrad_bf16_big<XH, YH>), grid, dim3(256), 0, st, X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin,
-                       Cout, p.rows_per_split, p.splits, dW, wsk);
+                       Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);
   } else {
     dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), gz);
     hipLaunchKernelGGL((k_spconv_wgrad_bf16<XH, YH>), grid, dim3(256), 0, st, X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin,
-                       Cout, p.rows_per_split, p.splits, dW, wsk);
+                       Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);
   }
   ES_CHECK_LAUNCH();
-  return wgrad_reduce(ws, p.splits, nw, dW, st);
+  return wgrad_reduce(ws, p.splits, nw, dW, accumulate, st);
 }
 
 extern "C" int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out,
-                                    int n_in, int K, int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream) {
-  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
+                                    int n_in, int K, int Cin, int Cout, float* dW, int accumulate, float* ws, size_t ws_floats,
+                                    void* stream) {
+  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, accumulate, ws, ws_floats, stream);
 }
 
 extern "C" int es_spconv_wgrad_bf16_src(const void* X, int x_half, int ldx, const void* dY, int dy_half, int ldy,
                                         const int* nbr, int n_out, int n_in, int K, int Cin, int Cout, float* dW,
-                                        float* ws, size_t ws_floats, void* stream) {
-  if (x_half && dy_half) return wgrad_bf16_launch<1, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
-  if (x_half) return wgrad_bf16_launch<1, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
-  if (dy_half) return wgrad_bf16_launch<0, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
-  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, ws, ws_floats, stream);
+                                        int accumulate, float* ws, size_t ws_floats, void* stream) {
+  if (x_half && dy_half) return wgrad_bf16_launch<1, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, accumulate, ws, ws_floats, stream);
+  if (x_half) return wgrad_bf16_launch<1, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, accumulate, ws, ws_floats, stream);
+  if (dy_half) return wgrad_bf16_launch<0, 1>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, accumulate, ws, ws_floats, stream);
+  return wgrad_bf16_launch<0, 0>(X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, accumulate, ws, ws_floats, stream);
 }
 
 // floats of workspace the weight-gradient launch of this shape wants for its row split (0: a single slice, none needed).

@@ -219,6 +219,28 @@ def _wgrad_stream(*keep):
 
 
 _WGRAD_WS = {}          # stream handle -> persistent workspace of the deterministic weight-gradient row split
+# The first weight-gradient launch a weight receives in a step OVERWRITES its slot of the gradient arena (a plain store: the
+# read-modify-write of a 1 GB gradient made the wide occupancy layers wait on 128 dependent loads per thread); later launches of
+# the same step (shared modules, the 8 taps of a transposed convolution have their own slots) accumulate.  Keyed by the slot's
+# device pointer, so aliases of one tensor share the stamp.  new_grad_epoch() is called where the arena is zeroed.
+GRAD_EPOCH = [1]
+_GRAD_STAMP = {}
+WGRAD_OVERWRITE = [os.environ.get('ES_WGRAD_OVERWRITE', '1') != '0']
+
+
+def new_grad_epoch():
+    GRAD_EPOCH[0] += 1
+    if len(_GRAD_STAMP) > 1 << 16:
+        _GRAD_STAMP.clear()
+
+
+def _first_write(ptr):
+    """0 (overwrite) for the first gradient written to `ptr` in this epoch, 1 (accumulate) afterwards"""
+    if not WGRAD_OVERWRITE[0]:
+        return 1
+    acc = 1 if _GRAD_STAMP.get(ptr) == GRAD_EPOCH[0] else 0
+    _GRAD_STAMP[ptr] = GRAD_EPOCH[0]
+    return acc
 
 
 def _wgrad(name, sw, dW, *args):
@@ -239,7 +261,7 @@ def _wgrad(name, sw, dW, *args):
             if ws is not None:
                 _KEEP.append(ws)                 # launches already queued on `sw` may still use the old buffer
             ws = _WGRAD_WS[sw] = torch.empty(max(int(need), 1 << 22), dtype=torch.float32, device=torch.device('cuda', torch.cuda.current_device()))
-    call(name, *args, dW, P(ws), ws.numel() if ws is not None else 0, sw)
+    call(name, *args, dW, _first_write(dW), P(ws), ws.numel() if ws is not None else 0, sw)
 
 
 def join_wgrad_streams(final=True):

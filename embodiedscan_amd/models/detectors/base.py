@@ -132,6 +132,7 @@ class DetectorBase:
             data = self.data_preprocessor(data, True)
         self._bind()
         self.arena.grad.zero_()
+        E.new_grad_epoch()                       # first weight-gradient launch per weight overwrites, later ones add
         self._tape_parts = []
         losses = self.forward(data['inputs'], data['data_samples'], mode='loss')
         E.mark('forward + losses')

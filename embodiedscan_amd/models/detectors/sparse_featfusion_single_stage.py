@@ -208,6 +208,7 @@ class SparseFeatureFusionSingleStage3DDetector:
             data = self.data_preprocessor(data, True)
         self._bind()
         self.arena.grad.zero_()
+        E.new_grad_epoch()                       # first weight-gradient launch per weight overwrites, later ones add
         losses = self.forward(data['inputs'], data['data_samples'], mode='loss')
         E.mark('A10-A16 head fwd + targets + losses')
         if is_dist():

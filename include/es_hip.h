@@ -105,21 +105,22 @@ int es_cast_weights_table(const void* table_dev, int n_entries, int total_tiles,
  * workgroup owns its partial tile; with one slice the tile is added straight into dW, with several the partial tiles go to
  * the caller's workspace `ws` ([slice][K][Cin][Cout], es_spconv_wgrad_workspace_floats) and are added to dW in slice order
  * by a second launch.  No float atomics: bit-identical gradients run to run.  ws NULL: ONE slice (correct, under-filled).
+ * accumulate 0: dW is OVERWRITTEN (the first gradient a weight receives in a step: no read of dW), 1: added to.
  * Replaces the backward of MinkowskiConvolution / nn.Conv2d / nn.Linear (mink_resnet.py:58-62, fcaf3d_head.py:907-984). */
 int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
-                    int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream);
+                    int Cin, int Cout, float* dW, int accumulate, float* ws, size_t ws_floats, void* stream);
 /* bf16-MFMA variant of es_spconv_wgrad (operands rounded to bf16 while staged, f32 accumulate into dW, which the caller
  * zeroes once per step).  Each (tap, row slice) workgroup compacts the valid (row, neighbour) pairs of its slice before
  * the GEMM, so absent neighbours cost one map read.  Same deterministic slice scheme as es_spconv_wgrad. */
 int es_spconv_wgrad_bf16(const float* X, int ldx, const float* dY, int ldy, const int* nbr, int n_out, int n_in, int K,
-                         int Cin, int Cout, float* dW, float* ws, size_t ws_floats, void* stream);
+                         int Cin, int Cout, float* dW, int accumulate, float* ws, size_t ws_floats, void* stream);
 /* Same operator with either operand taken from a bf16 copy ("shadow", es_cast_rows_bf16) of the row matrix: x_half /
  * dy_half non-zero -> X / dY point at (n, ld) bf16 rows (ld in elements).  Results are bit-identical to
  * es_spconv_wgrad_bf16 on the f32 originals when both launches use the same tile and slices (the f32 path rounds to the
  * same bf16 values while staging); the gathered bytes halve. */
 int es_spconv_wgrad_bf16_src(const void* X, int x_half, int ldx, const void* dY, int dy_half, int ldy, const int* nbr,
-                             int n_out, int n_in, int K, int Cin, int Cout, float* dW, float* ws, size_t ws_floats,
-                             void* stream);
+                             int n_out, int n_in, int K, int Cin, int Cout, float* dW, int accumulate, float* ws,
+                             size_t ws_floats, void* stream);
 /* floats of workspace the weight-gradient launch of this shape asks for (0: one slice).  bf16 = 0: es_spconv_wgrad;
  * 1: es_spconv_wgrad_bf16[_src] with these operand kinds, strides and pointers (their alignment selects the tile). */
 size_t es_spconv_wgrad_workspace_floats(int bf16, const void* X, int x_half, int ldx, const void* dY, int dy_half, int ldy,

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from . import coords as C
 from . import geometry as G
 from . import model as M
+from . import rounding as R
 from . import sparse as S
 
 EPS32 = float(torch.finfo(torch.float32).eps)
@@ -221,7 +222,7 @@ def mink_neck(xs, sd, batch_size, prefix='neck_3d.', voxel_size=0.01, thr=1000, 
             x = S.union_add(xs[i], x)
             x = S.prune(x, M.prune_mask(x, score, thr))
         out = _block(x, sd, f'{prefix}out_block_{i}', training)
-        cls = out.feats.detach() @ sd[prefix + 'conv_cls.kernel'] + sd[prefix + 'conv_cls.bias']
+        cls = R.op(lambda a, b: a @ b, out.feats.detach(), sd[prefix + 'conv_cls.kernel'], out.feats.shape[1]) + sd[prefix + 'conv_cls.bias']
         score = out.new(cls.max(dim=1, keepdim=True).values)
         rows = [torch.from_numpy(out.batch_rows(b)) for b in range(batch_size)]
         feats.append([out.feats[r] for r in rows])
@@ -232,14 +233,19 @@ def mink_neck(xs, sd, batch_size, prefix='neck_3d.', voxel_size=0.01, thr=1000, 
 
 
 # ----------------------------------------------------------------------------- decoder
+def _conv1d(x, w, b):
+    """1x1 Conv1d (a Linear layer over positions) through the operand-rounding switch"""
+    return R.op(lambda a, c: F.conv1d(a, c), x, w, w.shape[1], w.shape[0]) + b[None, :, None]
+
+
 def posembed(xyz, sd, p, training=True):
     """PositionEmbeddingLearned: (B, N, c) -> (B, N, E); BatchNorm1d over all B*N positions"""
     q = p + '.position_embedding_head'
     x = xyz.transpose(1, 2).contiguous()
-    x = F.conv1d(x, sd[q + '.0.weight'], sd[q + '.0.bias'])
+    x = _conv1d(x, sd[q + '.0.weight'], sd[q + '.0.bias'])
     x = F.relu(F.batch_norm(x, sd[q + '.1.running_mean'], sd[q + '.1.running_var'], sd[q + '.1.weight'], sd[q + '.1.bias'],
                             training, 0.1, 1e-5))
-    x = F.conv1d(x, sd[q + '.3.weight'], sd[q + '.3.bias'])
+    x = _conv1d(x, sd[q + '.3.weight'], sd[q + '.3.bias'])
     return x.transpose(1, 2).contiguous()
 
 

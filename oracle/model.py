@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 from . import coords as C
+from . import rounding as R
 from . import sparse as S
 from . import geometry as G
 
@@ -58,6 +59,11 @@ def _bn2d_eval(x, sd, p):
                         False, 0.0, 1e-5)
 
 
+def _conv2d(x, w, stride=1, padding=0):
+    """bias-free conv2d through the oracle's operand-rounding switch (oracle/rounding.py)"""
+    return R.op(lambda a, b: F.conv2d(a, b, None, stride, padding), x, w, w.shape[1], w.shape[0])
+
+
 def resnet50_w16(x, sd, prefix='backbone.'):
     """mmdet.ResNet depth=50 base_channels=16, norm_eval, out_indices (0,1,2,3)."""
     x = F.conv2d(x, sd[prefix + 'conv1.weight'], None, 2, 3)
@@ -69,11 +75,11 @@ def resnet50_w16(x, sd, prefix='backbone.'):
             p = f'{prefix}layer{li + 1}.{bi}.'
             stride = 2 if (bi == 0 and li > 0) else 1
             idt = x
-            o = F.relu(_bn2d_eval(F.conv2d(x, sd[p + 'conv1.weight']), sd, p + 'bn1'))
-            o = F.relu(_bn2d_eval(F.conv2d(o, sd[p + 'conv2.weight'], None, stride, 1), sd, p + 'bn2'))
-            o = _bn2d_eval(F.conv2d(o, sd[p + 'conv3.weight']), sd, p + 'bn3')
+            o = F.relu(_bn2d_eval(_conv2d(x, sd[p + 'conv1.weight']), sd, p + 'bn1'))
+            o = F.relu(_bn2d_eval(_conv2d(o, sd[p + 'conv2.weight'], stride, 1), sd, p + 'bn2'))
+            o = _bn2d_eval(_conv2d(o, sd[p + 'conv3.weight']), sd, p + 'bn3')
             if bi == 0:
-                idt = _bn2d_eval(F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride), sd, p + 'downsample.1')
+                idt = _bn2d_eval(_conv2d(x, sd[p + 'downsample.0.weight'], stride), sd, p + 'downsample.1')
             x = F.relu(o + idt)
         outs.append(x)
     return outs
@@ -255,9 +261,10 @@ def head_forward(xs, sd, prefix='bbox_head.', voxel_size=0.01, thr=100000, train
             x = S.union_add(xs[i], x)
             x = S.prune(x, prune_mask(x, score, thr))
         out = _block(x, sd, f'{prefix}out_block_{i}', training)
-        center = out.feats @ sd[prefix + 'conv_center.kernel']
-        cls = out.feats @ sd[prefix + 'conv_cls.kernel'] + sd[prefix + 'conv_cls.bias']
-        reg = out.feats @ sd[prefix + 'conv_reg.kernel']
+        mm = lambda w: R.op(lambda a, b: a @ b, out.feats, w, out.feats.shape[1], 16)    # one padded 320-column GEMM on the device
+        center = mm(sd[prefix + 'conv_center.kernel'])
+        cls = mm(sd[prefix + 'conv_cls.kernel']) + sd[prefix + 'conv_cls.bias']
+        reg = mm(sd[prefix + 'conv_reg.kernel'])
         dist = torch.exp(reg[:, :6] * sd[f'{prefix}scales.{i}.scale']).clamp(min=1e-3)
         bbox = torch.cat((dist, reg[:, 6:]), 1)
         if trace is not None:

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from . import coords as C
 from . import model as M
+from . import rounding as R
 from . import sparse as S
 
 
@@ -35,26 +36,30 @@ def prior_points(n_voxels, anchor_range):
 
 # ----------------------------------------------------------------------------- 2-D neck
 def fpn(feats, sd, prefix='neck.'):
-    lats = [F.conv2d(f, sd[f'{prefix}lateral_convs.{i}.conv.weight'], sd[f'{prefix}lateral_convs.{i}.conv.bias'])
+    lats = [M._conv2d(f, sd[f'{prefix}lateral_convs.{i}.conv.weight']) + sd[f'{prefix}lateral_convs.{i}.conv.bias'][None, :, None, None]
             for i, f in enumerate(feats)]
     for i in range(len(lats) - 1, 0, -1):
         lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode='nearest')
-    return [F.conv2d(l, sd[f'{prefix}fpn_convs.{i}.conv.weight'], sd[f'{prefix}fpn_convs.{i}.conv.bias'], padding=1)
+    return [M._conv2d(l, sd[f'{prefix}fpn_convs.{i}.conv.weight'], 1, 1) + sd[f'{prefix}fpn_convs.{i}.conv.bias'][None, :, None, None]
             for i, l in enumerate(lats)]
 
 
 # ----------------------------------------------------------------------------- dense 3-D neck
+def _conv3d(x, w, stride=1, padding=0):
+    return R.op(lambda a, b: F.conv3d(a, b, None, stride, padding), x, w, w.shape[1], w.shape[0])
+
+
 def _bn3(x, sd, p, training=True):
     return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'], sd[p + '.bias'], training,
                         0.1, 1e-5)
 
 
 def _res_module(x, sd, p, stride, training):
-    out = F.relu(_bn3(F.conv3d(x, sd[p + '.conv1.weight'], None, stride, 1), sd, p + '.norm1', training))
-    out = _bn3(F.conv3d(out, sd[p + '.conv2.weight'], None, 1, 1), sd, p + '.norm2', training)
+    out = F.relu(_bn3(_conv3d(x, sd[p + '.conv1.weight'], stride, 1), sd, p + '.norm1', training))
+    out = _bn3(_conv3d(out, sd[p + '.conv2.weight'], 1, 1), sd, p + '.norm2', training)
     idt = x
     if stride != 1:
-        idt = _bn3(F.conv3d(x, sd[p + '.downsample.0.weight'], None, stride), sd, p + '.downsample.1', training)
+        idt = _bn3(_conv3d(x, sd[p + '.downsample.0.weight'], stride, 0), sd, p + '.downsample.1', training)
     return F.relu(out + idt)
 
 
@@ -70,11 +75,11 @@ def imvoxel_neck(x, sd, prefix='neck_3d.', n_blocks=(1, 1, 1), training=True):
     for i in range(n_scales - 1, -1, -1):
         if i < n_scales - 1:
             p = f'{prefix}up_block_{i + 1}'
-            x = F.relu(_bn3(F.conv_transpose3d(x, sd[p + '.0.weight'], None, 2), sd, p + '.1', training))
-            x = F.relu(_bn3(F.conv3d(x, sd[p + '.3.weight'], None, 1, 1), sd, p + '.4', training))
+            x = F.relu(_bn3(R.op(lambda a, b: F.conv_transpose3d(a, b, None, 2), x, sd[p + '.0.weight'], sd[p + '.0.weight'].shape[0], sd[p + '.0.weight'].shape[1]), sd, p + '.1', training))
+            x = F.relu(_bn3(_conv3d(x, sd[p + '.3.weight'], 1, 1), sd, p + '.4', training))
             x = down[i] + x
         p = f'{prefix}out_block_{i}'
-        outs.append(F.relu(_bn3(F.conv3d(x, sd[p + '.0.weight'], None, 1, 1), sd, p + '.1', training)))
+        outs.append(F.relu(_bn3(_conv3d(x, sd[p + '.0.weight'], 1, 1), sd, p + '.1', training)))
     return outs[::-1]
 
 
@@ -199,7 +204,7 @@ def detector_forward(sd, points, imgs, metas, n_voxels, point_cloud_range, prior
     dense = dense.index_copy(0, (c[:, 0] * Y + c[:, 1]) * Z + c[:, 2], last.feats)
     point_volume = dense.reshape(X, Y, Z, -1).permute(3, 0, 1, 2)[None]
     x3 = imvoxel_neck(torch.cat([img_volume, point_volume], 1), sd, n_blocks=n_blocks, training=training)
-    return [F.conv3d(l, sd[f'bbox_head.occ.{i}.weight']) for i, l in enumerate(x3)]
+    return [_conv3d(l, sd[f'bbox_head.occ.{i}.weight'], 1, 0) for i, l in enumerate(x3)]
 
 
 def detector_loss(sd, points, imgs, metas, gt_occupancy, gt_masks, n_voxels, point_cloud_range, prior_range,

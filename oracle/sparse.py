@@ -39,7 +39,12 @@ def _cached(x, key, fn):
 
 
 def gather_conv(feats, nbr, weight):
-    """out[j] = sum_k feats[nbr[j,k]] @ weight[k]  (nbr == -1 contributes 0)."""
+    """out[j] = sum_k feats[nbr[j,k]] @ weight[k]  (nbr == -1 contributes 0); operands rounded in oracle.rounding's bf16 mode"""
+    from . import rounding as R
+    return R.op(lambda f, w: _gather_conv(f, nbr, w), feats, weight, feats.shape[1], weight.shape[-1])
+
+
+def _gather_conv(feats, nbr, weight):
     n_out, K = nbr.shape
     out = feats.new_zeros((n_out, weight.shape[-1]))
     nbr_t = torch.from_numpy(nbr.astype(np.int64))
@@ -61,7 +66,8 @@ def conv(x, weight, ksize, stride=1, bias=None):
         out_ts = x.ts * stride
         out_coords = _cached(x, ('stride', out_ts), lambda: C.stride_coords(x.coords, out_ts))
     if ksize == 1 and stride == 1:
-        out = x.feats @ w[0]
+        from . import rounding as R
+        out = R.op(lambda f, ww: f @ ww, x.feats, w[0], x.feats.shape[1], w.shape[-1])
     else:
         nbr = _cached(x, ('kmap', ksize, stride), lambda: C.kernel_map(x.coords, out_coords, ksize, x.ts))
         out = gather_conv(x.feats, nbr, w)
@@ -74,7 +80,9 @@ def gen_conv_transpose(x, weight):
     """MinkowskiGenerativeConvolutionTranspose(k=2, s=2); weight (8, Cin, Cout);
     child row 8*i+k = x[i] @ weight[k]."""
     out_coords = _cached(x, ('gen',), lambda: C.gen_transpose_coords(x.coords, x.ts))
-    out = torch.einsum('nc,kcd->nkd', x.feats, weight).reshape(-1, weight.shape[-1])
+    from . import rounding as R
+    out = R.op(lambda f, w: torch.einsum('nc,kcd->nkd', f, w).reshape(-1, w.shape[-1]), x.feats, weight, x.feats.shape[1],
+               weight.shape[-1])
     return x.new(out, out_coords, x.ts // 2)
 
 

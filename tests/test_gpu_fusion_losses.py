@@ -137,7 +137,7 @@ def test_optimizer_step():
         torch.nn.utils.clip_grad_norm_([pt], 10.0)
         opt.step()
         call('es_grad_norm', P(gd), n, P(partial), P(norm), s)
-        call('es_adamw_step', P(pd), P(gd), P(m), P(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step, 10.0, P(norm), s)
+        call('es_adamw_step', P(pd), P(gd), P(m), P(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step, 10.0, P(norm), 1.0, s)
     assert abs(float(norm.cpu()) - float(gr.norm())) / float(gr.norm()) < 1e-6
     err = float((pd.cpu() - pt.detach()).abs().max())
     print(f'AdamW 3 steps max abs err {err:.2e} (tol 1e-6)')

@@ -266,8 +266,9 @@ def _grounding_batch(dev, n=2):
 def test_grounder_train_step_vs_oracle(dev, mode):
     """SparseFeatureFusion3DGrounder forward + backward (2 scans x 3 views, MinkNeck pruning live at 300 voxels, 32
     queries, 2 decoder layers) against the oracle: query selection and Hungarian assignments identical; f32: losses 1e-3,
-    hidden states 1e-3, parameter gradients median 2e-3; bf16: losses 5e-2 (assignment-sensitive terms compared only
-    when the assignments agree)."""
+    hidden states 1e-3, parameter gradients median 2e-3; bf16: against the oracle's bf16-operand specification -- losses and
+    logits 2e-2, parameter gradients median 2e-2; an assignment that differs is reported with its cost margin (near tie
+    required), never skipped."""
     from embodiedscan_amd import engine as E, pipeline
     from oracle import grounding as OG, model as OM
     cfg, det, sd = _small_grounder(dev)
@@ -298,14 +299,34 @@ def test_grounder_train_step_vs_oracle(dev, mode):
     imgs = torch.stack([OM.preprocess_img(torch.from_numpy(s['img']), MEAN, STD) for s in scans])
     gtb = [torch.from_numpy(a['gt_boxes']) for a in anns]
     pms = [ds.gt_instances_3d.positive_maps.cpu() for ds in data['data_samples']]
-    ol, aux = OG.grounder_loss(osd, points_host, imgs, [s['meta'] for s in scans], th, tmask, gtb, pms, num_queries=32, num_layers=2,
-                               thr=300, return_aux=True)
+    # bf16 mode is compared with the oracle's bf16-OPERAND specification (oracle/rounding.py: every conv / Linear product
+    # on rounded operands, f32 accumulation; the attention core and the contrastive logits stay f32 there, bf16 MFMA here)
+    from contextlib import nullcontext
+    from oracle import rounding as R
+    with (R.bf16_operands() if mode == 'bf16' else nullcontext()):
+        ol, aux = OG.grounder_loss(osd, points_host, imgs, [s['meta'] for s in scans], th, tmask, gtb, pms, num_queries=32,
+                                   num_layers=2, thr=300, return_aux=True)
+        if mode == 'bf16':
+            sum(ol.values()).backward()
     same_q = torch.equal(idx.long(), aux['idx'])
     same_a = all(torch.equal((q2g[l][b] + 1).long(), aux['head'][l]['assign'][b]) for l in range(2) for b in range(2))
     print(f'{mode}: selected queries identical: {same_q}; Hungarian assignments identical: {same_a}')
     if mode == 'f32':
         assert same_q and same_a
-    tol = 1e-3 if mode == 'f32' else 5e-2
+    tol = 1e-3 if mode == 'f32' else 2e-2
+    if mode == 'bf16' and same_q and not same_a:
+        # not skipped: WHICH margin flipped -- cost of our assignment minus the optimal one on the oracle's own cost matrix
+        for l in range(2):
+            for b in range(2):
+                if torch.equal((q2g[l][b] + 1).long(), aux['head'][l]['assign'][b]):
+                    continue
+                G = gtb[b].shape[0]
+                gi, cost = OG.hungarian_assign(aux['head'][l]['cls'][b].detach(), aux['boxes'][l][b].detach(), gtb[b], pms[b],
+                                               tmask[b][None].repeat(max(G, 1), 1), return_cost=True)
+                mine = sum(float(cost[q, int(q2g[l][b][q])]) for q in torch.nonzero(q2g[l][b] >= 0).reshape(-1))
+                opt = sum(float(cost[q, int(gi[q]) - 1]) for q in torch.nonzero(gi > 0).reshape(-1))
+                print(f'bf16 layer {l} scan {b}: assignment differs, cost margin {mine - opt:.3e} on an optimal cost of {opt:.3e} (tol 2 %)')
+                assert mine - opt <= 2e-2 * max(abs(opt), 1.0)
     if same_q and same_a:
         T = tmask.shape[1]
         for l in range(2):
@@ -319,6 +340,14 @@ def test_grounder_train_step_vs_oracle(dev, mode):
             print(f'{mode} {k}: hip {float(losses[k]):.6f} oracle {float(ol[k]):.6f} rel err {e:.2e} (tol {tol:.0e})')
             assert e < tol
     assert all(np.isfinite(float(v)) for v in losses.values()) and torch.isfinite(det.arena.grad).all()
+    if mode == 'bf16' and same_q and same_a:
+        rel = {k: _rel(v, osd[k].grad) for k, v in grads.items() if osd[k].grad is not None and float(osd[k].grad.norm()) > 1e-6}
+        v = np.sort(np.array(list(rel.values())))
+        worst = max(rel, key=rel.get)
+        print(f'bf16 gradients vs the bf16-operand oracle: {len(v)} tensors, median rel-L2 {float(np.median(v)):.2e} (tol 2e-2), 90th '
+              f'percentile {float(v[int(0.9 * (len(v) - 1))]):.2e} (tol 1e-1), worst {rel[worst]:.2e} at {worst} (tol 5e-1); the attention '
+              f'core (bf16 P and V on the matrix cores here, f32 in the oracle) sets the floor')
+        assert float(np.median(v)) < 2e-2 and float(v[int(0.9 * (len(v) - 1))]) < 1e-1 and rel[worst] < 5e-1
     if mode == 'f32':
         sum(ol.values()).backward()
         # tensors whose true gradient is zero are skipped (norm < 1e-6): the last bias of cross_posembed shifts every key of a

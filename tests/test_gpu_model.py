@@ -141,56 +141,37 @@ def test_train_step_parity(setup):
 
 def test_train_step_bf16_mode(setup):
     """BASELINE config dtype: bf16 matrix cores (f32 accumulate, f32 master weights).  Integer outputs (targets) stay
-    bit exact; stated tolerance on the three losses: 2e-2 relative to the f32 oracle."""
+    bit exact; losses within 2e-2 of the f32 oracle.  GRADIENTS (the old gate compared bf16 with f32,
+    median 0.25 / worst 0.6, loose enough for a wrong dgrad on a small tensor to pass): the free-running bf16 backward is
+    compared with the oracle run under its bf16-OPERAND specification (oracle/rounding.py: y = r(x) r(w), dx = r(dy) r(w)^T,
+    dw = r(x)^T r(dy), f32 accumulation, layers with < 16 input channels exact) -- the same arithmetic up to summation
+    order, so losses agree to 1e-4 and per-tensor gradients to: median <= 2e-3, 90 % of the tensors <= 2e-2, worst <= 2e-1
+    relative L2 (the tail: ReLU gates / nearest-corner choices of the Chamfer loss that sit within f32 rounding of a
+    decision boundary flip between two summation orders)."""
     from embodiedscan_amd import engine as E, pipeline
-    from oracle import model as OM
+    from oracle import model as OM, rounding as R
     det, scans, dscans, sd = setup
     batch = pipeline.make_batch(dscans)
     points_host = [p.cpu() for p in batch['inputs']['points']]
-    grads, seeds = {}, None
     try:
-        for mode in ('f32', 'bf16'):
-            E.PRECISION[0] = mode
-            E.TAPE.clear()
-            E.WEIGHT_VERSION[0] += 1
-            data = det.data_preprocessor(batch, True)
-            det._bind()
-            det.arena.grad.zero_()
-            losses = det.forward(data['inputs'], data['data_samples'], mode='loss')
-            # The box-loss gradient is ill-conditioned at random init (normalising near-zero 6-D rotation vectors,
-            # nearest-corner assignment of the Chamfer loss): bf16-sized changes of the head outputs change it by ~70 %.
-            # To check the bf16 BACKWARD kernels, both passes therefore start from the same head-output gradient.
-            if mode == 'f32':
-                seeds = [lv['ho'].g.clone() for lv in det.bbox_head.last_levels]
-            else:
-                for lv, seed in zip(det.bbox_head.last_levels, seeds):
-                    assert lv['ho'].g.shape == seed.shape
-                    lv['ho'].g.copy_(seed)
-            E.TAPE.backward()
-            torch.cuda.synchronize()
-            grads[mode] = {k: v.clone() for k, v in det.arena.grad_dict().items()}
+        E.PRECISION[0] = 'bf16'
+        E.TAPE.clear()
+        E.WEIGHT_VERSION[0] += 1
+        data = det.data_preprocessor(batch, True)
+        det._bind()
+        det.arena.grad.zero_()
+        losses = det.forward(data['inputs'], data['data_samples'], mode='loss')
+        E.TAPE.backward()
+        torch.cuda.synchronize()
+        grads = {k: v.clone().cpu() for k, v in det.arena.grad_dict().items()}
     finally:
         E.PRECISION[0] = 'f32'
-    # gradients of the bf16 path (fused epilogues, gated dgrad, bf16 wgrad) against the f32 HIP path: relative L2 per
-    # parameter tensor.  Through ~100 layers of batch-normalised random-init network the bf16 rounding of activations
-    # (2^-9) plus flipped ReLU gates grows to ~10 % at the far end (measured: median 0.10-0.14, max 0.28-0.41;
-    # a wrong kernel gives ~1).  Stated tolerance: median 0.25, worst 0.6.
-    rel = {}
-    for k, g32 in grads['f32'].items():
-        n = float(g32.norm())
-        if n > 1e-6:
-            rel[k] = float((grads['bf16'][k] - g32).norm()) / n
-    worst = max(rel, key=rel.get)
-    med = float(np.median(list(rel.values())))
-    print(f'bf16 vs f32 gradients (same head-output gradient): {len(rel)} tensors, median rel-L2 {med:.2e} (tol 2.5e-1), '
-          f'worst {rel[worst]:.2e} at {worst} (tol 6e-1)')
-    assert med < 0.25 and rel[worst] < 0.6
     imgs = torch.stack([OM.preprocess_img(torch.from_numpy(s['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])
                         for s in scans])
+    args = (points_host, imgs, [s['meta'] for s in scans], [torch.from_numpy(s['gt_boxes']) for s in scans],
+            [torch.from_numpy(s['gt_labels']) for s in scans])
     with torch.no_grad():
-        olosses, aux = OM.detector_loss(sd, points_host, imgs, [s['meta'] for s in scans],
-                                        [torch.from_numpy(s['gt_boxes']) for s in scans],
-                                        [torch.from_numpy(s['gt_labels']) for s in scans], return_aux=True, training=True)
+        olosses, aux = OM.detector_loss(sd, *args, return_aux=True, training=True)
     tg = det.bbox_head.last_targets
     for b in range(len(scans)):
         np.testing.assert_array_equal(tg[b][2].cpu().numpy(), aux['targets'][b][2].numpy())
@@ -198,6 +179,24 @@ def test_train_step_bf16_mode(setup):
         e = abs(float(losses[k]) - float(olosses[k])) / abs(float(olosses[k]))
         print(f'bf16 mode {k}: hip {float(losses[k]):.6f} oracle(f32) {float(olosses[k]):.6f} rel err {e:.2e} (tol 2e-2)')
         assert e < 2e-2
+    # the bf16-operand specification, with autograd
+    osd = {k: v.clone().requires_grad_(k in grads) for k, v in sd.items()}
+    with R.bf16_operands():
+        rl = OM.detector_loss(osd, *args, training=True)
+        sum(rl.values()).backward()
+    for k in rl:
+        e = abs(float(losses[k]) - float(rl[k])) / abs(float(rl[k]))
+        print(f'bf16 mode {k}: hip {float(losses[k]):.6f} oracle(bf16 operands) {float(rl[k]):.6f} rel err {e:.2e} (tol 1e-4)')
+        assert e < 1e-4
+    rel = {k: _relerr(g, osd[k].grad) for k, g in grads.items() if osd[k].grad is not None and float(osd[k].grad.norm()) > 1e-9}
+    v = np.sort(np.array(list(rel.values())))
+    worst = max(rel, key=rel.get)
+    med, p90 = float(np.median(v)), float(v[int(0.9 * (len(v) - 1))])
+    print(f'bf16 gradients vs the bf16-operand oracle: {len(v)} tensors, median rel-L2 {med:.2e} (tol 2e-3), 90th percentile '
+          f'{p90:.2e} (tol 2e-2), worst {rel[worst]:.2e} at {worst} (tol 2e-1)')
+    for k in sorted(rel, key=rel.get, reverse=True)[:6]:
+        print(f'   {rel[k]:.3e} {k}')
+    assert med < 2e-3 and p90 < 2e-2 and rel[worst] < 2e-1
     assert torch.isfinite(det.arena.grad).all()
 
 

@@ -187,9 +187,13 @@ def _wgrad_case(dev, g, n, cin, cout, K):
         WG(name, st, P(again), *args)
         assert torch.equal(again, t), f'{name}: run-to-run difference {float((again - t).abs().max()):.3e}'
     # without a workspace the launch keeps ONE row slice: same value up to the f32 summation order
-    one = torch.zeros_like(ref)
-    call('es_spconv_wgrad_bf16_src', P(xh), 1, cin, P(dyh), 1, cout, P(nd), n, n, K, cin, cout, P(one), 0, 0, st)
+    # (accumulate = 0: the launch OVERWRITES dW -- every element, also for taps without a pair -- so garbage in, gradient out)
+    one = torch.full_like(ref, float('nan'))
+    call('es_spconv_wgrad_bf16_src', P(xh), 1, cin, P(dyh), 1, cout, P(nd), n, n, K, cin, cout, P(one), 0, 0, 0, st)
     assert float((one - b).norm() / b.norm()) < 1e-5
+    two = one.clone()
+    call('es_spconv_wgrad_bf16_src', P(xh), 1, cin, P(dyh), 1, cout, P(nd), n, n, K, cin, cout, P(two), 1, 0, 0, st)
+    assert float((two - 2 * one).norm() / b.norm()) < 1e-5
     torch.cuda.synchronize()
     # exact reference on the host for one tap
     k = 5
@@ -454,3 +458,16 @@ def test_bf16_kernels_on_large_maps_vs_oracle(dev):
                     wgrad_k1=rel(e16[0], x.t() @ dy))
         print(f'n={n} {cin}->{cout} vs CPU oracle: ' + '  '.join(f'{k} {v:.2e}' for k, v in errs.items()) + '  (tol 5e-3)')
         assert max(errs.values()) < 5e-3, errs
+        # the same launches against their ARITHMETIC SPECIFICATION: products of bf16-rounded operands, f32 accumulation
+        # (oracle/rounding.py) -- only the summation order is left, so the tolerance drops from 5e-3 to 2e-5 and a wrong
+        # tap / row / channel anywhere in a 1e5-row launch shows
+        from oracle import rounding as R
+        xr_, wr_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        with R.bf16_operands():
+            yr_ = S.gather_conv(xr_, nbr_h, wr_)
+            (yr_ * dy).sum().backward()
+        rb = lambda t: t.bfloat16().float()
+        errs = dict(fwd=rel(y16, yr_.detach()), dgrad=rel(dx16, xr_.grad), wgrad_k27=rel(d16, wr_.grad),
+                    wgrad_k1=rel(e16[0], rb(x).double().t() @ rb(dy).double()))
+        print(f'n={n} {cin}->{cout} vs bf16-operand specification: ' + '  '.join(f'{k} {v:.2e}' for k, v in errs.items()) + '  (tol 2e-5)')
+        assert max(errs.values()) < 2e-5, errs
