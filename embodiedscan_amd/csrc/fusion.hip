@@ -58,7 +58,7 @@ __device__ inline int project_view(const float* m, const float* P, float x, floa
 
 // one wave per point; lanes stride over channels.  PTS: the location comes from a float (n,3) array (the prior points of
 // the occupancy detector, dense_fusion_occ.py:156-202) instead of integer voxel coordinates * voxel_size.
-template <bool PTS>
+template <bool PTS, bool FH = false>
 __global__ __launch_bounds__(256) void k_point_sample_fwd(const int* __restrict__ coords, const float* __restrict__ pts,
                                                           int n, float voxel_size,
                                                           const float* __restrict__ meta, int meta_stride, int V,
@@ -87,11 +87,11 @@ __global__ __launch_bounds__(256) void k_point_sample_fwd(const int* __restrict_
     nvalid += valid ? 1 : 0;
     if (lane == 0) pix[(size_t)i * V + v] = p;
     if (p >= 0) {
-      const float* f = feats + (((size_t)c.x * V + v) * Hf * Wf + p) * C;
+      const size_t off = (((size_t)c.x * V + v) * Hf * Wf + p) * C;
 #pragma unroll
       for (int q = 0; q < MAXC; ++q) {
-        int ch = lane + q * 64;
-        if (ch < C) acc[q] += f[ch];                    // sum over ALL views, not masked
+        int ch = lane + q * 64;                          // sum over ALL views, not masked
+        if (ch < C) acc[q] += FH ? __uint_as_float((uint32_t)((const unsigned short*)feats)[off + ch] << 16) : feats[off + ch];
       }
     }
   }
@@ -110,6 +110,18 @@ extern "C" int es_point_sample_fwd(const int* coords, int n, float voxel_size, c
   if (C > 512) return -4;
   hipLaunchKernelGGL(k_point_sample_fwd<false>, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords,
                      (const float*)nullptr, n, voxel_size, meta, meta_stride, V, feats, Hf, Wf, C, out, ldo, pix, cnt);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+// the same with the feature maps stored in bf16 (activation storage of the image backbone, round 3)
+extern "C" int es_point_sample_fwd_h(const int* coords, int n, float voxel_size, const float* meta, int meta_stride,
+                                     int V, const void* feats_bf16, int Hf, int Wf, int C, float* out, int ldo, int* pix,
+                                     int* cnt, void* stream) {
+  if (n <= 0) return 0;
+  if (C > 512) return -4;
+  hipLaunchKernelGGL((k_point_sample_fwd<false, true>), dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords,
+                     (const float*)nullptr, n, voxel_size, meta, meta_stride, V, (const float*)feats_bf16, Hf, Wf, C, out, ldo,
+                     pix, cnt);
   ES_CHECK_LAUNCH();
   return 0;
 }

@@ -469,6 +469,35 @@ extern "C" int es_maxpool_fwd(const float* x, int ldx, const int* nbr, int n_out
   ES_CHECK_LAUNCH();
   return 0;
 }
+// forward-only max pooling of f32 rows into bf16 rows (the frozen stem of the image backbone: no argmax is kept)
+__global__ void k_maxpool_fwd_h(const float* __restrict__ x, int ldx, const int* __restrict__ nbr, int n_out, int K, int C,
+                                unsigned short* __restrict__ y) {
+  size_t tot = (size_t)n_out * C;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    int j = (int)(e / C), c = (int)(e - (size_t)j * C);
+    float best = -INFINITY;
+    bool any = false;
+    for (int k = 0; k < K; ++k) {
+      int i = nbr[(size_t)j * K + k];
+      if (i < 0) continue;
+      float v = x[(size_t)i * ldx + c];
+      if (!any || v > best) { best = v; any = true; }
+    }
+    float o = any ? best : 0.f;
+    // RNE to bf16 (the values are finite)
+    uint32_t u = __float_as_uint(o);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    y[e] = (unsigned short)(u >> 16);
+  }
+}
+extern "C" int es_maxpool_fwd_h(const float* x, int ldx, const int* nbr, int n_out, int K, int C, void* y_bf16, void* stream) {
+  if (n_out <= 0) return 0;
+  int g = es_cdiv((long long)n_out * C, 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_maxpool_fwd_h, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, nbr, n_out, K, C, (unsigned short*)y_bf16);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
 __global__ void k_maxpool_bwd(const float* __restrict__ dy, const int* __restrict__ arg, int n_out, int C,
                               float* __restrict__ dx, int ldo) {
   size_t tot = (size_t)n_out * C;
@@ -730,6 +759,44 @@ __global__ void k_affine_act_bwd4(const float4* __restrict__ dy, const float4* _
       dres[e] = o;
     }
   }
+}
+// the same with the activation y stored in bf16 (image backbone, round 3): only its sign is read
+__global__ void k_affine_act_bwd4_yh(const float4* __restrict__ dy, const uint2* __restrict__ y,
+                                     const float4* __restrict__ scale, size_t n4, int C4, int act,
+                                     float4* __restrict__ dx, int acc_x, float4* __restrict__ dres, int acc_r) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+    float4 g = dy[e];
+    if (act) {
+      uint2 v = y[e];                                    // 4 bf16: positive <=> sign bit clear and magnitude non-zero
+      if (!(__uint_as_float(v.x << 16) > 0.f)) g.x = 0.f;
+      if (!(__uint_as_float(v.x & 0xffff0000u) > 0.f)) g.y = 0.f;
+      if (!(__uint_as_float(v.y << 16) > 0.f)) g.z = 0.f;
+      if (!(__uint_as_float(v.y & 0xffff0000u) > 0.f)) g.w = 0.f;
+    }
+    if (dx) {
+      float4 s = scale[e % C4];
+      float4 o = {g.x * s.x, g.y * s.y, g.z * s.z, g.w * s.w};
+      if (acc_x) { float4 p = dx[e]; o.x = p.x + o.x; o.y = p.y + o.y; o.z = p.z + o.z; o.w = p.w + o.w; }
+      dx[e] = o;
+    }
+    if (dres) {
+      float4 o = g;
+      if (acc_r) { float4 p = dres[e]; o.x = p.x + g.x; o.y = p.y + g.y; o.z = p.z + g.z; o.w = p.w + g.w; }
+      dres[e] = o;
+    }
+  }
+}
+extern "C" int es_affine_act_bwd_yh(const float* dy, const void* y_bf16, const float* scale, size_t n, int C, int act,
+                                    float* dx, int acc_x, float* dres, int acc_r, void* stream) {
+  if (n == 0) return 0;
+  if ((C % 4) || ((((uintptr_t)dy) | ((uintptr_t)scale) | ((uintptr_t)dx) | ((uintptr_t)dres)) & 15) || (((uintptr_t)y_bf16) & 7))
+    return -7;
+  size_t n4 = n * (size_t)(C / 4);
+  int g = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_affine_act_bwd4_yh, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float4*)dy, (const uint2*)y_bf16,
+                     (const float4*)scale, n4, C / 4, act, (float4*)dx, acc_x, (float4*)dres, acc_r);
+  ES_CHECK_LAUNCH();
+  return 0;
 }
 extern "C" int es_affine_act_bwd(const float* dy, const float* y, const float* scale, size_t n, int C, int act,
                                  float* dx, int acc_x, float* dres, int acc_r, void* stream) {

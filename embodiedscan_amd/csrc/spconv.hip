@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
 // splits == 1: the tile is added straight into dW (sole owner, plain read-modify-write); splits > 1: the partial tiles go to
 // a caller-provided workspace laid out [slice][K][Cin][Cout] and k_wgrad_reduce adds them to dW in slice order.  No float
 // atomics anywhere: two runs give bit-identical weight gradients (rounds 1-2 used f32 atomics, 1e-6 run-to-run).
-#define WGRAD_WS_CAP_FLOATS (64ll << 20)     // 256 MB of partial tiles per launch at most (write + read back ~ 65 us)
+#define WGRAD_WS_CAP_FLOATS (16ll << 20)     // 64 MB of partial tiles per launch at most: the slices are written and read back
+                                            // once (session C: 151 slices of the 128 x 128 x 27 head kernels = 267 MB per launch, ~100 us of ~175)
 struct WgradPlan { int kind, splits, rows_per_split; };   // kind: 0 exact-f32 64x64, 1 bf16 64x64, 2 bf16 128x128, 3 bf16 256x256
 static int cap_splits(int splits, long long dw_floats, bool have_ws) {
   if (!have_ws) return 1;
@@ -410,6 +411,13 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define HBK 32
 #define HLD (HBK + 8)      // bf16 elements per LDS row (80 B: keeps 16-B alignment, spreads banks)
 
+// activation-storage flags of the image backbone (round 3): bit 0: the Y rows are bf16, bit 1: the ep_res rows are bf16
+#define ES_IO_Y16 1
+#define ES_IO_R16 2
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 v) {
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
 __device__ inline uint32_t pack_bf16(float a, float b) {
   f32x2_t x = {a, b};
   bf16x2_t y = __builtin_convertvector(x, bf16x2_t);
@@ -428,7 +436,8 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
                                                      int ldy, int accumulate,
                                                      const float* __restrict__ ep_scale,
                                                      const float* __restrict__ ep_shift,
-                                                     const float* __restrict__ ep_res, int ep_ldr, int ep_act) {
+                                                     const float* __restrict__ ep_res, int ep_ldr, int ep_act, int x_half,
+                                                     int io) {
   constexpr int NF = BNT / 16;      // 16-wide output fragments per wave
   constexpr int NB = BNT / 64;      // 16-byte weight pieces per thread and chunk
   __shared__ __attribute__((aligned(16))) unsigned short As[BM * HLD];
@@ -467,7 +476,14 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
     int c0 = it.ci * HBK;
     int idx = nbrS[a_r * K + it.k];
     int c = c0 + a_kk;
-    if (idx >= 0 && c < Cin) {
+    if (idx >= 0 && c < Cin && x_half) {                  // bf16 input rows (image backbone): widened exactly, re-rounded as is
+      const unsigned short* ph = (const unsigned short*)X + (size_t)idx * ldx + c;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = (c + q < Cin) ? __uint_as_float((uint32_t)ph[q] << 16) : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) R.a[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else if (idx >= 0 && c < Cin) {
       const float* p = X + (size_t)idx * ldx + c;
       if (vecA && c + 15 < Cin) {
 #pragma unroll
@@ -573,13 +589,19 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
           float* p = Y + (size_t)row * ldy + col;
           float v = acc[mf][nf][r] + bv;
           if (ep_scale) v = v * sc + sh;                  // same fused frozen-BN epilogue as the fast kernels
+          float rv = 0.f;
+          if (ep_res) {
+            if (io & ES_IO_R16) rv = __uint_as_float((uint32_t)((const unsigned short*)ep_res)[(size_t)row * ep_ldr + col] << 16);
+            else rv = ep_res[(size_t)row * ep_ldr + col];
+          }
           if (ep_act == 3) {                              // gate: pass v only where ep_res > 0 (fused ReLU backward)
-            if (!(ep_res[(size_t)row * ep_ldr + col] > 0.f)) v = 0.f;
+            if (!(rv > 0.f)) v = 0.f;
           } else {
-            if (ep_res) v += ep_res[(size_t)row * ep_ldr + col];
+            if (ep_res) v += rv;
             if (ep_act) v = fmaxf(v, 0.f);
           }
-          *p = accumulate ? (*p + v) : v;
+          if (io & ES_IO_Y16) ((unsigned short*)Y)[(size_t)row * ldy + col] = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
+          else *p = accumulate ? (*p + v) : v;
         }
       }
     }
@@ -602,7 +624,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
                                                           float* __restrict__ Y, int ldy, int accumulate,
                                                           const float* __restrict__ ep_scale,
                                                           const float* __restrict__ ep_shift,
-                                                          const float* __restrict__ ep_res, int ep_ldr, int ep_act) {
+                                                          const float* __restrict__ ep_res, int ep_ldr, int ep_act, int io) {
   constexpr int NF = BNT / 16;
   constexpr int NB = BNT / 64;
   constexpr int NBUF = PP ? 2 : 1;
@@ -813,13 +835,23 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
           } else {
             float v = acc[mf][nf][r] + bv;
             if (ep_scale) v = v * sc + sh;
+            float rv = 0.f;                               // residual / gate operand: f32 or bf16 rows
+            if (ep_res) {
+              if (io & ES_IO_R16) rv = __uint_as_float((uint32_t)((const unsigned short*)ep_res)[(size_t)row * ep_ldr + col] << 16);
+              else rv = ep_res[(size_t)row * ep_ldr + col];
+            }
             if (ep_act == 3) {                            // gate: pass v only where ep_res > 0 (fused ReLU backward)
-              if (!(ep_res[(size_t)row * ep_ldr + col] > 0.f)) v = 0.f;
+              if (!(rv > 0.f)) v = 0.f;
             } else {
-              if (ep_res) v += ep_res[(size_t)row * ep_ldr + col];
+              if (ep_res) v += rv;
               if (ep_act) v = fmaxf(v, 0.f);
             }
-            *p = accumulate ? (*p + v) : v;
+            if (io & ES_IO_Y16) {                         // bf16 activation rows: lanes (li, li^1) share one 4-byte store
+              float vn = __shfl_xor(v, 1, 64);
+              if (!(li & 1)) *(uint32_t*)((unsigned short*)Y + (size_t)row * ldy + col) = pack_bf16(v, vn);
+            } else {
+              *p = accumulate ? (*p + v) : v;
+            }
           }
         }
       }
@@ -836,13 +868,17 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
 //   * the weight slab (NT x 32 bf16) is ping-ponged through LDS: one barrier per k-step;
 //   * the epilogue goes through LDS so that global traffic is whole rows: the accumulator layout (lane = column) would
 //     write 64-B pieces; staged, every half-wave reads / writes 512 contiguous bytes of Y (and of the residual).
-template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_rowgemm_bf16(const float* __restrict__ X, int ldx,
+// XH: the input rows are bf16 (activation storage of the image backbone, round 3) -- the A fragment is then one 16-byte load
+// with no conversion.  io bit 0: Y rows are bf16 (4 channels = one 8-byte store), bit 1: the ep_res rows are bf16.
+template <int NT, bool XH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_rowgemm_bf16(const void* __restrict__ Xv, int ldx,
                                                       const unsigned short* __restrict__ W, int n_out, int n_in, int Cin,
                                                       int Cout, const float* __restrict__ bias, float* __restrict__ Y,
                                                       int ldy, int accumulate, const float* __restrict__ ep_scale,
                                                       const float* __restrict__ ep_shift,
-                                                      const float* __restrict__ ep_res, int ep_ldr, int ep_act) {
+                                                      const float* __restrict__ ep_res, int ep_ldr, int ep_act, int io) {
+  const float* X = (const float*)Xv;
+  const unsigned short* Xh = (const unsigned short*)Xv;
   constexpr int NF = NT / 16, SLD = NT + 4;
   constexpr int B_BYTES = 2 * NT * HLD * 2, S_BYTES = 4 * 16 * SLD * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[B_BYTES > S_BYTES ? B_BYTES : S_BYTES];
@@ -862,6 +898,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   const int rowA0 = row0 + li, rowA1 = row0 + 16 + li;
   const float* pa0 = X + (size_t)min(rowA0, n_rows - 1) * ldx + kq * 8;
   const float* pa1 = X + (size_t)min(rowA1, n_rows - 1) * ldx + kq * 8;
+  const unsigned short* ph0 = Xh + (size_t)min(rowA0, n_rows - 1) * ldx + kq * 8;
+  const unsigned short* ph1 = Xh + (size_t)min(rowA1, n_rows - 1) * ldx + kq * 8;
   const bool va0 = rowA0 < n_rows, va1 = rowA1 < n_rows;
   const int bc0 = t >> 2, bq = t & 3;                     // weight slab: NT x 32 bf16 = NT*4 16-byte granules
   const unsigned short* pb0 = W + (size_t)(n0 + (bc0 < NT ? bc0 : 0)) * Cin + bq * 8;
@@ -871,13 +909,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     const bool ka_ = (s_) * HBK + kq * 8 < Cin, kb_ = (s_) * HBK + bq * 8 < Cin;       \
     a00 = a01 = a10 = a11 = make_float4(0.f, 0.f, 0.f, 0.f);                           \
     bg0 = bg1 = make_uint4(0u, 0u, 0u, 0u);                                            \
-    if (va0 && ka_) {                                                                  \
-      const float4* q0_ = (const float4*)(pa0 + (s_) * HBK);                           \
-      a00 = q0_[0]; a01 = q0_[1];                                                      \
-    }                                                                                  \
-    if (va1 && ka_) {                                                                  \
-      const float4* q1_ = (const float4*)(pa1 + (s_) * HBK);                           \
-      a10 = q1_[0]; a11 = q1_[1];                                                      \
+    if (XH) {                       /* 8 bf16 = one 16-byte piece, kept as raw bits in a00 / a10 */     \
+      if (va0 && ka_) a00 = *(const float4*)(ph0 + (s_) * HBK);                        \
+      if (va1 && ka_) a10 = *(const float4*)(ph1 + (s_) * HBK);                        \
+    } else {                                                                           \
+      if (va0 && ka_) {                                                                \
+        const float4* q0_ = (const float4*)(pa0 + (s_) * HBK);                         \
+        a00 = q0_[0]; a01 = q0_[1];                                                    \
+      }                                                                                \
+      if (va1 && ka_) {                                                                \
+        const float4* q1_ = (const float4*)(pa1 + (s_) * HBK);                         \
+        a10 = q1_[0]; a11 = q1_[1];                                                    \
+      }                                                                                \
     }                                                                                  \
     if (kb_ && bc0 < NT) bg0 = *(const uint4*)(pb0 + (s_) * HBK);                      \
     if (NT > 64 && kb_) bg1 = *(const uint4*)(pb1 + (s_) * HBK);                       \
@@ -902,14 +945,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       int f = i * 64 + lane, rr = f / (NT / 4), c4 = f - rr * (NT / 4);
       int row = row0 + mf * 16 + rr;
       pf[mf][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pre && row < n_out) pf[mf][i] = *(const float4*)(pre + (size_t)row * pre_ld + n0 + c4 * 4);
+      if (pre && row < n_out) {
+        if (ep_res && (io & ES_IO_R16))
+          pf[mf][i] = bf16x4_to_f32(*(const uint2*)((const unsigned short*)ep_res + (size_t)row * pre_ld + n0 + c4 * 4));
+        else
+          pf[mf][i] = *(const float4*)(pre + (size_t)row * pre_ld + n0 + c4 * 4);
+      }
     }
   RG_LOAD(0);
   RG_STORE_B(0);
   __syncthreads();
   for (int s = 0; s < ns; ++s) {
-    uint4 pk0 = make_uint4(pack_bf16(a00.x, a00.y), pack_bf16(a00.z, a00.w), pack_bf16(a01.x, a01.y), pack_bf16(a01.z, a01.w));
-    uint4 pk1 = make_uint4(pack_bf16(a10.x, a10.y), pack_bf16(a10.z, a10.w), pack_bf16(a11.x, a11.y), pack_bf16(a11.z, a11.w));
+    uint4 pk0, pk1;
+    if (XH) {
+      pk0 = make_uint4(__float_as_uint(a00.x), __float_as_uint(a00.y), __float_as_uint(a00.z), __float_as_uint(a00.w));
+      pk1 = make_uint4(__float_as_uint(a10.x), __float_as_uint(a10.y), __float_as_uint(a10.z), __float_as_uint(a10.w));
+    } else {
+      pk0 = make_uint4(pack_bf16(a00.x, a00.y), pack_bf16(a00.z, a00.w), pack_bf16(a01.x, a01.y), pack_bf16(a01.z, a01.w));
+      pk1 = make_uint4(pack_bf16(a10.x, a10.y), pack_bf16(a10.z, a10.w), pack_bf16(a11.x, a11.y), pack_bf16(a11.z, a11.w));
+    }
     bf16x8_t fa0 = __builtin_bit_cast(bf16x8_t, pk0), fa1 = __builtin_bit_cast(bf16x8_t, pk1);
     if (s + 1 < ns) RG_LOAD(s + 1);
     const unsigned short* Bc = Bs + (s & 1) * NT * HLD;
@@ -953,6 +1007,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         return x;
       };
       float o0 = ep1(v.x, q.x, col), o1 = ep1(v.y, q.y, col + 1), o2 = ep1(v.z, q.z, col + 2), o3 = ep1(v.w, q.w, col + 3);
+      if (io & ES_IO_Y16) {                               // bf16 activation rows: 4 channels = 8 bytes (never accumulated)
+        *(uint2*)((unsigned short*)Y + (size_t)row * ldy + col) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+        continue;
+      }
       float4* py = (float4*)(Y + (size_t)row * ldy + col);
       if (accumulate) {
         float4 y0 = ep_res ? *py : q;                     // (residual AND accumulation: Y was not prefetched)
@@ -1022,26 +1080,35 @@ extern "C" size_t es_spconv_split_workspace_floats(int n_out, int K, int Cin, in
 static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out,
                                 int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy,
                                 int accumulate, const float* ep_scale, const float* ep_shift, const float* ep_res,
-                                int ep_ldr, int ep_act, void* stream, float* ws = nullptr, size_t ws_floats = 0) {
+                                int ep_ldr, int ep_act, void* stream, float* ws = nullptr, size_t ws_floats = 0,
+                                int y_half = 0, int r_half = 0) {
   if (n_out <= 0 || Cout <= 0) return 0;
   if (K > MAXK) return -2;
+  const int io = (y_half ? ES_IO_Y16 : 0) | ((r_half && ep_res) ? ES_IO_R16 : 0);
+  if (y_half && (accumulate || (ldy % 4) || (Cout % 4) || (((uintptr_t)Y) & 7))) return -7;   // bf16 rows: 8-byte stores
+  if ((io & ES_IO_R16) && ((ep_ldr % 4) || (((uintptr_t)ep_res) & 7))) return -7;
   hipStream_t st = (hipStream_t)stream;
   const unsigned short* Wh = (const unsigned short*)W_bf16;
   const float* X = (const float*)Xv;
   bool fast = (Cin % HBK == 0) && (ldx % (x_is_bf16 ? 8 : 4) == 0) && ((((uintptr_t)Xv) & 15) == 0) &&
               ((((uintptr_t)Wh) & 15) == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
               ((long long)K * Cout * Cin < (1ll << 31)) && (Cout % 64 == 0);
-  if (x_is_bf16 && !fast) return -7;            // bf16 input rows are only supported by the fast kernels
   dim3 g128(es_cdiv(n_out, BM), Cout / 128), g64(es_cdiv(n_out, BM), Cout / 64);
-  if (ES_OPT_ROWGEMM && K == 1 && nbr == nullptr && !x_is_bf16 && ep_act != 7 && n_in >= n_out && (Cin % 8 == 0) &&
-      (Cout % 16 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
-      (((((uintptr_t)Xv) | ((uintptr_t)Wh) | ((uintptr_t)Y)) & 15) == 0) &&
-      (!ep_res || ((ep_ldr % 4 == 0) && ((((uintptr_t)ep_res) & 15) == 0)))) {
+  if (ES_OPT_ROWGEMM && K == 1 && nbr == nullptr && ep_act != 7 && n_in >= n_out && (Cin % 8 == 0) &&
+      (Cout % 16 == 0) && (ldx % (x_is_bf16 ? 8 : 4) == 0) && (ldy % 4 == 0) &&
+      (((((uintptr_t)Xv) | ((uintptr_t)Wh)) & 15) == 0) && ((((uintptr_t)Y) & (y_half ? 7 : 15)) == 0) &&
+      (!ep_res || ((ep_ldr % 4 == 0) && ((((uintptr_t)ep_res) & ((io & ES_IO_R16) ? 7 : 15)) == 0)))) {
     const int nt = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0) ? 64 : (Cout % 32 == 0) ? 32 : 16;
     dim3 g(es_cdiv(n_out, BM), Cout / nt);
 #define RG_LAUNCH(NT_)                                                                                              \
-    hipLaunchKernelGGL(k_rowgemm_bf16<NT_>, g, dim3(256), 0, st, X, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy,   \
-                       accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act)
+    do {                                                                                                            \
+      if (x_is_bf16)                                                                                                \
+        hipLaunchKernelGGL((k_rowgemm_bf16<NT_, true>), g, dim3(256), 0, st, Xv, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy, \
+                           accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);                              \
+      else                                                                                                          \
+        hipLaunchKernelGGL((k_rowgemm_bf16<NT_, false>), g, dim3(256), 0, st, Xv, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy, \
+                           accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);                              \
+    } while (0)
     if (nt == 128) RG_LAUNCH(128);
     else if (nt == 64) RG_LAUNCH(64);
     else if (nt == 32) RG_LAUNCH(32);
@@ -1051,7 +1118,7 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
     return 0;
   }
   int det_split = 0;
-  if (fast && !(ep_scale || ep_res || ep_act) && K > 1) {
+  if (fast && !(ep_scale || ep_res || ep_act) && K > 1 && !y_half) {
     // too few workgroups for 256 CUs: split the tap list over gridDim.z (partial sums through the caller's workspace)
     int split = split_factor(n_out, K, Cout);
     if (split > 1 && ws != nullptr && ws_floats >= (size_t)split * n_out * Cout) {
@@ -1064,34 +1131,34 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
   if (fast && ES_OPT_PINGPONG) {
     if (x_is_bf16 && Cout % 128 == 0)
       hipLaunchKernelGGL((k_spconv_bf16_fast<128, true, true>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
     else if (x_is_bf16)
       hipLaunchKernelGGL((k_spconv_bf16_fast<64, true, true>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
     else if (Cout % 128 == 0)
       hipLaunchKernelGGL((k_spconv_bf16_fast<128, false, true>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
     else
       hipLaunchKernelGGL((k_spconv_bf16_fast<64, false, true>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                         Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
   } else if (fast && x_is_bf16 && Cout % 128 == 0) {
     hipLaunchKernelGGL((k_spconv_bf16_fast<128, true, false>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
   } else if (fast && x_is_bf16) {
     hipLaunchKernelGGL((k_spconv_bf16_fast<64, true, false>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
   } else if (fast && Cout % 128 == 0) {
     hipLaunchKernelGGL((k_spconv_bf16_fast<128, false, false>), g128, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
   } else if (fast) {
     hipLaunchKernelGGL((k_spconv_bf16_fast<64, false, false>), g64, dim3(256), 0, st, Xv, ldx, Wh, nbr, n_out, n_in, K, Cin,
-                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                       Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
   } else if (Cout >= 128) {
     hipLaunchKernelGGL(k_spconv_bf16<128>, dim3(es_cdiv(n_out, BM), es_cdiv(Cout, 128)), dim3(256), 0, st, X, ldx, Wh,
-                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, x_is_bf16, io);
   } else {
     hipLaunchKernelGGL(k_spconv_bf16<64>, dim3(es_cdiv(n_out, BM), es_cdiv(Cout, 64)), dim3(256), 0, st, X, ldx, Wh,
-                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act);
+                       nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, x_is_bf16, io);
   }
   ES_CHECK_LAUNCH();
   if (det_split) {
@@ -1128,6 +1195,18 @@ extern "C" int es_spconv_fwd_bf16_affine(const void* Xv, int ldx, const void* W_
                                          const float* res, int ldr, int act, float* Y, int ldy, void* stream) {
   return spconv_fwd_bf16_impl(Xv, 0, ldx, W_bf16, nbr, n_out, n_in, K, Cin, Cout, nullptr, Y, ldy, 0, scale, shift, res,
                               ldr, act, stream);
+}
+
+// the fused conv + frozen-BN (+ residual) (+ ReLU) / gated data-gradient launch with per-operand storage kinds: x_half,
+// res_half, y_half non-zero -> that row matrix is bf16 (ld in elements).  The image backbone keeps its ACTIVATIONS in bf16
+// (round 3): forward launches read and write bf16 rows, the gated data-gradient launches read the bf16 activation as their
+// gate and move f32 gradients.  Y bf16 is never accumulated into.
+extern "C" int es_spconv_fwd_bf16_io(const void* Xv, int x_half, int ldx, const void* W_bf16, const int* nbr, int n_out,
+                                     int n_in, int K, int Cin, int Cout, const float* scale, const float* shift,
+                                     const void* res, int res_half, int ldr, int act, void* Y, int y_half, int ldy,
+                                     void* stream) {
+  return spconv_fwd_bf16_impl(Xv, x_half, ldx, W_bf16, nbr, n_out, n_in, K, Cin, Cout, nullptr, (float*)Y, ldy, 0, scale, shift,
+                              (const float*)res, ldr, act, stream, nullptr, 0, y_half, res_half);
 }
 
 // f32 [K][A][B] -> bf16 natural [K][A][B] and/or bf16 transposed [K][B][A]
@@ -1596,7 +1675,7 @@ static WgradPlan wgrad_plan_bf16(int XH, int YH, const void* X, int ldx, const v
   }
   if (big) {
     int base = K * (Cin / 128) * (Cout / 128);
-    int splits = es_cdiv(8192, base);
+    int splits = es_cdiv(2048, base);                   // (atomics era: 8192 workgroups; every slice now costs a dW-sized write + read)
     int max_splits = es_cdiv(n_out, 512);
     if (splits > max_splits) splits = max_splits;
     splits = cap_splits(splits, nw, have_ws);
@@ -1604,7 +1683,7 @@ static WgradPlan wgrad_plan_bf16(int XH, int YH, const void* X, int ldx, const v
     return WgradPlan{2, es_cdiv(n_out, rows_per_split), rows_per_split};
   }
   int base = K * es_cdiv(Cin, WM) * es_cdiv(Cout, WN);
-  int splits = es_cdiv(4096, base);
+  int splits = es_cdiv(2048, base);
   int max_splits = es_cdiv(n_out, 256);
   if (splits > max_splits) splits = max_splits;
   splits = cap_splits(splits, nw, have_ws);

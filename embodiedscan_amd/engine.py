@@ -29,7 +29,7 @@ class Var:
 
     def shadow(self):
         if self.dh is None:
-            self.dh = _cast_rows(self.d)
+            self.dh = self.d if self.d.dtype == torch.bfloat16 else _cast_rows(self.d)     # bf16 rows are their own shadow
         return self.dh
 
     def grad_shadow(self):
@@ -128,6 +128,9 @@ SHADOW = [os.environ.get('ES_SHADOW', '1') == '1']   # gather from bf16 shadow c
                           # gather bytes, no conversion instructions in the staging loop; on by default since round 2 (the GPU
                           # suite passes identically with it; ES_SHADOW=0 restores f32 gathers)
 WGRAD_BF16 = [True]       # in bf16 mode also run the weight-gradient GEMMs on the bf16 matrix cores
+ACT16 = [os.environ.get('ES_ACT16', '1') != '0']   # round 3: the image backbone stores its ACTIVATIONS in bf16 (bf16 mode only):
+                          # the fused conv + frozen-BN (+ residual) + ReLU launches read and write bf16 rows, the data
+                          # gradients stay f32; halves the bytes of the HBM-bound 1x1 convolutions, no shadow copies
 WEIGHT_VERSION = [0]      # bumped by the optimiser: invalidates the bf16 weight copies
 
 
@@ -345,7 +348,7 @@ def _ld(t):
 def _grad_target(v, shape_like):
     """(tensor, accumulate flag) for writing the gradient of v."""
     if v.g is None:
-        v.g = torch.empty_like(shape_like)
+        v.g = torch.empty(shape_like.shape, dtype=torch.float32, device=shape_like.device)    # gradients are f32 rows
         return v.g, 0
     return v.g, 1
 
@@ -419,9 +422,13 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
                n_out, n_out, 1, 1, cout - bias_from)
     if need_dx and x.rg and gate is not None:
         assert x.g is None and bf, 'gated dgrad: x must have exactly one consumer'
-        x.g, x.gated = torch.empty_like(x.d), True
-        call('es_spconv_fwd_bf16_affine', P(gy), _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, P(gate), 0,
-             P(x.d), _ld(x.d), 3, P(x.g), _ld(x.g), s)
+        x.g, x.gated = torch.empty(x.d.shape, dtype=torch.float32, device=x.d.device), True
+        if x.d.dtype == torch.bfloat16:          # the gate operand is the bf16 activation (only its sign is read)
+            call('es_spconv_fwd_bf16_io', P(gy), 0, _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, P(gate), 0,
+                 P(x.d), 1, _ld(x.d), 3, P(x.g), 0, _ld(x.g), s)
+        else:
+            call('es_spconv_fwd_bf16_affine', P(gy), _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, P(gate), 0,
+                 P(x.d), _ld(x.d), 3, P(x.g), _ld(x.g), s)
     elif need_dx and x.rg:
         g, acc = _grad_target(x, x.d)
         if gh is not None:
@@ -432,18 +439,31 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
             call('es_spconv_fwd', P(gy), _ld(gy), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1, acc, s)
 
 
-def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True, sole_consumer=False):
+def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True, sole_consumer=False, out_bf16=False):
     """conv -> frozen-BN affine (+ residual) (+ ReLU) of the 2-D backbone.  In bf16 mode this is ONE launch (affine
     fused into the conv epilogue); in f32 mode conv() followed by affine_act().
     sole_consumer: promise that x feeds nothing but this conv; if x itself came out of a fused conv+BN+ReLU, its
-    ReLU/BN backward is then folded into this conv's data-gradient launch."""
+    ReLU/BN backward is then folded into this conv's data-gradient launch.
+    out_bf16: store the output rows in bf16 (ACT16); x / res may themselves be bf16 row matrices."""
     K, cin, cout = w.d.shape
     n_in = x.d.shape[0]
     if PRECISION[0] != 'bf16':
         return affine_act(conv(x, w, nbr, inv, n_out, need_dx=need_dx), scale, shift, act=act, res=res)
-    y = Var(empty((n_out, cout), x.d))
-    call('es_spconv_fwd_bf16_affine', P(x.d), _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(scale),
-         P(shift), P(res.d) if res is not None else 0, _ld(res.d) if res is not None else 0, act, P(y.d), cout, _stream())
+    h16 = torch.bfloat16
+    y16 = bool(out_bf16 and ACT16[0] and cout % 4 == 0)
+    x16, r16 = x.d.dtype == h16, (res is not None and res.d.dtype == h16)
+    y = Var(empty((n_out, cout), x.d, dtype=h16 if y16 else torch.float32))
+    if x16 or r16 or y16:
+        call('es_spconv_fwd_bf16_io', P(x.d), int(x16), _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(scale),
+             P(shift), P(res.d) if res is not None else 0, int(r16), _ld(res.d) if res is not None else 0, act, P(y.d),
+             int(y16), cout, _stream())
+    else:
+        call('es_spconv_fwd_bf16_affine', P(x.d), _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(scale),
+             P(shift), P(res.d) if res is not None else 0, _ld(res.d) if res is not None else 0, act, P(y.d), cout, _stream())
+    if y16:
+        y.dh = y.d                              # bf16 rows are their own gather shadow
+    if x16:
+        x.dh = x.d
 
     if act == 1 and res is None:
         y.gate = scale
@@ -461,8 +481,9 @@ def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=Tr
             if res is not None and res.rg:
                 t, accr = _grad_target(res, res.d)
                 gr = P(t)
-            gconv = torch.empty_like(y.d)       # gradient w.r.t. the (never materialised) conv output
-            call('es_affine_act_bwd', P(y.g), P(y.d), P(scale), n_out, cout, act, P(gconv), 0, gr, accr, _stream())
+            gconv = torch.empty((n_out, cout), dtype=torch.float32, device=y.d.device)   # gradient w.r.t. the conv output
+            call('es_affine_act_bwd_yh' if y.d.dtype == h16 else 'es_affine_act_bwd', P(y.g), P(y.d), P(scale), n_out, cout, act,
+                 P(gconv), 0, gr, accr, _stream())
         _conv_backward(x, w, nbr, inv, n_out, y, gconv, None, 0, need_dx, True, gate)
     TAPE.add(bwd)
     return y

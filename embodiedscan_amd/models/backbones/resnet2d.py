@@ -56,6 +56,9 @@ class ResNet:
         self.base = base_channels
         self.out_indices, self.frozen_stages = tuple(out_indices), frozen_stages
         self.grids = {}
+        # bf16 ACTIVATION storage (round 3; bf16 mode only): set by detectors whose only consumer of the feature maps is the
+        # projection fusion (mv-3ddet, grounder); the occupancy detector's FPN still takes f32 rows
+        self.act16 = False
 
     def bind(self, arena, prefix='backbone.'):
         self.arena, self.prefix = arena, prefix
@@ -123,7 +126,14 @@ class ResNet:
             call('es_spconv_fwd', P(xin), 3, w1.data_ptr() + 4 * 27 * 3 * self.base, P(nbr_b), stem[2], xin.shape[0], 22,
                  3, self.base, 0, P(y), self.base, 0, 1, s)
             cur = E.affine_act(E.Var(y, rg=False), *self.fold['bn1'], act=1)
-        cur = E.maxpool(cur, pool[0], pool[2], need_dx=False)
+        a16 = bool(self.act16 and E.ACT16[0] and E.PRECISION[0] == 'bf16' and self.frozen_stages >= 0)
+        if a16:                                 # frozen stem: forward-only pooling straight into bf16 rows
+            yp = torch.empty((pool[2], self.base), dtype=torch.bfloat16, device=dev)
+            call('es_maxpool_fwd_h', P(cur.d), self.base, P(pool[0]), pool[2], pool[0].shape[1], self.base, P(yp), s)
+            cur = E.Var(yp, rg=False)
+            cur.dh = yp
+        else:
+            cur = E.maxpool(cur, pool[0], pool[2], need_dx=False)
         cur.rg = self.frozen_stages < 0
         outs = []
         for li, nblk in enumerate(self.arch[50]):
@@ -134,22 +144,22 @@ class ResNet:
                 stride = 2 if (bi == 0 and li > 0) else 1
                 g_in = gin if bi == 0 else grids[li]
                 o = E.conv_affine(cur, self._par(p + 'conv1.weight'), None, None, cur.d.shape[0], *self.fold[p + 'bn1'],
-                                  act=1)
+                                  act=1, out_bf16=a16)
                 nbr, inv, n_out, _, _ = g_in.conv_map(3, stride, 1)
                 o = E.conv_affine(o, self._par(p + 'conv2.weight'), nbr, inv, n_out, *self.fold[p + 'bn2'], act=1,
-                                  sole_consumer=True)
+                                  sole_consumer=True, out_bf16=a16)
                 if bi == 0:
                     if stride == 1:
                         idt = E.conv_affine(cur, self._par(p + 'downsample.0.weight'), None, None, n_out,
-                                            *self.fold[p + 'downsample.1'], act=0)
+                                            *self.fold[p + 'downsample.1'], act=0, out_bf16=a16)
                     else:
                         dn, di, _, _, _ = g_in.conv_map(1, stride, 0)
                         idt = E.conv_affine(cur, self._par(p + 'downsample.0.weight'), dn, di, n_out,
-                                            *self.fold[p + 'downsample.1'], act=0)
+                                            *self.fold[p + 'downsample.1'], act=0, out_bf16=a16)
                 else:
                     idt = cur
                 cur = E.conv_affine(o, self._par(p + 'conv3.weight'), None, None, n_out, *self.fold[p + 'bn3'], act=1,
-                                    res=idt, sole_consumer=True)
+                                    res=idt, sole_consumer=True, out_bf16=a16)
                 if not E.TAPE.enabled:
                     cur.rg = False
             if li in self.out_indices:

@@ -25,6 +25,7 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         assert neck is None and neck_3d is not None and decoder is not None
         self.device = torch.device(device)
         self.backbone = MODELS.build(backbone)
+        self.backbone.act16 = True              # feature maps only feed the projection fusion: bf16 activation storage
         self.backbone_3d = MODELS.build(backbone_3d)
         self.neck_3d = MODELS.build(neck_3d)
         bbox_head = dict(bbox_head)

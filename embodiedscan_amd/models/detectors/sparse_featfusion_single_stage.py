@@ -32,6 +32,7 @@ class SparseFeatureFusionSingleStage3DDetector:
         assert neck is None and neck_3d is None, 'the shipped mv-3ddet config has no necks'
         self.device = torch.device(device)
         self.backbone = MODELS.build(backbone)
+        self.backbone.act16 = True              # its feature maps only feed the projection fusion: bf16 activation storage
         self.backbone_3d = MODELS.build(backbone_3d)
         bbox_head = dict(bbox_head)
         bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)

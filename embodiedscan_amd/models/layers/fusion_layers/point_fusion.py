@@ -56,8 +56,10 @@ def batch_point_sample_level(cs, voxel_size, meta_dev, n_views, feat, Hf, Wf, ou
     n = cs.n
     pix = torch.empty((n, n_views), dtype=torch.int32, device=out.device)
     cnt = torch.empty(n, dtype=torch.int32, device=out.device)
-    call('es_point_sample_fwd', P(cs.coords), n, float(voxel_size), P(meta_dev), meta_dev.shape[1], n_views, P(feat.d),
-         Hf, Wf, C, out.data_ptr() + 4 * col0, out.stride(0), P(pix), P(cnt), _stream())
+    # (feature maps stored in bf16 by the image backbone's activation storage: the _h variant widens them while summing)
+    call('es_point_sample_fwd_h' if feat.d.dtype == torch.bfloat16 else 'es_point_sample_fwd', P(cs.coords), n, float(voxel_size),
+         P(meta_dev), meta_dev.shape[1], n_views, P(feat.d), Hf, Wf, C, out.data_ptr() + 4 * col0, out.stride(0), P(pix), P(cnt),
+         _stream())
     return pix, cnt
 
 
@@ -67,7 +69,7 @@ def batch_point_sample_level_bwd(cs, n_views, dout, col0, pix, cnt, feat, Hf, Wf
         return
     acc = 1
     if feat.g is None:
-        feat.g, acc = torch.empty_like(feat.d), 0           # the gather writes every pixel
+        feat.g, acc = torch.empty(feat.d.shape, dtype=torch.float32, device=feat.d.device), 0   # the gather writes every pixel
     n_pix = feat.d.shape[0]
     head = torch.empty(n_pix, dtype=torch.int32, device=feat.d.device)
     nxt = torch.empty(max(cs.n * n_views, 1), dtype=torch.int32, device=feat.d.device)

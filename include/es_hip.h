@@ -94,6 +94,12 @@ int es_set_option(int key, int value);
 int es_spconv_fwd_bf16_affine(const void* X, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in, int K,
                               int Cin, int Cout, const float* scale, const float* shift, const float* res, int ldr,
                               int act, float* Y, int ldy, void* stream);
+/* Fused conv + frozen-BN (+ residual) (+ ReLU) / gated data gradient with per-operand storage kinds (round 3: the image
+ * backbone keeps its ACTIVATIONS in bf16): x_half / res_half / y_half non-zero -> that row matrix is bf16 (ld in elements).
+ * Replaces conv -> BatchNorm2d(eval) -> (+ identity) -> ReLU of mmdet.ResNet Bottleneck (configs/detection/...py:24-34). */
+int es_spconv_fwd_bf16_io(const void* X, int x_half, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in, int K,
+                          int Cin, int Cout, const float* scale, const float* shift, const void* res, int res_half, int ldr,
+                          int act, void* Y, int y_half, int ldy, void* stream);
 int es_cast_rows_bf16(const float* x, int ldx, int n, int C, void* h /* (n,C) bf16 */, void* stream);
 /* per-step bf16 copies of an f32 [K][A][B] kernel: natural [K][A][B] and/or transposed [K][B][A] (either may be NULL) */
 int es_cast_weight_bf16(const float* w, int K, int A, int B, void* natural, void* transposed, void* stream);
@@ -143,6 +149,8 @@ int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const float* x, int
                 void* stream);
 /* MinkowskiMaxPooling(k=2,s=2) and the 2-D stem max-pool.  mink_resnet.py:66-69 */
 int es_maxpool_fwd(const float* x, int ldx, const int* nbr, int n_out, int K, int C, float* y, int* arg, void* stream);
+/* forward-only variant writing bf16 rows (the frozen stem pooling of the image backbone: nn.MaxPool2d(3, 2, 1)) */
+int es_maxpool_fwd_h(const float* x, int ldx, const int* nbr, int n_out, int K, int C, void* y_bf16, void* stream);
 int es_maxpool_bwd(const float* dy, const int* arg, int n_out, int C, float* dx, int ldo, void* stream);
 /* mode 0: dst[i]=src[idx[i]]  1: dst[idx[i]]+=src[i]  2: dst[idx[i]]=src[i]  (idx NULL = identity) */
 int es_row_move(float* dst, int ldd, const float* src, int lds, const int* idx, int n, int C, int mode, void* stream);
@@ -158,6 +166,9 @@ int es_affine_act_fwd(const float* x, const float* scale, const float* shift, co
                       int act, float* y, void* stream);
 int es_affine_act_bwd(const float* dy, const float* y, const float* scale, size_t n, int C, int act, float* dx,
                       int acc_x, float* dres, int acc_r, void* stream);
+/* es_affine_act_bwd with the activation y stored in bf16 (only its sign is read); C % 4 == 0 */
+int es_affine_act_bwd_yh(const float* dy, const void* y_bf16, const float* scale, size_t n, int C, int act, float* dx,
+                         int acc_x, float* dres, int acc_r, void* stream);
 
 /* ---- A8 projection fusion.  point_fusion.py:208-311 ----------------------------------------------- */
 /* per-sample meta block layout (floats) */
@@ -180,6 +191,9 @@ int es_point_sample_fwd(const int* coords, int n, float voxel_size, const float*
                         int* pix /* (n,V) */, int* cnt /* (n) */, void* stream);
 /* the same for explicit float locations (n,3) (coords[:,0] still gives the sample): the 40x40x16 prior points of the
  * occupancy detector, dense_fusion_occ.py:156-202 */
+/* es_point_sample_fwd reading bf16 feature maps */
+int es_point_sample_fwd_h(const int* coords, int n, float voxel_size, const float* meta, int meta_stride, int V,
+                          const void* feats_bf16, int Hf, int Wf, int C, float* out, int ldo, int* pix, int* cnt, void* stream);
 int es_point_sample_fwd_pts(const int* coords, const float* points, int n, const float* meta, int meta_stride, int V,
                             const float* feats, int Hf, int Wf, int C, float* out, int ldo, int* pix, int* cnt,
                             void* stream);

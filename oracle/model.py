@@ -68,19 +68,19 @@ def resnet50_w16(x, sd, prefix='backbone.'):
     """mmdet.ResNet depth=50 base_channels=16, norm_eval, out_indices (0,1,2,3)."""
     x = F.conv2d(x, sd[prefix + 'conv1.weight'], None, 2, 3)
     x = F.relu(_bn2d_eval(x, sd, prefix + 'bn1'))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = R.act(F.max_pool2d(x, 3, 2, 1))         # R.act: activation STORAGE rounding of the bf16 specification (identity otherwise)
     outs = []
     for li, nblk in enumerate((3, 4, 6, 3)):
         for bi in range(nblk):
             p = f'{prefix}layer{li + 1}.{bi}.'
             stride = 2 if (bi == 0 and li > 0) else 1
             idt = x
-            o = F.relu(_bn2d_eval(_conv2d(x, sd[p + 'conv1.weight']), sd, p + 'bn1'))
-            o = F.relu(_bn2d_eval(_conv2d(o, sd[p + 'conv2.weight'], stride, 1), sd, p + 'bn2'))
+            o = R.act(F.relu(_bn2d_eval(_conv2d(x, sd[p + 'conv1.weight']), sd, p + 'bn1')))
+            o = R.act(F.relu(_bn2d_eval(_conv2d(o, sd[p + 'conv2.weight'], stride, 1), sd, p + 'bn2')))
             o = _bn2d_eval(_conv2d(o, sd[p + 'conv3.weight']), sd, p + 'bn3')
             if bi == 0:
-                idt = _bn2d_eval(_conv2d(x, sd[p + 'downsample.0.weight'], stride), sd, p + 'downsample.1')
-            x = F.relu(o + idt)
+                idt = R.act(_bn2d_eval(_conv2d(x, sd[p + 'downsample.0.weight'], stride), sd, p + 'downsample.1'))
+            x = R.act(F.relu(o + idt))
         outs.append(x)
     return outs
 

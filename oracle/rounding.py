@@ -10,6 +10,8 @@ import torch
 
 MODE = [None]          # None: exact f32 (the pinned oracle); 'bf16': operands rounded as described above
 MIN_CIN = 16
+ACT16 = [True]         # bf16 mode: the image backbone STORES its activations in bf16 (embodiedscan_amd.engine.ACT16); the backward
+                       # treats the stored value as the activation (straight-through: no gradient of the rounding)
 
 
 def r(t):
@@ -44,6 +46,13 @@ class _Rounded(torch.autograd.Function):
         return None, None, dx, dw
 
 
+def act(t):
+    """activation-storage rounding of the image backbone in bf16 mode (value r(t), gradient of the identity)"""
+    if MODE[0] != 'bf16' or not ACT16[0]:
+        return t
+    return t + (r(t.detach()) - t.detach())
+
+
 def op(fn, x, w, cin, cout=None):
     """fn(x, w) under the current mode; cin / cout: channel counts that decide whether the HIP path uses the bf16 cores"""
     if MODE[0] != 'bf16' or cin < MIN_CIN:
@@ -52,11 +61,16 @@ def op(fn, x, w, cin, cout=None):
 
 
 class bf16_operands:
-    """with bf16_operands(): ... -- run the oracle in bf16-operand mode"""
+    """with bf16_operands(): ... -- run the oracle in bf16-operand mode; act16: the image backbone stores bf16 activations
+    (mv-3ddet / grounder: yes; the occupancy detector, whose FPN takes f32 rows: no)"""
+
+    def __init__(self, act16=True):
+        self.act16 = act16
 
     def __enter__(self):
         import torch.nn.functional as F
         self.prev, MODE[0] = MODE[0], 'bf16'
+        self.prev_act, ACT16[0] = ACT16[0], self.act16
         # Linear layers (reg branches, FFN, text_feat_map, attention in / out projections -- F.multi_head_attention_forward
         # resolves `linear` in torch.nn.functional at call time): E.linear runs them on the convolution engine
         self.linear = F.linear
@@ -72,3 +86,4 @@ class bf16_operands:
         import torch.nn.functional as F
         F.linear = self.linear
         MODE[0] = self.prev
+        ACT16[0] = self.prev_act

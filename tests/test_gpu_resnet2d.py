@@ -2,11 +2,10 @@
 path at base 8) on the conv engine -- direct stem kernel, static image-grid maps, 1x1 / 3x3 / strided convs, fused
 conv + frozen-BN (+ residual) (+ ReLU) epilogues and the gated data-gradient launches of the bf16 mode -- against
 torch.nn.functional.conv2d + eval-mode batch_norm on the CPU: the four output feature maps and the gradients of every
-trainable conv kernel.  Feature maps: f32 1e-4, bf16 2e-2 (relative L2).  Kernel gradients: f32 median 1e-5 / worst 3e-2 (a
+trainable conv kernel.  Feature maps: f32 1e-4 (relative L2).  Kernel gradients: f32 median 1e-5 / worst 3e-2 (a
 ReLU pre-activation within f32 rounding of zero flips its gate between two f32 implementations and moves one small tensor
-by a fraction of a percent; measured 5e-3 on one of 42), bf16 median 0.3 / worst 0.7: end-to-end bf16 gradients of a
-random-init network are dominated by flipped gates (the per-kernel bf16 checks at 2.4e-3 in test_gpu_ops.py are the
-arithmetic gate; this one only catches wrong wiring, which gives >= 1)."""
+by a fraction of a percent; measured 5e-3 on one of 42).  bf16 (with f32 or bf16 activation storage): against the oracle's
+bf16-operand specification, see the test's docstring."""
 import numpy as np
 import pytest
 import torch
@@ -19,8 +18,13 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize('base,mode', [(16, 'f32'), (16, 'bf16'), (8, 'f32')])
-def test_resnet50_vs_torch(base, mode):
+@pytest.mark.parametrize('base,mode,act16', [(16, 'f32', False), (16, 'bf16', False), (16, 'bf16', True), (8, 'f32', False)])
+def test_resnet50_vs_torch(base, mode, act16):
+    """bf16 rows (round 3): compared with the oracle's bf16-OPERAND specification (oracle/rounding.py; act16: activations also
+    STORED in bf16 -- the fused launches read / write bf16 rows, the gated data gradients read the bf16 activation as their
+    gate): the same arithmetic up to summation order, so feature maps agree to 2e-3 and kernel gradients to median 5e-3 /
+    worst 2e-1 (a bf16 rounding boundary or a ReLU gate within f32 rounding of a decision flips now and then) instead of the
+    0.3 / 0.7 gate against f32."""
     from embodiedscan_amd import engine as E
     from embodiedscan_amd.models.backbones.resnet2d import ResNet
     from embodiedscan_amd.params import ParamArena, resnet50_specs
@@ -42,7 +46,11 @@ def test_resnet50_vs_torch(base, mode):
                  norm_cfg=dict(type='BN', requires_grad=False), norm_eval=True, style='pytorch').bind(arena, 'backbone.')
     n_img, H, W = 3, 96, 64
     x = torch.randn(n_img, 3, H, W, generator=g)
-    want = OM.resnet50_w16(x, sd)
+    from contextlib import nullcontext
+    from oracle import rounding as R
+    net.act16 = act16
+    with (R.bf16_operands(act16=act16) if mode == 'bf16' else nullcontext()):
+        want = OM.resnet50_w16(x, sd)
     dys = [torch.randn(o.shape, generator=g) for o in want]
     sum((o * d).sum() for o, d in zip(want, dys)).backward()
     E.PRECISION[0] = mode
@@ -51,11 +59,12 @@ def test_resnet50_vs_torch(base, mode):
         E.TAPE.clear()
         arena.grad.zero_()
         outs = net(x.permute(0, 2, 3, 1).contiguous().to(dev))
-        tf, tmed, tg = (1e-4, 1e-5, 3e-2) if mode == 'f32' else (2e-2, 0.3, 0.7)
+        tf, tmed, tg = (1e-4, 1e-5, 3e-2) if mode == 'f32' else (2e-3, 5e-3, 2e-1)
         for (o, h, w), r, d in zip(outs, want, dys):
             assert (h, w) == tuple(r.shape[2:])
-            e = _rel(o.d.cpu(), r.detach().permute(0, 2, 3, 1).reshape(-1, r.shape[1]))
-            print(f'ResNet-50(w{base}) {mode} feature map {h}x{w}x{r.shape[1]}: rel-L2 {e:.2e} (tol {tf:.0e})')
+            assert o.d.dtype == (torch.bfloat16 if act16 else torch.float32)
+            e = _rel(o.d.float().cpu(), r.detach().permute(0, 2, 3, 1).reshape(-1, r.shape[1]))
+            print(f'ResNet-50(w{base}) {mode}{"+act16" if act16 else ""} feature map {h}x{w}x{r.shape[1]}: rel-L2 {e:.2e} (tol {tf:.0e})')
             assert e < tf
             o.g = d.permute(0, 2, 3, 1).reshape(-1, d.shape[1]).contiguous().to(dev)
         E.TAPE.backward()
@@ -67,6 +76,6 @@ def test_resnet50_vs_torch(base, mode):
     worst = max(rel, key=rel.get)
     frozen = [k for k in sd if k.startswith('backbone.layer1.') or k.startswith('backbone.conv1')]
     assert all(k not in gd for k in frozen), 'frozen_stages=1: stem and layer1 carry no gradient'
-    print(f'ResNet-50(w{base}) {mode}: {len(rel)} conv kernels, gradient rel-L2 median {np.median(list(rel.values())):.2e}, worst '
+    print(f'ResNet-50(w{base}) {mode}{"+act16" if act16 else ""}: {len(rel)} conv kernels, gradient rel-L2 median {np.median(list(rel.values())):.2e}, worst '
           f'{rel[worst]:.2e} at {worst} (tol median {tmed:.0e} / worst {tg:.0e})')
     assert float(np.median(list(rel.values()))) < tmed and rel[worst] < tg
