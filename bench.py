@@ -184,6 +184,9 @@ def main():
     for it in range(args.steps):
         # (2 events per launch and one pair counter per kernel map cost ~3 ms of host time, so only the last step)
         hip.PROFILE = prof if it == args.steps - 1 else None
+        red = getattr(det.arena, 'reducer', None)
+        if red is not None:
+            red.profile = [] if it == args.steps - 1 else None    # N > 1: how long the optimiser waits for each gradient bucket
         losses = step()
         step_ev[it + 1].record()                                # end of the step's main-stream work (no sync)
     recs = resolve_pairs(hip, prof['records'])
@@ -302,6 +305,17 @@ def main():
     if world > 1:
         out['replicas_in_sync'] = in_sync
         out['rank_ms_per_step'] = rank_ms
+        red = getattr(det.arena, 'reducer', None)
+        if red is not None and red.profile:
+            exposed, mb = {}, {}
+            for part, floats, e0, e1 in red.profile:
+                exposed[part] = round(exposed.get(part, 0.0) + e0.elapsed_time(e1), 3)
+                mb[part] = round(mb.get(part, 0.0) + floats * 4 / 2 ** 20, 1)
+            out['allreduce_exposed_ms'] = dict(per_part={str(k): v for k, v in sorted(exposed.items())},
+                                               MiB_per_part={str(k): v for k, v in sorted(mb.items())},
+                                               note='rank 0, last timed step: time the compute stream stalls in the optimiser waiting for each '
+                                                    'gradient part (0 = 2-D backbone, 1 = 3-D backbone, 2 = head; launched from tape markers '
+                                                    'in backward-completion order 2, 1, 0; the clip norm is taken per bucket behind its all-reduce)')
     # GPU-side duration of each timed step (events on the main stream; the last one carries the launch profiling)
     out['step_ms'] = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(args.steps)]
     if world == 1 and not args.no_cpu_baseline:

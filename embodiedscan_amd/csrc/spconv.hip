@@ -304,12 +304,14 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
 // splits == 1: the tile is added straight into dW (sole owner, plain read-modify-write); splits > 1: the partial tiles go to
 // a caller-provided workspace laid out [slice][K][Cin][Cout] and k_wgrad_reduce adds them to dW in slice order.  No float
 // atomics anywhere: two runs give bit-identical weight gradients (rounds 1-2 used f32 atomics, 1e-6 run-to-run).
-#define WGRAD_WS_CAP_FLOATS (16ll << 20)     // 64 MB of partial tiles per launch at most: the slices are written and read back
-                                            // once (session C: 151 slices of the 128 x 128 x 27 head kernels = 267 MB per launch, ~100 us of ~175)
+#define WGRAD_WS_CAP_FLOATS (64ll << 20)     // 256 MB of partial tiles per launch (measured: a 64 MB cap -- 36 slices for the 128 x 128 x 27
+                                            // head kernels instead of 151 -- cost more in lost parallelism, 1.58 -> 1.82 ms per step, than
+                                            // it saved in workspace traffic; one slice of a 768^2 x 27 kernel: 2.3 -> 11 ms)
+#define WGRAD_WS_CAP_BIG (256ll << 20)       // weights above 8 M floats (the dense occupancy neck): up to 1 GB, i.e. still 4 .. 8 slices
 struct WgradPlan { int kind, splits, rows_per_split; };   // kind: 0 exact-f32 64x64, 1 bf16 64x64, 2 bf16 128x128, 3 bf16 256x256
 static int cap_splits(int splits, long long dw_floats, bool have_ws) {
   if (!have_ws) return 1;
-  long long cap = WGRAD_WS_CAP_FLOATS / (dw_floats > 0 ? dw_floats : 1);
+  long long cap = (dw_floats > (8ll << 20) ? WGRAD_WS_CAP_BIG : WGRAD_WS_CAP_FLOATS) / (dw_floats > 0 ? dw_floats : 1);
   if (cap < 1) cap = 1;
   if (splits > cap) splits = (int)cap;
   return splits < 1 ? 1 : splits;
@@ -478,11 +480,23 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
     int c = c0 + a_kk;
     if (idx >= 0 && c < Cin && x_half) {                  // bf16 input rows (image backbone): widened exactly, re-rounded as is
       const unsigned short* ph = (const unsigned short*)X + (size_t)idx * ldx + c;
-      float v[16];
+      if (c + 15 < Cin && (ldx & 7) == 0 && ((((uintptr_t)X) & 15) == 0)) {   // 16 channels = two 16-byte loads
+        const uint4 u0 = ((const uint4*)ph)[0], u1 = ((const uint4*)ph)[1];
+        R.a[0] = make_float4(__uint_as_float(u0.x << 16), __uint_as_float(u0.x & 0xffff0000u), __uint_as_float(u0.y << 16),
+                             __uint_as_float(u0.y & 0xffff0000u));
+        R.a[1] = make_float4(__uint_as_float(u0.z << 16), __uint_as_float(u0.z & 0xffff0000u), __uint_as_float(u0.w << 16),
+                             __uint_as_float(u0.w & 0xffff0000u));
+        R.a[2] = make_float4(__uint_as_float(u1.x << 16), __uint_as_float(u1.x & 0xffff0000u), __uint_as_float(u1.y << 16),
+                             __uint_as_float(u1.y & 0xffff0000u));
+        R.a[3] = make_float4(__uint_as_float(u1.z << 16), __uint_as_float(u1.z & 0xffff0000u), __uint_as_float(u1.w << 16),
+                             __uint_as_float(u1.w & 0xffff0000u));
+      } else {
+        float v[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = (c + q < Cin) ? __uint_as_float((uint32_t)ph[q] << 16) : 0.f;
+        for (int q = 0; q < 16; ++q) v[q] = (c + q < Cin) ? __uint_as_float((uint32_t)ph[q] << 16) : 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) R.a[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        for (int q = 0; q < 4; ++q) R.a[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      }
     } else if (idx >= 0 && c < Cin) {
       const float* p = X + (size_t)idx * ldx + c;
       if (vecA && c + 15 < Cin) {
@@ -600,8 +614,12 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
             if (ep_res) v += rv;
             if (ep_act) v = fmaxf(v, 0.f);
           }
-          if (io & ES_IO_Y16) ((unsigned short*)Y)[(size_t)row * ldy + col] = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
-          else *p = accumulate ? (*p + v) : v;
+          if (io & ES_IO_Y16) {                           // (Cout % 4 == 0: lanes li, li^1 are valid together) one 4-byte store per pair
+            float vn = __shfl_xor(v, 1, 64);
+            if (!(li & 1)) *(uint32_t*)((unsigned short*)Y + (size_t)row * ldy + col) = pack_bf16(v, vn);
+          } else {
+            *p = accumulate ? (*p + v) : v;
+          }
         }
       }
     }
@@ -1675,7 +1693,7 @@ static WgradPlan wgrad_plan_bf16(int XH, int YH, const void* X, int ldx, const v
   }
   if (big) {
     int base = K * (Cin / 128) * (Cout / 128);
-    int splits = es_cdiv(2048, base);                   // (atomics era: 8192 workgroups; every slice now costs a dW-sized write + read)
+    int splits = es_cdiv(8192, base);
     int max_splits = es_cdiv(n_out, 512);
     if (splits > max_splits) splits = max_splits;
     splits = cap_splits(splits, nw, have_ws);
@@ -1683,7 +1701,7 @@ static WgradPlan wgrad_plan_bf16(int XH, int YH, const void* X, int ldx, const v
     return WgradPlan{2, es_cdiv(n_out, rows_per_split), rows_per_split};
   }
   int base = K * es_cdiv(Cin, WM) * es_cdiv(Cout, WN);
-  int splits = es_cdiv(2048, base);
+  int splits = es_cdiv(4096, base);
   int max_splits = es_cdiv(n_out, 256);
   if (splits > max_splits) splits = max_splits;
   splits = cap_splits(splits, nw, have_ws);
