@@ -17,6 +17,28 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// run-time tuning switches (A/B measurements without a rebuild): key 1 = ping-pong LDS in the fast bf16 kernels
+static int ES_OPT_PINGPONG = 1;
+static int ES_OPT_WGRAD_HUGE = 1;      // 256 x 256 weight-gradient tile for wide layers (both operands bf16 shadows)
+static int ES_OPT_ROWGEMM = 1;         // streaming row GEMM for K = 1 on the identity map
+static int ES_OPT_WG_BIG_TARGET = 8192;    // workgroups a 128 x 128-tile weight-gradient launch aims for (row slices)
+static int ES_OPT_WG_BIG_ROWS = 512;       // ... and the fewest rows a slice may have
+static int ES_OPT_WG_SMALL_TARGET = 4096;  // the same for the 64 x 64 tile
+static int ES_OPT_WG_CAP_MB = 256;         // workspace of partial tiles per launch (weights <= 8 M floats)
+static int ES_OPT_FWD_SPLIT_WGS = 192;     // forward / dgrad launches with fewer workgroups split their tap list
+extern "C" int es_set_option(int key, int value) {
+  if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
+  if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }
+  if (key == 3) { ES_OPT_ROWGEMM = value; return 0; }
+  if (key == 4) { ES_OPT_WG_BIG_TARGET = value; return 0; }
+  if (key == 5) { ES_OPT_WG_BIG_ROWS = value; return 0; }
+  if (key == 6) { ES_OPT_WG_SMALL_TARGET = value; return 0; }
+  if (key == 7) { ES_OPT_WG_CAP_MB = value; return 0; }
+  if (key == 8) { ES_OPT_FWD_SPLIT_WGS = value; return 0; }
+  return -2;
+}
+
+
 #define BM 128
 #define BN 64
 #define BK 16
@@ -311,7 +333,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float* __restrict__ 
 struct WgradPlan { int kind, splits, rows_per_split; };   // kind: 0 exact-f32 64x64, 1 bf16 64x64, 2 bf16 128x128, 3 bf16 256x256
 static int cap_splits(int splits, long long dw_floats, bool have_ws) {
   if (!have_ws) return 1;
-  long long cap = (dw_floats > (8ll << 20) ? WGRAD_WS_CAP_BIG : WGRAD_WS_CAP_FLOATS) / (dw_floats > 0 ? dw_floats : 1);
+  long long cap = (dw_floats > (8ll << 20) ? WGRAD_WS_CAP_BIG : ((long long)ES_OPT_WG_CAP_MB << 18)) / (dw_floats > 0 ? dw_floats : 1);
   if (cap < 1) cap = 1;
   if (splits > cap) splits = (int)cap;
   return splits < 1 ? 1 : splits;
@@ -1039,17 +1061,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   }
 }
 
-// run-time tuning switches (A/B measurements without a rebuild): key 1 = ping-pong LDS in the fast bf16 kernels
-static int ES_OPT_PINGPONG = 1;
-static int ES_OPT_WGRAD_HUGE = 1;      // 256 x 256 weight-gradient tile for wide layers (both operands bf16 shadows)
-static int ES_OPT_ROWGEMM = 1;         // streaming row GEMM for K = 1 on the identity map
-extern "C" int es_set_option(int key, int value) {
-  if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
-  if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }
-  if (key == 3) { ES_OPT_ROWGEMM = value; return 0; }
-  return -2;
-}
-
 // 1 if (shape, alignment) is served by the fast kernels -- the host uses it to decide whether a bf16 shadow of X pays
 extern "C" int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout) {
   return (Cin % HBK == 0) && (ldx % 8 == 0) && (Cout % 64 == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
@@ -1060,7 +1071,7 @@ extern "C" int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cou
 static int split_factor(int n_out, int K, int Cout) {
   int wgs = (Cout % 128 == 0) ? es_cdiv(n_out, BM) * (Cout / 128) : es_cdiv(n_out, BM) * (Cout / 64);
   int split = 1;
-  while (split < 8 && wgs * split < 192 && split * 3 <= K) split *= 2;
+  while (split < 8 && wgs * split < ES_OPT_FWD_SPLIT_WGS && split * 3 <= K) split *= 2;
   return split;
 }
 // Y (+)= sum over the split slices of the partial sums, in slice order (bit-reproducible, unlike f32 atomics)
@@ -1693,15 +1704,15 @@ static WgradPlan wgrad_plan_bf16(int XH, int YH, const void* X, int ldx, const v
   }
   if (big) {
     int base = K * (Cin / 128) * (Cout / 128);
-    int splits = es_cdiv(8192, base);
-    int max_splits = es_cdiv(n_out, 512);
+    int splits = es_cdiv(ES_OPT_WG_BIG_TARGET, base);
+    int max_splits = es_cdiv(n_out, ES_OPT_WG_BIG_ROWS);
     if (splits > max_splits) splits = max_splits;
     splits = cap_splits(splits, nw, have_ws);
     int rows_per_split = es_cdiv(es_cdiv(n_out, splits), GR) * GR;
     return WgradPlan{2, es_cdiv(n_out, rows_per_split), rows_per_split};
   }
   int base = K * es_cdiv(Cin, WM) * es_cdiv(Cout, WN);
-  int splits = es_cdiv(4096, base);
+  int splits = es_cdiv(ES_OPT_WG_SMALL_TARGET, base);
   int max_splits = es_cdiv(n_out, 256);
   if (splits > max_splits) splits = max_splits;
   splits = cap_splits(splits, nw, have_ws);

@@ -290,6 +290,9 @@ def mark(name):
 
 
 DEBUG_GRADS = None      # tools/debug_grads.py sets a dict: id(Var) -> snapshot of its gradient when consumed
+DEBUG_CONV = None       # tests/test_gpu_insitu.py sets a list: one record per convolution backward of the step (operands as the
+                        # launches saw them + the data gradient this launch produced), for the in-situ check of every
+                        # weight- / data-gradient launch against its arithmetic specification
 
 
 def _cast_rows(t):
@@ -304,17 +307,13 @@ DET_SPLIT = [os.environ.get('ES_DET_SPLIT', '1') != '0']   # deterministic tap s
 
 
 def _split_ws(n_out, K, cin, cout, like):
-    """workspace for the deterministic tap split of an under-filled bf16 conv launch (mirrors split_factor() in
-    csrc/spconv.hip; the C side re-checks the size): (tensor or None, floats)"""
-    if not DET_SPLIT[0] or K <= 1 or cin % 32 or cout % 64 or n_out <= 0:
+    """workspace for the deterministic tap split of an under-filled bf16 conv launch (size from the library's own rule,
+    es_spconv_split_workspace_floats): (tensor or None, floats)"""
+    if not DET_SPLIT[0] or K <= 1 or n_out <= 0:
         return None, 0
-    wgs = -(-n_out // 128) * (cout // 128 if cout % 128 == 0 else cout // 64)
-    split = 1
-    while split < 8 and wgs * split < 192 and split * 3 <= K:
-        split *= 2
-    if split == 1:
+    nf = int(hip.raw('es_spconv_split_workspace_floats')(n_out, K, cin, cout))
+    if nf == 0:
         return None, 0
-    nf = split * n_out * cout
     return torch.empty(nf, dtype=torch.float32, device=like.device), nf
 
 
@@ -401,6 +400,11 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     K, cin, cout = w.d.shape
     n_in = x.d.shape[0]
     s = _stream()
+    rec = None
+    if DEBUG_CONV is not None:
+        rec = dict(x=x.d, w=w, nbr=nbr, n_out=n_out, gy=gy.clone(), bf=bool(bf), gate=gate, need_dx=bool(need_dx and x.rg),
+                   before=(x.g.clone() if (x.g is not None and need_dx and x.rg) else None))
+        DEBUG_CONV.append(rec)
     # bf16 shadow of the output gradient: gather source of the data-gradient launch and, with the input's shadow from
     # the forward pass, of the weight-gradient launch (made here, before the weight-gradient stream forks)
     gh = None
@@ -437,6 +441,8 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
             _fwd_bf16(P(gy), 0, _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc, gy)
         else:
             call('es_spconv_fwd', P(gy), _ld(gy), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1, acc, s)
+    if rec is not None and rec['need_dx']:
+        rec['dx'] = x.g.clone() if rec['before'] is None else x.g - rec['before']     # this launch's own contribution
 
 
 def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True, sole_consumer=False, out_bf16=False):

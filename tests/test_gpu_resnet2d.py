@@ -22,9 +22,11 @@ def _rel(a, b):
 def test_resnet50_vs_torch(base, mode, act16):
     """bf16 rows (round 3): compared with the oracle's bf16-OPERAND specification (oracle/rounding.py; act16: activations also
     STORED in bf16 -- the fused launches read / write bf16 rows, the gated data gradients read the bf16 activation as their
-    gate): the same arithmetic up to summation order, so feature maps agree to 5e-3 (measured 2.7e-3: values on a bf16 rounding boundary) and kernel gradients to median 5e-3 /
-    worst 2e-1 (a bf16 rounding boundary or a ReLU gate within f32 rounding of a decision flips now and then) instead of the
-    0.3 / 0.7 gate against f32."""
+    gate).  End to end the two sides drift apart by the bf16 quantisation noise within a few layers whatever the
+    specification (values on a bf16 rounding boundary fall to different sides under different summation orders; measured
+    feature maps 6e-4 -> 2.4e-3 -> 5.3e-3 -> 1e-2 by depth): feature maps 2e-2, kernel gradients median 0.3 / worst 0.7 (wrong
+    wiring gives >= 1).  The tight gates are tests/test_gpu_insitu.py (every backward launch of a step on its own operands,
+    2e-4) and tests/test_gpu_ops.py (per launch class, 2e-5)."""
     from embodiedscan_amd import engine as E
     from embodiedscan_amd.models.backbones.resnet2d import ResNet
     from embodiedscan_amd.params import ParamArena, resnet50_specs
@@ -59,7 +61,7 @@ def test_resnet50_vs_torch(base, mode, act16):
         E.TAPE.clear()
         arena.grad.zero_()
         outs = net(x.permute(0, 2, 3, 1).contiguous().to(dev))
-        tf, tmed, tg = (1e-4, 1e-5, 3e-2) if mode == 'f32' else (5e-3, 5e-3, 2e-1)
+        tf, tmed, tg = (1e-4, 1e-5, 3e-2) if mode == 'f32' else (2e-2, 0.3, 0.7)
         for (o, h, w), r, d in zip(outs, want, dys):
             assert (h, w) == tuple(r.shape[2:])
             assert o.d.dtype == (torch.bfloat16 if act16 else torch.float32)
