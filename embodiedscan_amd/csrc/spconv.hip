@@ -25,7 +25,8 @@ static int ES_OPT_WG_BIG_TARGET = 8192;    // workgroups a 128 x 128-tile weight
 static int ES_OPT_WG_BIG_ROWS = 512;       // ... and the fewest rows a slice may have
 static int ES_OPT_WG_SMALL_TARGET = 4096;  // the same for the 64 x 64 tile
 static int ES_OPT_WG_CAP_MB = 256;         // workspace of partial tiles per launch (weights <= 8 M floats)
-static int ES_OPT_FWD_SPLIT_WGS = 192;     // forward / dgrad launches with fewer workgroups split their tap list
+static int ES_OPT_FWD_SPLIT_WGS = 384;     // forward / dgrad launches with fewer workgroups split their tap list (sweep, session F:
+                                           // 192 -> 384 neutral on mv-3ddet, -0.8 ms on the occupancy step; 96: +3.5 / +4.7 ms)
 extern "C" int es_set_option(int key, int value) {
   if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
   if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }

@@ -442,7 +442,7 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         else:
             call('es_spconv_fwd', P(gy), _ld(gy), P(w.d), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), 1, acc, s)
     if rec is not None and rec['need_dx']:
-        rec['dx'] = x.g.clone() if rec['before'] is None else x.g - rec['before']     # this launch's own contribution
+        rec['after'] = x.g.clone()               # (gradient buffer after this launch; `before` = what it accumulated onto)
 
 
 def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True, sole_consumer=False, out_bf16=False):

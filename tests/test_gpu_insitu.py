@@ -6,7 +6,7 @@ so two summation orders that agree to 1e-6 on one layer put ~2.5e-4 of the next 
 rounding boundary, and after four or five layers the activations differ by the full bf16 quantisation noise (measured:
 feature maps 6e-4 -> 2.4e-3 -> 5.3e-3 by depth, parameter gradients 10 % median from a COMMON head-output gradient).  What CAN be
 held tightly is every launch on the operands it actually saw.  engine.DEBUG_CONV records, for each convolution backward
-of the step -- sparse 3-D (27 / 8 / 1 taps, strided, transposed), the image backbone's fused conv + BN + ReLU layers with
+of the step -- sparse 3-D (27 / 1 taps, strided), the image backbone's fused conv + BN + ReLU layers with
 their gated data gradients and bf16 activation rows, the head GEMMs -- the input rows, the output gradient, the map, and
 the data gradient the launch produced; the weight gradient is read from the arena after the step.  The specification
 (oracle/rounding.py): dw[k] = r(x[nbr[:, k]])^T r(gy), dx = sum_k scatter(r(gy) r(w[k])^T) (* BN scale and ReLU mask for a
@@ -105,11 +105,16 @@ def test_every_conv_backward_of_a_bf16_step_matches_its_specification():
                   (' bf16-rows' if r['x'].dtype == torch.bfloat16 else '') + ('' if bf else ' exact-f32')
             kinds.add((K, cin, cout, gate is not None, r['x'].dtype == torch.bfloat16, bf))
             if r['need_dx'] and float(dx.norm()) > 0:
-                e = _rel(r['dx'], dx)
+                # the launch either wrote the buffer or ACCUMULATED onto what another consumer of x had put there: compare
+                # after with before + specification; the f32 rounding of that sum is legitimately eps * |after|
+                after = r['after'].double().cpu()
+                want = dx if r['before'] is None else r['before'].double().cpu() + dx
+                e = float((after - want).norm() / dx.norm())
+                tol = 2e-4 + 4e-7 * float(after.norm() / dx.norm())
                 n_dx += 1
                 if e > worst_dx[0]:
                     worst_dx = (e, tag)
-                assert e < 2e-4, f'data gradient of {tag}: rel-L2 {e:.2e}'
+                assert e < tol, f'data gradient of {tag}: rel-L2 {e:.2e} (tol {tol:.1e})'
         if float(dw_sum.norm()) > 0:
             e = _rel(w.g, dw_sum)
             n_dw += 1

@@ -60,7 +60,7 @@ def main():
         ms = (time.perf_counter() - t0) / args.steps * 1e3
         print(json.dumps(dict(variant=label, ms_per_step=round(ms, 3))), flush=True)
         return ms
-    defaults = {4: 8192, 5: 512, 6: 4096, 7: 256, 8: 192}
+    defaults = {4: 8192, 5: 512, 6: 4096, 7: 256, 8: 384}
     names = {4: 'wgrad big target', 5: 'wgrad big min rows', 6: 'wgrad small target', 7: 'wgrad ws cap MB', 8: 'fwd split wgs'}
     run('default (first)')
     run('default (again)')
@@ -68,7 +68,7 @@ def main():
         hip.raw('es_set_option')(2, 0)
         run('256 x 256 weight-gradient tile OFF')
         hip.raw('es_set_option')(2, 1)
-    for key, values in ((4, (4096, 16384)), (5, (256, 1024, 2048)), (6, (2048, 8192)), (7, (128, 512)), (8, (96, 384))):
+    for key, values in ((4, (4096, 16384)), (5, (256, 1024, 2048)), (6, (2048, 8192)), (7, (128, 512)), (8, (192, 768))):
         for v in values:
             hip.raw('es_set_option')(key, v)
             run(f'{names[key]} = {v} (default {defaults[key]})')
