@@ -212,6 +212,11 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(((hi - lo) <= 1e-9 * hi.abs()).item())
+        # the clip norm was assembled from per-bucket sums of squares taken behind the all-reduces (optim.py): compare it with
+        # the norm of the mean gradient computed in one piece (the arena still holds the SUM over ranks of the last step)
+        ref_norm = float(det.arena.grad[:det.arena.n_train].double().pow(2).sum().sqrt().item()) * getattr(optim, 'last_gscale', 1.0)
+        got_norm = float(optim.norm.item())
+        in_sync = in_sync and abs(got_norm - ref_norm) <= 1e-4 * max(ref_norm, 1e-12)
     dt = float(tmax.item())
 
     if rank != 0:

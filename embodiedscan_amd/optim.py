@@ -105,6 +105,7 @@ class OptimWrapper:
                      float(self.eps), float(self.wd * dm), self.step, float(self.max_norm if self.max_norm else 0.0),
                      P(self.norm), gscale, s)
         self.last_norm = self.norm
+        self.last_gscale = gscale               # < 1: the arena still holds the SUM over ranks (mean folded into the AdamW pass)
         from . import engine
         engine.WEIGHT_VERSION[0] += 1          # bf16 weight copies are stale now
 
