@@ -246,7 +246,7 @@ def main():
         single = dict(kernel_ms_per_step=e1['ms'], launches=e1['launches'], algorithmic_tflops=e1['tflops'],
                       frac_of_binding_roof=e1['frac_binding'], pair_bytes_GBps=e1['pair_GBps'],
                       note='same launches, one extra untimed step with ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0 (stand-alone '
-                           'durations); rocprofv3 summary of this schedule: profiles/r2_single_stream_kernel_stats.txt')
+                           'durations); rocprofv3 summary of this schedule: profiles/r3_single_stream_kernel_stats.txt')
         scatter = scatter_totals([r for r in r1 if r[0] in SCATTER])
         classes = launch_classes(r1, mfma_peak)
         stages = {}
@@ -257,7 +257,7 @@ def main():
 
     # static PMC figures of the same command (separate rocprofv3 --pmc passes, see profiles/): bytes per engine launch
     traffic, traffic_note = None, 'traffic: null (no PMC summary for this precision under profiles/)'
-    for name in ('r2_pmc_traffic.json', 'r1_final_pmc_traffic.json'):
+    for name in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_final_pmc_traffic.json'):
         pmc_file = os.path.join(ROOT, 'profiles', name)
         if args.precision == 'bf16' and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))

@@ -631,9 +631,22 @@ __global__ __launch_bounds__(1024) void k_topk_mask(const float* __restrict__ v,
     for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t prefix = s_prefix;
-    for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
-      uint32_t u = f2ord(v[i]);
-      if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
+    // wave-aggregated histogram: the scores of a level share their leading digits, so plain per-element LDS atomics all
+    // hit two or three bins and serialise (session C: 390 us for 380 k scores, one workgroup per sample, on the head's
+    // critical path).  The lanes of a wave that hold the same digit are found with 8 ballots; one lane adds their count.
+    for (int b0 = r0; b0 < r1; b0 += blockDim.x) {
+      const int i = b0 + threadIdx.x;
+      uint32_t u = (i < r1) ? f2ord(v[i]) : 0u;
+      const bool live = (i < r1) && ((u & pmask) == prefix);
+      const int d = (int)((u >> shift) & 255);
+      unsigned long long m = __ballot(live);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        unsigned long long bal = __ballot((d >> b) & 1);
+        m &= ((d >> b) & 1) ? bal : ~bal;
+      }
+      const int lane = threadIdx.x & 63;
+      if (live && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&hist[d], (unsigned int)__popcll(m));
     }
     __syncthreads();
     if (threadIdx.x == 0) {

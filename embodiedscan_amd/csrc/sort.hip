@@ -49,10 +49,26 @@ __global__ __launch_bounds__(256) void k_rs_hist_all(const uint64_t* __restrict_
   __shared__ unsigned int h[RS_PASSES * 256];
   for (int e = threadIdx.x; e < RS_PASSES * 256; e += 256) h[e] = 0;
   __syncthreads();
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    uint64_t k = keys[i];
+  // (digits on which a whole wave agrees -- batch bits, constant coordinate bits: most of the upper passes -- cost one LDS atomic
+  // per wave instead of 64 serialised ones on the same bin)
+  for (int b0 = blockIdx.x * 256; b0 < n; b0 += gridDim.x * 256) {
+    const int i = b0 + threadIdx.x;
+    const bool ok = i < n;
+    const uint64_t k = ok ? keys[i] : 0ull;
+    const unsigned long long act = __ballot(ok);
+    const int lane = threadIdx.x & 63;
+    const int first = __ffsll((long long)act) - 1;            // lowest valid lane of this wave (-1: none)
 #pragma unroll
-    for (int p = 0; p < RS_PASSES; ++p) atomicAdd(&h[p * 256 + (int)((k >> (8 * p)) & 255)], 1u);
+    for (int p = 0; p < RS_PASSES; ++p) {
+      const int d = (int)((k >> (8 * p)) & 255);
+      const int d0 = __shfl(d, first < 0 ? 0 : first, 64);
+      const unsigned long long same = __ballot(ok && d == d0);
+      if (same == act) {
+        if (lane == first) atomicAdd(&h[p * 256 + d0], (unsigned int)__popcll(act));
+      } else if (ok) {
+        atomicAdd(&h[p * 256 + d], 1u);
+      }
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < RS_PASSES * 256; e += 256)
@@ -88,8 +104,16 @@ __global__ __launch_bounds__(256) void k_rs_count(const uint64_t* __restrict__ b
   __syncthreads();
   const int t0 = blockIdx.x * RS_TILE;
   for (int r = 0; r < RS_TILE / 256; ++r) {
-    int i = t0 + r * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&h[(int)((keys[i] >> (8 * pass)) & 255)], 1u);
+    const int i = t0 + r * 256 + threadIdx.x;
+    const bool ok = i < n;
+    const int d = ok ? (int)((keys[i] >> (8 * pass)) & 255) : 0;
+    unsigned long long m = __ballot(ok);                    // wave-aggregated: lanes with the same digit add once
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      unsigned long long bal = __ballot((d >> b) & 1);
+      m &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    if (ok && (m & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull) atomicAdd(&h[d], (unsigned int)__popcll(m));
   }
   __syncthreads();
   table[(size_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];

@@ -121,11 +121,20 @@ __global__ __launch_bounds__(1024) void k_tg_select(const float* __restrict__ ce
     for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t prefix = s_prefix;
-    for (int i = lb + threadIdx.x; i < le; i += blockDim.x) {
-      float v = cg[i];
-      if (v < 0.f) continue;
-      uint32_t u = f2ord_t(v);
-      if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
+    for (int b0 = lb; b0 < le; b0 += blockDim.x) {         // wave-aggregated histogram (see k_topk_mask, rowops.hip)
+      const int i = b0 + threadIdx.x;
+      const float v = (i < le) ? cg[i] : -1.f;
+      const uint32_t u = f2ord_t(v);
+      const bool live = (i < le) && !(v < 0.f) && ((u & pmask) == prefix);
+      const int d = (int)((u >> shift) & 255);
+      unsigned long long m = __ballot(live);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        unsigned long long bal = __ballot((d >> b) & 1);
+        m &= ((d >> b) & 1) ? bal : ~bal;
+      }
+      const int lane = threadIdx.x & 63;
+      if (live && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&hist[d], (unsigned int)__popcll(m));
     }
     __syncthreads();
     if (threadIdx.x == 0) {
