@@ -25,8 +25,9 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
-ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_wgrad',
-          'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src'}
+ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_fwd_bf16_io',
+          'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src'}
+FWD_X = ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_io')     # (X, x_half, ldx, W, nbr, n_out, n_in, K, Cin, Cout, ...)
 SCATTER = {'es_voxel_keys', 'es_unique_first', 'es_morton_sort', 'es_stride_keys', 'es_kernel_map', 'es_inverse_map',
            'es_union_plan', 'es_point_sample_fwd', 'es_point_sample_bwd', 'es_depth_to_points'}
 
@@ -598,7 +599,7 @@ def resolve_pairs(hip, records):
         if name == 'es_spconv_wgrad_bf16_src':
             key = a[6]
         elif name in ENGINE:
-            key = a[4] if (name.startswith('es_spconv_wgrad') or name in ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws')) else a[3]
+            key = a[4] if (name.startswith('es_spconv_wgrad') or name in FWD_X) else a[3]
         out.append((name, e0, e1, a, hip.PAIRS.get(key)))
     return out
 
@@ -606,7 +607,7 @@ def resolve_pairs(hip, records):
 def engine_args(name, a):
     if name == 'es_spconv_wgrad_bf16_src':      # (X, x_half, ldx, dY, dy_half, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream)
         return a[6], a[7], a[8], a[9], a[10], a[11]
-    if name in ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws'):
+    if name in FWD_X:
         return a[4], a[5], a[6], a[7], a[8], a[9]
     if not name.startswith('es_spconv_wgrad'):
         return a[3], a[4], a[5], a[6], a[7], a[8]
@@ -633,8 +634,10 @@ def engine_totals(records, mfma_peak):
         bx = by = 4.0
         if name == 'es_spconv_wgrad_bf16_src':
             bx, by = (2.0 if a[1] else 4.0), (2.0 if a[4] else 4.0)
-        elif name in ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws') and a[1]:
+        elif name in FWD_X and a[1]:
             bx = 2.0
+        if name == 'es_spconv_fwd_bf16_io' and a[17]:           # bf16 activation rows written by the image backbone
+            by = 2.0
         cb = float(n_in) * cin * bx + float(n_out) * cout * by + float(K) * cin * cout * (8.0 if wgrad else wb)
         tm, th = f / (mfma_peak * 1e12), cb / (K_PEAK_HBM * 1e9)
         flop, pair_b, comp_b = flop + f, pair_b + pb, comp_b + cb
