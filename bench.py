@@ -424,6 +424,9 @@ def run_other_config(kind, args, dev):
     hip.PROFILE = None
     peak = K_PEAK_MFMA[args.precision]
     eng = engine_totals([r for r in recs if r[0] in ENGINE], peak)
+    tok_timed = None
+    if kind == 'grounding':                   # token counts of the batch the LAST TIMED step ran on (the extra step below rotates on)
+        tok_timed = (det.last_queries['klen'].cpu().tolist(), det.last_text['mask'].sum(1).cpu().tolist(), det.neck_3d.last['Lmax'])
     # one extra untimed step on the single-stream schedule: stage times and stand-alone launch durations
     saved = (E.TWO_STREAMS[0], E.WGRAD_ASYNC[0])
     E.TWO_STREAMS[0] = E.WGRAD_ASYNC[0] = False
@@ -454,7 +457,7 @@ def run_other_config(kind, args, dev):
         tl = det.last_text['mask'].sum(1).cpu().tolist()
         Lmax = det.neck_3d.last['Lmax']
         att = attention_totals(r1, klen, tl, Lmax)              # stand-alone durations (single-stream step)
-        att_c = attention_totals(recs, klen, tl, Lmax)          # under the concurrent schedule of the timed step
+        att_c = attention_totals(recs, *tok_timed)              # under the concurrent schedule of the timed step
         tfl = att['tflops']
         roofline = dict(bound='mfma', achieved=tfl, peak=peak, unit='TFLOP/s', frac=round(tfl / peak, 5), traffic=traffic,
                         kernel='attention: k_attn_fwd + k_attn_bwd_dq + k_attn_bwd_dkv (+ k_attn_delta), head_dim 32, 8 heads',

@@ -3,7 +3,7 @@ import sqlite3
 import sys
 
 
-def main(db_path, out_path=None, top=60):
+def main(db_path, out_path=None, top=400):
     db = sqlite3.connect(db_path)
     rows = db.execute('select kernel_name, counter_name, sum(value), count(*), sum(duration) from counters_collection '
                       'group by kernel_name, counter_name').fetchall()
