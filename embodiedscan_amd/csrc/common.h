@@ -75,3 +75,12 @@ __device__ inline int es_wave_max_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// two floats -> packed bf16x2, round to nearest even (v_cvt_pk_bf16_f32): the one conversion every bf16 row / shadow uses
+__device__ inline uint32_t es_pack_bf16(float a, float b) {
+  typedef float es_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 es_bf16x2 __attribute__((ext_vector_type(2)));
+  es_f32x2 x = {a, b};
+  es_bf16x2 y = __builtin_convertvector(x, es_bf16x2);
+  return *(uint32_t*)&y;
+}

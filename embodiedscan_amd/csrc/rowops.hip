@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_norm_apply4(const float* __restrict__ x
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      const float* __restrict__ res, int ldr, int act,
-                                                     float* __restrict__ y, int ldy) {
+                                                     float* __restrict__ y, int ldy, unsigned short* __restrict__ yh) {
   const int C4 = C >> 2;
   const size_t tot = (size_t)n * C4, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < tot; e0 += 2 * stride) {
@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) void k_norm_apply4(const float* __restrict__ x
       float z0 = (xv.x - m.x) * is.x * ww.x + bb.x, z1 = (xv.y - m.y) * is.y * ww.y + bb.y;                    \
       float z2 = (xv.z - m.z) * is.z * ww.z + bb.z, z3 = (xv.w - m.w) * is.w * ww.w + bb.w;                    \
       if (res) { z0 += qv.x; z1 += qv.y; z2 += qv.z; z3 += qv.w; }                                             \
-      *(float4*)(y + (size_t)r * ldy + c) = make_float4(act_fwd(z0, act), act_fwd(z1, act), act_fwd(z2, act), act_fwd(z3, act)); \
+      z0 = act_fwd(z0, act); z1 = act_fwd(z1, act); z2 = act_fwd(z2, act); z3 = act_fwd(z3, act);             \
+      *(float4*)(y + (size_t)r * ldy + c) = make_float4(z0, z1, z2, z3);                                       \
+      if (yh) *(uint2*)(yh + (size_t)r * C + c) = make_uint2(es_pack_bf16(z0, z1), es_pack_bf16(z2, z3));      \
     }
     NA_ONE(x0, q0, r0, c0)
     if (v1) NA_ONE(x1, q1, r1, c1)
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void k_norm_apply4(const float* __restrict__ x
 extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg_off, int nseg, float eps,
                            const float* weight, const float* bias, const float* res, int ldr, int act,
                            float* running_mean, float* running_var, float momentum, float* mean, float* invstd,
-                           float* workspace, float* y, int ldy, void* stream) {
+                           float* workspace, float* y, int ldy, void* y_bf16, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0 || nseg > ES_MAX_SEG) return nseg > ES_MAX_SEG ? -3 : 0;
   Segs s = make_segs(seg_off, nseg);
@@ -209,12 +211,13 @@ extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg
     int g = es_cdiv((long long)n * (C >> 2), 512);
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(k_norm_apply4, dim3(g < 1 ? 1 : g), dim3(256), 0, st, x, ldx, n, C, s, mean, invstd, weight, bias,
-                       res, ldr, act, y, ldy);
+                       res, ldr, act, y, ldy, (unsigned short*)y_bf16);
   } else {
     int g = es_cdiv((long long)n * C, 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_norm_apply, dim3(g), dim3(256), 0, st, x, ldx, n, C, s, mean, invstd, weight, bias, res,
                        ldr, act, y, ldy);
+    if (y_bf16) return es_cast_rows_bf16(y, ldy, n, C, y_bf16, stream);
   }
   ES_CHECK_LAUNCH();
   return 0;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply4(const float* __restrict
                                                          const float* __restrict__ invstd, const float* __restrict__ w,
                                                          const float* __restrict__ sum_dz,
                                                          const float* __restrict__ sum_dzx, float* __restrict__ dx,
-                                                         int ldo, int accumulate) {
+                                                         int ldo, int accumulate, unsigned short* __restrict__ dxh) {
   const int C4 = C >> 2;
   const size_t tot = (size_t)n * C4, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t e0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < tot; e0 += 2 * stride) {
@@ -400,6 +403,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply4(const float* __restrict
       NB_ELT(xv.x, gv.x, ov.x, m.x, is.x, ww.x, sd.x, sq.x) NB_ELT(xv.y, gv.y, ov.y, m.y, is.y, ww.y, sd.y, sq.y) \
       NB_ELT(xv.z, gv.z, ov.z, m.z, is.z, ww.z, sd.z, sq.z) NB_ELT(xv.w, gv.w, ov.w, m.w, is.w, ww.w, sd.w, sq.w) \
       *(float4*)(dx + (size_t)r * ldo + c) = ov;                                                               \
+      if (dxh) *(uint2*)(dxh + (size_t)r * C + c) = make_uint2(es_pack_bf16(ov.x, ov.y), es_pack_bf16(ov.z, ov.w)); \
     }
     NB_ONE(x0, g0, o0, r0, c0)
     if (v1) NB_ONE(x1, g1, o1, r1, c1)
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply4(const float* __restrict
 extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const float* x, int ldx, int n, int C,
                            const int* seg_off, int nseg, const float* mean, const float* invstd,
                            const float* weight, int act, float* dweight, float* dbias, float* workspace, float* dx,
-                           int ldo, int accumulate, void* stream) {
+                           int ldo, int accumulate, void* dx_bf16, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0 || nseg > ES_MAX_SEG) return nseg > ES_MAX_SEG ? -3 : 0;
   Segs s = make_segs(seg_off, nseg);
@@ -431,12 +435,13 @@ extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const fl
     int g = es_cdiv((long long)n * (C >> 2), 512);
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(k_norm_bwd_apply4, dim3(g < 1 ? 1 : g), dim3(256), 0, st, dy, ldd, x, ldx, n, C, s, mean, invstd,
-                       weight, sums, sums + (size_t)nseg * C, dx, ldo, accumulate);
+                       weight, sums, sums + (size_t)nseg * C, dx, ldo, accumulate, (unsigned short*)dx_bf16);
   } else {
     int g = es_cdiv((long long)n * C, 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_norm_bwd_apply, dim3(g), dim3(256), 0, st, dy, ldd, x, ldx, n, C, s, mean, invstd, weight,
                        sums, sums + (size_t)nseg * C, dx, ldo, accumulate);
+    if (dx_bf16) return es_cast_rows_bf16(dx, ldo, n, C, dx_bf16, stream);
   }
   ES_CHECK_LAUNCH();
   return 0;

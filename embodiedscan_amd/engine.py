@@ -19,11 +19,12 @@ def _stream():
 class Var:
     """A row matrix (N, C) f32 on the device with an optional gradient (and lazily made bf16 shadows of both, the
     gather sources of the bf16 convolution kernels)."""
-    __slots__ = ('d', 'g', 'rg', 'dh', 'gh', 'gate', 'gated')
+    __slots__ = ('d', 'g', 'rg', 'dh', 'gh', 'gate', 'gated', 'fresh')
 
     def __init__(self, d, rg=True):
         self.d, self.g, self.rg = d, None, rg
         self.dh = self.gh = None
+        self.fresh = False      # True between conv() and the norm() that consumes its output (nobody else sees this Var)
         self.gate = None        # folded-BN scale of the fused conv+BN+ReLU that produced this Var (see conv_affine)
         self.gated = False      # True: .g already is the gradient w.r.t. the producer's (pre-BN) conv output
 
@@ -302,6 +303,7 @@ def _cast_rows(t):
     return h
 
 
+NORM_SHADOW = [os.environ.get('ES_NORM_SHADOW', '1') != '0']     # norm apply passes write the bf16 shadows of their outputs
 WGRAD_SHADOW = [os.environ.get('ES_WGRAD_SHADOW', '1') != '0']   # weight-gradient launches gather from the bf16 shadows too
 DET_SPLIT = [os.environ.get('ES_DET_SPLIT', '1') != '0']   # deterministic tap split (workspace + fixed-order reduction)
 
@@ -346,6 +348,7 @@ def _ld(t):
 
 def _grad_target(v, shape_like):
     """(tensor, accumulate flag) for writing the gradient of v."""
+    v.gh = None                                       # whatever shadow of the gradient exists is about to go stale
     if v.g is None:
         v.g = torch.empty(shape_like.shape, dtype=torch.float32, device=shape_like.device)    # gradients are f32 rows
         return v.g, 0
@@ -377,6 +380,8 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
             DEBUG_GRADS[id(y)] = y.g.clone()
         _conv_backward(x, w, nbr, inv, n_out, y, y.g, bias, bias_from, need_dx, bf)
     TAPE.add(bwd)
+    x.fresh = False
+    y.fresh = True
     return y
 
 
@@ -544,9 +549,16 @@ def norm(x, weight, bias, seg_off, eps, act=0, res=None, running=None, momentum=
     mean, invstd = empty((nseg, C), x.d), empty((nseg, C), x.d)
     y = Var(empty((n, C), x.d))
     rm, rv = (running if running is not None else (None, None))
+    # bf16 mode: the apply passes also write the bf16 gather shadows their consumers would otherwise make with a cast launch
+    # each (forward: of y, for the next convolution; backward: of the gradient handed to the producing convolution, when this
+    # norm is that Var's only consumer) -- bit-identical to the casts they replace
+    fuse = NORM_SHADOW[0] and PRECISION[0] == 'bf16' and SHADOW[0] and C >= 16 and C % 8 == 0
+    private, x.fresh = bool(x.fresh), False
+    if fuse:
+        y.dh = empty((n, C), x.d, dtype=torch.bfloat16)
     call('es_norm_fwd', P(x.d), _ld(x.d), n, C, so, nseg, float(eps), P(weight.d), P(bias.d),
          P(res.d) if res is not None else 0, _ld(res.d) if res is not None else 0, act, P(rm), P(rv), float(momentum),
-         P(mean), P(invstd), P(ws), P(y.d), C, _stream())
+         P(mean), P(invstd), P(ws), P(y.d), C, P(y.dh) if fuse else 0, _stream())
 
     def bwd():
         if y.g is None:
@@ -556,8 +568,10 @@ def norm(x, weight, bias, seg_off, eps, act=0, res=None, running=None, momentum=
             DEBUG_GRADS[id(y)] = y.g.clone()
         ws2 = empty((ws_n,), x.d)
         g, acc = _grad_target(x, x.d)
+        gh = empty((n, C), x.d, dtype=torch.bfloat16) if (fuse and private and _ld(g) == C) else None
         call('es_norm_bwd', P(y.g), _ld(y.g), P(y.d), C, P(x.d), _ld(x.d), n, C, so, nseg, P(mean), P(invstd),
-             P(weight.d), act, P(weight.g), P(bias.g), P(ws2), P(g), _ld(g), acc, s)
+             P(weight.d), act, P(weight.g), P(bias.g), P(ws2), P(g), _ld(g), acc, P(gh), s)
+        x.gh = gh
         if DEBUG_GRADS is not None:
             DEBUG_GRADS[('norm', id(y))] = dict(dx=g.clone(), dz=y.g.clone(), mean=mean.clone(), invstd=invstd.clone(),
                                                 x=x.d.clone(), yd=y.d.clone(), acc=acc, n=n, C=C, act=act)

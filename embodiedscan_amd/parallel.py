@@ -3,14 +3,23 @@ processes its own scans end to end; the only collectives are the all-reduce of t
 from markers on the backward tape so that they travel under the rest of the backward pass) and ONE all-reduce of the
 per-sample positive counts (the reference issues `reduce_mean` once per sample inside a Python loop,
 embodiedscan/utils/dist_utils.py:4-10 called from dense_heads/fcaf3d_head.py:1183).
-Backend: "nccl" (== RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests.  No RCCL run of this code exists yet (the
-driver's scaling bench is the first); it is covered by 2-rank gloo tests."""
+Backend: "nccl" (== RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests.  Covered by 2-rank gloo tests (CPU, and two
+ranks sharing one GPU: profiles/r3_bench_2ranks_gloo_one_gpu.json) and by a one-rank RCCL run of the forced data-parallel path
+on the GPU box (tests/test_gpu_zz_rccl.py); a multi-GPU RCCL run is the driver's scaling bench."""
+import os
+
 import torch
 import torch.distributed as dist
 
+# ES_FORCE_DIST=1 (or FORCE_DIST[0] = True): take the data-parallel path in a ONE-rank process group as well.  Every collective is
+# then the identity, so the step must reproduce the single-process step bit for bit -- which is how the exchange code (async
+# bucket all-reduces on arena slices, the side-stream clip norm, reduce_mean) is exercised on real RCCL on a one-GPU box
+# (tests/test_gpu_zz_rccl.py).
+FORCE_DIST = [os.environ.get('ES_FORCE_DIST', '0') == '1']
+
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_DIST[0])
 
 
 def allreduce_mean_(flat):

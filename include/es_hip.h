@@ -85,7 +85,10 @@ int es_spconv_fwd_bf16_ws(const void* X, int x_is_bf16, int ldx, const void* W_b
 int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout);
 /* run-time tuning switches for A/B measurements: key 1 = ping-pong LDS buffers in the fast bf16 kernels (default 1),
  * key 2 = 256x256 weight-gradient tile for layers with C_in, C_out multiples of 256 and bf16-shadow operands (default 1),
- * key 3 = streaming row-GEMM kernel for K = 1 launches on the identity map (default 1) */
+ * key 3 = streaming row-GEMM kernel for K = 1 launches on the identity map (default 1),
+ * keys 4-8 = weight-gradient slice targets / workspace cap / forward tap-split threshold (spconv.hip, options block),
+ * key 10 = LDS-DMA staging (global_load_lds) in the fast bf16 kernels for bf16 input rows: 0 off, 1 = 32-channel chunks,
+ * 2 = 64-channel chunks where C_in % 64 == 0 -- bit-identical results in every mode (tests/test_gpu_dma.py) */
 int es_set_option(int key, int value);
 /* Y = act((X*W) * scale[c] + shift[c] (+ res)): conv2d + frozen BatchNorm2d (+ residual) (+ ReLU) of mmdet.ResNet in one
  * launch (any shape; the tap-split of under-filled launches is not applied to fused calls).  act: 0 none, 1 ReLU,
@@ -141,12 +144,14 @@ size_t es_norm_workspace_floats(int n, int C, const int* seg_off_host, int nseg)
 int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg_off_host, int nseg, float eps,
                 const float* weight, const float* bias, const float* res, int ldr, int act, float* running_mean,
                 float* running_var, float momentum, float* mean, float* invstd, float* workspace, float* y, int ldy,
-                void* stream);
-/* dy is overwritten with the pre-activation gradient (== gradient of the residual input). */
+                void* y_bf16, void* stream);
+/* y_bf16 / dx_bf16 (0 = none): a dense (n, C) bf16 copy of the rows the apply pass has just computed, written by the same
+ * pass -- the gather source ("shadow") of the bf16 convolution that consumes them; bit-identical to es_cast_rows_bf16 of
+ * y / dx.  dy is overwritten with the pre-activation gradient (== gradient of the residual input). */
 int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const float* x, int ldx, int n, int C,
                 const int* seg_off_host, int nseg, const float* mean, const float* invstd, const float* weight,
                 int act, float* dweight, float* dbias, float* workspace, float* dx, int ldo, int accumulate,
-                void* stream);
+                void* dx_bf16, void* stream);
 /* MinkowskiMaxPooling(k=2,s=2) and the 2-D stem max-pool.  mink_resnet.py:66-69 */
 int es_maxpool_fwd(const float* x, int ldx, const int* nbr, int n_out, int K, int C, float* y, int* arg, void* stream);
 /* forward-only variant writing bf16 rows (the frozen stem pooling of the image backbone: nn.MaxPool2d(3, 2, 1)) */

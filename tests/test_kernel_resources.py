@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'embodiedscan_amd', 'csrc')
 HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-munsafe-fp-atomics',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',         # = csrc/Makefile
          '-Wno-unused-result', '-Rpass-analysis=kernel-resource-usage']
 
 # (source, substring of the mangled kernel name) -> minimum waves/SIMD
@@ -21,6 +21,8 @@ FLOORS = {
     ('spconv.hip', 'k_spconv_wgrad_bf16_big'): 3,
     ('spconv.hip', '19k_spconv_wgrad_bf16IL'): 6,
     ('rowops.hip', 'k_norm_stats'): 8,
+    ('spconv.hip', 'k_spconv_bf16_dmaILi128ELi1'): 3,      # 46 KB of LDS: three workgroups per CU
+    ('spconv.hip', 'k_spconv_bf16_dmaILi128ELi2'): 2,      # 78 KB: two
 }
 
 # kernels that are KNOWN to use scratch memory today (anything else spilling is a regression)
@@ -51,7 +53,7 @@ def _resources(src):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
 @pytest.mark.parametrize('src', ['spconv.hip', 'rowops.hip', 'losses.hip', 'targets.hip', 'coords.hip', 'fusion.hip',
                                  'optim.hip', 'data.hip', 'predict.hip', 'dense.hip', 'occ.hip', 'transformer.hip',
-                                 'ground.hip'])      # sort.hip is rocPRIM's radix sort
+                                 'ground.hip', 'sort.hip'])
 def test_no_spills_and_occupancy_floors(src):
     ks = _resources(src)
     assert ks, 'no kernel-resource-usage remarks parsed'
@@ -59,7 +61,7 @@ def test_no_spills_and_occupancy_floors(src):
         if any(k in name for k in KNOWN_SCRATCH):
             continue
         assert r.get('ScratchSize', 0) == 0 and r.get('VGPRs Spill', 0) == 0 and r.get('SGPRs Spill', 0) == 0, (name, r)
-        assert r.get('LDS Size', 0) <= 64 * 1024, (name, r)
+        assert r.get('LDS Size', 0) <= 80 * 1024, (name, r)        # two workgroups per CU at least (160 KB of LDS per CU)
     for (s, key), floor in FLOORS.items():
         if s != src:
             continue

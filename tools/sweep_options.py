@@ -17,6 +17,9 @@ def main():
     ap.add_argument('--steps', type=int, default=12)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='mv3ddet', choices=['mv3ddet', 'occupancy'])
+    ap.add_argument('--variants', default=None,
+                    help='semicolon-separated variants, each a comma-separated list of key=value for es_set_option, e.g. '
+                         '"10=1;10=2;10=2,8=192": only these (each bracketed by the defaults) instead of the full sweep')
     args = ap.parse_args()
     import torch
     import bench as B
@@ -64,6 +67,26 @@ def main():
     names = {4: 'wgrad big target', 5: 'wgrad big min rows', 6: 'wgrad small target', 7: 'wgrad ws cap MB', 8: 'fwd split wgs'}
     run('default (first)')
     run('default (again)')
+    if args.variants:
+        base = dict(defaults)
+        base[10] = 0
+        for var in args.variants.split(';'):
+            kv = [tuple(p.split('=')) for p in var.split(',') if p]
+            old = {}
+            for k, v in kv:
+                if k.isdigit():                       # es_set_option key
+                    hip.raw('es_set_option')(int(k), int(v))
+                else:                                 # engine flag (a one-element list), e.g. NORM_SHADOW=0, ACT16=0
+                    old[k] = getattr(E, k)[0]
+                    getattr(E, k)[0] = bool(int(v))
+            run('options ' + var)
+            for k, _ in kv:
+                if k.isdigit():
+                    hip.raw('es_set_option')(int(k), base[int(k)])
+                else:
+                    getattr(E, k)[0] = old[k]
+            run('default (after ' + var + ')')
+        return
     if occ:
         hip.raw('es_set_option')(2, 0)
         run('256 x 256 weight-gradient tile OFF')
