@@ -176,27 +176,33 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # time EXACTLY `steps` steps; the convolution engine launches of the last timed step are bracketed by HIP events
+    # time EXACTLY `steps` steps; the convolution engine launches of ONE EXTRA step after them are bracketed by HIP events
     # recorded on the stream each kernel is launched on (the step runs on four compute streams + the copy stream)
     prof = {'names': ENGINE, 'records': [], 'event': lambda: torch.cuda.Event(enable_timing=True)}
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     step_ev[0].record()
     t0 = time.perf_counter()
     for it in range(args.steps):
-        # (2 events per launch and one pair counter per kernel map cost ~3 ms of host time, so only the last step)
-        hip.PROFILE = prof if it == args.steps - 1 else None
-        red = getattr(det.arena, 'reducer', None)
-        if red is not None:
-            red.profile = [] if it == args.steps - 1 else None    # N > 1: how long the optimiser waits for each gradient bucket
-        losses = step()
+        losses = step()                                         # no instrumentation of any kind inside the timed region
         step_ev[it + 1].record()                                # end of the step's main-stream work (no sync)
-    recs = resolve_pairs(hip, prof['records'])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # one extra UNTIMED step on the same (four-stream) schedule with every engine launch bracketed by HIP events (2 events per
+    # launch and a pair counter per kernel map cost ~3 ms of host time, and instrumented launches cannot be replayed from the
+    # image backbone's hipGraph -- so this step is kept out of the timed region since round 3)
+    hip.PROFILE = prof
+    red = getattr(det.arena, 'reducer', None)
+    if red is not None:
+        red.profile = []                                        # N > 1: how long the optimiser waits for each gradient bucket
+    step()
+    recs = resolve_pairs(hip, prof['records'])
+    torch.cuda.synchronize()
     hip.PROFILE = None
+    if red is not None:
+        prof_red, red.profile = red.profile, None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     in_sync = True
     rank_ms = None
@@ -250,6 +256,14 @@ def main():
                            'durations); rocprofv3 summary of this schedule: profiles/r3_single_stream_kernel_stats.txt')
         scatter = scatter_totals([r for r in r1 if r[0] in SCATTER])
         classes = launch_classes(r1, mfma_peak)
+        if os.environ.get('ES_BENCH_DUMP'):                     # dev: every engine launch of the single-stream step, in order
+            with open(os.environ['ES_BENCH_DUMP'], 'w') as f:
+                for name, ev0, ev1, a, _ in r1:
+                    if name in ENGINE:
+                        nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
+                        f.write(json.dumps(dict(fn=name, K=K, cin=cin, cout=cout, n_out=n_out, n_in=n_in, map=bool(nbr),
+                                                us=round(ev0.elapsed_time(ev1) * 1e3, 1),
+                                                args=[x for x in a if isinstance(x, int) and abs(x) < (1 << 31)])) + '\n')
         stages = {}
         for (n0, ev0), (n1, ev1) in zip(marks[:-1], marks[1:]):
             stages[n1] = round(stages.get(n1, 0.0) + ev0.elapsed_time(ev1), 3)
@@ -290,7 +304,8 @@ def main():
                          'sum of binding-roof times / sum of HIP-event launch durations; bound/achieved/peak/frac = the '
                          'roof that binds the family in total; durations are HIP-event times on the launch stream under the '
                          'concurrent 4-stream schedule (kernels of different streams share the chip, so the sum exceeds wall '
-                         'time); classes = the top engine launch classes of the single-stream step (stand-alone durations); '
+                         'time), taken on ONE EXTRA untimed step right after the timed ones -- per-launch events cost ~3 ms of '
+                         'host time and keep the image backbone off its hipGraph, so the timed steps carry no instrumentation; classes = the top engine launch classes of the single-stream step (stand-alone durations); '
                          + traffic_note)
 
     out = dict(metric='scans/sec (train step) mv-3ddet, 20x(480x640) RGB-D views', value=round(world * args.batch * args.steps / dt, 4),
@@ -311,18 +326,18 @@ def main():
     if world > 1:
         out['replicas_in_sync'] = in_sync
         out['rank_ms_per_step'] = rank_ms
-        red = getattr(det.arena, 'reducer', None)
-        if red is not None and red.profile:
+        if red is not None and prof_red:
             exposed, mb = {}, {}
-            for part, floats, e0, e1 in red.profile:
+            for part, floats, e0, e1 in prof_red:
                 exposed[part] = round(exposed.get(part, 0.0) + e0.elapsed_time(e1), 3)
                 mb[part] = round(mb.get(part, 0.0) + floats * 4 / 2 ** 20, 1)
             out['allreduce_exposed_ms'] = dict(per_part={str(k): v for k, v in sorted(exposed.items())},
                                                MiB_per_part={str(k): v for k, v in sorted(mb.items())},
-                                               note='rank 0, last timed step: time the compute stream stalls in the optimiser waiting for each '
+                                               note='rank 0, the extra instrumented step: time the compute stream stalls in the optimiser waiting for each '
                                                     'gradient part (0 = 2-D backbone, 1 = 3-D backbone, 2 = head; launched from tape markers '
                                                     'in backward-completion order 2, 1, 0; the clip norm is taken per bucket behind its all-reduce)')
-    # GPU-side duration of each timed step (events on the main stream; the last one carries the launch profiling)
+    out['hipgraph'] = dict(E.GRAPH_STATS, what='image-backbone forward sequences (engine.graphed): captured / replayed / run eagerly')
+    # GPU-side duration of each timed step (events on the main stream)
     out['step_ms'] = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(args.steps)]
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'], out['parity'] = cpu_baseline(scans[0], sd0, det, parity_hip, args)
@@ -415,17 +430,19 @@ def run_other_config(kind, args, dev):
     step_ev[0].record()
     t0 = time.perf_counter()
     for it in range(steps):
-        hip.PROFILE = prof if it == steps - 1 else None
         losses = step()
         step_ev[it + 1].record()
-    recs = resolve_pairs(hip, prof['records'])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    hip.PROFILE = prof                          # one extra untimed step under the same schedule, every engine launch bracketed
+    step()
+    recs = resolve_pairs(hip, prof['records'])
+    torch.cuda.synchronize()
     hip.PROFILE = None
     peak = K_PEAK_MFMA[args.precision]
     eng = engine_totals([r for r in recs if r[0] in ENGINE], peak)
     tok_timed = None
-    if kind == 'grounding':                   # token counts of the batch the LAST TIMED step ran on (the extra step below rotates on)
+    if kind == 'grounding':                   # token counts of the batch the instrumented step ran on (the next extra step rotates on)
         tok_timed = (det.last_queries['klen'].cpu().tolist(), det.last_text['mask'].sum(1).cpu().tolist(), det.neck_3d.last['Lmax'])
     # one extra untimed step on the single-stream schedule: stage times and stand-alone launch durations
     saved = (E.TWO_STREAMS[0], E.WGRAD_ASYNC[0])
@@ -457,7 +474,7 @@ def run_other_config(kind, args, dev):
         tl = det.last_text['mask'].sum(1).cpu().tolist()
         Lmax = det.neck_3d.last['Lmax']
         att = attention_totals(r1, klen, tl, Lmax)              # stand-alone durations (single-stream step)
-        att_c = attention_totals(recs, *tok_timed)              # under the concurrent schedule of the timed step
+        att_c = attention_totals(recs, *tok_timed)              # under the concurrent schedule (instrumented extra step)
         tfl = att['tflops']
         roofline = dict(bound='mfma', achieved=tfl, peak=peak, unit='TFLOP/s', frac=round(tfl / peak, 5), traffic=traffic,
                         kernel='attention: k_attn_fwd + k_attn_bwd_dq + k_attn_bwd_dkv (+ k_attn_delta), head_dim 32, 8 heads',

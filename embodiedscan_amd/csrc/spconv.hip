@@ -27,8 +27,15 @@ static int ES_OPT_WG_SMALL_TARGET = 4096;  // the same for the 64 x 64 tile
 static int ES_OPT_WG_CAP_MB = 256;         // workspace of partial tiles per launch (weights <= 8 M floats)
 static int ES_OPT_FWD_SPLIT_WGS = 384;     // forward / dgrad launches with fewer workgroups split their tap list (sweep, session F:
                                            // 192 -> 384 neutral on mv-3ddet, -0.8 ms on the occupancy step; 96: +3.5 / +4.7 ms)
-static int ES_OPT_DMA = 0;                 // LDS-DMA fast kernel (k_spconv_bf16_dma) for bf16 input rows: 0 off, 1 = 32-channel
-                                           // chunks, 2 = 64-channel chunks where C_in % 64 == 0
+static int ES_OPT_DMA = 2;                 // LDS-DMA fast kernel (k_spconv_bf16_dma) for bf16 input rows: 0 off, 1 = 32-channel
+                                           // chunks, 2 = 64-channel chunks where C_in % 64 == 0 ...
+static int ES_OPT_DMA_MIN_CIN = 768;       // ... for layers with at least this many input channels.  Session K (profiles/r3k_*): the
+                                           // dense occupancy neck (768 .. 3072 channels) runs 13.5 % faster with 64-channel DMA chunks
+                                           // (97.4 -> 84.3 ms per 7 steps, step 57.4 -> 56.1 ms); the 64 .. 256-channel sparse layers of
+                                           // mv-3ddet are equal within 2 % either way (LDS activity -62 %, no bank conflicts left, same
+                                           // MFMA busy: those launches are bound by the gather through L2, not by LDS)
+static int ES_OPT_ROWGEMM2 = 1;            // second-generation row GEMM (swapped MFMA operands, register epilogue with 16-byte accesses)
+static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
 extern "C" int es_set_option(int key, int value) {
   if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
   if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }
@@ -39,6 +46,9 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 7) { ES_OPT_WG_CAP_MB = value; return 0; }
   if (key == 8) { ES_OPT_FWD_SPLIT_WGS = value; return 0; }
   if (key == 10) { ES_OPT_DMA = value; return 0; }
+  if (key == 11) { ES_OPT_DMA_MIN_CIN = value; return 0; }
+  if (key == 12) { ES_OPT_RG128_MIN_CIN = value; return 0; }
+  if (key == 13) { ES_OPT_ROWGEMM2 = value; return 0; }
   return -2;
 }
 
@@ -1268,6 +1278,195 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
   }
 }
 
+// Second generation of the row GEMM (round 3, late).  tools/bench_rowgemm.py showed the kernel above at 0.8 .. 1.6 TB/s on the
+// OUTPUT-heavy launches (the 16->64 / 32->128 / 64->256 expansion convolutions of the image backbone with their bf16
+// residual, the head's 128->320 GEMM) where an elementwise pass over the same bytes runs at 5 .. 7 TB/s, and at 2 .. 5 TB/s on
+// the input-heavy ones: the time goes into the epilogue (64 ds_write_b32 + 16 ds_read_b128 per thread, three workgroup
+// barriers, 8-byte global accesses for bf16 rows, 2 waves per SIMD because 64 registers hold the prefetched residual).
+// Here the MFMA operands are SWAPPED -- the weight fragment is the A operand, the input rows the B operand -- so that a lane
+// ends up with output CHANNELS (kq * 4 + r) of ONE row (li) instead of rows of one channel; with the weight rows of a
+// fragment pair permuted (fragment 2p takes channels 32p + 8q + {0..3}, fragment 2p + 1 channels 32p + 8q + {4..7}) a lane
+// owns 8 consecutive channels of its row: one 16-byte store for bf16 rows, two for f32 rows, straight from the accumulators --
+// no LDS staging, no barrier after the k loop, the residual is prefetched in the same layout (16 bytes per 8 channels).
+template <int NT, bool XH>
+__global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ Xv, int ldx,
+                                                       const unsigned short* __restrict__ W, int n_out, int n_in, int Cin,
+                                                       int Cout, const float* __restrict__ bias, float* __restrict__ Y,
+                                                       int ldy, int accumulate, const float* __restrict__ ep_scale,
+                                                       const float* __restrict__ ep_shift,
+                                                       const float* __restrict__ ep_res, int ep_ldr, int ep_act, int io) {
+  static_assert(NT % 32 == 0, "fragment pairs");
+  const float* X = (const float*)Xv;
+  const unsigned short* Xh = (const unsigned short*)Xv;
+  constexpr int NF = NT / 16, NP = NT / 32;
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * NT * HLD];       // [2][NT][HLD]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * BM + wv * 32, n0 = blockIdx.y * NT;
+  const int n_rows = min(n_out, n_in);
+  if (n_rows <= 0) return;
+  f32x4 acc[2][NF];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int ns = (Cin + HBK - 1) / HBK;
+  float4 a00, a01, a10, a11;
+  uint4 bg0, bg1;
+  const int rowA0 = row0 + li, rowA1 = row0 + 16 + li;
+  const float* pa0 = X + (size_t)min(rowA0, n_rows - 1) * ldx + kq * 8;
+  const float* pa1 = X + (size_t)min(rowA1, n_rows - 1) * ldx + kq * 8;
+  const unsigned short* ph0 = Xh + (size_t)min(rowA0, n_rows - 1) * ldx + kq * 8;
+  const unsigned short* ph1 = Xh + (size_t)min(rowA1, n_rows - 1) * ldx + kq * 8;
+  const int abl = io >> 8;                                // dev ablation: 1 no stores, 2 no input-row loads, 4 no residual loads
+  const bool va0 = rowA0 < n_rows && !(abl & 2), va1 = rowA1 < n_rows && !(abl & 2);
+  const int bc0 = t >> 2, bq = t & 3;
+  const unsigned short* pb0 = W + (size_t)(n0 + (bc0 < NT ? bc0 : 0)) * Cin + bq * 8;
+  const unsigned short* pb1 = W + (size_t)(n0 + (NT > 64 ? 64 : 0) + bc0) * Cin + bq * 8;
+#define RG2_LOAD(s_)                                                                   \
+  do {                                                                                 \
+    const bool ka_ = (s_) * HBK + kq * 8 < Cin, kb_ = (s_) * HBK + bq * 8 < Cin;       \
+    a00 = a01 = a10 = a11 = make_float4(0.f, 0.f, 0.f, 0.f);                           \
+    bg0 = bg1 = make_uint4(0u, 0u, 0u, 0u);                                            \
+    if (XH) {                                                                          \
+      if (va0 && ka_) a00 = *(const float4*)(ph0 + (s_) * HBK);                        \
+      if (va1 && ka_) a10 = *(const float4*)(ph1 + (s_) * HBK);                        \
+    } else {                                                                           \
+      if (va0 && ka_) {                                                                \
+        const float4* q0_ = (const float4*)(pa0 + (s_) * HBK);                         \
+        a00 = q0_[0]; a01 = q0_[1];                                                    \
+      }                                                                                \
+      if (va1 && ka_) {                                                                \
+        const float4* q1_ = (const float4*)(pa1 + (s_) * HBK);                         \
+        a10 = q1_[0]; a11 = q1_[1];                                                    \
+      }                                                                                \
+    }                                                                                  \
+    if (kb_ && bc0 < NT) bg0 = *(const uint4*)(pb0 + (s_) * HBK);                      \
+    if (NT > 64 && kb_) bg1 = *(const uint4*)(pb1 + (s_) * HBK);                       \
+  } while (0)
+#define RG2_STORE_B(buf_)                                                              \
+  do {                                                                                 \
+    if (bc0 < NT) *(uint4*)&Bs[((buf_) * NT + bc0) * HLD + bq * 8] = bg0;              \
+    if (NT > 64) *(uint4*)&Bs[((buf_) * NT + 64 + bc0) * HLD + bq * 8] = bg1;          \
+  } while (0)
+  // this lane's output: row (mf * 16 + li), channels n0 + 32 p + 8 kq + {0 .. 7}
+  const int rowE0 = row0 + li, rowE1 = row0 + 16 + li;
+  const int colE = n0 + kq * 8;
+  // second operand of the epilogue (residual / gate rows, or Y itself when accumulating), requested before the k loop
+  const bool r16 = (io & ES_IO_R16) != 0;
+  const float* pre = ep_res ? ep_res : (accumulate ? Y : nullptr);
+  const int pre_ld = ep_res ? ep_ldr : ldy;
+  float4 pf[2][NP][2];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int p2 = 0; p2 < NP; ++p2) {
+      const int row = mf ? rowE1 : rowE0, col = colE + 32 * p2;
+      pf[mf][p2][0] = pf[mf][p2][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pre && row < n_out && !((io >> 8) & 4)) {
+        if (ep_res && r16) {                              // 8 bf16 = 16 bytes, kept as raw bits in [0]
+          pf[mf][p2][0] = *(const float4*)((const unsigned short*)ep_res + (size_t)row * pre_ld + col);
+        } else {
+          const float4* q = (const float4*)(pre + (size_t)row * pre_ld + col);
+          pf[mf][p2][0] = q[0];
+          pf[mf][p2][1] = q[1];
+        }
+      }
+    }
+  RG2_LOAD(0);
+  RG2_STORE_B(0);
+  __syncthreads();
+  // weight row this lane reads for fragment nf (as the A operand: lane li = output channel within the fragment)
+  const int wrow = (li >> 2) * 8 + (li & 3);              // + 32 * (nf >> 1) + 4 * (nf & 1)
+  for (int s = 0; s < ns; ++s) {
+    uint4 pk0, pk1;
+    if (XH) {
+      pk0 = make_uint4(__float_as_uint(a00.x), __float_as_uint(a00.y), __float_as_uint(a00.z), __float_as_uint(a00.w));
+      pk1 = make_uint4(__float_as_uint(a10.x), __float_as_uint(a10.y), __float_as_uint(a10.z), __float_as_uint(a10.w));
+    } else {
+      pk0 = make_uint4(pack_bf16(a00.x, a00.y), pack_bf16(a00.z, a00.w), pack_bf16(a01.x, a01.y), pack_bf16(a01.z, a01.w));
+      pk1 = make_uint4(pack_bf16(a10.x, a10.y), pack_bf16(a10.z, a10.w), pack_bf16(a11.x, a11.y), pack_bf16(a11.z, a11.w));
+    }
+    bf16x8_t fa0 = __builtin_bit_cast(bf16x8_t, pk0), fa1 = __builtin_bit_cast(bf16x8_t, pk1);
+    if (s + 1 < ns) RG2_LOAD(s + 1);
+    const unsigned short* Bc = Bs + (s & 1) * NT * HLD;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      bf16x8_t b = *(const bf16x8_t*)&Bc[(32 * (nf >> 1) + 4 * (nf & 1) + wrow) * HLD + kq * 8];
+      acc[0][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, fa0, acc[0][nf], 0, 0, 0);
+      acc[1][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, fa1, acc[1][nf], 0, 0, 0);
+    }
+    if (s + 1 < ns) RG2_STORE_B((s + 1) & 1);
+    if (s + 1 < ns) __syncthreads();
+  }
+#undef RG2_LOAD
+#undef RG2_STORE_B
+  // epilogue straight from the accumulators (no early exits inside the unrolled loops: a `continue` here kept pf[][][] in
+  // scratch memory -- 272 bytes per lane, and the kernel at half its speed)
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    const int row = mf ? rowE1 : rowE0;
+    const bool row_ok = row < n_out;
+#pragma unroll
+    for (int p2 = 0; p2 < NP; ++p2) {
+      const int col = colE + 32 * p2;
+      float v[8], q[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * p2][r]; v[4 + r] = acc[mf][2 * p2 + 1][r]; }
+      const float4 h0 = pf[mf][p2][0], h1 = pf[mf][p2][1];
+      if (ep_res && r16) {
+        const uint32_t u[4] = {__float_as_uint(h0.x), __float_as_uint(h0.y), __float_as_uint(h0.z), __float_as_uint(h0.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { q[2 * e] = __uint_as_float(u[e] << 16); q[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
+      } else {
+        q[0] = h0.x; q[1] = h0.y; q[2] = h0.z; q[3] = h0.w; q[4] = h1.x; q[5] = h1.y; q[6] = h1.z; q[7] = h1.w;
+      }
+      // per-channel epilogue constants: 8 consecutive channels = two 16-byte loads each (L1 / L2 hits)
+      float bb[8], sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { bb[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
+      if (bias) {
+        const float4 t0 = *(const float4*)(bias + col), t1 = *(const float4*)(bias + col + 4);
+        bb[0] = t0.x; bb[1] = t0.y; bb[2] = t0.z; bb[3] = t0.w; bb[4] = t1.x; bb[5] = t1.y; bb[6] = t1.z; bb[7] = t1.w;
+      }
+      if (ep_scale) {
+        const float4 t0 = *(const float4*)(ep_scale + col), t1 = *(const float4*)(ep_scale + col + 4);
+        sc[0] = t0.x; sc[1] = t0.y; sc[2] = t0.z; sc[3] = t0.w; sc[4] = t1.x; sc[5] = t1.y; sc[6] = t1.z; sc[7] = t1.w;
+        if (ep_shift) {
+          const float4 u0 = *(const float4*)(ep_shift + col), u1 = *(const float4*)(ep_shift + col + 4);
+          sh[0] = u0.x; sh[1] = u0.y; sh[2] = u0.z; sh[3] = u0.w; sh[4] = u1.x; sh[5] = u1.y; sh[6] = u1.z; sh[7] = u1.w;
+        }
+      }
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e] + bb[e];
+        if (ep_scale) x = x * sc[e] + sh[e];
+        if (ep_act == 3) {
+          if (!(q[e] > 0.f)) x = 0.f;
+        } else {
+          if (ep_res) x += q[e];
+          if (ep_act) x = fmaxf(x, 0.f);
+        }
+        o[e] = x;
+      }
+      if (io & ES_IO_Y16) {
+        if (row_ok && !((abl & 1) && o[0] != 12345.678f))   // (ablation: value-dependent so that the arithmetic stays)
+          *(uint4*)((unsigned short*)Y + (size_t)row * ldy + col) =
+              make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
+      } else if (row_ok) {
+        float4* py = (float4*)(Y + (size_t)row * ldy + col);
+        if (accumulate) {
+          float4 y0 = h0, y1 = h1;
+          if (ep_res) { y0 = py[0]; y1 = py[1]; }         // (residual AND accumulation: Y was not prefetched)
+          o[0] += y0.x; o[1] += y0.y; o[2] += y0.z; o[3] += y0.w; o[4] += y1.x; o[5] += y1.y; o[6] += y1.z; o[7] += y1.w;
+        }
+        py[0] = make_float4(o[0], o[1], o[2], o[3]);
+        py[1] = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  }
+}
+
 // 1 if (shape, alignment) is served by the fast kernels -- the host uses it to decide whether a bf16 shadow of X pays
 extern "C" int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout) {
   return (Cin % HBK == 0) && (ldx % 8 == 0) && (Cout % 64 == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
@@ -1320,7 +1519,7 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
                                 int y_half = 0, int r_half = 0) {
   if (n_out <= 0 || Cout <= 0) return 0;
   if (K > MAXK) return -2;
-  const int io = (y_half ? ES_IO_Y16 : 0) | ((r_half && ep_res) ? ES_IO_R16 : 0);
+  const int io = (y_half ? ES_IO_Y16 : 0) | ((r_half && ep_res) ? ES_IO_R16 : 0) | (y_half & 0xff00);   // (bits 8-15: dev ablation switches of k_rowgemm2_bf16, tools/bench_rowgemm.py)
   if (y_half && (accumulate || (ldy % 4) || (Cout % 4) || (((uintptr_t)Y) & 7))) return -7;   // bf16 rows: 8-byte stores
   if ((io & ES_IO_R16) && ((ep_ldr % 4) || (((uintptr_t)ep_res) & 7))) return -7;
   hipStream_t st = (hipStream_t)stream;
@@ -1334,7 +1533,7 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
       (Cout % 16 == 0) && (ldx % (x_is_bf16 ? 8 : 4) == 0) && (ldy % 4 == 0) &&
       (((((uintptr_t)Xv) | ((uintptr_t)Wh)) & 15) == 0) && ((((uintptr_t)Y) & (y_half ? 7 : 15)) == 0) &&
       (!ep_res || ((ep_ldr % 4 == 0) && ((((uintptr_t)ep_res) & ((io & ES_IO_R16) ? 7 : 15)) == 0)))) {
-    const int nt = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0) ? 64 : (Cout % 32 == 0) ? 32 : 16;
+    const int nt = (Cout % 128 == 0 && Cin >= ES_OPT_RG128_MIN_CIN) ? 128 : (Cout % 64 == 0) ? 64 : (Cout % 32 == 0) ? 32 : 16;
     dim3 g(es_cdiv(n_out, BM), Cout / nt);
 #define RG_LAUNCH(NT_)                                                                                              \
     do {                                                                                                            \
@@ -1345,10 +1544,26 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
         hipLaunchKernelGGL((k_rowgemm_bf16<NT_, false>), g, dim3(256), 0, st, Xv, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy, \
                            accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);                              \
     } while (0)
-    if (nt == 128) RG_LAUNCH(128);
+#define RG2_LAUNCH(NT_)                                                                                             \
+    do {                                                                                                            \
+      if (x_is_bf16)                                                                                                \
+        hipLaunchKernelGGL((k_rowgemm2_bf16<NT_, true>), g, dim3(256), 0, st, Xv, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy, \
+                           accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);                              \
+      else                                                                                                          \
+        hipLaunchKernelGGL((k_rowgemm2_bf16<NT_, false>), g, dim3(256), 0, st, Xv, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy, \
+                           accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);                              \
+    } while (0)
+    // second-generation kernel: 16-byte epilogue accesses need 8-channel alignment of every row matrix it touches
+    const bool g2 = ES_OPT_ROWGEMM2 && nt >= 32 && (ldy % (y_half ? 8 : 4) == 0) && ((((uintptr_t)Y) & 15) == 0) &&
+                    (!ep_res || ((ep_ldr % ((io & ES_IO_R16) ? 8 : 4) == 0) && ((((uintptr_t)ep_res) & 15) == 0)));
+    if (g2 && nt == 128) RG2_LAUNCH(128);
+    else if (g2 && nt == 64) RG2_LAUNCH(64);
+    else if (g2) RG2_LAUNCH(32);
+    else if (nt == 128) RG_LAUNCH(128);
     else if (nt == 64) RG_LAUNCH(64);
     else if (nt == 32) RG_LAUNCH(32);
     else RG_LAUNCH(16);
+#undef RG2_LAUNCH
 #undef RG_LAUNCH
     ES_CHECK_LAUNCH();
     return 0;
@@ -1364,7 +1579,7 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
       g128.z = g64.z = split;
     }                                      // (without a workspace the launch keeps one workgroup per tile: no f32 atomics)
   }
-  if (fast && ES_OPT_DMA && x_is_bf16) {
+  if (fast && ES_OPT_DMA && x_is_bf16 && Cin >= ES_OPT_DMA_MIN_CIN) {
     const unsigned short* Xh = (const unsigned short*)Xv;
     const bool kb2 = (ES_OPT_DMA >= 2) && (Cin % 64 == 0);
 #define DMA_LAUNCH(BNT_, KB_, grid_)                                                                                  \

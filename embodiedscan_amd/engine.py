@@ -16,6 +16,9 @@ def _stream():
     return hip.stream()
 
 
+_NEW_VARS = None            # list while graphed() captures a segment
+
+
 class Var:
     """A row matrix (N, C) f32 on the device with an optional gradient (and lazily made bf16 shadows of both, the
     gather sources of the bf16 convolution kernels)."""
@@ -24,6 +27,8 @@ class Var:
     def __init__(self, d, rg=True):
         self.d, self.g, self.rg = d, None, rg
         self.dh = self.gh = None
+        if _NEW_VARS is not None:
+            _NEW_VARS.append(self)     # a segment is being captured: its Vars are reset before every replay (graphed())
         self.fresh = False      # True between conv() and the norm() that consumes its output (nobody else sees this Var)
         self.gate = None        # folded-BN scale of the fused conv+BN+ReLU that produced this Var (see conv_affine)
         self.gated = False      # True: .g already is the gradient w.r.t. the producer's (pre-BN) conv output
@@ -155,6 +160,84 @@ class Tape:
 
 
 TAPE = Tape()
+
+# ------------------------------------------------------------------ captured launch sequences (hipGraph)
+# The image backbone's forward is ~65 launches with static shapes, static addresses and no host round trip, but queuing them
+# costs the host ~4 ms per step -- during which the point branch (whose kernels the image branch is meant to run under) has not
+# even been issued (profiles/r3s_timeline.txt: main stream idle for the first 4 ms of every step).  graphed() captures such
+# a sequence once into a hipGraph (torch.cuda.CUDAGraph: activations live in the graph's private pool) and replays it with ONE
+# launch per step; the backward closures the sequence put on the tape are kept and re-registered at every replay (they run
+# eagerly, on the same buffers), the gradient fields of the sequence's Vars are reset first.
+GRAPHS = [os.environ.get('ES_GRAPHS', '1') != '0']
+GRAPH_STATS = dict(captured=0, replayed=0, eager=0, failed=0)
+
+
+class _Segment:
+    __slots__ = ('graph', 'outs', 'fns', 'vars', 'calls', 'failed')
+
+    def __init__(self):
+        self.graph = self.outs = None
+        self.fns, self.vars, self.calls, self.failed = [], [], 0, False
+
+
+def reset_graphs(cache):
+    """forget captured sequences (kernel-selection options or folded constants changed)"""
+    cache.clear()
+
+
+def graphed(cache, key, fn):
+    """outs = fn(), through a hipGraph from the third call with the same key on (1st call: eager -- lazily built maps and
+    shadows; 2nd: captured, then replayed).  Eager whenever per-launch instrumentation is on, on the default stream (capture
+    needs a non-default stream: the side stream of the two-stream schedule), or after a failed capture."""
+    global _NEW_VARS
+    instrumented = hip.PROFILE is not None or DEBUG_CONV is not None or DEBUG_GRADS is not None
+    if not GRAPHS[0] or instrumented or _NEW_VARS is not None or \
+            torch.cuda.current_stream() == torch.cuda.default_stream():
+        GRAPH_STATS['eager'] += 1
+        return fn()
+    seg = cache.get(key)
+    if seg is None:
+        if len(cache) > 8:
+            cache.clear()
+        seg = cache[key] = _Segment()
+    seg.calls += 1
+    if seg.failed or seg.calls == 1:
+        GRAPH_STATS['eager'] += 1
+        return fn()
+    if seg.graph is None:
+        n0 = len(TAPE.fns)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        _NEW_VARS = []
+        try:
+            g.capture_begin(capture_error_mode='thread_local')
+            try:
+                outs = fn()
+            finally:
+                g.capture_end()
+        except Exception as e:                                  # leave the eager path in charge
+            _NEW_VARS = None
+            seg.failed = True
+            GRAPH_STATS['failed'] += 1
+            del TAPE.fns[n0:]
+            import warnings
+            warnings.warn(f'hipGraph capture of {key} failed ({e!r}): running this sequence eagerly')
+            torch.cuda.synchronize()
+            return fn()
+        seg.vars, _NEW_VARS = _NEW_VARS, None
+        seg.graph, seg.outs = g, outs
+        seg.fns = TAPE.fns[n0:]
+        del TAPE.fns[n0:]
+        GRAPH_STATS['captured'] += 1
+    for v in seg.vars:
+        v.g = v.gh = None
+        v.gated = False
+    seg.graph.replay()
+    GRAPH_STATS['replayed'] += 1
+    if TAPE.enabled:
+        TAPE.fns.extend(seg.fns)
+    return seg.outs
+
 
 # ------------------------------------------------------------------ side stream
 # Independent branches of the step (image branch vs. point branch, samples of the loss) are issued on two HIP streams so

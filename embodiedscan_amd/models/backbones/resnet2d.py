@@ -59,6 +59,7 @@ class ResNet:
         # bf16 ACTIVATION storage (round 3; bf16 mode only): set by detectors whose only consumer of the feature maps is the
         # projection fusion (mv-3ddet, grounder); the occupancy detector's FPN still takes f32 rows
         self.act16 = False
+        self._graphs, self._fold_version = {}, 0
 
     def bind(self, arena, prefix='backbone.'):
         self.arena, self.prefix = arena, prefix
@@ -78,6 +79,7 @@ class ResNet:
         """fold every frozen BatchNorm2d into (scale, shift) -- call again after load_state_dict."""
         a, pre = self.arena, self.prefix
         self.fold = {}
+        self._fold_version += 1                   # captured launch sequences hold pointers to the old constants
         for name in [k[len(pre):-len('.running_var')] for k in a.p if k.startswith(pre) and k.endswith('.running_var')]:
             C = a.p[pre + name + '.weight'].numel()
             sc = torch.empty(C, dtype=torch.float32, device=a.data.device)
@@ -167,4 +169,8 @@ class ResNet:
         E.TAPE.enabled = prev
         return outs
 
-    __call__ = forward
+    def __call__(self, x):
+        """forward(x) through engine.graphed(): the launch sequence is static for a given input buffer, grid and mode"""
+        key = (x.data_ptr(), tuple(x.shape), E.PRECISION[0], bool(self.act16 and E.ACT16[0]), E.TAPE.enabled, self._fold_version,
+               self.arena.data.data_ptr(), E.SHADOW[0], E.WGRAD_SHADOW[0])
+        return E.graphed(self._graphs, key, lambda: self.forward(x))

@@ -17,6 +17,7 @@ class Det3DDataPreprocessor:
         self.pad_size_divisor, self.pad_value = pad_size_divisor, pad_value
         # the owning detector sets this (constructor argument / detector.to()); None = follow the incoming tensors
         self.device = torch.device(device) if device is not None else None
+        self._img_buf = {}
 
     def to(self, device):
         self.device = torch.device(device)
@@ -46,7 +47,14 @@ class Det3DDataPreprocessor:
             assert img.dtype == torch.uint8 and C == 3
             d = max(int(self.pad_size_divisor), 1)
             Hp, Wp = (H + d - 1) // d * d, (W + d - 1) // d * d      # bottom / right padding (utils.py:43-62)
-            nhwc = torch.empty((B * V, Hp, Wp, 3), dtype=torch.float32, device=dev)
+            # ONE buffer per image geometry, rewritten every step: the image backbone's launch sequence is replayed from a
+            # hipGraph and reads its input at a fixed address (the previous step's readers were joined into this stream long ago)
+            key = (B * V, Hp, Wp, str(dev))
+            nhwc = self._img_buf.get(key)
+            if nhwc is None:
+                if len(self._img_buf) > 4:
+                    self._img_buf.clear()
+                nhwc = self._img_buf[key] = torch.empty((B * V, Hp, Wp, 3), dtype=torch.float32, device=dev)
             call('es_preprocess_img', P(img.contiguous()), B * V, H, W, Hp, Wp, int(self.flip), farr(self.mean),
                  farr(self.std), float(self.pad_value), P(nhwc), torch.cuda.current_stream(dev).cuda_stream)
             out['imgs'] = nhwc.view(B, V, Hp, Wp, 3).permute(0, 1, 4, 2, 3)

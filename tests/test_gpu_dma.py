@@ -51,6 +51,7 @@ def test_dma_kernel_is_bit_identical_to_the_register_staged_kernel():
                 outs = {}
                 for mode in (0, 1, 2):
                     opt(10, mode)
+                    opt(11, 0)                       # every layer width (the default keeps the DMA kernel for >= 768 channels)
                     opt(3, 0)                        # K = 1: keep the launch on the conv kernels (not the row GEMM)
                     o = []
                     y = torch.empty(n_out, cout, device=dev)
@@ -95,7 +96,8 @@ def test_dma_kernel_is_bit_identical_to_the_register_staged_kernel():
                     print(f'LDS-DMA kernel, 64-channel chunks, 3x3x3 128->128 on {n_out} voxels: vs f64 on the bf16 operands {err:.1e}')
                     assert err < 1e-6
     finally:
-        opt(10, 0)
+        opt(10, 2)
+        opt(11, 768)
         opt(3, 1)
     print(f'LDS-DMA conv kernel: {n_checked} outputs identical to the register-staged kernel '
           f'({len(maps)} maps x 7 channel shapes x 2 chunk sizes x up to 9 launch modes)')
