@@ -242,6 +242,61 @@ extern "C" int es_batch_offsets(const int64_t* keys, int n, int n_batch, int* of
   ES_CHECK_LAUNCH();
   return 0;
 }
+// ---------------------------------------------------------------- all strided sets of a backbone in ONE host round trip
+// MinkResNet needs the coordinate sets at tensor strides 2, 4, ... of the root set; each is the hash-unique (first occurrence)
+// of the previous one floored to the next stride, and each used to cost a row-count read-back plus one for its per-sample
+// offsets -- on the critical path of every step (profiles/r3_stream_timeline.txt: the main stream is ~25 % busy for the first
+// 4.5 ms).  The chain is not needed: flooring commutes (floor(floor(x, 2), 4) == floor(x, 4)) and first-occurrence order is
+// preserved -- the first row of level l that maps to a level-(l+1) key K is the image of the first ROOT row that maps to K
+// (any earlier root row mapping to K would have an earlier image) -- so every level is the hash-unique of the ROOT keys floored
+// to its stride, in root order: same rows, same row order, same key -> row tables as the chain.  All levels are queued back to
+// back, their counts and per-sample offsets land in one small device array, and ONE copy + ONE synchronisation brings them to
+// the host.  res layout per level: [count, offsets[0 .. n_batch]].
+__global__ void k_batch_offsets_dev(const int64_t* __restrict__ keys, const int* __restrict__ n_dev, int nb, int* __restrict__ off) {
+  int b = threadIdx.x;
+  if (b > nb) return;
+  int lo = 0, hi = *n_dev;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if ((int)(keys[mid] >> (3 * ES_FIELD)) < b) lo = mid + 1; else hi = mid;
+  }
+  off[b] = lo;
+}
+extern "C" int es_strided_chain(const int64_t* root_keys, int n, int n_batch, int n_levels, const int* ts_host,
+                                int64_t* tmp_keys, int* scratch, void** tkeys, void** tvals, const int* caps_host,
+                                void** out_keys, int* res_dev, int* res_host, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int per = n_batch + 2;
+  for (int i = 0; i < n_levels * per; ++i) res_host[i] = 0;
+  if (n <= 0 || n_levels <= 0) return 0;
+  int* flag = scratch;
+  int* pos = scratch + n;
+  int* bsum = pos + n;
+  const int g = es_cdiv(n, 256);
+  for (int l = 0; l < n_levels; ++l) {
+    int64_t* tk = (int64_t*)tkeys[l];
+    int* tv = (int*)tvals[l];
+    int64_t* ok = (int64_t*)out_keys[l];
+    const int cap = caps_host[l];
+    if (cap <= 0 || (cap & (cap - 1))) return -4;
+    const uint32_t mask = (uint32_t)cap - 1;
+    int* total = res_dev + l * per;
+    ES_TRY(hipMemsetAsync(tk, 0xFF, (size_t)cap * 8, st));
+    ES_TRY(hipMemsetAsync(tv, 0x7F, (size_t)cap * 4, st));
+    hipLaunchKernelGGL(k_stride_keys, dim3(g), dim3(256), 0, st, root_keys, n, ts_host[l], tmp_keys);
+    hipLaunchKernelGGL(k_insert_min, dim3(g), dim3(256), 0, st, tmp_keys, n, tk, tv, mask);
+    hipLaunchKernelGGL(k_flag_winner, dim3(g), dim3(256), 0, st, tmp_keys, n, tk, tv, mask, flag);
+    int rc = scan_i32(flag, n, pos, bsum, total, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_compact_unique, dim3(g), dim3(256), 0, st, tmp_keys, n, flag, pos, tk, tv, mask, ok, (int*)nullptr);
+    hipLaunchKernelGGL(k_batch_offsets_dev, dim3(1), dim3(n_batch + 1 > 64 ? 256 : 64), 0, st, ok, total, n_batch, total + 1);
+    ES_CHECK_LAUNCH();
+  }
+  ES_TRY(hipMemcpyAsync(res_host, res_dev, (size_t)n_levels * per * 4, hipMemcpyDeviceToHost, st));
+  ES_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
 __global__ void k_gen_children(const int64_t* __restrict__ in, int n, int half, int64_t* __restrict__ out) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * 8) return;

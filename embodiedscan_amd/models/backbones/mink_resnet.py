@@ -41,15 +41,14 @@ class MinkResNet:
     def prefetch_coords(self, cs):
         """every strided coordinate set of the forward pass (each costs one row-count read-back) ahead of the feature
         kernels; returns the sets of the output levels.  The results are cached on the sets, forward() re-uses them."""
-        cur = cs.strided(2)
-        cur.offsets()                      # per-sample segments of the instance norm behind conv1
-        if self.pool:
-            cur = cur.strided(2)
-        outs = []
-        for _ in self.blocks:
-            cur = cur.strided(2)
-            cur.offsets()
-            outs.append(cur)
+        # all levels and their per-sample offsets in one host round trip (sparse.strided_chain; ES_COORD_BATCH=0: the chain of
+        # one read-back per level and per offsets vector that rounds 1-3 used)
+        from ... import sparse as _sp
+        sets = _sp.strided_chain(cs, 1 + int(bool(self.pool)) + len(self.blocks))
+        sets[0].offsets()                  # per-sample segments of the instance norm behind conv1 (already on the host)
+        outs = sets[1 + int(bool(self.pool)):]
+        for o in outs:
+            o.offsets()
         return outs
 
     def forward(self, x):

@@ -106,6 +106,54 @@ class CoordSet:
         return self.cache['gen']
 
 
+COORD_BATCH = [__import__('os').environ.get('ES_COORD_BATCH', '1') != '0']
+
+
+def strided_chain(root, n_levels):
+    """The sets root.strided(2), .strided(2).strided(2), ... (n_levels of them) with their per-sample offsets, in ONE host
+    round trip (es_strided_chain: every level straight from the root keys -- same rows, row order and tables as the chain).
+    Installs them in the caches the chain would have filled (`a.strided(2)` then finds its child) and returns the list."""
+    have, cur = [], root
+    for _ in range(n_levels):                               # already built (a second call in the same step)?
+        nxt = cur.cache.get(('stride', 2))
+        if nxt is None:
+            break
+        have.append(nxt)
+        cur = nxt
+    if len(have) == n_levels:
+        return have
+    dev, n, B = root.device, root.n, root.n_batch
+    if not COORD_BATCH[0] or n <= 0 or have:
+        out, cur = [], root
+        for _ in range(n_levels):
+            cur = cur.strided(2)
+            out.append(cur)
+        return out
+    cap = _pow2_cap(n)
+    ts = [root.ts * (2 ** (l + 1)) for l in range(n_levels)]
+    tk = [torch.empty(cap, dtype=torch.int64, device=dev) for _ in range(n_levels)]
+    tv = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(n_levels)]
+    ok = [torch.empty(n, dtype=torch.int64, device=dev) for _ in range(n_levels)]
+    tmp = torch.empty(n, dtype=torch.int64, device=dev)
+    scratch = torch.empty(2 * n + n // 2048 + 8, dtype=torch.int32, device=dev)
+    per = B + 2
+    res = torch.empty(n_levels * per, dtype=torch.int32, device=dev)
+    res_host = (ctypes.c_int * (n_levels * per))()
+    ptrs = lambda ts_: (ctypes.c_void_p * n_levels)(*[t.data_ptr() for t in ts_])
+    call('es_strided_chain', P(root.keys), n, B, n_levels, (ctypes.c_int * n_levels)(*ts), P(tmp), P(scratch), ptrs(tk), ptrs(tv),
+         (ctypes.c_int * n_levels)(*([cap] * n_levels)), ptrs(ok), P(res), res_host, _stream())
+    out, cur = [], root
+    for l in range(n_levels):
+        m = int(res_host[l * per])
+        cs = CoordSet(ok[l][:m], m, ts[l], B, tk[l], tv[l])
+        cs._off_dev = res[l * per + 1:(l + 1) * per]
+        cs._off_host = [int(res_host[l * per + 1 + b]) for b in range(B + 1)]
+        cur.cache[('stride', 2)] = cs
+        out.append(cs)
+        cur = cs
+    return out
+
+
 def unique_first(keys, n, ts, n_batch, want_src=True):
     """hash-unique in first-occurrence order.  Returns (CoordSet, src_rows int32)."""
     dev = keys.device

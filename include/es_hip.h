@@ -44,6 +44,14 @@ int es_keys_to_coords(const int64_t* keys, int n, int* coords /* (n,4) b,x,y,z *
 /* points = float(coords[:, 1:]) * voxel_size  (sparse_featfusion_single_stage.py:167-168, fcaf3d_head.py:1145-1147) */
 int es_coords_to_points(const int* coords, int n, float voxel_size, float* points /* (n,3) */, void* stream);
 int es_batch_offsets(const int64_t* keys, int n, int n_batch, int* offsets_dev /* n_batch+1 */, void* stream);
+/* every strided set of the backbone (tensor strides ts[0 .. n_levels-1] of the root set) in one host round trip: each level is
+ * the first-occurrence hash-unique of the ROOT keys floored to its stride -- the same rows, row order and key -> row tables as
+ * the chain level l -> l+1 that MinkowskiEngine's strided convolutions induce (mink_resnet.py:131-143) -- with its row count and
+ * per-sample offsets: res[l * (n_batch + 2)] = count, then n_batch + 1 offsets.  tkeys / tvals / out_keys: host arrays of
+ * n_levels device pointers (caps[l] table slots, n rows of keys); tmp_keys n keys; scratch 2n + n/2048 + 8 ints. */
+int es_strided_chain(const int64_t* root_keys, int n, int n_batch, int n_levels, const int* ts_host, int64_t* tmp_keys,
+                     int* scratch, void** tkeys, void** tvals, const int* caps_host, void** out_keys, int* res_dev,
+                     int* res_host, void* stream);
 /* MinkowskiGenerativeConvolutionTranspose(k=2,s=2) output coordinates.  fcaf3d_head.py:937-941 */
 int es_gen_children_keys(const int64_t* in_keys, int n, int half_ts, int64_t* out_keys /* 8n */, void* stream);
 /* A6: nbr[j*K + k] = input row at out_j + offset_k * in_ts, or -1 (K = ksize^3, x fastest). */

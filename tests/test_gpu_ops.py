@@ -73,6 +73,35 @@ def test_voxelize_and_maps_bit_exact(dev):
     np.testing.assert_array_equal(pr.coords.cpu().numpy(), ou[m.cpu().numpy().astype(bool)])
 
 
+def test_strided_chain_one_round_trip_equals_the_level_by_level_chain(dev):
+    """sparse.strided_chain (every strided set of the backbone straight from the root keys, one host round trip) against the
+    chain root.strided(2).strided(2)...: identical keys in identical row order, identical per-sample offsets, and tables that
+    give identical 3x3x3 / stride-2 kernel maps (bit exact), on a ragged two-sample cloud with negative coordinates."""
+    from embodiedscan_amd import sparse
+    pts = [_pts(5, 30000, -3.0, 3.0).to(dev), _pts(6, 11000, -1.0, 2.5).to(dev)]
+    a, _ = sparse.voxelize(pts, 0.02)
+    b, _ = sparse.voxelize(pts, 0.02)
+    assert torch.equal(a.keys, b.keys)
+    L = 6
+    sparse.COORD_BATCH[0] = True
+    fast = sparse.strided_chain(a, L)
+    slow, cur = [], b
+    for _ in range(L):
+        cur = cur.strided(2)
+        slow.append(cur)
+    prev_f, prev_s = a, b
+    for l, (f, s) in enumerate(zip(fast, slow)):
+        assert f.n == s.n and f.ts == s.ts == 2 ** (l + 1), (l, f.n, s.n)
+        assert torch.equal(f.keys, s.keys), f'level {l}: row order differs'
+        assert f.offsets() == s.offsets(), (l, f.offsets(), s.offsets())
+        assert torch.equal(f.offsets_dev().cpu(), s.offsets_dev().cpu())
+        assert prev_f.strided(2) is f                                   # installed where the chain would have cached it
+        assert torch.equal(prev_f.kernel_map(f, 3), prev_s.kernel_map(s, 3))      # parent table, child rows
+        assert torch.equal(f.kernel_map(f, 3), s.kernel_map(s, 3))                # the level's own table
+        prev_f, prev_s = f, s
+    print(f'strided_chain: {L} levels {[f.n for f in fast]} rows from {a.n} voxels identical to the chain (keys, order, offsets, maps)')
+
+
 def _sparse_case(dev, n=20000, seed=3):
     from embodiedscan_amd import sparse
     from oracle import coords as C
