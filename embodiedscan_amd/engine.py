@@ -144,6 +144,7 @@ class Tape:
     def __init__(self):
         self.fns = []
         self.enabled = True
+        self.epoch = 0                  # bumped whenever the tape is emptied (graphed(): one replay of a segment per epoch)
 
     def add(self, fn):
         if self.enabled:
@@ -154,9 +155,11 @@ class Tape:
             fn()
         join_wgrad_streams()
         self.fns = []
+        self.epoch += 1
 
     def clear(self):
         self.fns = []
+        self.epoch += 1
 
 
 TAPE = Tape()
@@ -173,11 +176,11 @@ GRAPH_STATS = dict(captured=0, replayed=0, eager=0, failed=0)
 
 
 class _Segment:
-    __slots__ = ('graph', 'outs', 'fns', 'vars', 'calls', 'failed')
+    __slots__ = ('graph', 'outs', 'fns', 'vars', 'calls', 'failed', 'epoch')
 
     def __init__(self):
         self.graph = self.outs = None
-        self.fns, self.vars, self.calls, self.failed = [], [], 0, False
+        self.fns, self.vars, self.calls, self.failed, self.epoch = [], [], 0, False, -1
 
 
 def reset_graphs(cache):
@@ -201,9 +204,12 @@ def graphed(cache, key, fn):
             cache.clear()
         seg = cache[key] = _Segment()
     seg.calls += 1
-    if seg.failed or seg.calls == 1:
+    # a replay hands out the SAME Vars and closures as the one before: two of them on one tape (the sequence run twice before a
+    # backward pass) would double-count gradients, so the second run in a tape epoch is eager
+    if seg.failed or seg.calls == 1 or (TAPE.enabled and seg.epoch == TAPE.epoch):
         GRAPH_STATS['eager'] += 1
         return fn()
+    seg.epoch = TAPE.epoch
     if seg.graph is None:
         n0 = len(TAPE.fns)
         g = torch.cuda.CUDAGraph()

@@ -122,7 +122,7 @@ class DetectorBase:
             for part in range(len(red.parts)):
                 if part not in done:
                     red.launch(part)
-        E.TAPE.fns = []
+        E.TAPE.clear()
 
     def train_step(self, data, optim_wrapper):
         E.TAPE.clear()

@@ -272,4 +272,4 @@ class SparseFeatureFusionSingleStage3DDetector:
         E.join_wgrad_streams()
         if red is not None:
             red.launch(0)                                      # 2-D backbone gradients complete
-        E.TAPE.fns = []
+        E.TAPE.clear()
