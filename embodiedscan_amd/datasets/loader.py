@@ -51,13 +51,15 @@ class ScanLoader:
     not depend on thread scheduling."""
 
     def __init__(self, dataset, batch_size=4, rank=0, world=1, shuffle=True, seed=0, times=1, num_threads=8, prefetch=16,
-                 pin=True, drop_last=True, workers='thread', slot_bytes=None, worker_timeout=120.0):
+                 pin=True, drop_last=True, workers='thread', slot_bytes=None, worker_timeout=120.0, exact_draws=None):
         """slot_bytes: size of one shared pinned slot in process mode (None: estimated from the frame headers of every
         source of the dataset -- EmbodiedScan mixes ScanNet / 3RScan / Matterport3D resolutions); a scan that still does
         not fit is decoded by the parent instead of aborting the epoch.  worker_timeout: seconds without any result
         after which the workers' liveness is checked (a worker killed by the OOM killer or a signal raises instead of
         hanging the training loop)."""
         assert workers in ('thread', 'process')
+        if exact_draws is not None:          # None: whatever the dataset's pipeline says (default: the reference's exact stream);
+            dataset.pipeline.exact_draws = bool(exact_draws)   # False: O(k) PointSample draws (loading.draw_without_order)
         self.dataset, self.batch_size = dataset, batch_size
         self.rank, self.world, self.shuffle, self.seed, self.times = rank, world, shuffle, seed, times
         self.num_threads, self.prefetch, self.pin, self.drop_last = max(1, num_threads), max(1, prefetch), pin, drop_last

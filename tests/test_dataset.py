@@ -436,3 +436,31 @@ def test_points_range_filter_precedes_point_sample(tmp_path):
                               pipeline=[pipe[0]] + PIPE[1:3] + pipe[4:])
     p2 = OP.scan_to_points(ds2.load_scan(0, np.random.RandomState(1))).numpy()
     assert not ((p2 > lo) & (p2 < hi)).all()
+
+
+def test_fast_point_sample_draws_same_law_not_same_stream():
+    """ScanPipeline(exact_draws=False): PointSample by an O(k) draw instead of the legacy RandomState permutation of the whole
+    population (loading.draw_without_order).  Same law -- k distinct members of range(n), every member equally likely,
+    with replacement iff n < k -- reproducible from the seed, and only non-zero depth pixels are ever chosen; the exact mode
+    stays the reference's stream (the test above)."""
+    import numpy as np
+    from embodiedscan_amd.datasets.loading import draw_without_order, sample_pixels
+    a = draw_without_order(np.random.RandomState(3), 300000, 10000, exact=False)
+    b = draw_without_order(np.random.RandomState(3), 300000, 10000, exact=False)
+    assert np.array_equal(a, b) and len(np.unique(a)) == 10000 and a.min() >= 0 and a.max() < 300000
+    assert not np.array_equal(a, np.random.RandomState(3).choice(300000, 10000, replace=False))     # a different stream
+    assert np.array_equal(draw_without_order(np.random.RandomState(3), 300000, 10000, exact=True),
+                          np.random.RandomState(3).choice(300000, 10000, replace=False))
+    # n < k: with replacement, the legacy call in both modes
+    assert np.array_equal(draw_without_order(np.random.RandomState(4), 50, 200, exact=False),
+                          np.random.RandomState(4).choice(50, 200, replace=True))
+    # uniformity: 400 draws of 1000 from 20000 -> every decile of the population receives 10 % +- 0.5 %
+    rng = np.random.RandomState(5)
+    hist = np.zeros(10)
+    for _ in range(400):
+        hist += np.bincount(draw_without_order(rng, 20000, 1000, exact=False) // 2000, minlength=10)
+    assert np.all(np.abs(hist / hist.sum() - 0.1) < 0.005), hist / hist.sum()
+    depth = np.zeros((48, 64), np.float32)
+    depth[10:30, 5:50] = 1.5
+    pix = sample_pixels(depth, 300, np.random.RandomState(6), exact=False)
+    assert len(pix) == 300 and len(np.unique(pix)) == 300 and np.all(depth.reshape(-1)[pix] > 0)

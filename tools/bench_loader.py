@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--repeat', type=int, default=200)
     ap.add_argument('--seconds', type=float, default=8.0)
     ap.add_argument('--device-workers', type=int, default=64)
+    ap.add_argument('--fast-draws', action='store_true', help='O(k) PointSample draws instead of the exact RandomState stream')
     args = ap.parse_args()
     import torch
     from embodiedscan_amd import pipeline, synth
@@ -49,7 +50,8 @@ def main():
                 if kind == 'thread' and th > 16:
                     continue                                  # GIL-bound: more threads do not help (see loader.py)
                 ld = ScanLoader(ds, batch_size=4, shuffle=True, seed=0, times=args.repeat, num_threads=th,
-                                prefetch=min(max(16, 2 * th), 64), pin=dev is not None, workers=kind)
+                                prefetch=min(max(16, 2 * th), 64), pin=dev is not None, workers=kind,
+                                exact_draws=not args.fast_draws)
                 it = iter(ld)
                 ld.done(next(it))                             # untimed: forks the workers, allocates and pins the slots
                 t = time.time()
