@@ -1288,14 +1288,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 // fragment pair permuted (fragment 2p takes channels 32p + 8q + {0..3}, fragment 2p + 1 channels 32p + 8q + {4..7}) a lane
 // owns 8 consecutive channels of its row: one 16-byte store for bf16 rows, two for f32 rows, straight from the accumulators --
 // no LDS staging, no barrier after the k loop, the residual is prefetched in the same layout (16 bytes per 8 channels).
-template <int NT, bool XH>
+// MT (experimental, ES_GEN_FUSED): the 8 taps of a generative transposed convolution in ONE launch -- forward: blockIdx.z = tap
+// (its own weight slice and output column block); data gradient: the taps are extra steps of the k loop (tap t reads the
+// input columns t * a_tap .. and the weight slice t * w_tap ..).  MT = false compiles to the kernel described above.
+struct RowGemmTaps { int z_w, z_y_bytes, taps, a_tap, w_tap; };
+template <int NT, bool XH, bool MT = false>
 __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ Xv, int ldx,
                                                        const unsigned short* __restrict__ W, int n_out, int n_in, int Cin,
                                                        int Cout, const float* __restrict__ bias, float* __restrict__ Y,
                                                        int ldy, int accumulate, const float* __restrict__ ep_scale,
                                                        const float* __restrict__ ep_shift,
-                                                       const float* __restrict__ ep_res, int ep_ldr, int ep_act, int io) {
+                                                       const float* __restrict__ ep_res, int ep_ldr, int ep_act, int io,
+                                                       RowGemmTaps tp) {
   static_assert(NT % 32 == 0, "fragment pairs");
+  if (MT) {
+    W += (size_t)blockIdx.z * tp.z_w;
+    Y = (float*)((char*)Y + (size_t)blockIdx.z * tp.z_y_bytes);
+  }
   const float* X = (const float*)Xv;
   const unsigned short* Xh = (const unsigned short*)Xv;
   constexpr int NF = NT / 16, NP = NT / 32;
@@ -1324,24 +1333,26 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
   const unsigned short* pb1 = W + (size_t)(n0 + (NT > 64 ? 64 : 0) + bc0) * Cin + bq * 8;
 #define RG2_LOAD(s_)                                                                   \
   do {                                                                                 \
-    const bool ka_ = (s_) * HBK + kq * 8 < Cin, kb_ = (s_) * HBK + bq * 8 < Cin;       \
+    const int tap_ = MT ? (s_) / ns : 0, ss_ = (s_) - tap_ * ns;                        \
+    const int ao_ = ss_ * HBK + (MT ? tap_ * tp.a_tap : 0), bo_ = ss_ * HBK + (MT ? tap_ * tp.w_tap : 0); \
+    const bool ka_ = ss_ * HBK + kq * 8 < Cin, kb_ = ss_ * HBK + bq * 8 < Cin;         \
     a00 = a01 = a10 = a11 = make_float4(0.f, 0.f, 0.f, 0.f);                           \
     bg0 = bg1 = make_uint4(0u, 0u, 0u, 0u);                                            \
     if (XH) {                                                                          \
-      if (va0 && ka_) a00 = *(const float4*)(ph0 + (s_) * HBK);                        \
-      if (va1 && ka_) a10 = *(const float4*)(ph1 + (s_) * HBK);                        \
+      if (va0 && ka_) a00 = *(const float4*)(ph0 + ao_);                                    \
+      if (va1 && ka_) a10 = *(const float4*)(ph1 + ao_);                                    \
     } else {                                                                           \
       if (va0 && ka_) {                                                                \
-        const float4* q0_ = (const float4*)(pa0 + (s_) * HBK);                         \
+        const float4* q0_ = (const float4*)(pa0 + ao_);                                     \
         a00 = q0_[0]; a01 = q0_[1];                                                    \
       }                                                                                \
       if (va1 && ka_) {                                                                \
-        const float4* q1_ = (const float4*)(pa1 + (s_) * HBK);                         \
+        const float4* q1_ = (const float4*)(pa1 + ao_);                                     \
         a10 = q1_[0]; a11 = q1_[1];                                                    \
       }                                                                                \
     }                                                                                  \
-    if (kb_ && bc0 < NT) bg0 = *(const uint4*)(pb0 + (s_) * HBK);                      \
-    if (NT > 64 && kb_) bg1 = *(const uint4*)(pb1 + (s_) * HBK);                       \
+    if (kb_ && bc0 < NT) bg0 = *(const uint4*)(pb0 + bo_);                                  \
+    if (NT > 64 && kb_) bg1 = *(const uint4*)(pb1 + bo_);                                   \
   } while (0)
 #define RG2_STORE_B(buf_)                                                              \
   do {                                                                                 \
@@ -1377,7 +1388,8 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
   __syncthreads();
   // weight row this lane reads for fragment nf (as the A operand: lane li = output channel within the fragment)
   const int wrow = (li >> 2) * 8 + (li & 3);              // + 32 * (nf >> 1) + 4 * (nf & 1)
-  for (int s = 0; s < ns; ++s) {
+  const int nst = MT ? ns * tp.taps : ns;
+  for (int s = 0; s < nst; ++s) {
     uint4 pk0, pk1;
     if (XH) {
       pk0 = make_uint4(__float_as_uint(a00.x), __float_as_uint(a00.y), __float_as_uint(a00.z), __float_as_uint(a00.w));
@@ -1387,7 +1399,7 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
       pk1 = make_uint4(pack_bf16(a10.x, a10.y), pack_bf16(a10.z, a10.w), pack_bf16(a11.x, a11.y), pack_bf16(a11.z, a11.w));
     }
     bf16x8_t fa0 = __builtin_bit_cast(bf16x8_t, pk0), fa1 = __builtin_bit_cast(bf16x8_t, pk1);
-    if (s + 1 < ns) RG2_LOAD(s + 1);
+    if (s + 1 < nst) RG2_LOAD(s + 1);
     const unsigned short* Bc = Bs + (s & 1) * NT * HLD;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
@@ -1395,8 +1407,8 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
       acc[0][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, fa0, acc[0][nf], 0, 0, 0);
       acc[1][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, fa1, acc[1][nf], 0, 0, 0);
     }
-    if (s + 1 < ns) RG2_STORE_B((s + 1) & 1);
-    if (s + 1 < ns) __syncthreads();
+    if (s + 1 < nst) RG2_STORE_B((s + 1) & 1);
+    if (s + 1 < nst) __syncthreads();
   }
 #undef RG2_LOAD
 #undef RG2_STORE_B
@@ -1548,10 +1560,10 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
     do {                                                                                                            \
       if (x_is_bf16)                                                                                                \
         hipLaunchKernelGGL((k_rowgemm2_bf16<NT_, true>), g, dim3(256), 0, st, Xv, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy, \
-                           accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);                              \
+                           accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io, RowGemmTaps{0, 0, 1, 0, 0});   \
       else                                                                                                          \
         hipLaunchKernelGGL((k_rowgemm2_bf16<NT_, false>), g, dim3(256), 0, st, Xv, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy, \
-                           accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);                              \
+                           accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io, RowGemmTaps{0, 0, 1, 0, 0});  \
     } while (0)
     // second-generation kernel: 16-byte epilogue accesses need 8-channel alignment of every row matrix it touches
     const bool g2 = ES_OPT_ROWGEMM2 && nt >= 32 && (ldy % (y_half ? 8 : 4) == 0) && ((((uintptr_t)Y) & 15) == 0) &&
@@ -1667,6 +1679,44 @@ extern "C" int es_spconv_fwd_bf16_io(const void* Xv, int x_half, int ldx, const 
                                      void* stream) {
   return spconv_fwd_bf16_impl(Xv, x_half, ldx, W_bf16, nbr, n_out, n_in, K, Cin, Cout, nullptr, (float*)Y, ldy, 0, scale, shift,
                               (const float*)res, ldr, act, stream, nullptr, 0, y_half, res_half);
+}
+
+// MinkowskiGenerativeConvolutionTranspose(k = 2, s = 2) on f32 rows (fcaf3d_head.py up-blocks): y[8 i + t] = x[i] @ w[t].  The
+// eight taps used to be eight K = 1 launches (and eight accumulating data-gradient launches) of a few dozen workgroups each
+// on the coarse levels; here ONE launch with gridDim.z = 8 (forward) / one launch whose k loop walks the taps (data gradient).
+// Return 1: shape / alignment not served (the caller issues the per-tap launches).  Experimental (ES_GEN_FUSED=1).
+template <bool DGRAD>
+static int gen_transpose_launch(const float* X, int ldx, const unsigned short* Wh, int n, int Kred, int Ncol, float* Y, int ldy,
+                                int accumulate, RowGemmTaps tp, int gz, hipStream_t st) {
+  if (n <= 0) return 0;
+  if ((Ncol % 32) || (Kred % 8) || (ldx % 4) || (ldy % 4) || ((((uintptr_t)X) | ((uintptr_t)Wh) | ((uintptr_t)Y)) & 15) ||
+      ((tp.z_y_bytes | (tp.a_tap * 4)) & 15) || ((tp.w_tap | tp.z_w) % 8))
+    return 1;
+  const int nt = (Ncol % 128 == 0) ? 128 : (Ncol % 64 == 0) ? 64 : 32;
+  dim3 g(es_cdiv(n, BM), Ncol / nt, gz);
+#define GT_LAUNCH(NT_)                                                                                                   \
+  hipLaunchKernelGGL((k_rowgemm2_bf16<NT_, false, true>), g, dim3(256), 0, st, (const void*)X, ldx, Wh, n, n, Kred, Ncol,  \
+                     (const float*)nullptr, Y, ldy, accumulate, (const float*)nullptr, (const float*)nullptr,             \
+                     (const float*)nullptr, 0, 0, 0, tp)
+  if (nt == 128) GT_LAUNCH(128);
+  else if (nt == 64) GT_LAUNCH(64);
+  else GT_LAUNCH(32);
+#undef GT_LAUNCH
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int es_gen_transpose_fwd_bf16(const float* X, int ldx, const void* Wt_bf16, int n, int Cin, int Cout, float* Y,
+                                         void* stream) {
+  // tap t: weights Wt[t] ([Cout][Cin], reduction contiguous), output columns t * Cout .. of the (n, 8 Cout) row matrix
+  return gen_transpose_launch<false>(X, ldx, (const unsigned short*)Wt_bf16, n, Cin, Cout, Y, 8 * Cout, 0,
+                                     RowGemmTaps{Cout * Cin, Cout * 4, 1, 0, 0}, 8, (hipStream_t)stream);
+}
+extern "C" int es_gen_transpose_dgrad_bf16(const float* dY, const void* Wn_bf16, int n, int Cin, int Cout, float* dX, int ldx,
+                                           int accumulate, void* stream) {
+  // dX[i] (+)= sum_t dY[8 i + t] @ w[t]^T: reduction over the Cout columns of tap t (input columns t * Cout ..) with the
+  // natural copy Wn[t] ([Cin][Cout]) as the [output column][reduction] operand
+  return gen_transpose_launch<true>(dY, 8 * Cout, (const unsigned short*)Wn_bf16, n, Cout, Cin, dX, ldx, accumulate,
+                                    RowGemmTaps{0, 0, 8, Cout, Cin * Cout}, 1, (hipStream_t)stream);
 }
 
 // f32 [K][A][B] -> bf16 natural [K][A][B] and/or bf16 transposed [K][B][A]

@@ -392,6 +392,7 @@ def _cast_rows(t):
     return h
 
 
+GEN_FUSED = [os.environ.get('ES_GEN_FUSED', '0') == '1']          # generative transposed conv: 8 taps in one launch (experimental)
 NORM_SHADOW = [os.environ.get('ES_NORM_SHADOW', '1') != '0']     # norm apply passes write the bf16 shadows of their outputs
 WGRAD_SHADOW = [os.environ.get('ES_WGRAD_SHADOW', '1') != '0']   # weight-gradient launches gather from the bf16 shadows too
 DET_SPLIT = [os.environ.get('ES_DET_SPLIT', '1') != '0']   # deterministic tap split (workspace + fixed-order reduction)
@@ -597,7 +598,10 @@ def gen_conv_transpose(x, w):
     y = Var(empty((n * 8, cout), x.d))
     s = _stream()
     bf = PRECISION[0] == 'bf16'
-    for k in range(8):
+    fused = False
+    if bf and GEN_FUSED[0] and x.d.dtype == torch.float32:      # all eight taps in one launch (experimental, default off)
+        fused = hip.raw('es_gen_transpose_fwd_bf16')(P(x.d), _ld(x.d), P(w.bf16()[1]), n, cin, cout, P(y.d), s) == 0
+    for k in range(0 if not fused else 8, 8):
         if bf:
             call('es_spconv_fwd_bf16', P(x.d), 0, _ld(x.d), w.bf16()[1].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cin,
                  cout, 0, y.d.data_ptr() + 4 * k * cout, 8 * cout, 0, s)
@@ -611,11 +615,16 @@ def gen_conv_transpose(x, w):
         s = _stream()
         g, acc = _grad_target(x, x.d) if x.rg else (None, 0)
         sw = _wgrad_stream(y.g, x.d) if w.g is not None else s
+        dfused = False
+        if g is not None and bf and GEN_FUSED[0] and y.g.is_contiguous():      # (n * 8, cout) rows = (n, 8 cout)
+            dfused = hip.raw('es_gen_transpose_dgrad_bf16')(P(y.g), P(w.bf16()[0]), n, cin, cout, P(g), _ld(g), acc, s) == 0
         for k in range(8):
             gy = y.g.data_ptr() + 4 * k * cout
             if w.g is not None:
                 _wgrad('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', sw,
                        w.g.data_ptr() + 4 * k * cin * cout, P(x.d), _ld(x.d), gy, 8 * cout, 0, n, n, 1, cin, cout)
+            if dfused:
+                continue
             if g is not None and bf:
                 call('es_spconv_fwd_bf16', gy, 0, 8 * cout, w.bf16()[0].data_ptr() + 2 * k * cin * cout, 0, n, n, 1, cout,
                      cin, 0, P(g), _ld(g), 1 if (acc or k > 0) else 0, s)

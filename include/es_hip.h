@@ -91,6 +91,14 @@ int es_spconv_fwd_bf16_ws(const void* X, int x_is_bf16, int ldx, const void* W_b
 /* X may also be a bf16 row matrix (x_is_bf16 = 1, ldx in bf16 elements): the shadow made by es_cast_rows_bf16; only for
  * shapes where es_spconv_bf16_is_fast() returns 1 */
 int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout);
+/* MinkowskiGenerativeConvolutionTranspose(kernel 2, stride 2) of the head's up-blocks (fcaf3d_head.py:919-932) in one launch
+ * per direction instead of eight K = 1 launches: forward Y (n, 8 Cout)[i, t Cout + c] = sum_k bf16(X[i, k]) Wt[t][c][k]; data
+ * gradient dX[i] (+)= sum_t dY[i, t Cout ..] @ Wn[t]^T.  X / dY / Y / dX f32 rows, Wt / Wn the per-step bf16 copies
+ * (es_cast_weight_bf16).  Returns 1 when the shape / alignment is not served (Cout % 32, 16-byte rows): the caller then issues
+ * the per-tap es_spconv_fwd_bf16 launches.  Experimental in round 3 (host switch ES_GEN_FUSED, default off). */
+int es_gen_transpose_fwd_bf16(const float* X, int ldx, const void* Wt_bf16, int n, int Cin, int Cout, float* Y, void* stream);
+int es_gen_transpose_dgrad_bf16(const float* dY, const void* Wn_bf16, int n, int Cin, int Cout, float* dX, int ldx,
+                                int accumulate, void* stream);
 /* run-time tuning switches for A/B measurements: key 1 = ping-pong LDS buffers in the fast bf16 kernels (default 1),
  * key 2 = 256x256 weight-gradient tile for layers with C_in, C_out multiples of 256 and bf16-shadow operands (default 1),
  * key 3 = streaming row-GEMM kernel for K = 1 launches on the identity map (default 1),
