@@ -34,6 +34,7 @@ static int ES_OPT_DMA_MIN_CIN = 768;       // ... for layers with at least this 
                                            // (97.4 -> 84.3 ms per 7 steps, step 57.4 -> 56.1 ms); the 64 .. 256-channel sparse layers of
                                            // mv-3ddet are equal within 2 % either way (LDS activity -62 %, no bank conflicts left, same
                                            // MFMA busy: those launches are bound by the gather through L2, not by LDS)
+static int ES_OPT_WGRAD_TR = 0;            // experimental weight-gradient tile (LDS-DMA + ds_read_b64_tr_b16), see k_spconv_wgrad_bf16_tr
 static int ES_OPT_ROWGEMM2 = 1;            // second-generation row GEMM (swapped MFMA operands, register epilogue with 16-byte accesses)
 static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
 extern "C" int es_set_option(int key, int value) {
@@ -49,6 +50,7 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 11) { ES_OPT_DMA_MIN_CIN = value; return 0; }
   if (key == 12) { ES_OPT_RG128_MIN_CIN = value; return 0; }
   if (key == 13) { ES_OPT_ROWGEMM2 = value; return 0; }
+  if (key == 14) { ES_OPT_WGRAD_TR = value; return 0; }
   return -2;
 }
 
@@ -2040,6 +2042,113 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
     }
 }
 
+// EXPERIMENTAL (es_set_option key 14, default off; not yet run on hardware -- the round's GPU minutes were spent; parity test
+// gated by ES_TEST_EXPERIMENTAL): the 128 x 128 weight-gradient tile with LDS-DMA staging and TRANSPOSED LDS reads.
+// The kernels above transpose the gathered rows with VALU packing and 16 ds_write_b32 per thread and chunk so that the MFMA
+// fragments are k-contiguous 16-byte LDS reads: 64 + 40 LDS cycles per wave and chunk against 80 cycles of MFMA issue, 15 % MFMA
+// busy (profiles/r3_mfma_util.txt).  gfx950 has ds_read_b64_tr_b16: rows can stay in their NATURAL layout [pair][channel] in LDS
+// -- written by global_load_lds straight from the gathered bf16 rows, no registers, no conversion, no ds_write -- and a 16-lane
+// group reads a 4 (pairs) x 16 (channels) block transposed: lane i gets channel i of the 4 pairs.  Two such reads give the
+// 8 k-values of a 16x16x32 fragment.  Per wave and chunk: 16 transposed reads (2 LDS cycles each) for 16 MFMAs.
+// ASSUMED semantics of the transposed read (tools/probes/tr_read.hip prints the real ones): within a 16-lane group, lane i
+// supplies the address of the 8 bytes at block row (i >> 2), block columns 4 (i & 3) ..; it receives column i, rows 0 .. 3.
+// Tile rows are 256 bytes (128 channels); the 16-byte granule g of pair p is stored at slot g ^ (key(p) << 1), key(p) =
+// (p & 3) | ((p >> 3) & 1) << 2: the 8 pair rows a 32-lane read group touches land on 8 distinct 32-byte bank positions.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_tr(const unsigned short* __restrict__ Xh, int ldx,
+                                                              const unsigned short* __restrict__ dYh, int ldy,
+                                                              const int* __restrict__ nbr, int n_out, int n_in, int K,
+                                                              int Cin, int Cout, int rows_per_split, int n_slices,
+                                                              float* __restrict__ dW, float* __restrict__ ws, int accumulate) {
+  constexpr int TB = GR * 256;                              // bytes of one operand tile: 32 pairs x 128 channels
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TB + 2 * QCAP * 4 + 16];
+  int* const s_qj = (int*)(smem + 4 * TB);
+  int* const s_qi = s_qj + QCAP;
+  int* const s_wc = s_qi + QCAP;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int nCt = Cin / 128;
+  int bx, by, bz;
+  if (!xcd_slice_order(n_slices, bx, by, bz)) return;
+  const int k = bx / nCt, c0 = (bx % nCt) * 128, n0 = by * 128;
+  const int rbeg = bz * rows_per_split, rend = min(n_out, rbeg + rows_per_split);
+  PairRing q{s_qj, s_qi, s_wc, 0, 0, rbeg};
+  const long long sj = K, koff = k;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto key = [](int p) { return ((p & 3) | (((p >> 3) & 1) << 2)) << 1; };
+  // DMA piece e = (j * 4 + wv) * 64 + lane of a tile: pair e >> 4, slot e & 15 (16 granules per 256-byte row)
+  auto issue = [&](int buf, int head) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = (j * 4 + wv) * 64 + lane, pr = e >> 4, g = (e & 15) ^ key(pr);
+      const int qq = head + pr;
+      const bool v = qq < q.tail;
+      const int row = v ? q.qj[qq & (QCAP - 1)] : 0, idx = v ? q.qi[qq & (QCAP - 1)] : 0;
+      const unsigned short* px = v ? (Xh + idx * ldx + c0 + g * 8) : g_zero_granule;
+      const unsigned short* py = v ? (dYh + row * ldy + n0 + g * 8) : g_zero_granule;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)px,
+                                       (__attribute__((address_space(3))) void*)(smem + (buf * 2 + 0) * TB + (j * 4 + wv) * 1024),
+                                       16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
+                                       (__attribute__((address_space(3))) void*)(smem + (buf * 2 + 1) * TB + (j * 4 + wv) * 1024),
+                                       16, 0, 0);
+    }
+  };
+  // transposed fragment of channel block cb (16 channels) of a tile: the 8 pairs kq * 8 .. of channel li
+  auto frag = [&](const unsigned char* tile, int cb) -> bf16x8_t {
+    s16x4_t h[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int pr = kq * 8 + r * 4 + (li >> 2);
+      const int g = cb * 2 + ((li & 3) >> 1);
+      const unsigned char* a = tile + pr * 256 + ((g ^ key(pr)) * 16) + (li & 1) * 8;
+      h[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
+    }
+    s16x8_t v = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  ring_fill(q, nbr, sj, koff, rend, n_in);
+  int buf = 0;
+  if (q.head < q.tail) issue(0, q.head);
+  while (q.head < q.tail) {
+    q.head += GR;
+    ring_fill(q, nbr, sj, koff, rend, n_in);               // the NEXT chunk's pairs are in the ring before its DMA is issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // the current chunk has landed; the other buffer has been consumed
+    if (q.head < q.tail) issue(buf ^ 1, q.head);
+    const unsigned char* xt = smem + (buf * 2 + 0) * TB;
+    const unsigned char* yt = smem + (buf * 2 + 1) * TB;
+    bf16x8_t a[4], b[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) a[mf] = frag(xt, wr * 4 + mf);
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) b[nf] = frag(yt, wc * 4 + nf);
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+    buf ^= 1;
+  }
+  if (q.tail == 0 && !ws && accumulate) return;
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int col = n0 + (wc * 4 + nf) * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = c0 + (wr * 4 + mf) * 16 + kq * 4 + r;
+        wgrad_emit(dW, ws, bz, (size_t)K * Cin * Cout, ((size_t)k * Cin + c) * Cout + col, acc[mf][nf][r], accumulate);
+      }
+    }
+}
+
 // 256 x 256 tile of dW[k] per workgroup of 8 waves (each a 64 x 128 slab: 32 MFMAs per 32-pair chunk), both operands
 // from bf16 shadows.  The 128 x 128 tile moves (128 + 128) * 2 B per pair and 16 k outputs = 64 flop/B through L2 -> LDS,
 // which is what bounds the weight gradients of the wide (768 .. 3072 channel) dense layers; this tile doubles that.
@@ -2215,6 +2324,10 @@ static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, co
     dim3 grid(K * (Cin / 256), Cout / 256, gz);
     hipLaunchKernelGGL(k_spconv_wgrad_bf16_huge, grid, dim3(512), 0, st, (const unsigned short*)X, ldx,
                        (const unsigned short*)dY, ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);
+  } else if (p.kind == 2 && XH && YH && ES_OPT_WGRAD_TR && (ldx % 8 == 0) && (ldy % 8 == 0)) {
+    dim3 grid(K * (Cin / 128), Cout / 128, gz);                // experimental: LDS-DMA staging + transposed LDS reads
+    hipLaunchKernelGGL(k_spconv_wgrad_bf16_tr, grid, dim3(256), 0, st, (const unsigned short*)X, ldx, (const unsigned short*)dY,
+                       ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);
   } else if (p.kind == 2) {
     dim3 grid(K * (Cin / 128), Cout / 128, gz);
     hipLaunchKernelGGL((k_spconv_wgrad_bf16_big<XH, YH>), grid, dim3(256), 0, st, X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin,

@@ -106,7 +106,9 @@ int es_gen_transpose_dgrad_bf16(const float* dY, const void* Wn_bf16, int n, int
  * key 10 = LDS-DMA staging (global_load_lds) in the fast bf16 kernels for bf16 input rows: 0 off, 1 = 32-channel chunks,
  * 2 = 64-channel chunks where C_in % 64 == 0 (default) -- bit-identical results in every mode (tests/test_gpu_dma.py);
  * key 11 = fewest input channels for which key 10 applies (default 768: the dense occupancy neck);
- * key 12 = fewest input channels for which the K = 1 row GEMM uses 128-column tiles (default 0) */
+ * key 12 = fewest input channels for which the K = 1 row GEMM uses 128-column tiles (default 0);
+ * key 13 = second-generation row GEMM (default 1); key 14 = EXPERIMENTAL weight-gradient tile with LDS-DMA staging and
+ * transposed LDS reads (default 0, not yet run on hardware) */
 int es_set_option(int key, int value);
 /* Y = act((X*W) * scale[c] + shift[c] (+ res)): conv2d + frozen BatchNorm2d (+ residual) (+ ReLU) of mmdet.ResNet in one
  * launch (any shape; the tap-split of under-filled launches is not applied to fused calls).  act: 0 none, 1 ReLU,
