@@ -938,8 +938,11 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
 // fragment read of a DMA pipeline: cdna_hip_programming.md 5, trap (a)).
 __device__ __attribute__((aligned(16))) unsigned short g_zero_granule[8];
 
-template <int BNT, int KB>
-__global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void k_spconv_bf16_dma(
+// NBUF = 3 (EXPERIMENTAL, option 10 value 3, not yet run on hardware): a ring of three LDS buffers with TWO chunks of DMA in
+// flight -- the wait before the barrier is a counted vmcnt (this wave's pieces of the NEXT chunk stay outstanding) and the barrier
+// is the raw s_barrier (a __syncthreads() would drain the DMA queue: cdna_hip_programming.md 5, "glds with > 1 tile in flight").
+template <int BNT, int KB, int NBUF = 2>
+__global__ __launch_bounds__(256, (KB == 1 && NBUF == 2) ? 3 : 2) void k_spconv_bf16_dma(
     const unsigned short* __restrict__ Xh, int ldx, const unsigned short* __restrict__ W, const int* __restrict__ nbr,
     int n_out, int n_in, int K, int Cin, int Cout, const float* __restrict__ bias, float* __restrict__ Y, int ldy,
     int accumulate, const float* __restrict__ ep_scale, const float* __restrict__ ep_shift,
@@ -950,7 +953,7 @@ __global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void k_spconv_bf16_dma(
   constexpr int A_BYTES = BM * RB, B_BYTES = BNT * RB;
   constexpr int NA = BM * G / 256, NBI = BNT * G / 256;    // DMA instructions per thread and chunk (A, B)
   constexpr int NFW = BNT / 32;                  // 16-wide column fragments per wave (wave tile 64 x BNT / 2)
-  constexpr int OFF_B = 2 * A_BYTES, OFF_MAP = OFF_B + 2 * B_BYTES, OFF_TAPS = OFF_MAP + BM * MAXK * 4,
+  constexpr int OFF_B = NBUF * A_BYTES, OFF_MAP = OFF_B + NBUF * B_BYTES, OFF_TAPS = OFF_MAP + BM * MAXK * 4,
                 OFF_FLAG = OFF_TAPS + 32 * 4, OFF_NT = OFF_FLAG + 32 * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_NT + 16];
   int* const nbrS = (int*)(smem + OFF_MAP);
@@ -1068,11 +1071,27 @@ __global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void k_spconv_bf16_dma(
     const int nch = (nT - tBeg) * nC;
     set_tap();
     issue(0);
-    for (int c = 0; c < nch; ++c) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of chunk c have landed ...
-      __syncthreads();                                        // ... everybody's have, and chunk c - 1 has been consumed
-      if (c + 1 < nch) issue((c + 1) & 1);
-      compute(c & 1);
+    if (NBUF == 2) {
+      for (int c = 0; c < nch; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk c have landed ...
+        __syncthreads();                                      // ... everybody's have, and chunk c - 1 has been consumed
+        if (c + 1 < nch) issue((c + 1) & 1);
+        compute(c & 1);
+      }
+    } else {
+      constexpr int PER = NA + NBI;                           // DMA instructions of one chunk per wave
+      if (nch > 1) issue(1);
+      int b0 = 0, b2 = 2;                                     // buffers of chunk c and of chunk c + 2
+      for (int c = 0; c < nch; ++c) {
+        if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");   // chunk c landed, c + 1 may be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // everybody's pieces of chunk c; chunk c - 1 has been consumed
+        if (c + 2 < nch) issue(b2);                           // into the buffer chunk c - 1 was read from
+        compute(b0);
+        b0 = b0 == 2 ? 0 : b0 + 1;
+        b2 = b2 == 2 ? 0 : b2 + 1;
+      }
     }
   }
   // epilogue: as k_spconv_bf16_fast, for the 2 x 2 wave tiling
@@ -1595,11 +1614,18 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
   }
   if (fast && ES_OPT_DMA && x_is_bf16 && Cin >= ES_OPT_DMA_MIN_CIN) {
     const unsigned short* Xh = (const unsigned short*)Xv;
-    const bool kb2 = (ES_OPT_DMA >= 2) && (Cin % 64 == 0);
+    const bool kb2 = (ES_OPT_DMA == 2) && (Cin % 64 == 0);
 #define DMA_LAUNCH(BNT_, KB_, grid_)                                                                                  \
     hipLaunchKernelGGL((k_spconv_bf16_dma<BNT_, KB_>), grid_, dim3(256), 0, st, Xh, ldx, Wh, nbr, n_out, n_in, K, Cin, Cout, \
                        bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io)
-    if (Cout % 128 == 0) { if (kb2) DMA_LAUNCH(128, 2, g128); else DMA_LAUNCH(128, 1, g128); }
+    if (ES_OPT_DMA == 3) {                                  // experimental three-buffer ring, 32-channel chunks
+      if (Cout % 128 == 0)
+        hipLaunchKernelGGL((k_spconv_bf16_dma<128, 1, 3>), g128, dim3(256), 0, st, Xh, ldx, Wh, nbr, n_out, n_in, K, Cin, Cout,
+                           bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
+      else
+        hipLaunchKernelGGL((k_spconv_bf16_dma<64, 1, 3>), g64, dim3(256), 0, st, Xh, ldx, Wh, nbr, n_out, n_in, K, Cin, Cout,
+                           bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io);
+    } else if (Cout % 128 == 0) { if (kb2) DMA_LAUNCH(128, 2, g128); else DMA_LAUNCH(128, 1, g128); }
     else                 { if (kb2) DMA_LAUNCH(64, 2, g64);   else DMA_LAUNCH(64, 1, g64); }
 #undef DMA_LAUNCH
   } else if (fast && ES_OPT_PINGPONG) {

@@ -74,3 +74,46 @@ def test_transposed_read_weight_gradient_tile_matches_the_register_transposing_t
     d = float((out[1] - out[0]).abs().max())
     assert torch.equal(out[1], out[0]), (cin, cout, d, float(out[0].abs().max()))
     print(f'transposed-read weight-gradient tile {cin}->{cout} on {n} voxels: identical to the register-transposing tile')
+
+
+def test_three_buffer_dma_ring_matches_the_register_staged_kernel():
+    """(3) k_spconv_bf16_dma<*, 1, 3> (es_set_option key 10 value 3): a ring of three LDS buffers with two chunks of DMA in
+    flight (counted vmcnt + raw s_barrier) -- same products, same order as the register-staged kernel, so bit-identical."""
+    from embodiedscan_amd import hip, sparse
+    from embodiedscan_amd.hip import call, P
+    dev = torch.device('cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    opt = hip.raw('es_set_option')
+    g = torch.Generator().manual_seed(9)
+    pts = [(torch.rand(30000, 3, generator=g) * 4 - 2).to(dev), (torch.rand(15000, 3, generator=g) * 4 - 2).to(dev)]
+    cs, _ = sparse.voxelize(pts, 0.04)
+    small, _ = sparse.voxelize([(torch.rand(1500, 3, generator=g) * 4 - 2).to(dev)], 0.04)
+    try:
+        for S in (cs, small):
+            nbr = S.kernel_map(S, 3)
+            n, K = S.n, 27
+            for cin, cout in ((32, 64), (128, 128), (256, 256), (96, 128)):
+                xh = torch.randn(n, cin, generator=g).to(dev).bfloat16().contiguous()
+                w = (torch.randn(K, cin, cout, generator=g) / (K * cin) ** 0.5).to(dev)
+                wt = torch.empty((K, cout, cin), dtype=torch.bfloat16, device=dev)
+                wn = torch.empty((K, cin, cout), dtype=torch.bfloat16, device=dev)
+                call('es_cast_weight_bf16', P(w), K, cin, cout, P(wn), P(wt), st)
+                bias = torch.randn(cout, generator=g).to(dev)
+                nf = int(hip.raw('es_spconv_split_workspace_floats')(n, K, cin, cout))
+                outs = {}
+                for mode in (0, 3):
+                    opt(10, mode)
+                    opt(11, 0)
+                    y = torch.empty(n, cout, device=dev)
+                    if nf:
+                        ws = torch.empty(nf, device=dev)
+                        call('es_spconv_fwd_bf16_ws', P(xh), 1, cin, P(wt), P(nbr), n, n, K, cin, cout, P(bias), P(y), cout, 0, P(ws), nf, st)
+                    else:
+                        call('es_spconv_fwd_bf16', P(xh), 1, cin, P(wt), P(nbr), n, n, K, cin, cout, P(bias), P(y), cout, 0, st)
+                    torch.cuda.synchronize()
+                    outs[mode] = y
+                assert torch.equal(outs[3], outs[0]), (n, cin, cout, float((outs[3] - outs[0]).abs().max()))
+    finally:
+        opt(10, 2)
+        opt(11, 768)
+    print('three-buffer DMA ring: identical to the register-staged kernel on 8 shapes')
