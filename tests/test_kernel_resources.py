@@ -21,8 +21,9 @@ FLOORS = {
     ('spconv.hip', 'k_spconv_wgrad_bf16_big'): 3,
     ('spconv.hip', '19k_spconv_wgrad_bf16IL'): 6,
     ('rowops.hip', 'k_norm_stats'): 8,
-    ('spconv.hip', 'k_spconv_bf16_dmaILi128ELi1'): 3,      # 46 KB of LDS: three workgroups per CU
-    ('spconv.hip', 'k_spconv_bf16_dmaILi128ELi2'): 2,      # 78 KB: two
+    ('spconv.hip', 'k_spconv_bf16_dmaILi128ELi1ELi2'): 3,  # 46 KB of LDS: three workgroups per CU
+    ('spconv.hip', 'k_spconv_bf16_dmaILi128ELi2ELi2'): 2,  # 78 KB: two
+    ('spconv.hip', 'k_spconv_bf16_dmaILi128ELi1ELi3'): 2,  # experimental three-buffer ring: 62 KB
 }
 
 # kernels that are KNOWN to use scratch memory today (anything else spilling is a regression)
