@@ -105,6 +105,7 @@ int es_gen_transpose_dgrad_bf16(const float* dY, const void* Wn_bf16, int n, int
  * keys 4-8 = weight-gradient slice targets / workspace cap / forward tap-split threshold (spconv.hip, options block),
  * key 10 = LDS-DMA staging (global_load_lds) in the fast bf16 kernels for bf16 input rows: 0 off, 1 = 32-channel chunks,
  * 2 = 64-channel chunks where C_in % 64 == 0 (default) -- bit-identical results in every mode (tests/test_gpu_dma.py);
+ * 3 = EXPERIMENTAL three-buffer ring with two chunks in flight (32-channel chunks; not yet run on hardware);
  * key 11 = fewest input channels for which key 10 applies (default 768: the dense occupancy neck);
  * key 12 = fewest input channels for which the K = 1 row GEMM uses 128-column tiles (default 0);
  * key 13 = second-generation row GEMM (default 1); key 14 = EXPERIMENTAL weight-gradient tile with LDS-DMA staging and
