@@ -33,8 +33,29 @@ LAYOUTS = {
     'unpadded 64-B rows, no key': (64, lambda r: 0, (0,)),
 }
 
+def worst_tr():
+    """transposed reads (ds_read_b64_tr_b16: two 32-lane groups, bank = (addr / 4) % 64, 8 bytes per lane) of the experimental
+    weight-gradient tile k_spconv_wgrad_bf16_tr: 256-byte pair rows, granule g of pair p at slot g ^ key(p)"""
+    key = lambda p: ((p & 3) | (((p >> 3) & 1) << 2)) << 1
+    w = 0
+    for cb in range(8):
+        for r in range(2):
+            for grp in (range(0, 32), range(32, 64)):
+                banks = {}
+                for lane in grp:
+                    li, kq = lane & 15, lane >> 4
+                    pr = kq * 8 + r * 4 + (li >> 2)
+                    g = cb * 2 + ((li & 3) >> 1)
+                    a = pr * 256 + ((g ^ key(pr)) * 16) + (li & 1) * 8
+                    for b in ((a // 4) % 64, (a // 4 + 1) % 64):
+                        banks.setdefault(b, set()).add(a)
+                w = max(w, max(len(v) for v in banks.values()))
+    return w
+
+
 if __name__ == '__main__':
     for name, (rb, key, hs) in LAYOUTS.items():
         print(f'{name}: documented lane groups {worst(rb, key, hs)}-way, contiguous groups {worst(rb, key, hs, CONTIG)}-way')
+    print(f'transposed fragment reads of the experimental weight-gradient tile (ds_read_b64_tr_b16): {worst_tr()}-way')
     for rb in range(64, 177, 16):
         print(f'padded rows of {rb} B, no key: {worst(rb, lambda r: 0)}-way (documented groups)')
