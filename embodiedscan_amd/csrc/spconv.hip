@@ -34,7 +34,8 @@ static int ES_OPT_DMA_MIN_CIN = 768;       // ... for layers with at least this 
                                            // (97.4 -> 84.3 ms per 7 steps, step 57.4 -> 56.1 ms); the 64 .. 256-channel sparse layers of
                                            // mv-3ddet are equal within 2 % either way (LDS activity -62 %, no bank conflicts left, same
                                            // MFMA busy: those launches are bound by the gather through L2, not by LDS)
-static int ES_OPT_WGRAD_TR = 0;            // experimental weight-gradient tile (LDS-DMA + ds_read_b64_tr_b16), see k_spconv_wgrad_bf16_tr
+static int ES_OPT_WGRAD_TR = 1;            // weight-gradient 128 x 128 tile with LDS-DMA staging + ds_read_b64_tr_b16 (k_spconv_wgrad_bf16_tr): run on
+                                           // hardware in round 4 (profiles/r4a_*): bit-identical to the register-transposing tile, step -0.2 ms
 static int ES_OPT_ROWGEMM2 = 1;            // second-generation row GEMM (swapped MFMA operands, register epilogue with 16-byte accesses)
 static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
 extern "C" int es_set_option(int key, int value) {
@@ -2068,16 +2069,18 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
     }
 }
 
-// EXPERIMENTAL (es_set_option key 14, default off; not yet run on hardware -- the round's GPU minutes were spent; parity test
-// gated by ES_TEST_EXPERIMENTAL): the 128 x 128 weight-gradient tile with LDS-DMA staging and TRANSPOSED LDS reads.
+// es_set_option key 14 (default ON since round 4: bit-identical to the register-transposing tile on the GPU,
+// tests/test_gpu_experimental.py; -0.2 ms per mv-3ddet step): the 128 x 128 weight-gradient tile with LDS-DMA staging and
+// TRANSPOSED LDS reads.
 // The kernels above transpose the gathered rows with VALU packing and 16 ds_write_b32 per thread and chunk so that the MFMA
 // fragments are k-contiguous 16-byte LDS reads: 64 + 40 LDS cycles per wave and chunk against 80 cycles of MFMA issue, 15 % MFMA
 // busy (profiles/r3_mfma_util.txt).  gfx950 has ds_read_b64_tr_b16: rows can stay in their NATURAL layout [pair][channel] in LDS
 // -- written by global_load_lds straight from the gathered bf16 rows, no registers, no conversion, no ds_write -- and a 16-lane
 // group reads a 4 (pairs) x 16 (channels) block transposed: lane i gets channel i of the 4 pairs.  Two such reads give the
 // 8 k-values of a 16x16x32 fragment.  Per wave and chunk: 16 transposed reads (2 LDS cycles each) for 16 MFMAs.
-// ASSUMED semantics of the transposed read (tools/probes/tr_read.hip prints the real ones): within a 16-lane group, lane i
-// supplies the address of the 8 bytes at block row (i >> 2), block columns 4 (i & 3) ..; it receives column i, rows 0 .. 3.
+// Semantics of the transposed read, CONFIRMED by tools/probes/tr_read.hip on MI355X (profiles/r4a_tr_read.txt): within a
+// 16-lane group, lane i supplies the address of the 8 bytes at block row (i >> 2), block columns 4 (i & 3) ..; it receives
+// column i, rows 0 .. 3.
 // Tile rows are 256 bytes (128 channels); the 16-byte granule g of pair p is stored at slot g ^ (key(p) << 1), key(p) =
 // (p & 3) | ((p >> 3) & 1) << 2: the 8 pair rows a 32-lane read group touches land on 8 distinct 32-byte bank positions.
 typedef short s16x4_t __attribute__((ext_vector_type(4)));

@@ -392,7 +392,8 @@ def _cast_rows(t):
     return h
 
 
-GEN_FUSED = [os.environ.get('ES_GEN_FUSED', '0') == '1']          # generative transposed conv: 8 taps in one launch (experimental)
+GEN_FUSED = [os.environ.get('ES_GEN_FUSED', '1') != '0']          # generative transposed conv: 8 taps in one launch per direction (round 4:
+                                                                  # run on hardware, forward bit-identical, step -0.6 ms; profiles/r4a_*)
 NORM_SHADOW = [os.environ.get('ES_NORM_SHADOW', '1') != '0']     # norm apply passes write the bf16 shadows of their outputs
 WGRAD_SHADOW = [os.environ.get('ES_WGRAD_SHADOW', '1') != '0']   # weight-gradient launches gather from the bf16 shadows too
 DET_SPLIT = [os.environ.get('ES_DET_SPLIT', '1') != '0']   # deterministic tap split (workspace + fixed-order reduction)
@@ -599,7 +600,7 @@ def gen_conv_transpose(x, w):
     s = _stream()
     bf = PRECISION[0] == 'bf16'
     fused = False
-    if bf and GEN_FUSED[0] and x.d.dtype == torch.float32:      # all eight taps in one launch (experimental, default off)
+    if bf and GEN_FUSED[0] and x.d.dtype == torch.float32:      # all eight taps in one launch
         fused = hip.raw('es_gen_transpose_fwd_bf16')(P(x.d), _ld(x.d), P(w.bf16()[1]), n, cin, cout, P(y.d), s) == 0
     for k in range(0 if not fused else 8, 8):
         if bf:

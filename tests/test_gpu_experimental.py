@@ -1,5 +1,6 @@
-"""EXPERIMENTAL paths written at the end of round 3, after the round's GPU minutes were spent: NOT YET RUN ON A GPU, off by default,
-skipped unless ES_TEST_EXPERIMENTAL=1.
+"""Three kernel paths written at the end of round 3 and first run on hardware in round 4 (profiles/r4a_experimental.txt: all green).
+(1) and (2) are ON by default since; (3) is a run-time option (es_set_option 10 = 3) that measured no faster than the
+two-buffer kernel on the 64 .. 256-channel sparse layers (profiles/r4a_sweep.txt).
 (1) the generative transposed convolution of the head's up-blocks as ONE launch per direction (engine.GEN_FUSED / es_gen_transpose_fwd_bf16 / es_gen_transpose_dgrad_bf16) against the
 eight per-tap launches: forward bit-identical (same products, same order), data gradient equal to 1e-6 relative (the taps are
 summed in one accumulator chain instead of eight read-modify-write passes), weight gradients untouched.
@@ -11,8 +12,7 @@ import os
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get('ES_TEST_EXPERIMENTAL') != '1', reason='experimental path: set ES_TEST_EXPERIMENTAL=1')]
+pytestmark = [pytest.mark.gpu]
 
 
 @pytest.mark.parametrize('n,cin,cout', [(740, 1024, 512), (5920, 512, 256), (47360, 256, 128), (333, 64, 96)])
@@ -37,7 +37,7 @@ def test_fused_generative_transpose_matches_the_per_tap_launches(n, cin, cout):
             torch.cuda.synchronize()
             res[fused] = (y.d.clone(), xv.g.clone(), wp.g.clone())
     finally:
-        E.GEN_FUSED[0] = False
+        E.GEN_FUSED[0] = True
         E.PRECISION[0] = 'f32'
     assert torch.equal(res[True][0], res[False][0]), float((res[True][0] - res[False][0]).abs().max())
     e = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
@@ -70,7 +70,7 @@ def test_transposed_read_weight_gradient_tile_matches_the_register_transposing_t
             torch.cuda.synchronize()
             out[mode] = dw
     finally:
-        hip.raw('es_set_option')(14, 0)
+        hip.raw('es_set_option')(14, 1)
     d = float((out[1] - out[0]).abs().max())
     assert torch.equal(out[1], out[0]), (cin, cout, d, float(out[0].abs().max()))
     print(f'transposed-read weight-gradient tile {cin}->{cout} on {n} voxels: identical to the register-transposing tile')
