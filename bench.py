@@ -22,6 +22,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # the host driver only supports dmabuf IPC: RCCL's peer buffers fail with hipIpcGetMemHandle errors without it
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# The step runs on seven HIP streams (main, image branch, two weight-gradient streams, H2D copy, next-batch prefetch, + RCCL's).
+# ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin; streams that share a queue are
+# SERIALISED in submission order -- measured in round 4: the prefetch stream's kernels sat behind the whole backward pass of
+# the previous step (profiles/r4b_timeline.txt) until every stream had a queue of its own.  Must be set before HIP initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
@@ -162,17 +167,32 @@ def main():
         parity_hip = {k: float(v) for k, v in l0.items()}
         del d0, b0, data, l0
 
-    def step():
-        dscans = feeder.next()                                # this step's batch has landed in HBM; next copy queued
+    # Software pipeline over batches (round 4): right after train_step(i) has been queued, the WEIGHT-INDEPENDENT prefix of step
+    # i+1 -- wait for its H2D copy, A1-A3 depth -> points, image normalisation, A4 voxelisation + Morton order, the strided
+    # chain with its row-count read-backs, the 3-D backbone's / head's kernel maps and unions (A6) -- is issued on a
+    # high-priority side stream (det.prefetch), i.e. under step i's backward pass; what the reference does with DataLoader
+    # workers on host cores.  Every timed step prefetches for its successor (the first timed step's prefix was issued by the
+    # last warm-up step, the last timed step issues the prefix of a step that is not timed): K full steps of work in the
+    # timed region.  ES_NEXT_PREFETCH=0 restores the serial step.
+    nxt = [None]
+    use_prefetch = os.environ.get('ES_NEXT_PREFETCH', '1') != '0' and hasattr(det, 'prefetch')
+
+    def make():
+        return pipeline.make_batch(feeder.next())             # this batch has landed in HBM (next copy queued); A1-A3 on device
+
+    def step(prefetch_next=True):
         E.mark('_begin')
-        batch = pipeline.make_batch(dscans)                   # A1-A3 on device
+        batch, nxt[0] = (nxt[0] if nxt[0] is not None else make()), None
         out = det.train_step(batch, optim)
         feeder.done()
+        if use_prefetch and prefetch_next:
+            nxt[0] = det.prefetch(make)
         return out
 
-    # two priming steps that are NOT part of --warmup: the first builds the lazily made maps / allocator blocks, the second captures
-    # the image backbone's launch sequence into its hipGraph (engine.graphed) -- so that even `--warmup 0` times steady steps
-    for _ in range(2):
+    # four priming steps that are NOT part of --warmup: the preprocessor alternates between two output buffers, and for each of
+    # them the first step builds the lazily made maps / allocator blocks and the second captures the image backbone's launch
+    # sequence into a hipGraph (engine.graphed: one graph per input address) -- so that even `--warmup 0` times steady steps
+    for _ in range(4):
         step()
     for _ in range(args.warmup):
         losses = step()
@@ -201,7 +221,7 @@ def main():
     red = getattr(det.arena, 'reducer', None)
     if red is not None:
         red.profile = []                                        # N > 1: how long the optimiser waits for each gradient bucket
-    step()
+    step(prefetch_next=False)                                   # (consumes the batch the last timed step prepared)
     recs = resolve_pairs(hip, prof['records'])
     torch.cuda.synchronize()
     hip.PROFILE = None
@@ -247,7 +267,7 @@ def main():
         prof1 = dict(prof, names=ENGINE | SCATTER, records=[])
         hip.PROFILE = prof1
         E.MARKS = []
-        step()
+        step(prefetch_next=False)                               # serial step: the coordinate phase is inside, on the one stream
         marks, E.MARKS = E.MARKS, None
         hip.PROFILE = None
         E.TWO_STREAMS[0], E.WGRAD_ASYNC[0] = saved

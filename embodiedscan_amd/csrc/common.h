@@ -84,3 +84,24 @@ __device__ inline uint32_t es_pack_bf16(float a, float b) {
   es_bf16x2 y = __builtin_convertvector(x, es_bf16x2);
   return *(uint32_t*)&y;
 }
+
+// Deterministic cross-workgroup reduction without a second launch and without float atomics: every workgroup stores its
+// partial result in a workspace, then calls es_last_block(); exactly one workgroup -- the last to arrive -- gets `true` and
+// adds the partials up in WORKGROUP ORDER (a fixed order: bit-reproducible run to run).  `ticket` is one unsigned int in
+// global memory that must be 0 before the launch and is 0 again after it (launches sharing a ticket must be stream-ordered).
+// Release / acquire: every thread fences its own stores before the barrier; the winner fences again before it reads.
+__device__ inline bool es_last_block(unsigned int* ticket, unsigned int nblocks) {
+  __shared__ unsigned int es_s_last;
+  __threadfence();
+  __syncthreads();
+  if ((threadIdx.x | threadIdx.y | threadIdx.z) == 0) {
+    unsigned int t = atomicAdd(ticket, 1u);
+    es_s_last = (t == nblocks - 1u) ? 1u : 0u;
+    if (es_s_last) *ticket = 0u;
+  }
+  __syncthreads();
+  const bool last = es_s_last != 0u;
+  if (last) __threadfence();
+  return last;
+}
+#define ES_TICKET_FLOATS 4          // floats reserved at the head of a workspace for the ticket (keeps partials 16-byte aligned)

@@ -413,10 +413,11 @@ extern "C" int es_union_plan(const int64_t* keys_a, int na, const int64_t* tkeys
     if (nb > 0) hipLaunchKernelGGL(k_union_fix, dim3(es_cdiv(nb, 256)), dim3(256), 0, st, nb, hit, pos_a, pos_b);
   }
   ES_CHECK_LAUNCH();
-  int new_cnt = 0;
-  ES_TRY(hipMemcpyAsync(&new_cnt, total, 4, hipMemcpyDeviceToHost, st));
+  // (straight into the caller's buffer -- pinned host memory on the product path: a copy into a pageable stack variable is staged by
+  // the runtime and was seen to wait for work queued on OTHER streams)
+  ES_TRY(hipMemcpyAsync(count_host, total, 4, hipMemcpyDeviceToHost, st));
   ES_TRY(hipStreamSynchronize(st));
-  *count_host = na + new_cnt;
+  *count_host += na;
   return 0;
 }
 

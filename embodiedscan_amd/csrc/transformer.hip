@@ -398,11 +398,15 @@ extern "C" int es_layernorm_fwd(const float* x, const float* res, int n, int C, 
   return 0;
 }
 // dz = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * w;  dw += sum_rows dy * xhat, db += sum_rows dy
-// (per-workgroup partial sums over a slice of rows, then atomics)
+// Parameter gradients (round 4, deterministic): every workgroup stores the partial sums of its slice of rows in the workspace,
+// the last workgroup to arrive (es_last_block) adds them in workgroup order into dw / db -- one writer, fixed order, no float
+// atomics (rounds 2-3 used unsafeAtomicAdd here: the grounder's gradients were reproducible to ~1e-6 only).
+#define LN_ROWS_PER_BLOCK 32
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ z, int n, int C,
                                                 const float* __restrict__ w, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, float* __restrict__ dz, int accumulate,
-                                                float* __restrict__ dw, float* __restrict__ db, int rows_per_block) {
+                                                float* __restrict__ dw, float* __restrict__ db, int rows_per_block,
+                                                float* __restrict__ ws) {
   __shared__ float sw[4][512], sb[4][512];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float aw[8], ab[8], wc[8];
@@ -442,25 +446,41 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
       }
     }
   }
+  if (!dw && !db) return;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     int c = lane + q * 64;
     if (c < C) { sw[wv][c] = aw[q]; sb[wv][c] = ab[q]; }
   }
   __syncthreads();
+  float* part = ws + ES_TICKET_FLOATS;                              // [block][2][C]
   for (int c = threadIdx.x; c < C; c += 256) {
-    float a = sw[0][c] + sw[1][c] + sw[2][c] + sw[3][c], bsum = sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c];
-    if (dw) unsafeAtomicAdd(dw + c, a);
-    if (db) unsafeAtomicAdd(db + c, bsum);
+    part[((size_t)blockIdx.x * 2) * C + c] = sw[0][c] + sw[1][c] + sw[2][c] + sw[3][c];
+    part[((size_t)blockIdx.x * 2 + 1) * C + c] = sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c];
+  }
+  if (!es_last_block((unsigned int*)ws, gridDim.x)) return;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, bsum = 0.f;
+    for (unsigned int blk = 0; blk < gridDim.x; ++blk) {
+      a += part[((size_t)blk * 2) * C + c];
+      bsum += part[((size_t)blk * 2 + 1) * C + c];
+    }
+    if (dw) dw[c] += a;
+    if (db) db[c] += bsum;
   }
 }
+extern "C" size_t es_layernorm_bwd_workspace_floats(int n, int C) {
+  return (size_t)ES_TICKET_FLOATS + (size_t)es_cdiv(n > 0 ? n : 1, LN_ROWS_PER_BLOCK) * 2 * C;
+}
 extern "C" int es_layernorm_bwd(const float* dy, const float* z, int n, int C, const float* w, const float* mean,
-                                const float* rstd, float* dz, int accumulate, float* dw, float* db, void* stream) {
+                                const float* rstd, float* dz, int accumulate, float* dw, float* db, float* workspace,
+                                size_t workspace_floats, void* stream) {
   if (n <= 0) return 0;
   if (C > 512) return -4;
-  int rpb = 32;
+  if ((dw || db) && (!workspace || workspace_floats < es_layernorm_bwd_workspace_floats(n, C))) return -5;
+  int rpb = LN_ROWS_PER_BLOCK;
   hipLaunchKernelGGL(k_ln_bwd, dim3(es_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, dy, z, n, C, w, mean, rstd, dz, accumulate,
-                     dw, db, rpb);
+                     dw, db, rpb, workspace);
   ES_CHECK_LAUNCH();
   return 0;
 }
@@ -535,60 +555,95 @@ extern "C" int es_contrastive_fwd(const float* v, int B, int L, const float* tex
   return 0;
 }
 // backward: dv[b,i,:] = sum_t dl[b,i,t] text[b,t,:] / sqrt(C);  dtext[b,t,:] += sum_i dl[b,i,t] v[b,i,:] / sqrt(C);
-// dbias += sum dl.  dlogits must be 0 at masked positions.  One wave per visual row for dv; dtext / dbias via atomics of
-// per-workgroup partial sums held in LDS.
+// dbias += sum dl.  dlogits must be 0 at masked positions.  One launch, two kinds of workgroups (round 4, deterministic: no
+// float atomics): blockIdx.x < nA -> one wave per visual row for dv (the sample's text block in LDS); blockIdx.x >= nA -> ONE
+// workgroup per (sample, text token) walks the sample's rows in ascending order, threads over channels, and is the only
+// writer of its dtext row; its sum of dl goes to the workspace and the last workgroup to arrive (es_last_block) adds those B * T
+// partials in index order into dbias.
 __global__ __launch_bounds__(256) void k_contrastive_bwd(const float* __restrict__ dl, int Tout, const float* __restrict__ v, int L,
                                                          const float* __restrict__ text, int T, int C,
                                                          const int* __restrict__ tlen, float* __restrict__ dv, int acc_v,
-                                                         float* __restrict__ dtext, float* __restrict__ dbias) {
-  extern __shared__ float sh[];                         // text block [T*C] | dtext partial [T*C]
+                                                         float* __restrict__ dtext, float* __restrict__ dbias, int nA,
+                                                         float* __restrict__ ws) {
+  extern __shared__ float sh[];                         // dv workgroups: the sample's text block [tl * C]
   const int b = blockIdx.y;
   const int tl = min(tlen[b], T);
-  float* ts = sh;
-  float* dts = sh + (size_t)T * C;
-  for (int e = threadIdx.x; e < tl * C; e += 256) { ts[e] = text[(size_t)b * T * C + e]; dts[e] = 0.f; }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
   const float inv = 1.f / sqrtf((float)C);
-  float bsum = 0.f;
-  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < L; i += gridDim.x * 4) {
-    const float* vr = v + ((size_t)b * L + i) * C;
-    const float* dr = dl + ((size_t)b * L + i) * Tout;
-    float vv[8], g[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { vv[q] = (lane + q * 64) < C ? vr[lane + q * 64] : 0.f; g[q] = 0.f; }
-    for (int t = 0; t < tl; ++t) {
-      float d = dr[t];
-      if (d == 0.f) continue;
-      if (lane == 0) bsum += d;
-      d *= inv;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        int c = lane + q * 64;
-        if (c < C) { g[q] += d * ts[t * C + c]; atomicAdd(&dts[t * C + c], d * vv[q]); }
-      }
-    }
+  const bool reduce = (dtext != nullptr) || (dbias != nullptr);
+  if ((int)blockIdx.x < nA) {
     if (dv) {
+      float* ts = sh;
+      for (int e = threadIdx.x; e < tl * C; e += 256) ts[e] = text[(size_t)b * T * C + e];
+      __syncthreads();
+      const int lane = threadIdx.x & 63;
+      for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < L; i += nA * 4) {
+        const float* dr = dl + ((size_t)b * L + i) * Tout;
+        float g[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        int c = lane + q * 64;
-        if (c < C) { float* p = dv + ((size_t)b * L + i) * C + c; *p = acc_v ? *p + g[q] : g[q]; }
+        for (int q = 0; q < 8; ++q) g[q] = 0.f;
+        for (int t = 0; t < tl; ++t) {
+          float d = dr[t];
+          if (d == 0.f) continue;
+          d *= inv;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            int c = lane + q * 64;
+            if (c < C) g[q] += d * ts[t * C + c];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          int c = lane + q * 64;
+          if (c < C) { float* p = dv + ((size_t)b * L + i) * C + c; *p = acc_v ? *p + g[q] : g[q]; }
+        }
       }
     }
+  } else if (reduce) {
+    const int t = (int)blockIdx.x - nA;
+    float a0 = 0.f, a1 = 0.f, bs = 0.f;
+    const int c0 = threadIdx.x, c1 = threadIdx.x + 256;
+    if (t < tl) {
+      for (int i = 0; i < L; ++i) {
+        float d = dl[((size_t)b * L + i) * Tout + t];
+        if (d == 0.f) continue;                          // (uniform across the workgroup)
+        bs += d;
+        d *= inv;
+        const float* vr = v + ((size_t)b * L + i) * C;
+        if (c0 < C) a0 += d * vr[c0];
+        if (c1 < C) a1 += d * vr[c1];
+      }
+      if (dtext) {
+        float* o = dtext + ((size_t)b * T + t) * C;
+        if (c0 < C) o[c0] += a0;
+        if (c1 < C) o[c1] += a1;
+      }
+    }
+    if (threadIdx.x == 0) ws[ES_TICKET_FLOATS + (size_t)b * T + t] = bs;
   }
-  __syncthreads();
-  if (dtext)
-    for (int e = threadIdx.x; e < tl * C; e += 256) if (dts[e] != 0.f) unsafeAtomicAdd(dtext + (size_t)b * T * C + e, dts[e]);
-  if (dbias && lane == 0 && bsum != 0.f) unsafeAtomicAdd(dbias, bsum);
+  if (!reduce) return;
+  if (!es_last_block((unsigned int*)ws, gridDim.x * gridDim.y)) return;
+  if (dbias && threadIdx.x == 0) {
+    float tot = 0.f;
+    const int nb = gridDim.y * T;
+    for (int e = 0; e < nb; ++e) tot += ws[ES_TICKET_FLOATS + e];
+    dbias[0] += tot;
+  }
 }
+extern "C" size_t es_contrastive_bwd_workspace_floats(int B, int T) { return (size_t)ES_TICKET_FLOATS + (size_t)(B > 0 ? B : 1) * T; }
 extern "C" int es_contrastive_bwd(const float* dlogits, int Tout, const float* v, int B, int L, const float* text, int T, int C,
-                                  const int* tlen_dev, float* dv, int acc_v, float* dtext, float* dbias, void* stream) {
+                                  const int* tlen_dev, float* dv, int acc_v, float* dtext, float* dbias, float* workspace,
+                                  size_t workspace_floats, void* stream) {
   if (B <= 0 || L <= 0) return 0;
-  size_t sh = (size_t)2 * T * C * sizeof(float);
+  size_t sh = (size_t)T * C * sizeof(float);
   if (C > 512 || sh > 160 * 1024 - 1024) return -4;
+  const bool reduce = dtext || dbias;
+  if (reduce && (!workspace || workspace_floats < es_contrastive_bwd_workspace_floats(B, T))) return -5;
   if (sh > 64 * 1024) ES_TRY(hipFuncSetAttribute((const void*)k_contrastive_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-  hipLaunchKernelGGL(k_contrastive_bwd, dim3(min(es_cdiv(L, 4), 64), B), dim3(256), sh, (hipStream_t)stream, dlogits, Tout, v, L,
-                     text, T, C, tlen_dev, dv, acc_v, dtext, dbias);
+  const int nA = dv ? min(es_cdiv(L, 4), 64) : 0;
+  const int nx = nA + (reduce ? T : 0);
+  if (nx <= 0) return 0;
+  hipLaunchKernelGGL(k_contrastive_bwd, dim3(nx, B), dim3(256), sh, (hipStream_t)stream, dlogits, Tout, v, L, text, T, C, tlen_dev,
+                     dv, acc_v, dtext, dbias, nA, workspace);
   ES_CHECK_LAUNCH();
   return 0;
 }
@@ -635,6 +690,90 @@ extern "C" int es_ground_decode_bwd(const float* pred, int ldp, const float* dbo
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_ground_decode_bwd, dim3(es_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, ldp, dbox, n, dpred, ldg,
                      accumulate);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ 9-DoF "FCAF" box coder (grounding_head.py:308-363;
+// configs/grounding/mv-grounding_8xb12_embodiedscan-vg-9dof_fcaf-coder.py:64)
+// d = clamp(exp(pred[0:6]), 2e-2) (log distances to the six faces); s = ((d1 - d0) / 2, (d3 - d2) / 2, (d5 - d4) / 2);
+// box = (point + R(euler) s, (d0 + d1, d2 + d3, d4 + d5), euler), euler = pred[6:9], R = Rz(a) Rx(b) Ry(c) (rotation_3d_in_euler
+// multiplies the row vector by R^T).  The reference writes d in place into bbox_pred; nothing reads bbox_pred afterwards, so this
+// is a pure function of (pred, point) and autograd differentiates through exp / clamp (gradient passes where exp >= 2e-2).
+struct FcafRot { float c0[3], c1[3], c2[3], sa, ca, sb, cb, sc, cc; };
+__device__ inline FcafRot fcaf_rot(float a, float b, float c) {
+  FcafRot r;
+  r.sa = sinf(a); r.ca = cosf(a); r.sb = sinf(b); r.cb = cosf(b); r.sc = sinf(c); r.cc = cosf(c);
+  r.c0[0] = r.ca * r.cc - r.sa * r.sb * r.sc; r.c0[1] = r.sa * r.cc + r.ca * r.sb * r.sc; r.c0[2] = -(r.cb * r.sc);
+  r.c1[0] = -(r.sa * r.cb);                   r.c1[1] = r.ca * r.cb;                      r.c1[2] = r.sb;
+  r.c2[0] = r.ca * r.sc + r.sa * r.sb * r.cc; r.c2[1] = r.sa * r.sc - r.ca * r.sb * r.cc; r.c2[2] = r.cb * r.cc;
+  return r;
+}
+__global__ void k_ground_decode_fcaf_fwd(const float* __restrict__ pred, int ldp, const float* __restrict__ pts, int n,
+                                         float* __restrict__ box) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = pred + (size_t)i * ldp;
+  float* o = box + (size_t)i * 9;
+  float d[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) d[j] = fmaxf(expf(p[j]), 2e-2f);
+  const float s0 = (d[1] - d[0]) * 0.5f, s1 = (d[3] - d[2]) * 0.5f, s2 = (d[5] - d[4]) * 0.5f;
+  const FcafRot r = fcaf_rot(p[6], p[7], p[8]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o[c] = pts[(size_t)i * 3 + c] + (r.c0[c] * s0 + r.c1[c] * s1 + r.c2[c] * s2);
+    o[3 + c] = d[2 * c] + d[2 * c + 1];
+    o[6 + c] = p[6 + c];
+  }
+}
+extern "C" int es_ground_decode_fcaf_fwd(const float* pred, int ldp, const float* points, int n, float* box, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_ground_decode_fcaf_fwd, dim3(es_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, ldp, points, n, box);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+__global__ void k_ground_decode_fcaf_bwd(const float* __restrict__ pred, int ldp, const float* __restrict__ dbox, int n,
+                                         float* __restrict__ dpred, int ldg, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = pred + (size_t)i * ldp;
+  const float* g = dbox + (size_t)i * 9;
+  float* o = dpred + (size_t)i * ldg;
+  float e[6], d[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { e[j] = expf(p[j]); d[j] = fmaxf(e[j], 2e-2f); }
+  const float s0 = (d[1] - d[0]) * 0.5f, s1 = (d[3] - d[2]) * 0.5f, s2 = (d[5] - d[4]) * 0.5f;
+  const FcafRot r = fcaf_rot(p[6], p[7], p[8]);
+  // gradient w.r.t. the shift: R^T g_center
+  const float gs0 = r.c0[0] * g[0] + r.c0[1] * g[1] + r.c0[2] * g[2];
+  const float gs1 = r.c1[0] * g[0] + r.c1[1] * g[1] + r.c1[2] * g[2];
+  const float gs2 = r.c2[0] * g[0] + r.c2[1] * g[1] + r.c2[2] * g[2];
+  const float gs[3] = {gs0, gs1, gs2};
+  float out[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float lo = -0.5f * gs[c] + g[3 + c], hi = 0.5f * gs[c] + g[3 + c];       // d d[2c], d d[2c+1]
+    out[2 * c] = e[2 * c] >= 2e-2f ? lo * e[2 * c] : 0.f;
+    out[2 * c + 1] = e[2 * c + 1] >= 2e-2f ? hi * e[2 * c + 1] : 0.f;
+  }
+  // v = R s; dv/da = (-v.y, v.x, 0); dv/dc = col0 * s2 - col2 * s0; dv/db from the element-wise derivative of Rz Rx Ry
+  const float v0 = r.c0[0] * s0 + r.c1[0] * s1 + r.c2[0] * s2, v1 = r.c0[1] * s0 + r.c1[1] * s1 + r.c2[1] * s2;
+  const float da = g[0] * (-v1) + g[1] * v0;
+  const float b0 = (-(r.sa * r.cb * r.sc)) * s0 + (r.sa * r.sb) * s1 + (r.sa * r.cb * r.cc) * s2;
+  const float b1 = (r.ca * r.cb * r.sc) * s0 + (-(r.ca * r.sb)) * s1 + (-(r.ca * r.cb * r.cc)) * s2;
+  const float b2 = (r.sb * r.sc) * s0 + r.cb * s1 + (-(r.sb * r.cc)) * s2;
+  const float db = g[0] * b0 + g[1] * b1 + g[2] * b2;
+  const float dc = g[0] * (r.c0[0] * s2 - r.c2[0] * s0) + g[1] * (r.c0[1] * s2 - r.c2[1] * s0) + g[2] * (r.c0[2] * s2 - r.c2[2] * s0);
+  out[6] = g[6] + da; out[7] = g[7] + db; out[8] = g[8] + dc;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) o[j] = accumulate ? o[j] + out[j] : out[j];
+}
+extern "C" int es_ground_decode_fcaf_bwd(const float* pred, int ldp, const float* dbox, int n, float* dpred, int ldg, int accumulate,
+                                         void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_ground_decode_fcaf_bwd, dim3(es_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, ldp, dbox, n, dpred,
+                     ldg, accumulate);
   ES_CHECK_LAUNCH();
   return 0;
 }

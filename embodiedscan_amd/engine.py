@@ -193,7 +193,7 @@ def graphed(cache, key, fn):
     shadows; 2nd: captured, then replayed).  Eager whenever per-launch instrumentation is on, on the default stream (capture
     needs a non-default stream: the side stream of the two-stream schedule), or after a failed capture."""
     global _NEW_VARS
-    instrumented = hip.PROFILE is not None or DEBUG_CONV is not None or DEBUG_GRADS is not None
+    instrumented = hip.PROFILE is not None or DEBUG_CONV is not None or DEBUG_GRADS is not None or DEBUG_OPS is not None
     if not GRAPHS[0] or instrumented or _NEW_VARS is not None or \
             torch.cuda.current_stream() == torch.cuda.default_stream():
         GRAPH_STATS['eager'] += 1
@@ -368,11 +368,35 @@ def join_wgrad_streams(final=True):
             ws['used'] = False
     if final:
         _KEEP.clear()
+
+
+_TICKET_WS = {}         # stream handle -> zero-initialised f32 workspace of the last-block reductions queued on that stream
+
+
+def ticket_ws(floats, like):
+    """(tensor, floats) workspace for a kernel that reduces per-workgroup partials in its last workgroup (csrc/common.h
+    es_last_block): its head holds a ticket counter that must be 0 before every launch and is left 0 by every launch, so ONE
+    zero-initialised buffer per stream serves all such launches of the stream (they are ordered); grown on demand."""
+    h = _stream()
+    ws = _TICKET_WS.get(h)
+    if ws is None or ws.numel() < floats or ws.device != like.device:
+        if ws is not None:
+            _KEEP.append(ws)                     # launches already queued may still use the old buffer
+        ws = _TICKET_WS[h] = torch.zeros(max(int(floats), 1 << 16), dtype=torch.float32, device=like.device)
+    return ws, ws.numel()
+
+
 MARKS = None            # bench.py sets a list: stage boundaries as (name, event) recorded on the current stream
+
+
+HOST_MARKS = None       # tools/host_profile.py sets a list: (name, host perf_counter) at the same stage boundaries
 
 
 def mark(name):
     """stage boundary for the per-stage timing of bench.py (SURVEY 8d "Reporting"); free when MARKS is None"""
+    if HOST_MARKS is not None:
+        import time
+        HOST_MARKS.append((name, time.perf_counter()))
     if MARKS is not None:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(hip.stream_obj())
@@ -383,6 +407,8 @@ DEBUG_GRADS = None      # tools/debug_grads.py sets a dict: id(Var) -> snapshot 
 DEBUG_CONV = None       # tests/test_gpu_insitu.py sets a list: one record per convolution backward of the step (operands as the
                         # launches saw them + the data gradient this launch produced), for the in-situ check of every
                         # weight- / data-gradient launch against its arithmetic specification
+DEBUG_OPS = None        # ... and a list for the other backward launches with parameters or matrix-core arithmetic: attention
+                        # (kind 'attn'), LayerNorm ('ln'), ContrastiveEmbed ('contrastive', appended by GroundingHead)
 
 
 def _cast_rows(t):
@@ -499,7 +525,7 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     rec = None
     if DEBUG_CONV is not None:
         rec = dict(x=x.d, w=w, nbr=nbr, n_out=n_out, gy=gy.clone(), bf=bool(bf), gate=gate, need_dx=bool(need_dx and x.rg),
-                   before=(x.g.clone() if (x.g is not None and need_dx and x.rg) else None))
+                   before=(x.g.clone() if (x.g is not None and need_dx and x.rg) else None), bias=bias, bias_from=bias_from)
         DEBUG_CONV.append(rec)
     # bf16 shadow of the output gradient: gather source of the data-gradient launch and, with the input's shadow from
     # the forward pass, of the weight-gradient launch (made here, before the weight-gradient stream forks)
@@ -614,6 +640,12 @@ def gen_conv_transpose(x, w):
         if y.g is None:
             return
         s = _stream()
+        recs = None
+        if DEBUG_CONV is not None:                     # the 8 taps as 8 identity-map K = 1 records sharing one data gradient
+            before = x.g.clone() if (x.rg and x.g is not None) else None
+            recs = [dict(x=x.d, w=ParamSlice(w, k), nbr=None, n_out=n, gy=y.g.view(n, 8, cout)[:, k].clone(), bf=bool(bf), gate=None,
+                         need_dx=bool(x.rg), before=before, bias=None, bias_from=0, group=id(y), group_size=8) for k in range(8)]
+            DEBUG_CONV.extend(recs)
         g, acc = _grad_target(x, x.d) if x.rg else (None, 0)
         sw = _wgrad_stream(y.g, x.d) if w.g is not None else s
         dfused = False
@@ -632,6 +664,8 @@ def gen_conv_transpose(x, w):
             elif g is not None:
                 call('es_spconv_fwd', gy, 8 * cout, w.d.data_ptr() + 4 * k * cin * cout, 0, n, n, 1, cout, cin, 0,
                      P(g), _ld(g), 1, 1 if (acc or k > 0) else 0, s)
+        if recs is not None and x.rg:
+            recs[-1]['after'] = x.g.clone()          # (after all eight taps)
     TAPE.add(bwd)
     return y
 
@@ -864,7 +898,15 @@ def layernorm(x, w, b, res=None, eps=1e-5):
         s = _stream()
         tgt = [v for v in ((x, res) if res is not None else (x,)) if v.rg]
         dz = torch.empty_like(y.d)
-        call('es_layernorm_bwd', P(y.g), P(z), n, C, P(w.d), P(mean), P(rstd), P(dz), 0, P(w.g), P(b.g), s)
+        ws, nws = ticket_ws(hip.raw('es_layernorm_bwd_workspace_floats')(n, C), y.d)
+        rec = None
+        if DEBUG_OPS is not None:
+            rec = dict(kind='ln', dy=y.g.clone(), z=z.clone(), w=w.d.clone(), mean=mean.clone(), rstd=rstd.clone(), n=n, C=C,
+                       wp=w, bp=b, dw0=w.g.clone(), db0=b.g.clone())
+            DEBUG_OPS.append(rec)
+        call('es_layernorm_bwd', P(y.g), P(z), n, C, P(w.d), P(mean), P(rstd), P(dz), 0, P(w.g), P(b.g), P(ws), nws, s)
+        if rec is not None:
+            rec.update(dz=dz.clone(), dw1=w.g.clone(), db1=b.g.clone())
         owned = False                            # dz may be handed to exactly one input as its gradient buffer
         for v in tgt:
             if v.g is None:
@@ -897,7 +939,15 @@ def attention(q, k, v, B, H, Lq, Lk, klen=None):
             else:
                 gs.append(1)
         assert gs[0] == gs[1] == gs[2], 'attention inputs must be fresh projections (single consumer)'
+        rec = None
+        if DEBUG_OPS is not None:
+            rec = dict(kind='attn', q=q.d.clone(), k=k.d.clone(), v=v.d.clone(), o=o.d.clone(), do=o.g.clone(), lse=lse.clone(),
+                       klen=None if klen is None else klen.clone(), B=B, H=H, Lq=Lq, Lk=Lk, bf=bf, acc=gs[0],
+                       before=[t.g.clone() for t in (q, k, v)] if gs[0] else None)
+            DEBUG_OPS.append(rec)
         call('es_attn_bwd', P(q.d), _ld(q.d), P(k.d), _ld(k.d), P(v.d), _ld(v.d), P(o.d), H * 32, P(o.g), _ld(o.g), P(lse), B, H,
              Lq, Lk, P(klen), P(delta), P(q.g), _ld(q.g), P(k.g), _ld(k.g), P(v.g), _ld(v.g), gs[0], bf, _stream())
+        if rec is not None:
+            rec.update(delta=delta.clone(), dq=q.g.clone(), dk=k.g.clone(), dv=v.g.clone())
     TAPE.add(bwd)
     return o

@@ -51,6 +51,27 @@ class MinkResNet:
             o.offsets()
         return outs
 
+    def prefetch_maps(self, cs):
+        """build every kernel / inverse map forward() and its backward will ask for (cached on the sets; no host round trip):
+        the detector's next-batch prefetch calls this under the previous step's backward pass"""
+        o1 = cs.strided(2)
+        cs.kernel_map(o1, 3)
+        # (conv1's data gradient is never taken: its input is the raw point feature)
+        if self.pool:
+            o2 = o1.strided(2)
+            o1.kernel_map(o2, 2)
+            cs = o2
+        else:
+            cs = o1
+        for layer in self.blocks:
+            oc = cs.strided(2)
+            for k in (3, 1):
+                cs.kernel_map(oc, k)
+                cs.inverse_map(oc, k)
+            cs = oc
+            cs.kernel_map(cs, 3)                         # conv2 of every block, conv1 of the blocks behind the first
+            cs.inverse_map(cs, 3)
+
     def forward(self, x):
         tr = self.training
         cs = x.cs

@@ -171,6 +171,9 @@ class ResNet:
 
     def __call__(self, x):
         """forward(x) through engine.graphed(): the launch sequence is static for a given input buffer, grid and mode"""
+        # the table-driven bf16 weight cast must run OUTSIDE the captured sequence (inside, capture would stamp every kernel as
+        # cast without executing the launch, and every replay would redo it): bring the copies up to date first
+        E.refresh_weight_copies()
         key = (x.data_ptr(), tuple(x.shape), E.PRECISION[0], bool(self.act16 and E.ACT16[0]), E.TAPE.enabled, self._fold_version,
                self.arena.data.data_ptr(), E.SHADOW[0], E.WGRAD_SHADOW[0])
         return E.graphed(self._graphs, key, lambda: self.forward(x))

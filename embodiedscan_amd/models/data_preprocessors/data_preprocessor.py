@@ -9,6 +9,8 @@ from ...registry import MODELS
 
 @MODELS.register_module()
 class Det3DDataPreprocessor:
+    RING = 2                                     # persistent output buffers per image geometry (see forward())
+
     def __init__(self, mean=None, std=None, bgr_to_rgb=False, rgb_to_bgr=False, pad_size_divisor=1, pad_value=0,
                  voxel=False, device=None, **kw):
         assert not voxel, 'voxel=True (mmcv hard/dynamic voxelisation) is not used by the shipped configs'
@@ -47,14 +49,20 @@ class Det3DDataPreprocessor:
             assert img.dtype == torch.uint8 and C == 3
             d = max(int(self.pad_size_divisor), 1)
             Hp, Wp = (H + d - 1) // d * d, (W + d - 1) // d * d      # bottom / right padding (utils.py:43-62)
-            # ONE buffer per image geometry, rewritten every step: the image backbone's launch sequence is replayed from a
-            # hipGraph and reads its input at a fixed address (the previous step's readers were joined into this stream long ago)
+            # A RING of RING buffers per image geometry, rewritten in turn: the image backbone's launch sequence is replayed from a
+            # hipGraph (one captured graph per input address) and so wants few, stable input addresses.  ALIASING CONTRACT: the
+            # `imgs` returned by call n stay valid until call n + RING of the same geometry (round-3 advisor: with ONE buffer the
+            # output of call n was overwritten by call n + 1, which breaks any caller that preprocesses the next batch while
+            # the previous one is still live -- prefetching loops, tests comparing two batches); clone() to keep them longer.
             key = (B * V, Hp, Wp, str(dev))
-            nhwc = self._img_buf.get(key)
-            if nhwc is None:
+            ring = self._img_buf.get(key)
+            if ring is None:
                 if len(self._img_buf) > 4:
                     self._img_buf.clear()
-                nhwc = self._img_buf[key] = torch.empty((B * V, Hp, Wp, 3), dtype=torch.float32, device=dev)
+                ring = self._img_buf[key] = dict(bufs=[torch.empty((B * V, Hp, Wp, 3), dtype=torch.float32, device=dev)
+                                                       for _ in range(self.RING)], n=0)
+            nhwc = ring['bufs'][ring['n'] % self.RING]
+            ring['n'] += 1
             call('es_preprocess_img', P(img.contiguous()), B * V, H, W, Hp, Wp, int(self.flip), farr(self.mean),
                  farr(self.std), float(self.pad_value), P(nhwc), torch.cuda.current_stream(dev).cuda_stream)
             out['imgs'] = nhwc.view(B, V, Hp, Wp, 3).permute(0, 1, 4, 2, 3)

@@ -176,18 +176,25 @@ class FCAF3DHeadRotMat:
         new_set, src = sparse.compact(x.cs, mask, offsets=kept)
         return SparseTensor(new_set, E.gather_rows(x.F, src))
 
-    def prefetch_coords(self, level_sets):
+    def prefetch_coords(self, level_sets, maps=False):
         """Coordinate work of the top-down pass that does not depend on features -- generative children, unions and their
         per-sample offsets (each a small device->host read-back) -- done BEFORE the feature kernels are queued, while the
         image branch keeps the GPU busy.  The forward pass then finds everything cached and issues without host stalls.
         Stops at the first level whose pruning is live (its output set depends on scores)."""
         x = level_sets[-1]
         thr = self.pts_prune_threshold
+        if maps:                                        # next-batch prefetch: the 3^3 maps of the out_block convolutions too
+            x.kernel_map(x, 3), x.inverse_map(x, 3)
         for i in range(len(level_sets) - 2, -1, -1):
-            u, _, _ = sparse.union(level_sets[i], x.children())
+            c = x.children()
+            if maps:                                    # up_block's 3^3 convolution runs on the generated children
+                c.kernel_map(c, 3), c.inverse_map(c, 3)
+            u, _, _ = sparse.union(level_sets[i], c)
             off = u.offsets()
             if any(off[b + 1] - off[b] > thr for b in range(u.n_batch)):
-                break
+                break                                   # pruning is live: the set the out_block sees depends on scores
+            if maps:
+                u.kernel_map(u, 3), u.inverse_map(u, 3)
             x = u
 
     def _levels(self, inputs):

@@ -1,5 +1,5 @@
 """GroundingHead (embodiedscan/models/dense_heads/grounding_head.py:102-824) on the MI355X kernels, for the shipped
-configuration: box_coder 'baseline' with 9 regression outputs, share_pred_layer=True, sigmoid FocalLoss on the token
+configurations: box_coder 'baseline' or 'FCAF' with 9 regression outputs, share_pred_layer=True, sigmoid FocalLoss on the token
 logits, 4-group decoupled BBoxCDLoss, HungarianAssigner3D(BinaryFocalLossCost, BBox3DL1Cost, IoU3DCost).
 Per decoder layer the loss is five launches for the WHOLE batch: contrastive logits, costs + assignment (device-side
 Hungarian, no D2H / scipy), labels + focal loss with its gradient, corner-Chamfer loss on the matched pairs with its
@@ -25,7 +25,9 @@ class GroundingHead:
         self.max_text_len = self.contrastive_cfg.get('max_text_len', 256)
         assert self.contrastive_cfg.get('log_scale', None) == 'auto' and self.contrastive_cfg.get('bias', False), \
             "the fused kernel implements ContrastiveEmbed(log_scale='auto', bias=True) of the shipped config"
-        assert box_coder == 'baseline' and num_reg == 9 and num_reg_fcs == 2, 'shipped: baseline coder, 9 outputs'
+        # the shipped configs use 9 regression outputs with either coder (configs/grounding/*.py; ..._fcaf-coder.py:64: 'FCAF')
+        assert box_coder in ('baseline', 'FCAF') and num_reg == 9 and num_reg_fcs == 2, 'shipped: 9 outputs, baseline or FCAF coder'
+        self.box_coder = box_coder
         assert share_pred_layer, 'shipped: share_pred_layer=True'
         loss_cls = loss_cls or {}
         assert loss_cls.get('type') == 'mmdet.FocalLoss' and loss_cls.get('use_sigmoid', False)
@@ -57,10 +59,13 @@ class GroundingHead:
         return self.reg[2](h)
 
     def decode(self, points, reg):
-        """_bbox_pred_to_bbox (grounding_head.py:286-296): Var (n,9) boxes from raw (n,3) points and the reg Var"""
+        """_bbox_pred_to_bbox (grounding_head.py:267-363, 'baseline' :292-296 or 'FCAF' :308-363): Var (n,9) boxes from raw (n,3)
+        points and the reg Var"""
         n = reg.d.shape[0]
         box = E.Var(torch.empty((n, 9), dtype=torch.float32, device=reg.d.device))
-        call('es_ground_decode_fwd', P(reg.d), reg.d.stride(0), P(points), n, P(box.d), hip.stream())
+        fwd, bwd_name = (('es_ground_decode_fwd', 'es_ground_decode_bwd') if self.box_coder == 'baseline' else
+                         ('es_ground_decode_fcaf_fwd', 'es_ground_decode_fcaf_bwd'))
+        call(fwd, P(reg.d), reg.d.stride(0), P(points), n, P(box.d), hip.stream())
 
         def bwd():
             if box.g is None:
@@ -68,7 +73,7 @@ class GroundingHead:
             acc = 1 if reg.g is not None else 0
             if reg.g is None:
                 reg.g = torch.empty_like(reg.d)
-            call('es_ground_decode_bwd', P(reg.d), reg.d.stride(0), P(box.g), n, P(reg.g), reg.g.stride(0), acc, hip.stream())
+            call(bwd_name, P(reg.d), reg.d.stride(0), P(box.g), n, P(reg.g), reg.g.stride(0), acc, hip.stream())
         E.TAPE.add(bwd)
         return box
 
@@ -94,8 +99,18 @@ class GroundingHead:
                     gv, acc = None, 0
                 if text.rg and text.g is None:
                     text.g = torch.zeros_like(text.d)
+                ws, nws = E.ticket_ws(hip.raw('es_contrastive_bwd_workspace_floats')(B, T), visual.d)
+                rec = None
+                if E.DEBUG_OPS is not None:
+                    rec = dict(kind='contrastive', dl=logits.g.clone(), v=visual.d.clone(), text=text.d.clone(), tlen=tlen.clone(),
+                               B=B, L=L, T=T, C=C, acc=acc, dv0=gv.clone() if (gv is not None and acc) else None,
+                               dtext0=text.g.clone() if text.rg else None, dbias0=self.cls_bias.g.clone())
+                    E.DEBUG_OPS.append(rec)
                 call('es_contrastive_bwd', P(logits.g), T, P(visual.d), B, L, P(text.d), T, C, P(tlen), P(gv), acc,
-                     P(text.g) if text.rg else 0, P(self.cls_bias.g), s)
+                     P(text.g) if text.rg else 0, P(self.cls_bias.g), P(ws), nws, s)
+                if rec is not None:
+                    rec.update(dv1=None if gv is None else gv.clone(), dtext1=text.g.clone() if text.rg else None,
+                               dbias1=self.cls_bias.g.clone())
             E.TAPE.add(bwd)
         return logits, rowmax
 
@@ -157,6 +172,8 @@ class GroundingHead:
             logits, _ = self.cls_branch(hidden_states[l], text_feats, B, Q, T, tlen)
             boxes = all_layers_pred_bboxes[l]
             q2g = self.assigner.match(logits.d.view(B, Q, T), boxes.d.view(B, Q, 9), gt_boxes, pos_map, gt_off, Gmax, tlen, s)
+            if getattr(self, 'force_assign', None) is not None:      # test hook (teacher forcing): the oracle's assignment of layer l
+                free, q2g = q2g, self.force_assign[l].to(device=dev, dtype=torch.int32).reshape(B, Q).contiguous()
             lsum = torch.zeros(1, dtype=torch.float64, device=dev)
             logits.g = torch.empty_like(logits.d)
             call('es_ground_focal', P(logits.d), T, B, Q, P(q2g), P(pos_map), P(gt_off), P(tlen), T, self.focal_alpha,
@@ -170,6 +187,8 @@ class GroundingHead:
             losses[name + 'loss_cls'] = loss_cls
             losses[name + 'loss_bbox'] = lbox[0]
             self.last.append(dict(logits=logits, boxes=boxes, q2g=q2g))
+            if getattr(self, 'force_assign', None) is not None:
+                self.last[-1]['q2g_free'] = free
         out = dict(loss_cls=losses['loss_cls'], loss_bbox=losses['loss_bbox'])
         out.update({k: v for k, v in losses.items() if k.startswith('d')})
         return out

@@ -49,13 +49,21 @@ class DenseFusionOccPredictor(DetectorBase):
                                    n_blocks=self.neck_3d.n_blocks, num_classes=self.bbox_head.num_classes,
                                    head_in=self.bbox_head.in_channels)
         self._init_base(specs, device, seed, data_preprocessor)
+        self._bucket_groups = self.bucket_groups_for(self.neck_3d.n_scales)
         self._prior = None
 
     # gradient buckets: part 0 = the image branch (ResNet-50 + FPN: complete last), 1 = MinkResNet34, 2 = the fine half of
     # the dense neck (down_layer_0/1: 0.3 GB), implicit part 3 = the coarse half + head (down_layer_2, up / out blocks: 2.6 GB of
     # the 2.9 GB of gradients) -- its all-reduce starts when the reverse replay leaves down_layer_2, in 256 MB chunks, under
     # the backward of the fine neck levels and both backbones instead of as one 2.9 GB call at the end
-    _bucket_groups = (('backbone.', 'neck.'), ('backbone_3d.',), ('neck_3d.down_layer_0', 'neck_3d.down_layer_1'))
+    # Part 2 must be exactly the down layers recorded BEFORE the neck's tape mark (imvoxel_neck.forward places it in front of
+    # down_layer_{n_scales - 1}): derived from the neck's depth, not hard-coded (round-3 advisor: with n_blocks of another
+    # length a down layer behind the mark would have been all-reduced before its gradient was complete).
+    @staticmethod
+    def bucket_groups_for(n_scales):
+        return (('backbone.', 'neck.'), ('backbone_3d.',), tuple(f'neck_3d.down_layer_{i}.' for i in range(n_scales - 1)))
+
+    _bucket_groups = (('backbone.', 'neck.'), ('backbone_3d.',), ('neck_3d.down_layer_0.', 'neck_3d.down_layer_1.'))   # n_scales = 3
 
     def _children(self):
         return [(self.backbone, 'backbone.'), (self.neck, 'neck.'), (self.backbone_3d, 'backbone_3d.'),

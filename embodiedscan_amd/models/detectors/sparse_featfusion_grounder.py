@@ -46,6 +46,7 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
                                                ffn=self.decoder.ffn_channels, in_channels=self.neck_3d.in_channels), seed=seed)
         self.training = True
         self._bound = False
+        self._pf_init()
 
     # gradient buckets (data parallel): the backbones, the MinkNeck, and -- implicit last part -- decoder + head +
     # text_feat_map, whose gradients are complete first: four all-reduces, each under the backward of what precedes it
@@ -158,6 +159,11 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         Q = min(self.num_queries, min(lens))
         idx = torch.empty((B, Q), dtype=torch.int32, device=dev)
         call('es_topk_sorted', P(rowmax), B, Lmax, P(klen), Q, P(idx), s)
+        if getattr(self, 'force_queries', None) is not None:
+            # test hook (teacher forcing, tests/test_gpu_grounding.py): take the oracle's query indices so that a bf16 run can be
+            # compared with its specification element by element even when the top-k boundary would flip a near tie
+            self.free_queries = idx
+            idx = self.force_queries.to(device=dev, dtype=torch.int32).reshape(B, Q).contiguous()
         gidx = (idx + (torch.arange(B, device=dev, dtype=torch.int32) * Lmax)[:, None]).reshape(-1).contiguous()
         query = E.gather_rows(feats, gidx)
         qcoords = torch.empty((B * Q, 3), dtype=torch.float32, device=dev)

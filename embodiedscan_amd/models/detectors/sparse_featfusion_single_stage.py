@@ -45,6 +45,7 @@ class SparseFeatureFusionSingleStage3DDetector:
         self.arena = ParamArena(detector_specs(self.bbox_head.num_classes), seed=seed)
         self.training = True
         self._bound = False
+        self._pf_init()
         # The image branch (2-D backbone forward, and its backward) and the point branch (coordinate pipeline + 3-D
         # backbone) only meet in the fusion layer, so they are issued on two HIP streams (engine.side_stream): the deep,
         # under-filled sparse launches of the point branch then run in the shadow of the image branch's full-chip ones.
@@ -94,6 +95,87 @@ class SparseFeatureFusionSingleStage3DDetector:
         self.bbox_head.training = mode
         return self
 
+    # ------------------------------------------------------------------ next-batch prefetch (round 4)
+    # The reference hides the data side of step i+1 behind step i with DataLoader workers (A1-A3 on host cores).  Here A1-A4 and
+    # the coordinate manager's work (A6: strided sets, kernel maps, unions) run on the GPU, and everything in them is
+    # WEIGHT-INDEPENDENT: depth -> points, image normalisation, voxel keys, Morton order, the strided chain with its row-count
+    # read-backs, the backbone's kernel / inverse maps, the head's unions.  prefetch() issues that prefix for the NEXT batch on a
+    # high-priority side stream right after train_step() of the current batch has been queued: its kernels (~2 ms, small
+    # grids) and its host round trips run under the current step's backward pass, and the next train_step() starts with the
+    # 3-D backbone's first convolution instead of 4.5 ms of coordinate work with the chip a quarter busy
+    # (profiles/r3v_timeline.txt).  Nothing that depends on the weights is touched (the image backbone of step i+1 must see
+    # the weights AFTER step i's update), so the step computes exactly what it computed before (tests/test_gpu_prefetch.py:
+    # bit-identical losses and gradients with and without).
+    # Allocator discipline: tensors made here come from the prefetch stream's pool but are read by main-stream kernels of the
+    # next step.  They are kept referenced until the prefetch stream has waited for an event recorded on the main stream
+    # at the end of the step that used them -- one step late, when that event has long fired -- so a recycled block can never
+    # be rewritten by a prefetch kernel while a main-stream kernel still reads it.
+    def _pf_init(self):
+        self._pf_stream = None
+        self._prefetched = None        # dict of the batch prepared ahead (consumed by the next train_step on the same `data`)
+        self._pf_cur = None            # ... of the batch the running train_step is using
+        self._pf_hold = []             # [(event at the end of the step, prefetched dict)] awaiting release
+
+    def prefetch(self, make_data):
+        """data = make_data() (e.g. pipeline.make_batch of the next scans: A1-A3 are launched on the prefetch stream) + the
+        weight-independent prefix of train_step(data, ...) issued now.  Returns `data`; hand exactly this object to the next
+        train_step().  Optional: train_step() on any other data works as before."""
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        st = self._pf_stream
+        while len(self._pf_hold) > 1:                          # the step before the last one has long finished on the device
+            ev, old = self._pf_hold.pop(0)
+            st.wait_event(ev)
+            del old
+        self._bind()
+        try:
+            with torch.cuda.stream(st):
+                hip.refresh_stream()
+                data = make_data()
+                pre = self.data_preprocessor(data, True) if self.data_preprocessor is not None else data
+                pts = self._points_f32(pre['inputs']['points'])
+                cs, src = sparse.voxelize(pts, self.voxel_size)
+                self._prefetch_coords(cs, maps=True)
+                ready = torch.cuda.Event()
+                ready.record(st)
+        finally:
+            hip.refresh_stream()                               # launches follow torch's current stream again
+        self._prefetched = dict(data=data, pre=pre, pts=pts, cs=cs, src=src, ready=ready)
+        return data
+
+    @staticmethod
+    def _points_f32(points):
+        return [p if (p.dtype == torch.float32 and p.stride(-1) == 1) else p.float().contiguous() for p in points]
+
+    def _prefetch_coords(self, cs, maps=False):
+        """all data-dependent row counts of the point branch (strided sets, unions of the head's top-down pass) are read back
+        here; maps=True (next-batch prefetch): also build the 3-D backbone's kernel / inverse maps now"""
+        lv_sets = self.backbone_3d.prefetch_coords(cs)
+        if maps and hasattr(self.backbone_3d, 'prefetch_maps'):
+            self.backbone_3d.prefetch_maps(cs)
+        for m in (getattr(self, 'bbox_head', None), getattr(self, 'neck_3d', None)):
+            if m is not None and hasattr(m, 'prefetch_coords'):
+                m.prefetch_coords(lv_sets, maps=maps)
+                break
+
+    def _pf_take(self, data):
+        """train_step entry: the prefetched batch if `data` is the object prefetch() returned, else None"""
+        pf, self._prefetched = self._prefetched, None
+        if pf is not None and pf['data'] is data:
+            hip.stream_obj().wait_event(pf['ready'])
+            self._pf_cur = pf
+            return pf
+        self._pf_cur = None
+        return None
+
+    def _pf_done(self):
+        """train_step exit: the batch's prefetched tensors stay referenced until the prefetch stream has seen this event"""
+        if self._pf_cur is not None:
+            ev = torch.cuda.Event()
+            ev.record(hip.stream_obj())
+            self._pf_hold.append((ev, self._pf_cur))
+            self._pf_cur = None
+
     # ------------------------------------------------------------------ features
     def extract_feat(self, batch_inputs_dict, batch_data_samples):
         """sparse_featfusion_single_stage.py:86-221.  Returns 4 SparseTensors with [3-D | image] channels."""
@@ -118,9 +200,12 @@ class SparseFeatureFusionSingleStage3DDetector:
             img_feats = self.backbone(nhwc)
         E.mark('A7 2-D backbone fwd')
         self._tape_marks = [len(E.TAPE.fns)]                   # end of the 2-D backbone's closures
-        points = batch_inputs_dict['points']
-        pts = [p if (p.dtype == torch.float32 and p.stride(-1) == 1) else p.float().contiguous() for p in points]
-        cs, src = sparse.voxelize(pts, self.voxel_size)
+        pf = self._pf_cur
+        if pf is not None and batch_inputs_dict is pf['pre']['inputs']:
+            pts, cs, src = pf['pts'], pf['cs'], pf['src']      # voxelised (and mapped) under the previous step's backward
+        else:
+            pts = self._points_f32(batch_inputs_dict['points'])
+            cs, src = sparse.voxelize(pts, self.voxel_size)
         # voxel features (:109-116): the whole point row (xyz + extra columns) with use_xyz_feat, else the columns behind xyz
         c0 = 0 if self.use_xyz_feat else 3
         Cf = int(pts[0].shape[1]) - c0
@@ -131,11 +216,7 @@ class SparseFeatureFusionSingleStage3DDetector:
         # all data-dependent row counts of the point branch (strided sets, unions of the head's top-down pass) are read back
         # here, under the image branch's kernels; the 3-D backbone and the head are then queued without host stalls
         if os.environ.get('ES_PREFETCH_COORDS', '1') != '0':
-            lv_sets = self.backbone_3d.prefetch_coords(cs)
-            for m in (getattr(self, 'bbox_head', None), getattr(self, 'neck_3d', None)):
-                if m is not None and hasattr(m, 'prefetch_coords'):
-                    m.prefetch_coords(lv_sets)
-                    break
+            self._prefetch_coords(cs)                          # (everything is cached already after a next-batch prefetch)
         E.mark('A4 voxelise')
         x = self.backbone_3d(SparseTensor(cs, E.Var(feats, rg=False)))
         E.mark('A5+A6 3-D backbone fwd + maps')
@@ -205,7 +286,10 @@ class SparseFeatureFusionSingleStage3DDetector:
         E.TAPE.clear()
         hip.refresh_stream()
         E.mark('A1-A3 depth->points')            # whatever the caller queued before train_step (pipeline.make_batch)
-        if self.data_preprocessor is not None:
+        pf = self._pf_take(data)
+        if pf is not None:
+            data = pf['pre']                     # preprocessed, voxelised and mapped by prefetch() under the previous step
+        elif self.data_preprocessor is not None:
             data = self.data_preprocessor(data, True)
         self._bind()
         self.arena.grad.zero_()
@@ -224,6 +308,7 @@ class SparseFeatureFusionSingleStage3DDetector:
         E.mark('backward (head, 3-D, 2-D)')
         optim_wrapper.update_params(self.arena)
         E.mark('all-reduce wait + clip + AdamW')
+        self._pf_done()
         return losses
 
     # gradient buckets of the data-parallel exchange (parallel.BucketedGradReducer): parts 0 / 1 = the backbones, the

@@ -51,16 +51,23 @@ class MinkNeck:
         new_set, src = sparse.compact(x.cs, mask, offsets=kept)
         return SparseTensor(new_set, E.gather_rows(x.F, src))
 
-    def prefetch_coords(self, level_sets):
+    def prefetch_coords(self, level_sets, maps=False):
         """feature-independent coordinate work of the top-down pass ahead of the feature kernels (see
         FCAF3DHeadRotMat.prefetch_coords); stops at the first level whose pruning is live"""
         x = level_sets[-1]
         thr = self.pts_prune_threshold
+        if maps:
+            x.kernel_map(x, 3), x.inverse_map(x, 3)
         for i in range(len(level_sets) - 2, -1, -1):
-            u, _, _ = sparse.union(level_sets[i], x.children())
+            c = x.children()
+            if maps:
+                c.kernel_map(c, 3), c.inverse_map(c, 3)
+            u, _, _ = sparse.union(level_sets[i], c)
             off = u.offsets()
             if any(off[b + 1] - off[b] > thr for b in range(u.n_batch)):
                 break
+            if maps:
+                u.kernel_map(u, 3), u.inverse_map(u, 3)
             x = u
 
     def levels(self, inputs):

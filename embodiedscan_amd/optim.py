@@ -22,7 +22,7 @@ class OptimWrapper:
         n = arena.n_train
         self.m = torch.zeros(n, dtype=torch.float32, device=arena.data.device)
         self.v = torch.zeros(n, dtype=torch.float32, device=arena.data.device)
-        self.partial = torch.empty(2048 * 64, dtype=torch.float64, device=arena.data.device)     # 2048 per reduced chunk
+        self.partial = torch.empty(2048 * 64, dtype=torch.float64, device=arena.data.device)     # workspace of es_grad_norm
         self.norm = torch.zeros(1, dtype=torch.float32, device=arena.data.device)
 
     def _build_groups(self, arena):
@@ -72,20 +72,17 @@ class OptimWrapper:
         n = arena.n_train
         self.step += 1
         gscale = 1.0
-        if reducer is not None and reducer.sumsq is None and arena.grad.is_cuda:
+        if reducer is not None and not reducer.use_sumsq and arena.grad.is_cuda:
             # clip norm under the bucket all-reduces: every reduced chunk's sum of squares is taken on the reducer's side
-            # stream right behind its collective (takes effect from the next step's launches on)
-            grad, partial = arena.grad, self.partial
-            reducer.sumsq = lambda a, b, slot: call('es_sumsq_partial', grad.data_ptr() + 4 * a, b - a,
-                                                    partial.data_ptr() + 8 * 2048 * slot, torch.cuda.current_stream().cuda_stream)
-            fresh = True
-        else:
-            fresh = False
+            # stream right behind its collective, into the REDUCER's buffer (takes effect from the next step's launches on;
+            # any number of OptimWrappers may come and go on one detector)
+            reducer.use_sumsq = True
         chunks = reducer.finish() if reducer is not None else 0   # buckets launched during backward (parallel.py) ...
-        if chunks and not fresh and reducer.sumsq is not None and chunks <= 64:
+        if chunks and reducer.last_sumsq_ok:
             import torch.distributed as dist
+            from .parallel import SUMSQ_BLOCK
             gscale = 1.0 / dist.get_world_size()              # the arena holds the SUM over ranks: mean folded into AdamW
-            call('es_norm_from_partials', P(self.partial), 2048 * chunks, gscale, P(self.norm), s)
+            call('es_norm_from_partials', P(reducer.partial), SUMSQ_BLOCK * chunks, gscale, P(self.norm), s)
         else:
             if chunks:
                 reducer.scale_()
@@ -126,7 +123,9 @@ class MultiStepLR:
     def lr_at(self, epoch):
         """mmengine counts a scheduler's steps from its `begin` (_ParamScheduler.step only runs inside [begin, end) and
         `last_step` starts at 0 there): a milestone m is passed after m epochs SINCE begin"""
-        e = min(max(epoch, self.begin), self.end) - self.begin
+        # ... and the last step it takes is the one at global epoch end - 1 (it does not run at `end`), so a milestone equal to
+        # end - begin is never reached (round-3 advisor)
+        e = min(max(epoch, self.begin), self.end - 1) - self.begin
         return self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= e)
 
     def step(self):

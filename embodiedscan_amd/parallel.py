@@ -42,6 +42,8 @@ def reduce_mean(t):
 # upper bound of one all-reduce call: a 2.9 GB bucket (the occupancy neck) is issued as several calls so that the ring
 # pipeline of the first chunk starts while later chunks are still being queued and the exposed tail is one chunk, not 3 GB
 MAX_BUCKET_FLOATS = 64 << 20          # 256 MB
+SUMSQ_BLOCK = 2048                    # doubles es_sumsq_partial writes per reduced chunk
+MAX_SUMSQ_CHUNKS = 64                 # chunks per step whose sum of squares is taken behind their collective
 
 
 class BucketedGradReducer:
@@ -84,7 +86,14 @@ class BucketedGradReducer:
         assert allr and allr[0][0] == 0 and allr[-1][1] == arena.n_train and \
             all(a[1] == b[0] for a, b in zip(allr[:-1], allr[1:])), f'gradient buckets do not tile the arena: {allr}'
         self.work = []                       # (work handle, a, b)
-        self.sumsq = None                    # callable(a, b, slot) queued behind a range's all-reduce (set by OptimWrapper)
+        # Clip norm under the collectives.  The reducer OWNS the buffer of partial sums (round-3 advisor: a closure installed by
+        # the first OptimWrapper kept writing into that wrapper's buffer after a second wrapper took over the detector), one
+        # block of SUMSQ_BLOCK doubles per reduced chunk, at most MAX_SUMSQ_CHUNKS chunks; a step with more chunks takes no
+        # side-stream sums at all past the bound and reports sumsq_ok = False, and the optimiser falls back to one pass over the arena.
+        self.use_sumsq = False               # switched on by OptimWrapper.update_params (takes effect from the next step's launches)
+        self.partial = None                  # (MAX_SUMSQ_CHUNKS * SUMSQ_BLOCK,) f64 on the gradient's device
+        self.sumsq_ok = True                 # every chunk launched since the last finish() has its partial block
+        self.last_sumsq_ok = False           # ... of the step finish() closed
         self.n_chunks = 0
         self.profile = None                  # bench.py: list that receives (part, floats, exposed_ms) per waited chunk
         self._side = None
@@ -107,21 +116,27 @@ class BucketedGradReducer:
             w = dist.all_reduce(self.arena.grad[a:b], async_op=True)
             slot = self.n_chunks
             self.n_chunks += 1
-            if self.sumsq is not None and self.arena.grad.is_cuda:
+            if self.use_sumsq and self.arena.grad.is_cuda and slot < MAX_SUMSQ_CHUNKS:
+                from .hip import call
                 if self._side is None:
                     self._side = torch.cuda.Stream()
+                if self.partial is None or self.partial.device != self.arena.grad.device:
+                    self.partial = torch.empty(MAX_SUMSQ_CHUNKS * SUMSQ_BLOCK, dtype=torch.float64, device=self.arena.grad.device)
                 with torch.cuda.stream(self._side):
                     w.wait()                         # orders the side stream behind the collective (no host block)
-                    self.sumsq(a, b, slot)
+                    call('es_sumsq_partial', self.arena.grad.data_ptr() + 4 * a, b - a,
+                         self.partial.data_ptr() + 8 * SUMSQ_BLOCK * slot, self._side.cuda_stream)
                     ev = torch.cuda.Event()
                     ev.record(self._side)
                 self.work.append((w, a, b, part, ev))
             else:
+                self.sumsq_ok = False                # this step's norm needs a pass over the arena
                 self.work.append((w, a, b, part, None))
 
     def finish(self):
         """wait for every launched chunk; returns the number of chunks reduced (0: nothing was launched).  The sums are
         NOT scaled here: the caller folds 1/world into its next pass over the gradients (OptimWrapper) or calls scale_()."""
+        self.last_sumsq_ok, self.sumsq_ok = (self.sumsq_ok and bool(self.work)), True
         if not self.work:
             return 0
         n = len(self.work)

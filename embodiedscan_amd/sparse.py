@@ -16,6 +16,31 @@ def _stream():
     return hip.stream()
 
 
+# Row counts come back through PINNED host memory: a device-to-host copy into pageable memory is staged and ordered by the
+# runtime in a way that made the read-backs of the next-batch prefetch stream wait for the whole train step queued on the
+# other streams (round 4, profiles/r4b_timeline.txt); into pinned memory it is a plain stream-ordered DMA.
+_PIN = {}
+
+
+def _pinned_ints(n=64):
+    t = _PIN.get('buf')
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 256), dtype=torch.int32)
+        if torch.cuda.is_available():
+            t = t.pin_memory()
+        _PIN['buf'] = t
+    return t
+
+
+def read_ints(dev_tensor):
+    """host list of a small device int32 tensor: async copy into the pinned buffer + a sync of the CURRENT stream only"""
+    n = dev_tensor.numel()
+    pin = _pinned_ints(n)
+    pin[:n].copy_(dev_tensor.reshape(-1), non_blocking=True)
+    torch.cuda.current_stream(dev_tensor.device).synchronize()
+    return [int(v) for v in pin[:n].tolist()]
+
+
 def _pow2_cap(n):
     c = 1024
     while c < 2 * n + 2:
@@ -63,7 +88,7 @@ class CoordSet:
     def offsets(self):
         """host list of n_batch+1 row offsets (one small D2H copy, cached)."""
         if self._off_host is None:
-            self._off_host = [int(v) for v in self.offsets_dev().cpu().tolist()]
+            self._off_host = read_ints(self.offsets_dev())
         return self._off_host
 
     # ------------------------------------------------------------------ derived sets / maps
@@ -138,10 +163,11 @@ def strided_chain(root, n_levels):
     scratch = torch.empty(2 * n + n // 2048 + 8, dtype=torch.int32, device=dev)
     per = B + 2
     res = torch.empty(n_levels * per, dtype=torch.int32, device=dev)
-    res_host = (ctypes.c_int * (n_levels * per))()
+    res_host = _pinned_ints(n_levels * per)
     ptrs = lambda ts_: (ctypes.c_void_p * n_levels)(*[t.data_ptr() for t in ts_])
     call('es_strided_chain', P(root.keys), n, B, n_levels, (ctypes.c_int * n_levels)(*ts), P(tmp), P(scratch), ptrs(tk), ptrs(tv),
-         (ctypes.c_int * n_levels)(*([cap] * n_levels)), ptrs(ok), P(res), res_host, _stream())
+         (ctypes.c_int * n_levels)(*([cap] * n_levels)), ptrs(ok), P(res), res_host.data_ptr(), _stream())
+    res_host = res_host[:n_levels * per].tolist()
     out, cur = [], root
     for l in range(n_levels):
         m = int(res_host[l * per])
@@ -163,10 +189,10 @@ def unique_first(keys, n, ts, n_batch, want_src=True):
     scratch = torch.empty(2 * n + n // 2048 + 8, dtype=torch.int32, device=dev)
     out_keys = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     out_src = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    cnt = ctypes.c_int(0)
+    cnt = _pinned_ints()
     call('es_unique_first', P(keys), n, P(tkeys), P(tvals), cap, P(scratch), P(out_keys), P(out_src),
-         ctypes.byref(cnt), _stream())
-    m = cnt.value
+         cnt.data_ptr(), _stream())
+    m = int(cnt[0])
     return CoordSet(out_keys[:m], m, ts, n_batch, tkeys, tvals), out_src[:m]
 
 
@@ -230,10 +256,10 @@ def _union(a, b):
     pos_a = torch.empty(max(a.n, 1), dtype=torch.int32, device=dev)
     pos_b = torch.empty(max(b.n, 1), dtype=torch.int32, device=dev)
     out_keys = torch.empty(a.n + b.n, dtype=torch.int64, device=dev)
-    cnt = ctypes.c_int(0)
+    cnt = _pinned_ints()
     call('es_union_plan', P(a.keys), a.n, P(tk), P(tv), cap, P(b.keys), b.n, P(a.offsets_dev()), P(b.offsets_dev()),
-         a.n_batch, P(scratch), P(pos_a), P(pos_b), P(out_keys), ctypes.byref(cnt), _stream())
-    m = cnt.value
+         a.n_batch, P(scratch), P(pos_a), P(pos_b), P(out_keys), cnt.data_ptr(), _stream())
+    m = int(cnt[0])
     return CoordSet(out_keys[:m], m, a.ts, a.n_batch), pos_a[:a.n], pos_b[:b.n]
 
 
@@ -251,10 +277,10 @@ def compact(cs, mask, offsets=None):
         out = CoordSet(out_keys[:m], m, cs.ts, cs.n_batch)
         out._off_host = [int(v) for v in offsets]
         return out, out_src[:m]
-    cnt = ctypes.c_int(0)
-    call('es_compact_mask', P(cs.keys), cs.n, P(mask), P(scratch), P(out_keys), P(out_src), ctypes.byref(cnt),
+    cnt = _pinned_ints()
+    call('es_compact_mask', P(cs.keys), cs.n, P(mask), P(scratch), P(out_keys), P(out_src), cnt.data_ptr(),
          _stream())
-    m = cnt.value
+    m = int(cnt[0])
     return CoordSet(out_keys[:m], m, cs.ts, cs.n_batch), out_src[:m]
 
 

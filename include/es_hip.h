@@ -354,20 +354,33 @@ int es_attn_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V
 /* y = LayerNorm(x (+ res)) over the C columns of (n,C) rows (C <= 512); z = x + res is stored when z != NULL */
 int es_layernorm_fwd(const float* x, const float* res, int n, int C, const float* w, const float* b, float eps, float* y,
                      float* z, float* mean, float* rstd, void* stream);
+/* dw / db (+=) are reduced deterministically (round 4): partial sums per workgroup in `workspace` (>= es_layernorm_bwd_workspace_floats
+ * floats; its first 4 floats hold a ticket counter that must be 0 on entry and is 0 again on exit -- keep one zero-initialised
+ * workspace per stream), added in workgroup order by the last workgroup to arrive.  No float atomics. */
+size_t es_layernorm_bwd_workspace_floats(int n, int C);
 int es_layernorm_bwd(const float* dy, const float* z, int n, int C, const float* w, const float* mean, const float* rstd,
-                     float* dz, int accumulate, float* dw, float* db, void* stream);
+                     float* dz, int accumulate, float* dw, float* db, float* workspace, size_t workspace_floats, void* stream);
 int es_relu_fwd(float* x, size_t n, void* stream);
 int es_relu_bwd(float* dy, const float* y, size_t n, void* stream);
 /* ContrastiveEmbed (grounding_head.py:62-99, log_scale='auto', bias): logits (B,L,Tout) = <v, text> / sqrt(C) + bias for
  * t < tlen[b] (and rows < vlen[b]), -inf elsewhere; rowmax (B,L) = max over tokens (either output may be NULL) */
 int es_contrastive_fwd(const float* v, int B, int L, const float* text, int T, int C, const int* tlen_dev, const int* vlen_dev,
                        const float* bias_dev, float* logits, int Tout, float* rowmax, void* stream);
+size_t es_contrastive_bwd_workspace_floats(int B, int T);
+/* dtext: one workgroup per (sample, token) adds the rows in ascending order; dbias: per-workgroup partials in `workspace` (same
+ * ticket convention as es_layernorm_bwd) summed in index order by the last workgroup.  Deterministic, no float atomics. */
 int es_contrastive_bwd(const float* dlogits, int Tout, const float* v, int B, int L, const float* text, int T, int C,
-                       const int* tlen_dev, float* dv, int acc_v, float* dtext /* += */, float* dbias /* += */, void* stream);
+                       const int* tlen_dev, float* dv, int acc_v, float* dtext /* += */, float* dbias /* += */, float* workspace,
+                       size_t workspace_floats, void* stream);
 /* GroundingHead._bbox_pred_to_bbox, box_coder 'baseline', 9 outputs: (pred[:3] + point, clamp(exp(pred[3:6]), 2e-2), pred[6:]) */
 int es_ground_decode_fwd(const float* pred, int ldp, const float* points, int n, float* box /* (n,9) */, void* stream);
 int es_ground_decode_bwd(const float* pred, int ldp, const float* dbox, int n, float* dpred, int ldg, int accumulate,
                          void* stream);
+/* GroundingHead._bbox_pred_to_bbox, box_coder 'FCAF', 9 outputs (grounding_head.py:308-363, configs/grounding/..._fcaf-coder.py:64):
+ * d = clamp(exp(pred[:6]), 2e-2); box = (point + R(pred[6:]) ((d1-d0)/2, (d3-d2)/2, (d5-d4)/2), (d0+d1, d2+d3, d4+d5), pred[6:]) */
+int es_ground_decode_fcaf_fwd(const float* pred, int ldp, const float* points, int n, float* box /* (n,9) */, void* stream);
+int es_ground_decode_fcaf_bwd(const float* pred, int ldp, const float* dbox, int n, float* dpred, int ldg, int accumulate,
+                              void* stream);
 /* N2: exact IoU of 9-DoF Euler (ZXY) boxes, (N,M) -- EulerInstance3DBoxes.overlaps / pytorch3d box3d_overlap */
 int es_box3d_iou(const float* boxes1, int N, const float* boxes2, int M, float* iou, void* stream);
 /* N2: HungarianAssigner3D for every sample of one decoder layer: costs (BinaryFocalLossCost w_cls, BBox3DL1Cost w_l1,

@@ -160,8 +160,21 @@ def reg_branch(x, sd, p='bbox_head.reg_branches.0.'):
     return F.linear(h, sd[p + '4.weight'], sd[p + '4.bias'])
 
 
-def bbox_pred_to_bbox(points, pred):
-    return torch.cat((pred[..., :3] + points, torch.exp(pred[..., 3:6]).clamp(min=2e-2), pred[..., 6:]), -1)
+def bbox_pred_to_bbox(points, pred, coder='baseline'):
+    """GroundingHead._bbox_pred_to_bbox with 9 outputs: 'baseline' (grounding_head.py:292-296) = (offset + point, clamped exp of
+    the log size, Euler angles); 'FCAF' (:308-363, configs/grounding/..._fcaf-coder.py) = the six outputs are log distances to
+    the faces (exp, clamp 2e-2 -- written in place by the reference, a pure function for autograd), the centre is the point
+    shifted by the ROTATED half difference of opposite distances (rotation_3d_in_euler: shift @ R^T, R = Rz Rx Ry), the size
+    is the sum of opposite distances"""
+    if coder == 'baseline':
+        return torch.cat((pred[..., :3] + points, torch.exp(pred[..., 3:6]).clamp(min=2e-2), pred[..., 6:]), -1)
+    assert coder == 'FCAF' and pred.shape[-1] == 9
+    d = torch.exp(pred[..., :6]).clamp(min=2e-2)
+    shift = torch.stack(((d[..., 1] - d[..., 0]) / 2, (d[..., 3] - d[..., 2]) / 2, (d[..., 5] - d[..., 4]) / 2), -1)
+    R = G.euler_to_matrix_zxy(pred[..., 6:9])
+    center = points + torch.matmul(R, shift.unsqueeze(-1)).squeeze(-1)
+    size = torch.stack((d[..., 0] + d[..., 1], d[..., 2] + d[..., 3], d[..., 4] + d[..., 5]), -1)
+    return torch.cat((center, size, pred[..., 6:9]), -1)
 
 
 def py_sigmoid_focal_loss_sum(pred, target, gamma=2.0, alpha=0.25):
@@ -275,7 +288,8 @@ def decoder_layer(query, key, value, query_pos, key_pos, kpm, text, tpm, sd, p, 
     return _ln(query + h, sd, p + 'norms.3')
 
 
-def forward_transformer(feats_list, xyz_list, text_feats, text_token_mask, sd, num_queries=256, num_layers=6, H=8, training=True):
+def forward_transformer(feats_list, xyz_list, text_feats, text_token_mask, sd, num_queries=256, num_layers=6, H=8, training=True,
+                        coder='baseline'):
     """pre_decoder + forward_decoder (sparse_featfusion_grounder.py:324-447) -> (hidden (L,B,Q,E), boxes (L,B,Q,9), aux)"""
     B = len(feats_list)
     Lmax, Lmin = max(f.shape[0] for f in feats_list), min(f.shape[0] for f in feats_list)
@@ -289,7 +303,7 @@ def forward_transformer(feats_list, xyz_list, text_feats, text_token_mask, sd, n
     sc = enc.max(-1)[0]
     # torch.topk leaves the order among equal scores unspecified: descending score, ties by lower index
     idx = torch.stack([torch.argsort(sc[b], descending=True, stable=True)[:topk] for b in range(B)])
-    boxes0 = bbox_pred_to_bbox(coords, reg_branch(feats, sd))
+    boxes0 = bbox_pred_to_bbox(coords, reg_branch(feats, sd), coder)
     g3, g9, gE = idx.unsqueeze(-1).repeat(1, 1, 3), idx.unsqueeze(-1).repeat(1, 1, 9), idx.unsqueeze(-1).repeat(1, 1, E)
     qcoords, pred, query = torch.gather(coords, 1, g3), torch.gather(boxes0, 1, g9).detach().clone(), torch.gather(feats, 1, gE)
     inter, inter_boxes = [], []
@@ -298,7 +312,7 @@ def forward_transformer(feats_list, xyz_list, text_feats, text_token_mask, sd, n
         key_pos = posembed(coords, sd, 'decoder.cross_posembed', training)
         query = decoder_layer(query, feats, feats, query_pos, key_pos, ~fmask, text_feats, ~text_token_mask, sd,
                               f'decoder.layers.{lid}.', H)
-        new = bbox_pred_to_bbox(qcoords, reg_branch(query, sd))
+        new = bbox_pred_to_bbox(qcoords, reg_branch(query, sd), coder)
         pred = new.detach().clone()
         inter.append(_ln(query, sd, 'decoder.norm'))
         inter_boxes.append(new)
@@ -321,12 +335,12 @@ def head_loss(hidden, boxes, text_feats, text_token_mask, sd, gt_boxes_list, pos
 
 
 def grounder_loss(sd, points, imgs, metas, text_hidden, text_token_mask, gt_boxes_list, positive_maps_list, num_queries=256,
-                  num_layers=6, voxel_size=0.01, thr=1000, return_aux=False):
+                  num_layers=6, voxel_size=0.01, thr=1000, return_aux=False, coder='baseline'):
     """SparseFeatureFusion3DGrounder.loss with the frozen text encoder's output `text_hidden` (B,T,D) as an input"""
     xs = M.extract_feat(sd, points, imgs, metas, voxel_size, True)
     fl, sl, pl = mink_neck(xs, sd, len(points), voxel_size=voxel_size, thr=thr)
     text = F.linear(text_hidden, sd['text_feat_map.weight'], sd['text_feat_map.bias'])
-    hidden, boxes, aux = forward_transformer(fl, pl, text, text_token_mask, sd, num_queries, num_layers)
+    hidden, boxes, aux = forward_transformer(fl, pl, text, text_token_mask, sd, num_queries, num_layers, coder=coder)
     losses, haux = head_loss(hidden, boxes, text, text_token_mask, sd, gt_boxes_list, positive_maps_list, return_aux=True)
     if return_aux:
         aux.update(hidden=hidden, boxes=boxes, head=haux, text=text, feats_list=fl, points_list=pl)

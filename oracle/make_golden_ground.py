@@ -4,6 +4,7 @@ Run in the build container only (needs /root/reference):   python -m oracle.make
 TEST INFRASTRUCTURE (mechanism: oracle/make_golden.py).  Reference entry points exercised (file:line):
   ContrastiveEmbed.forward                          models/dense_heads/grounding_head.py:62-99
   GroundingHead._bbox_pred_to_bbox ('baseline', 9)  models/dense_heads/grounding_head.py:267-296
+  GroundingHead._bbox_pred_to_bbox ('FCAF', 9)      models/dense_heads/grounding_head.py:308-363  (-> ground_coder_fcaf.npz)
   GroundingHead.loss_by_feat_single (+ get_targets / _get_targets_single)   :226-265,365-425,686-822
   HungarianAssigner3D.assign                        models/task_modules/assigners/hungarian_assigner.py:56-138
   BinaryFocalLossCost / BBox3DL1Cost / IoU3DCost    models/losses/match_cost.py:49-75,95-113,213-265
@@ -108,6 +109,20 @@ def main(out_dir=None):
     rec.update(pe_x=x.numpy(), pe_y=y.detach().numpy())
     np.savez_compressed(os.path.join(out_dir, 'ground_head.npz'), **rec)
     print('wrote ground_head.npz to', out_dir)
+
+    # box_coder='FCAF', 9 outputs (grounding_head.py:308-363; configs/grounding/..._fcaf-coder.py:64): forward and the gradient
+    # w.r.t. the raw regression output (the reference writes exp().clamp() IN PLACE into bbox_pred -- autograd sees through it)
+    g2 = torch.Generator().manual_seed(20250925)
+    r2 = lambda *s, lo=-1., hi=1.: torch.rand(*s, generator=g2) * (hi - lo) + lo
+    pts2 = r2(B, Q, 3, lo=-2, hi=2)
+    pred2 = torch.cat([r2(B, Q, 6, lo=-5, hi=1), r2(B, Q, 3, lo=-3, hi=3)], -1).requires_grad_(True)
+    head2 = types.SimpleNamespace(box_coder='FCAF')
+    boxes2 = GroundingHead._bbox_pred_to_bbox(head2, pts2, pred2 * 1.0)
+    gb2 = torch.randn(B, Q, 9, generator=g2)
+    (boxes2 * gb2).sum().backward()
+    np.savez_compressed(os.path.join(out_dir, 'ground_coder_fcaf.npz'), points=pts2.numpy(), reg=pred2.detach().numpy(),
+                        boxes=boxes2.detach().numpy(), dboxes=gb2.numpy(), dreg=pred2.grad.numpy())
+    print('wrote ground_coder_fcaf.npz to', out_dir)
 
 
 if __name__ == '__main__':

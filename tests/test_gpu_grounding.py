@@ -73,6 +73,7 @@ def test_attention_fwd_bwd_vs_torch(dev, bf16, tol):
 
 
 def test_layernorm_contrastive_decode_topk_vs_torch(dev):
+    from embodiedscan_amd import hip
     from embodiedscan_amd.hip import P, call
     g = torch.Generator().manual_seed(2)
     st = torch.cuda.current_stream().cuda_stream
@@ -87,8 +88,12 @@ def test_layernorm_contrastive_decode_topk_vs_torch(dev):
     mean, rstd = torch.empty(n, device=dev), torch.empty(n, device=dev)
     call('es_layernorm_fwd', P(xd), P(rd), n, C, P(wd), P(bd), 1e-5, P(y), P(z), P(mean), P(rstd), st)
     dz, dw, db = torch.empty(n, C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-    call('es_layernorm_bwd', P(dyd), P(z), n, C, P(wd), P(mean), P(rstd), P(dz), 0, P(dw), P(db), st)
+    ws = torch.zeros(int(hip.raw('es_layernorm_bwd_workspace_floats')(n, C)), device=dev)
+    call('es_layernorm_bwd', P(dyd), P(z), n, C, P(wd), P(mean), P(rstd), P(dz), 0, P(dw), P(db), P(ws), ws.numel(), st)
+    dw2, db2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)          # second launch on the same workspace: the ticket was reset,
+    call('es_layernorm_bwd', P(dyd), P(z), n, C, P(wd), P(mean), P(rstd), P(dz), 0, P(dw2), P(db2), P(ws), ws.numel(), st)   # bit-identical sums
     torch.cuda.synchronize()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and int(ws[:1].view(torch.int32)) == 0
     e = max(_rel(y, ref.detach()), _rel(dz, xt.grad), _rel(dw, wt.grad), _rel(db, bt.grad))
     print(f'LayerNorm(+residual) fwd/bwd worst rel-L2 {e:.2e} (tol 1e-5)')
     assert e < 1e-5 and torch.equal(xt.grad, rt.grad)
@@ -108,8 +113,12 @@ def test_layernorm_contrastive_decode_topk_vs_torch(dev):
     lo, rm = torch.empty(B, L, Tout, device=dev), torch.empty(B, L, device=dev)
     call('es_contrastive_fwd', P(vd), B, L, P(td), T, C, P(tld), P(vld), P(bd2), P(lo), Tout, P(rm), st)
     dvv, dtt, dbb = torch.empty_like(vd), torch.zeros_like(td), torch.zeros(1, device=dev)
-    call('es_contrastive_bwd', P(dld), Tout, P(vd), B, L, P(td), T, C, P(tld), P(dvv), 0, P(dtt), P(dbb), st)
+    cws = torch.zeros(int(hip.raw('es_contrastive_bwd_workspace_floats')(B, T)), device=dev)
+    call('es_contrastive_bwd', P(dld), Tout, P(vd), B, L, P(td), T, C, P(tld), P(dvv), 0, P(dtt), P(dbb), P(cws), cws.numel(), st)
+    dtt2, dbb2 = torch.zeros_like(td), torch.zeros(1, device=dev)
+    call('es_contrastive_bwd', P(dld), Tout, P(vd), B, L, P(td), T, C, P(tld), 0, 0, P(dtt2), P(dbb2), P(cws), cws.numel(), st)
     torch.cuda.synchronize()
+    assert torch.equal(dtt, dtt2) and torch.equal(dbb, dbb2)                   # deterministic, with and without the dv workgroups
     refm = ref.detach().masked_fill(~keep, float('-inf'))
     assert torch.equal(torch.isinf(lo.cpu()), torch.isinf(refm))
     e = max(_rel(torch.nan_to_num(lo.cpu(), 0, 0, 0), torch.nan_to_num(refm, 0, 0, 0)), _rel(dvv, vt_.grad), _rel(dtt, tt_.grad),
@@ -140,6 +149,32 @@ def test_layernorm_contrastive_decode_topk_vs_torch(dev):
     call('es_ground_decode_bwd', P(predd), 9, P(gbd), 50, P(dp), 9, 0, st)
     torch.cuda.synchronize()
     assert _rel(box, refb.detach()) < 1e-6 and _rel(dp, pt.grad) < 1e-6
+
+
+def test_fcaf_box_coder_vs_reference(dev):
+    """es_ground_decode_fcaf_fwd / _bwd against what the REFERENCE's GroundingHead._bbox_pred_to_bbox(box_coder='FCAF') and its
+    autograd produced (tests/golden/ground_coder_fcaf.npz, oracle/make_golden_ground.py): boxes 1e-6, gradient w.r.t. the raw
+    regression output 1e-5 (incl. rows whose exp falls below the 2e-2 clamp: zero gradient there); accumulate mode adds"""
+    from embodiedscan_amd.hip import P, call
+    d = np.load(os.path.join(GOLDEN, 'ground_coder_fcaf.npz'))
+    st = torch.cuda.current_stream().cuda_stream
+    reg, pts, gb = (torch.from_numpy(d[k]).reshape(-1, d[k].shape[-1]).to(dev).contiguous() for k in ('reg', 'points', 'dboxes'))
+    n = reg.shape[0]
+    wide = torch.zeros(n, 16, device=dev)                     # the regression output as a column slice of a wider buffer
+    wide[:, 3:12] = reg
+    box, dp = torch.empty(n, 9, device=dev), torch.full((n, 9), 7.0, device=dev)
+    call('es_ground_decode_fcaf_fwd', wide.data_ptr() + 12, 16, P(pts), n, P(box), st)
+    call('es_ground_decode_fcaf_bwd', wide.data_ptr() + 12, 16, P(gb), n, P(dp), 9, 0, st)
+    torch.cuda.synchronize()
+    e1, e2 = _rel(box, d['boxes'].reshape(-1, 9)), _rel(dp, d['dreg'].reshape(-1, 9))
+    print(f"FCAF box coder vs the reference: boxes rel-L2 {e1:.2e} (tol 1e-6), d/d reg {e2:.2e} (tol 1e-5); "
+          f"{int((torch.exp(reg[:, :6]) < 2e-2).sum())} clamped distances")
+    assert e1 < 1e-6 and e2 < 1e-5
+    clamped = (torch.exp(reg[:, :6]) < 2e-2)
+    assert clamped.any() and float(dp[:, :6][clamped].abs().max()) == 0.0
+    call('es_ground_decode_fcaf_bwd', wide.data_ptr() + 12, 16, P(gb), n, P(dp), 9, 1, st)
+    torch.cuda.synchronize()
+    assert _rel(dp, 2 * d['dreg'].reshape(-1, 9)) < 1e-5
 
 
 def test_box3d_iou_vs_oracle(dev):
@@ -226,9 +261,9 @@ def test_matching_and_losses_vs_reference(dev):
 TEXT_CFG = dict(hidden_size=64, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128, max_position_embeddings=64)
 
 
-def _small_grounder(dev, num_layers=2, num_queries=32, thr=300):
+def _small_grounder(dev, num_layers=2, num_queries=32, thr=300, config='mv_grounding.py'):
     from embodiedscan_amd.config import build_detector, load_config
-    cfg = load_config(os.path.join(ROOT, 'configs', 'mv_grounding.py'))
+    cfg = load_config(os.path.join(ROOT, 'configs', config))
     m = cfg['model']
     m['num_queries'] = num_queries
     m['decoder']['num_layers'] = num_layers
@@ -253,28 +288,22 @@ def _small_grounder(dev, num_layers=2, num_queries=32, thr=300):
     return cfg, det, sd
 
 
-def _grounding_batch(dev, n=2):
+def _grounding_batch(dev, n=2, n_points=12000):
     from embodiedscan_amd import pipeline
     from embodiedscan_amd.synth import make_grounding_sample, make_scan
-    scans = [make_scan(31 + i, n_views=3, height=120, width=160, img_size=(128, 128), n_points=12000, n_boxes=8) for i in range(n)]
+    scans = [make_scan(31 + i, n_views=3, height=120, width=160, img_size=(128, 128), n_points=n_points, n_boxes=8) for i in range(n)]
     anns = [make_grounding_sample(s, seed=i) for i, s in enumerate(scans)]
     dscans = [pipeline.upload_scan(s, dev) for s in scans]
     return scans, anns, dscans
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16'])
-def test_grounder_train_step_vs_oracle(dev, mode):
-    """SparseFeatureFusion3DGrounder forward + backward (2 scans x 3 views, MinkNeck pruning live at 300 voxels, 32
-    queries, 2 decoder layers) against the oracle: query selection and Hungarian assignments identical; f32: losses 1e-3,
-    hidden states 1e-3, parameter gradients median 2e-3; bf16: against the oracle's bf16-operand specification -- losses and
-    logits 2e-2, parameter gradients median 2e-2; an assignment that differs is reported with its cost margin (near tie
-    required), never skipped."""
+def _hip_grounder_step(det, dscans, anns, mode, force=None):
+    """one forward + backward of the small grounder on the HIP path; force = (query indices (B,Q), [per layer (B,Q) q2g]) from the oracle"""
     from embodiedscan_amd import engine as E, pipeline
-    from oracle import grounding as OG, model as OM
-    cfg, det, sd = _small_grounder(dev)
-    scans, anns, dscans = _grounding_batch(dev)
-    names = set(det.arena.grad_dict().keys())
     E.PRECISION[0] = mode
+    det.force_queries = det.bbox_head.force_assign = None
+    if force is not None:
+        det.force_queries, det.bbox_head.force_assign = force
     try:
         E.WEIGHT_VERSION[0] += 1
         E.TAPE.clear()
@@ -283,15 +312,42 @@ def test_grounder_train_step_vs_oracle(dev, mode):
         data = det.data_preprocessor(batch, True)
         det._bind()
         det.arena.grad.zero_()
+        E.new_grad_epoch()
         losses = det.forward(data['inputs'], data['data_samples'], mode='loss')
-        hid = [h.d.cpu() for h in [l['logits'] for l in det.bbox_head.last]]
-        q2g = [l['q2g'].cpu() for l in det.bbox_head.last]
-        idx = det.last_queries['idx'].cpu()
+        out = dict(losses={k: float(v) for k, v in losses.items()}, points=points_host, data=data,
+                   hid=[l['logits'].d.cpu() for l in det.bbox_head.last],
+                   q2g=[l.get('q2g_free', l['q2g']).cpu() for l in det.bbox_head.last],
+                   idx=(det.free_queries if force is not None else det.last_queries['idx']).cpu())
         det._backward(None)
         torch.cuda.synchronize()
-        grads = {k: v.cpu() for k, v in det.arena.grad_dict().items()}
+        out['grads'] = {k: v.cpu() for k, v in det.arena.grad_dict().items()}
     finally:
         E.PRECISION[0] = 'f32'
+        det.force_queries = det.bbox_head.force_assign = None
+    return out
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_grounder_train_step_vs_oracle(dev, mode):
+    """SparseFeatureFusion3DGrounder forward + backward (2 scans x 3 views, MinkNeck pruning live at 300 voxels, 32
+    queries, 2 decoder layers) against the oracle.
+    f32: query selection and Hungarian assignments identical; losses 1e-3, hidden states 1e-3, parameter gradients median 2e-3.
+    bf16 (round 4: NEVER vacuous): the discrete decisions of a bf16 run -- the top-32 query boundary, a Hungarian near tie --
+    may legitimately differ from the oracle's, after which nothing downstream is comparable.  So the free run only REPORTS them
+    (with the cost margin of a flipped assignment on the oracle's own cost matrix, which must be a near tie), and a second,
+    TEACHER-FORCED run takes the oracle's query indices and assignments (detector.force_queries / head.force_assign) and is
+    held to the oracle's bf16-operand specification in every run: logits and losses 2e-2, parameter gradients median 2e-2 /
+    90th percentile 1e-1 / worst 5e-1."""
+    from oracle import grounding as OG, model as OM
+    # MinkNeck pruning is live (300 voxels) in the f32 leg, where the pruned sets are identical; the bf16 leg keeps every voxel
+    # so that the oracle's token indices address the same tokens on both sides (a bf16 flip at the pruning boundary would
+    # re-number all later tokens; bf16 pruning at scale is covered by tests/test_gpu_config4.py)
+    thr = 300 if mode == 'f32' else 10 ** 6
+    cfg, det, sd = _small_grounder(dev, thr=thr)
+    scans, anns, dscans = _grounding_batch(dev, n_points=12000 if mode == 'f32' else 6000)   # (<= 8192 tokens per scan unpruned)
+    names = set(det.arena.grad_dict().keys())
+    h = _hip_grounder_step(det, dscans, anns, mode)
+    losses, hid, q2g, idx, grads, data, points_host = h['losses'], h['hid'], h['q2g'], h['idx'], h['grads'], h['data'], h['points']
     # ---- oracle on the same inputs; the frozen text encoder's output is an input of both paths
     th = det.last_text['hidden'].float().cpu()
     tmask = det.last_text['mask'].cpu()
@@ -305,48 +361,62 @@ def test_grounder_train_step_vs_oracle(dev, mode):
     from oracle import rounding as R
     with (R.bf16_operands() if mode == 'bf16' else nullcontext()):
         ol, aux = OG.grounder_loss(osd, points_host, imgs, [s['meta'] for s in scans], th, tmask, gtb, pms, num_queries=32,
-                                   num_layers=2, thr=300, return_aux=True)
+                                   num_layers=2, thr=thr, return_aux=True)
         if mode == 'bf16':
             sum(ol.values()).backward()
+    lens_h, lens_o = list(det.neck_3d.last['lens']), [int(f.shape[0]) for f in aux['feats_list']]
+    assert lens_h == lens_o, (lens_h, lens_o)
+    for b in range(2):                                   # token order: the oracle's index i is the HIP path's token i
+        ch = det.neck_3d.last['points'].view(2, det.neck_3d.last['Lmax'], 3)[b, :lens_h[b]].cpu()
+        assert float((ch - aux['coords'][b][:lens_h[b]]).abs().max()) < 1e-6
     same_q = torch.equal(idx.long(), aux['idx'])
     same_a = all(torch.equal((q2g[l][b] + 1).long(), aux['head'][l]['assign'][b]) for l in range(2) for b in range(2))
-    print(f'{mode}: selected queries identical: {same_q}; Hungarian assignments identical: {same_a}')
+    print(f'{mode} free run: selected queries identical: {same_q}; Hungarian assignments identical: {same_a}')
     if mode == 'f32':
         assert same_q and same_a
     tol = 1e-3 if mode == 'f32' else 2e-2
-    if mode == 'bf16' and same_q and not same_a:
-        # not skipped: WHICH margin flipped -- cost of our assignment minus the optimal one on the oracle's own cost matrix
-        for l in range(2):
-            for b in range(2):
-                if torch.equal((q2g[l][b] + 1).long(), aux['head'][l]['assign'][b]):
-                    continue
-                G = gtb[b].shape[0]
-                gi, cost = OG.hungarian_assign(aux['head'][l]['cls'][b].detach(), aux['boxes'][l][b].detach(), gtb[b], pms[b],
-                                               tmask[b][None].repeat(max(G, 1), 1), return_cost=True)
-                mine = sum(float(cost[q, int(q2g[l][b][q])]) for q in torch.nonzero(q2g[l][b] >= 0).reshape(-1))
-                opt = sum(float(cost[q, int(gi[q]) - 1]) for q in torch.nonzero(gi > 0).reshape(-1))
-                print(f'bf16 layer {l} scan {b}: assignment differs, cost margin {mine - opt:.3e} on an optimal cost of {opt:.3e} (tol 2 %)')
-                assert mine - opt <= 2e-2 * max(abs(opt), 1.0)
-    if same_q and same_a:
-        T = tmask.shape[1]
-        for l in range(2):
-            ref = aux['head'][l]['cls'][:, :, :T].reshape(-1, T)
-            keep = ~torch.isinf(ref)
-            e = _rel(hid[l][keep], ref[keep].detach())
-            print(f'{mode} decoder layer {l} token logits rel-L2 {e:.2e} (tol {tol:.0e})')
-            assert e < tol
-        for k in ol:
-            e = abs(float(losses[k]) - float(ol[k])) / max(abs(float(ol[k])), 1e-6)
-            print(f'{mode} {k}: hip {float(losses[k]):.6f} oracle {float(ol[k]):.6f} rel err {e:.2e} (tol {tol:.0e})')
-            assert e < tol
+    if mode == 'bf16':
+        n_common = [len(set(idx[b].tolist()) & set(aux['idx'][b].tolist())) for b in range(2)]
+        print(f'bf16 free run: {n_common} of 32 selected queries in common with the oracle')
+        assert min(n_common) >= 24, 'more than a quarter of the queries differ: not a boundary effect'
+        if same_q and not same_a:
+            # WHICH margin flipped -- cost of our assignment minus the optimal one on the oracle's own cost matrix
+            for l in range(2):
+                for b in range(2):
+                    if torch.equal((q2g[l][b] + 1).long(), aux['head'][l]['assign'][b]):
+                        continue
+                    G = gtb[b].shape[0]
+                    gi, cost = OG.hungarian_assign(aux['head'][l]['cls'][b].detach(), aux['boxes'][l][b].detach(), gtb[b], pms[b],
+                                                   tmask[b][None].repeat(max(G, 1), 1), return_cost=True)
+                    mine = sum(float(cost[q, int(q2g[l][b][q])]) for q in torch.nonzero(q2g[l][b] >= 0).reshape(-1))
+                    opt = sum(float(cost[q, int(gi[q]) - 1]) for q in torch.nonzero(gi > 0).reshape(-1))
+                    print(f'bf16 layer {l} scan {b}: assignment differs, cost margin {mine - opt:.3e} on an optimal cost of {opt:.3e} (tol 2 %)')
+                    assert mine - opt <= 2e-2 * max(abs(opt), 1.0)
+        # the teacher-forced run: same discrete decisions as the oracle -> everything is comparable, in every run
+        force = (aux['idx'].int(), [torch.stack([aux['head'][l]['assign'][b] - 1 for b in range(2)]).int() for l in range(2)])
+        h = _hip_grounder_step(det, dscans, anns, mode, force=force)
+        losses, hid, grads = h['losses'], h['hid'], h['grads']
+        assert all(np.isfinite(v) for v in losses.values())
+    T = tmask.shape[1]
+    for l in range(2):
+        ref = aux['head'][l]['cls'][:, :, :T].reshape(-1, T)
+        keep = ~torch.isinf(ref)
+        e = _rel(hid[l][keep], ref[keep].detach())
+        print(f'{mode} decoder layer {l} token logits rel-L2 {e:.2e} (tol {tol:.0e})')
+        assert e < tol
+    for k in ol:
+        e = abs(float(losses[k]) - float(ol[k])) / max(abs(float(ol[k])), 1e-6)
+        print(f'{mode} {k}: hip {float(losses[k]):.6f} oracle {float(ol[k]):.6f} rel err {e:.2e} (tol {tol:.0e})')
+        assert e < tol
     assert all(np.isfinite(float(v)) for v in losses.values()) and torch.isfinite(det.arena.grad).all()
-    if mode == 'bf16' and same_q and same_a:
+    if mode == 'bf16':
         rel = {k: _rel(v, osd[k].grad) for k, v in grads.items() if osd[k].grad is not None and float(osd[k].grad.norm()) > 1e-6}
         v = np.sort(np.array(list(rel.values())))
         worst = max(rel, key=rel.get)
-        print(f'bf16 gradients vs the bf16-operand oracle: {len(v)} tensors, median rel-L2 {float(np.median(v)):.2e} (tol 2e-2), 90th '
+        print(f'bf16 (teacher-forced) gradients vs the bf16-operand oracle: {len(v)} tensors, median rel-L2 {float(np.median(v)):.2e} (tol 2e-2), 90th '
               f'percentile {float(v[int(0.9 * (len(v) - 1))]):.2e} (tol 1e-1), worst {rel[worst]:.2e} at {worst} (tol 5e-1); the attention '
               f'core (bf16 P and V on the matrix cores here, f32 in the oracle) sets the floor')
+        assert len(v) > 100
         assert float(np.median(v)) < 2e-2 and float(v[int(0.9 * (len(v) - 1))]) < 1e-1 and rel[worst] < 5e-1
     if mode == 'f32':
         sum(ol.values()).backward()
@@ -386,3 +456,42 @@ def test_grounder_train_and_predict(dev):
     assert r.bboxes_3d.tensor.shape == (32, 9) and r.scores_3d.shape == (32,)
     assert float(r.scores_3d.min()) >= 0 and float(r.scores_3d.max()) <= 1 and torch.isfinite(r.bboxes_3d.tensor).all()
     print(f'train 3 steps: total loss {hist[0]:.4f} -> {hist[-1]:.4f}; predict: {r.scores_3d.shape[0]} boxes, best score {float(r.scores_3d.max()):.4f}')
+
+
+def test_grounder_with_fcaf_coder_vs_oracle(dev):
+    """configs/mv_grounding_fcaf.py (= the reference's mv-grounding_..._fcaf-coder.py: box_coder='FCAF') shrunk like the test above,
+    f32 mode: query selection and assignments identical to the oracle (whose FCAF coder is pinned to the reference's own,
+    tests/test_oracle_golden.py), losses 1e-3, token logits 1e-3, parameter gradients median 2e-3 / worst 1e-1"""
+    from oracle import grounding as OG, model as OM
+    cfg, det, sd = _small_grounder(dev, config='mv_grounding_fcaf.py')
+    assert det.bbox_head.box_coder == 'FCAF'
+    scans, anns, dscans = _grounding_batch(dev)
+    names = set(det.arena.grad_dict().keys())
+    h = _hip_grounder_step(det, dscans, anns, 'f32')
+    th, tmask = det.last_text['hidden'].float().cpu(), det.last_text['mask'].cpu()
+    osd = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+    imgs = torch.stack([OM.preprocess_img(torch.from_numpy(s['img']), MEAN, STD) for s in scans])
+    gtb = [torch.from_numpy(a['gt_boxes']) for a in anns]
+    pms = [ds.gt_instances_3d.positive_maps.cpu() for ds in h['data']['data_samples']]
+    ol, aux = OG.grounder_loss(osd, h['points'], imgs, [s['meta'] for s in scans], th, tmask, gtb, pms, num_queries=32, num_layers=2,
+                               thr=300, return_aux=True, coder='FCAF')
+    sum(ol.values()).backward()
+    assert torch.equal(h['idx'].long(), aux['idx'])
+    assert all(torch.equal((h['q2g'][l][b] + 1).long(), aux['head'][l]['assign'][b]) for l in range(2) for b in range(2))
+    T = tmask.shape[1]
+    for l in range(2):
+        ref = aux['head'][l]['cls'][:, :, :T].reshape(-1, T)
+        keep = ~torch.isinf(ref)
+        assert _rel(h['hid'][l][keep], ref[keep].detach()) < 1e-3
+        e = _rel(det.bbox_head.last[l]['boxes'].d, aux['boxes'][l].detach().reshape(-1, 9))
+        print(f'FCAF coder, decoder layer {l}: decoded boxes rel-L2 {e:.2e} (tol 1e-4)')
+        assert e < 1e-4
+    for k in ol:
+        e = abs(h['losses'][k] - float(ol[k])) / max(abs(float(ol[k])), 1e-6)
+        print(f'FCAF coder {k}: hip {h["losses"][k]:.6f} oracle {float(ol[k]):.6f} rel err {e:.2e} (tol 1e-3)')
+        assert e < 1e-3
+    rel = {k: _rel(v, osd[k].grad) for k, v in h['grads'].items() if osd[k].grad is not None and float(osd[k].grad.norm()) > 1e-6}
+    worst = max(rel, key=rel.get)
+    med = float(np.median(list(rel.values())))
+    print(f'FCAF coder, f32 gradients vs oracle autograd: {len(rel)} tensors, median rel-L2 {med:.2e} (tol 2e-3), worst {rel[worst]:.2e} at {worst} (tol 1e-1)')
+    assert med < 2e-3 and rel[worst] < 1e-1

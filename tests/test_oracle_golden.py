@@ -219,6 +219,14 @@ def test_grounding_head_matches_reference(golden_dir):
     np.testing.assert_allclose(torch.nan_to_num(cls, 0, 0, 0).numpy(), torch.nan_to_num(ref, 0, 0, 0).numpy(), rtol=1e-5, atol=1e-6)
     boxes = OG.bbox_pred_to_bbox(torch.from_numpy(d['points']), torch.from_numpy(d['reg']))
     np.testing.assert_allclose(boxes.numpy(), d['boxes'], rtol=1e-6, atol=1e-7)
+    # box_coder='FCAF' (configs/grounding/..._fcaf-coder.py): forward and gradient vs the reference's in-place implementation
+    f = np.load(os.path.join(golden_dir, 'ground_coder_fcaf.npz'))
+    reg = torch.from_numpy(f['reg']).clone().requires_grad_(True)
+    bf = OG.bbox_pred_to_bbox(torch.from_numpy(f['points']), reg, 'FCAF')
+    np.testing.assert_allclose(bf.detach().numpy(), f['boxes'], rtol=1e-5, atol=1e-6)
+    (bf * torch.from_numpy(f['dboxes'])).sum().backward()
+    np.testing.assert_allclose(reg.grad.numpy(), f['dreg'], rtol=1e-4, atol=1e-5)
+    assert float((torch.exp(reg[..., :6]) < 2e-2).float().mean()) > 0.05        # the clamp branch is exercised
     B = hidden.shape[0]
     gtb = [torch.from_numpy(d[f'gt_boxes{b}']) for b in range(B)]
     pms = [torch.from_numpy(d[f'pos_map{b}']) for b in range(B)]
