@@ -22,11 +22,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # the host driver only supports dmabuf IPC: RCCL's peer buffers fail with hipIpcGetMemHandle errors without it
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-# The step runs on seven HIP streams (main, image branch, two weight-gradient streams, H2D copy, next-batch prefetch, + RCCL's).
-# ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin; streams that share a queue are
-# SERIALISED in submission order -- measured in round 4: the prefetch stream's kernels sat behind the whole backward pass of
-# the previous step (profiles/r4b_timeline.txt) until every stream had a queue of its own.  Must be set before HIP initialises.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
@@ -81,6 +76,26 @@ class Feeder:
         if not self.resident:
             self.freed[self.i % 2].record(self.torch.cuda.current_stream())
         self.i += 1
+
+
+def stage_times(step_fn, runs=3):
+    """per-stage HIP-event times (engine.mark boundaries) of `runs` warmed steps on the CURRENT schedule -> median per stage"""
+    import statistics
+    import torch
+    from embodiedscan_amd import engine as E
+    step_fn()                                                   # warm this schedule (allocator blocks, eager image backbone)
+    torch.cuda.synchronize()
+    per = []
+    for _ in range(runs):
+        E.MARKS = []
+        step_fn()
+        marks, E.MARKS = E.MARKS, None
+        torch.cuda.synchronize()
+        st = {}
+        for (n0, ev0), (n1, ev1) in zip(marks[:-1], marks[1:]):
+            st[n1] = st.get(n1, 0.0) + ev0.elapsed_time(ev1)
+        per.append(st)
+    return {k: round(statistics.median(p.get(k, 0.0) for p in per), 3) for k in per[0]}
 
 
 def main():
@@ -173,9 +188,14 @@ def main():
     # high-priority side stream (det.prefetch), i.e. under step i's backward pass; what the reference does with DataLoader
     # workers on host cores.  Every timed step prefetches for its successor (the first timed step's prefix was issued by the
     # last warm-up step, the last timed step issues the prefix of a step that is not timed): K full steps of work in the
-    # timed region.  ES_NEXT_PREFETCH=0 restores the serial step.
+    # timed region.  MEASURED AND REJECTED as the default (round 4, profiles/r4g_host_profile_*.txt, r4h/r4i sweeps): the host needs
+    # only ~9 ms to queue a step, so the device was never waiting for it; with the prefetch chain (~220 small launches + five
+    # host round trips) running beside the step, the 3-D backbone's forward -- itself a chain of small dependent launches --
+    # slows from 3.2 to 7-10 ms and the backward from 14 to 18-20 ms: 39.5 ms / step against 26.5 serial, whatever the stream
+    # priority, the number of hardware queues, or a gate that holds the prefetch back until the 3-D forward has finished.
+    # ES_NEXT_PREFETCH=1 enables it (bit-identical results: tests/test_gpu_prefetch.py).
     nxt = [None]
-    use_prefetch = os.environ.get('ES_NEXT_PREFETCH', '1') != '0' and hasattr(det, 'prefetch')
+    use_prefetch = os.environ.get('ES_NEXT_PREFETCH', '0') == '1' and hasattr(det, 'prefetch')
 
     def make():
         return pipeline.make_batch(feeder.next())             # this batch has landed in HBM (next copy queued); A1-A3 on device
@@ -264,11 +284,10 @@ def main():
     if world == 1:
         saved = (E.TWO_STREAMS[0], E.WGRAD_ASYNC[0])
         E.TWO_STREAMS[0] = E.WGRAD_ASYNC[0] = False
+        stages = stage_times(lambda: step(prefetch_next=False))     # median of 3 warmed serial steps (coordinate phase inside)
         prof1 = dict(prof, names=ENGINE | SCATTER, records=[])
         hip.PROFILE = prof1
-        E.MARKS = []
-        step(prefetch_next=False)                               # serial step: the coordinate phase is inside, on the one stream
-        marks, E.MARKS = E.MARKS, None
+        step(prefetch_next=False)                                   # + one with every engine / scatter launch bracketed
         hip.PROFILE = None
         E.TWO_STREAMS[0], E.WGRAD_ASYNC[0] = saved
         r1 = resolve_pairs(hip, prof1['records'])
@@ -288,22 +307,24 @@ def main():
                         f.write(json.dumps(dict(fn=name, K=K, cin=cin, cout=cout, n_out=n_out, n_in=n_in, map=bool(nbr),
                                                 us=round(ev0.elapsed_time(ev1) * 1e3, 1),
                                                 args=[x for x in a if isinstance(x, int) and abs(x) < (1 << 31)])) + '\n')
-        stages = {}
-        for (n0, ev0), (n1, ev1) in zip(marks[:-1], marks[1:]):
-            stages[n1] = round(stages.get(n1, 0.0) + ev0.elapsed_time(ev1), 3)
-        stages['_note'] = 'single-stream schedule, HIP-event time between stage boundaries of ONE untimed step; includes ' \
-                          'host-induced gaps; the default four-stream schedule overlaps A7 with A4-A6 and the two backward branches'
+        stages['_note'] = 'single-stream schedule (ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0): HIP-event time between stage boundaries, MEDIAN of 3 ' \
+                          'untimed steps after one warm-up step on that schedule; includes host-induced gaps; the default four-stream ' \
+                          'schedule overlaps A7 with A4-A6 and the two backward branches'
 
     # static PMC figures of the same command (separate rocprofv3 --pmc passes, see profiles/): bytes per engine launch
-    traffic, traffic_note = None, 'traffic: null (no PMC summary for this precision under profiles/)'
-    for name in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_final_pmc_traffic.json'):
+    traffic, traffic_extra, traffic_note = None, {}, 'traffic: null (no PMC summary for this precision under profiles/)'
+    for name in ('r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_final_pmc_traffic.json'):
         pmc_file = os.path.join(ROOT, 'profiles', name)
         if args.precision == 'bf16' and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             traffic = pmc['bytes_per_launch']
-            traffic_note = (f"traffic is STATIC: HBM bytes per engine launch from the committed PMC passes of this command "
-                            f"(profiles/{name}: {pmc['bytes_per_step'] / 1e9:.1f} GB per step over "
-                            f"{pmc['launches'] // pmc['steps']} launches), not re-measured by this run")
+            # `traffic` is per launch of the PMC family (the engine kernels AND their reduction helpers); multiply by ITS launch
+            # count -- not by roofline.launches_per_step, which counts engine entry points -- to get the bytes per step
+            traffic_extra = dict(traffic_launches_per_step=pmc['launches'] // pmc['steps'], traffic_bytes_per_step=pmc['bytes_per_step'],
+                                 traffic_source=f'profiles/{name}')
+            traffic_note = (f"traffic is STATIC: HBM bytes per launch of the convolution-engine kernel family from the committed PMC passes "
+                            f"of this command (profiles/{name}: {pmc['bytes_per_step'] / 1e9:.1f} GB per step over "
+                            f"{pmc['launches'] // pmc['steps']} kernel launches = traffic x traffic_launches_per_step), not re-measured by this run")
             break
     if eng['t_mfma'] >= eng['t_hbm']:
         roof = dict(bound='mfma', achieved=eng['tflops'], peak=mfma_peak, unit='TFLOP/s',
@@ -311,7 +332,7 @@ def main():
     else:
         roof = dict(bound='hbm', achieved=eng['comp_GBps'], peak=K_PEAK_HBM, unit='GB/s',
                     frac=round(eng['comp_GBps'] / K_PEAK_HBM, 4))
-    roofline = dict(roof, traffic=traffic,
+    roofline = dict(roof, traffic=traffic, **traffic_extra,
                     kernel='convolution engine: k_spconv_bf16* / k_rowgemm_bf16 (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
                     else 'convolution engine: k_spconv / k_spconv_wgrad (exact-f32 MFMA)',
                     launches_per_step=eng['launches'], kernel_ms_per_step=eng['ms'],
@@ -416,7 +437,8 @@ def run_other_config(kind, args, dev):
     o = OTHER[kind]
     hip.PAIRS.clear()                     # map pointers of the previous detector may be recycled
     batch = args.grounding_batch if kind == 'grounding' else 1
-    steps, warmup = max(1, min(args.steps, args.other_steps)), max(1, min(args.warmup, 3))
+    steps, warmup = max(1, min(args.steps, args.other_steps)), max(5, min(args.warmup, 8))   # >= 5: the first steps of a fresh detector run
+                                                                                             # 3-4x long (lazy maps, allocator, two graph captures)
     cfg = load_config(os.path.join(ROOT, 'configs', o['cfg']))
     det = build_detector(cfg, device=dev, seed=0).to(dev)
     optim = build_optim_wrapper(cfg)
@@ -446,7 +468,7 @@ def run_other_config(kind, args, dev):
         feeder.done()
         return out
 
-    for _ in range(2):                         # priming (lazy maps, allocator, hipGraph capture), outside `warmup`
+    for _ in range(4):                         # priming (lazy maps, allocator, one hipGraph capture per preprocessor buffer), outside `warmup`
         step()
     for _ in range(warmup):
         losses = step()
@@ -473,28 +495,27 @@ def run_other_config(kind, args, dev):
     # one extra untimed step on the single-stream schedule: stage times and stand-alone launch durations
     saved = (E.TWO_STREAMS[0], E.WGRAD_ASYNC[0])
     E.TWO_STREAMS[0] = E.WGRAD_ASYNC[0] = False
+    stages = stage_times(step)                  # median of 3 warmed single-stream steps
     prof1 = dict(prof, records=[])
     hip.PROFILE = prof1
-    E.MARKS = []
     step()
-    marks, E.MARKS = E.MARKS, None
     hip.PROFILE = None
     E.TWO_STREAMS[0], E.WGRAD_ASYNC[0] = saved
     r1 = resolve_pairs(hip, prof1['records'])
     torch.cuda.synchronize()
-    stages = {}
-    for (n0, ev0), (n1, ev1) in zip(marks[:-1], marks[1:]):
-        stages[n1] = round(stages.get(n1, 0.0) + ev0.elapsed_time(ev1), 3)
-    stages['_note'] = 'single-stream schedule (ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0), HIP-event time between stage boundaries of ONE untimed step'
+    stages['_note'] = 'single-stream schedule (ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0): HIP-event time between stage boundaries, MEDIAN of 3 untimed ' \
+                      'steps after one warm-up step on that schedule'
     e1 = engine_totals([r for r in r1 if r[0] in ENGINE], peak)
 
     traffic, tnote = None, 'traffic: null (no PMC summary committed for this configuration)'
-    pmc_file = os.path.join(ROOT, 'profiles', f'r3_pmc_traffic_{kind}.json')
-    if args.precision == 'bf16' and os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file))
-        traffic = pmc['bytes_per_launch']
-        tnote = (f"traffic is STATIC: HBM bytes per launch of the named family from the committed PMC passes of `bench.py --only {kind}` "
-                 f"(profiles/r3_pmc_traffic_{kind}.json), not re-measured by this run")
+    for tag in ('r4', 'r3'):
+        pmc_file = os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic_{kind}.json')
+        if args.precision == 'bf16' and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            traffic = pmc['bytes_per_launch']
+            tnote = (f"traffic is STATIC: HBM bytes per launch of the named family from the committed PMC passes of `bench.py --only {kind}` "
+                     f"(profiles/{tag}_pmc_traffic_{kind}.json: {pmc['launches'] // pmc['steps']} launches per step), not re-measured by this run")
+            break
     if kind == 'grounding':
         klen = det.last_queries['klen'].cpu().tolist()
         tl = det.last_text['mask'].sum(1).cpu().tolist()

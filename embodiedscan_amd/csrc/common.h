@@ -104,4 +104,22 @@ __device__ inline bool es_last_block(unsigned int* ticket, unsigned int nblocks)
   if (last) __threadfence();
   return last;
 }
+// The same election with a RELEASE-only fence in every workgroup and NO acquire in the winner.  A seq_cst agent-scope fence is
+// buffer_wbl2 + buffer_inv on gfx950: executed by every workgroup of a streaming kernel the invalidate throws away the XCD's whole
+// L2 again and again (measured: the tap-split convolutions ran 2x longer, profiles/r4k_critical.txt).  The winner may read the
+// partials with plain loads when -- as in split_tail -- (a) nobody reads them before the election, so its CU / XCD caches hold
+// no stale copy (caches are invalidated at kernel start), (b) no two workgroups write into one 128-byte line, and (c) the reads
+// are control-dependent on the ticket value.
+__device__ inline bool es_last_block_release_only(unsigned int* ticket, unsigned int nblocks) {
+  __shared__ unsigned int es_s_last2;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if ((threadIdx.x | threadIdx.y | threadIdx.z) == 0) {
+    unsigned int t = atomicAdd(ticket, 1u);
+    es_s_last2 = (t == nblocks - 1u) ? 1u : 0u;
+    if (es_s_last2) *ticket = 0u;
+  }
+  __syncthreads();
+  return es_s_last2 != 0u;
+}
 #define ES_TICKET_FLOATS 4          // floats reserved at the head of a workspace for the ticket (keeps partials 16-byte aligned)

@@ -56,8 +56,17 @@ __device__ inline int project_view(const float* m, const float* P, float x, floa
   return (int)iy * Wf + (int)ix;
 }
 
-// one wave per point; lanes stride over channels.  PTS: the location comes from a float (n,3) array (the prior points of
-// the occupancy detector, dense_fusion_occ.py:156-202) instead of integer voxel coordinates * voxel_size.
+// One wave per point, 16 points per workgroup.  Round 4 (north_star: "per-view point projection ... staged through LDS with
+// coalesced HBM reads"): the sample's meta block (reverse-augmentation ops + the V projection matrices, 32 + 16 V floats) is
+// staged ONCE per workgroup in LDS (rows are batch-major, so the 16 points of a workgroup belong to one sample except at a
+// sample boundary, where the waves read the block from global memory); lane v projects the point into view v -- ONE projection
+// per lane instead of all V projections in all 64 lanes (rounds 1-3) -- the pixel indices go out as one coalesced row of V
+// ints, and are then broadcast lane by lane for the channel-strided feature fetch (coalesced along C).  Same arithmetic per
+// (point, view) as before: bit-identical outputs.
+// PTS: the location comes from a float (n,3) array (the prior points of the occupancy detector, dense_fusion_occ.py:156-202)
+// instead of integer voxel coordinates * voxel_size.
+#define PS_PTS 16
+#define PS_MAXMETA 1088                                    // 32 + 16 * 66 floats: up to 66 views staged
 template <bool PTS, bool FH = false>
 __global__ __launch_bounds__(256) void k_point_sample_fwd(const int* __restrict__ coords, const float* __restrict__ pts,
                                                           int n, float voxel_size,
@@ -65,42 +74,59 @@ __global__ __launch_bounds__(256) void k_point_sample_fwd(const int* __restrict_
                                                           const float* __restrict__ feats, int Hf, int Wf, int C,
                                                           float* __restrict__ out, int ldo, int* __restrict__ pix,
                                                           int* __restrict__ cnt) {
-  int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= n) return;
-  int4 c = ((const int4*)coords)[i];
-  const float* m = meta + (size_t)c.x * meta_stride;
-  float x, y, z;
-  if (PTS) {
-    x = pts[(size_t)i * 3]; y = pts[(size_t)i * 3 + 1]; z = pts[(size_t)i * 3 + 2];
-  } else {
-    x = __fmul_rn((float)c.y, voxel_size); y = __fmul_rn((float)c.z, voxel_size); z = __fmul_rn((float)c.w, voxel_size);
-  }
-  undo_aug(m, x, y, z);
-  int nvalid = 0;
+  __shared__ float metaS[PS_MAXMETA];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * PS_PTS, i1 = min(n, i0 + PS_PTS);
+  const int b0 = coords[(size_t)i0 * 4], b1 = coords[(size_t)(i1 - 1) * 4];
+  const int nmeta = ES_FUSE_PROJ + 16 * V;
+  const bool staged = (b0 == b1) && (nmeta <= PS_MAXMETA);   // workgroup-uniform
+  if (staged)
+    for (int e = threadIdx.x; e < nmeta; e += 256) metaS[e] = meta[(size_t)b0 * meta_stride + e];
+  __syncthreads();
   const int MAXC = 8;                                   // supports C <= 512
-  float acc[MAXC];
+  for (int i = i0 + wv; i < i1; i += 4) {               // wave-uniform
+    int4 c = ((const int4*)coords)[i];
+    const float* m = staged ? metaS : meta + (size_t)c.x * meta_stride;
+    float x, y, z;
+    if (PTS) {
+      x = pts[(size_t)i * 3]; y = pts[(size_t)i * 3 + 1]; z = pts[(size_t)i * 3 + 2];
+    } else {
+      x = __fmul_rn((float)c.y, voxel_size); y = __fmul_rn((float)c.z, voxel_size); z = __fmul_rn((float)c.w, voxel_size);
+    }
+    undo_aug(m, x, y, z);
+    int nvalid = 0;
+    float acc[MAXC];
 #pragma unroll
-  for (int q = 0; q < MAXC; ++q) acc[q] = 0.f;
-  for (int v = 0; v < V; ++v) {
-    bool valid;
-    int p = project_view(m, m + ES_FUSE_PROJ + v * 16, x, y, z, Hf, Wf, valid);
-    nvalid += valid ? 1 : 0;
-    if (lane == 0) pix[(size_t)i * V + v] = p;
-    if (p >= 0) {
-      const size_t off = (((size_t)c.x * V + v) * Hf * Wf + p) * C;
+    for (int q = 0; q < MAXC; ++q) acc[q] = 0.f;
+    for (int v0 = 0; v0 < V; v0 += 64) {                // (V <= 64 in every shipped config: one trip)
+      const int v = v0 + lane;
+      bool valid = false;
+      int p = -1;
+      if (v < V) {
+        p = project_view(m, m + ES_FUSE_PROJ + v * 16, x, y, z, Hf, Wf, valid);
+        pix[(size_t)i * V + v] = p;
+      }
+      nvalid += (int)__popcll(__ballot(valid));
+      const int nv = min(64, V - v0);
+      for (int u = 0; u < nv; ++u) {                    // views in ascending order: the summation order of rounds 1-3
+        const int pu = __shfl(p, u, 64);
+        if (pu >= 0) {
+          const size_t off = (((size_t)c.x * V + (v0 + u)) * Hf * Wf + pu) * C;
 #pragma unroll
-      for (int q = 0; q < MAXC; ++q) {
-        int ch = lane + q * 64;                          // sum over ALL views, not masked
-        if (ch < C) acc[q] += FH ? __uint_as_float((uint32_t)((const unsigned short*)feats)[off + ch] << 16) : feats[off + ch];
+          for (int q = 0; q < MAXC; ++q) {
+            int ch = lane + q * 64;                      // sum over ALL views, not masked
+            if (ch < C) acc[q] += FH ? __uint_as_float((uint32_t)((const unsigned short*)feats)[off + ch] << 16) : feats[off + ch];
+          }
+        }
       }
     }
-  }
-  if (lane == 0) cnt[i] = nvalid;
-  float d = (float)max(nvalid, 1);
+    if (lane == 0) cnt[i] = nvalid;
+    float d = (float)max(nvalid, 1);
 #pragma unroll
-  for (int q = 0; q < MAXC; ++q) {
-    int ch = lane + q * 64;
-    if (ch < C) out[(size_t)i * ldo + ch] = nvalid > 0 ? __fdiv_rn(acc[q], d) : 0.f;
+    for (int q = 0; q < MAXC; ++q) {
+      int ch = lane + q * 64;
+      if (ch < C) out[(size_t)i * ldo + ch] = nvalid > 0 ? __fdiv_rn(acc[q], d) : 0.f;
+    }
   }
 }
 extern "C" int es_point_sample_fwd(const int* coords, int n, float voxel_size, const float* meta, int meta_stride,
@@ -108,7 +134,7 @@ extern "C" int es_point_sample_fwd(const int* coords, int n, float voxel_size, c
                                    int* cnt, void* stream) {
   if (n <= 0) return 0;
   if (C > 512) return -4;
-  hipLaunchKernelGGL(k_point_sample_fwd<false>, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords,
+  hipLaunchKernelGGL(k_point_sample_fwd<false>, dim3(es_cdiv(n, PS_PTS)), dim3(256), 0, (hipStream_t)stream, coords,
                      (const float*)nullptr, n, voxel_size, meta, meta_stride, V, feats, Hf, Wf, C, out, ldo, pix, cnt);
   ES_CHECK_LAUNCH();
   return 0;
@@ -119,7 +145,7 @@ extern "C" int es_point_sample_fwd_h(const int* coords, int n, float voxel_size,
                                      int* cnt, void* stream) {
   if (n <= 0) return 0;
   if (C > 512) return -4;
-  hipLaunchKernelGGL((k_point_sample_fwd<false, true>), dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords,
+  hipLaunchKernelGGL((k_point_sample_fwd<false, true>), dim3(es_cdiv(n, PS_PTS)), dim3(256), 0, (hipStream_t)stream, coords,
                      (const float*)nullptr, n, voxel_size, meta, meta_stride, V, (const float*)feats_bf16, Hf, Wf, C, out, ldo,
                      pix, cnt);
   ES_CHECK_LAUNCH();
@@ -130,7 +156,7 @@ extern "C" int es_point_sample_fwd_pts(const int* coords, const float* points, i
                                        int* cnt, void* stream) {
   if (n <= 0) return 0;
   if (C > 512) return -4;
-  hipLaunchKernelGGL(k_point_sample_fwd<true>, dim3(es_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coords, points, n,
+  hipLaunchKernelGGL(k_point_sample_fwd<true>, dim3(es_cdiv(n, PS_PTS)), dim3(256), 0, (hipStream_t)stream, coords, points, n,
                      0.f, meta, meta_stride, V, feats, Hf, Wf, C, out, ldo, pix, cnt);
   ES_CHECK_LAUNCH();
   return 0;

@@ -348,11 +348,12 @@ extern "C" int es_ground_focal(const float* logits, int Tout, int B, int Q, cons
 
 // ------------------------------------------------------------------ per-sample sorted top-k (one workgroup per sample)
 // idx[b, 0..k) = rows (local to the sample) of the k largest values in descending order, ties: lower row first.
-// Segment length <= 8192 (bitonic sort of (value, row) keys in LDS).
-#define TK_MAX 8192
+// Segment length <= 16384 (bitonic sort of (value, row) keys in dynamic LDS: 8 B per key of the next power of two >= L; the
+// reference's token lists hold at most 4 levels x pts_prune_threshold = 4000 rows, 128 KB of the CU's 160 KB cover 16384).
+#define TK_MAX 16384
 __global__ __launch_bounds__(1024) void k_topk_sorted(const float* __restrict__ vals, int L, const int* __restrict__ vlen, int k,
                                                       int* __restrict__ idx) {
-  __shared__ unsigned long long key[TK_MAX];
+  extern __shared__ unsigned long long key[];
   const int b = blockIdx.x;
   const int n = vlen ? min(vlen[b], L) : L;
   int P = 1;
@@ -384,7 +385,11 @@ __global__ __launch_bounds__(1024) void k_topk_sorted(const float* __restrict__ 
 extern "C" int es_topk_sorted(const float* vals, int B, int L, const int* vlen_dev, int k, int* idx, void* stream) {
   if (B <= 0 || k <= 0) return 0;
   if (L > TK_MAX) return -4;
-  hipLaunchKernelGGL(k_topk_sorted, dim3(B), dim3(1024), 0, (hipStream_t)stream, vals, L, vlen_dev, k, idx);
+  int P2 = 1;
+  while (P2 < L) P2 <<= 1;
+  const size_t sh = (size_t)P2 * sizeof(unsigned long long);
+  if (sh > 64 * 1024) ES_TRY(hipFuncSetAttribute((const void*)k_topk_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+  hipLaunchKernelGGL(k_topk_sorted, dim3(B), dim3(1024), sh, (hipStream_t)stream, vals, L, vlen_dev, k, idx);
   ES_CHECK_LAUNCH();
   return 0;
 }

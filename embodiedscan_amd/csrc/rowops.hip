@@ -189,6 +189,117 @@ __global__ __launch_bounds__(256) void k_norm_apply4(const float* __restrict__ x
   }
 }
 
+// ------------------------------------------------------------------ column-block norm for SHORT matrices (round 4)
+// The three-launch pipeline above (row-chunk statistics -> finalize -> apply) is built for long matrices; on the deep levels of
+// the sparse networks (190 .. 12 000 rows x 256 .. 1024 channels: 29 of the 47 norm layers of an mv-3ddet step) each of its
+// launches runs for 4 - 10 us and the two launch boundaries on the step's dependent chain cost more than the kernels.  Here ONE
+// workgroup of 1024 threads owns 16 channels (4 float4 lanes x 256 row stripes) of ALL rows: per-channel statistics need no
+// other workgroup, so statistics, finalize and apply are one launch (backward: statistics + parameter gradients + apply).
+// Statistics: per-thread f32 sums about the first row (a shift that is itself a sample), combined over the 1024 threads in f64
+// in a fixed order (wave shuffles, then 16 wave partials) -- deterministic; var = Q/n - (S/n)^2 in f64 on shifted sums.
+// The apply arithmetic is the k_norm_apply4 / k_norm_bwd_apply4 expression, element for element.
+int ES_OPT_NORM_CB_ROWS = 4096;       // es_set_option key 15: matrices with at most this many rows take the one-launch path (0: off).
+                                      // Measured on the mv-3ddet step (profiles/r4j_sweep.txt): 4096 -> 26.6 ms, off -> 26.8, 16384 -> 27.3
+                                      // (8 .. 16 k rows x 256 channels are only 16 workgroups: too few), 65536 -> 33.1
+#define NCB_TY 256
+__device__ inline void cb_reduce4(double v[4], double (*sm)[4][4]) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tx = threadIdx.x & 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) v[i] += __shfl_xor(v[i], o, 64);
+  }
+  __syncthreads();                                 // (sm may still be read by the previous reduction)
+  if ((lane >> 2) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm[wv][tx][i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += sm[w][tx][i];
+    v[i] = tot;
+  }
+}
+__global__ __launch_bounds__(1024) void k_norm_fwd_cb(const float* __restrict__ x, int ldx, int n, int C, float eps,
+                                                      const float* __restrict__ w, const float* __restrict__ b,
+                                                      const float* __restrict__ res, int ldr, int act, float* running_mean,
+                                                      float* running_var, float momentum, float* __restrict__ mean,
+                                                      float* __restrict__ invstd, float* __restrict__ y, int ldy,
+                                                      unsigned short* __restrict__ yh) {
+  __shared__ double sm[16][4][4];
+  const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2, c = blockIdx.x * 16 + tx * 4;
+  const float4 k = *(const float4*)(x + c);                                    // row 0: the shift
+  float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+  for (int rb = ty; rb < n; rb += 4 * NCB_TY) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int r = rb + u * NCB_TY;
+      v[u] = r < n ? *(const float4*)(x + (size_t)r * ldx + c) : k;              // (a padding row contributes 0)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float dx = v[u].x - k.x, dy = v[u].y - k.y, dz = v[u].z - k.z, dw = v[u].w - k.w;
+      s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+      q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+    }
+  }
+  double a[4] = {s.x, s.y, s.z, s.w}, bq[4] = {q.x, q.y, q.z, q.w};
+  cb_reduce4(a, sm);
+  cb_reduce4(bq, sm);
+  const double inv_n = 1.0 / (double)n;
+  const float kk[4] = {k.x, k.y, k.z, k.w};
+  float m4[4], is4[4];
+  double var4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double ms = a[i] * inv_n, var = bq[i] * inv_n - ms * ms;
+    if (var < 0) var = 0;
+    var4[i] = var;
+    m4[i] = (float)((double)kk[i] + ms);
+    is4[i] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  if (ty == 0) {
+    *(float4*)(mean + c) = make_float4(m4[0], m4[1], m4[2], m4[3]);
+    *(float4*)(invstd + c) = make_float4(is4[0], is4[1], is4[2], is4[3]);
+    if (running_mean && n > 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        running_mean[c + i] = (1.f - momentum) * running_mean[c + i] + momentum * m4[i];
+        running_var[c + i] = (1.f - momentum) * running_var[c + i] + momentum * (float)(var4[i] * n / (n - 1));
+      }
+    }
+  }
+  const float4 ww = *(const float4*)(w + c), bb = *(const float4*)(b + c);
+  for (int rb = ty; rb < n; rb += 4 * NCB_TY) {
+    float4 v[4], qv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int r = rb + u * NCB_TY;
+      int rc = r < n ? r : rb;
+      v[u] = *(const float4*)(x + (size_t)rc * ldx + c);
+      if (res) qv[u] = *(const float4*)(res + (size_t)rc * ldr + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int r = rb + u * NCB_TY;
+      if (r >= n) continue;
+      float z0 = (v[u].x - m4[0]) * is4[0] * ww.x + bb.x, z1 = (v[u].y - m4[1]) * is4[1] * ww.y + bb.y;
+      float z2 = (v[u].z - m4[2]) * is4[2] * ww.z + bb.z, z3 = (v[u].w - m4[3]) * is4[3] * ww.w + bb.w;
+      if (res) { z0 += qv[u].x; z1 += qv[u].y; z2 += qv[u].z; z3 += qv[u].w; }
+      z0 = act_fwd(z0, act); z1 = act_fwd(z1, act); z2 = act_fwd(z2, act); z3 = act_fwd(z3, act);
+      *(float4*)(y + (size_t)r * ldy + c) = make_float4(z0, z1, z2, z3);
+      if (yh) *(uint2*)(yh + (size_t)r * C + c) = make_uint2(es_pack_bf16(z0, z1), es_pack_bf16(z2, z3));
+    }
+  }
+}
+static bool norm_cb_ok(int n, int C, int nseg) {
+  return ES_OPT_NORM_CB_ROWS > 0 && nseg == 1 && n >= 1 && n <= ES_OPT_NORM_CB_ROWS && (C & 15) == 0;
+}
+
 // workspace floats: nseg * cdiv(max_seg_rows, 64) * 2 * C
 extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg_off, int nseg, float eps,
                            const float* weight, const float* bias, const float* res, int ldr, int act,
@@ -197,6 +308,15 @@ extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0 || nseg > ES_MAX_SEG) return nseg > ES_MAX_SEG ? -3 : 0;
   Segs s = make_segs(seg_off, nseg);
+  const bool vec0 = ((C & 3) == 0) && ((ldx & 3) == 0) && ((ldy & 3) == 0) && (!res || (ldr & 3) == 0) &&
+                    (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)weight) | ((uintptr_t)bias) |
+                       ((uintptr_t)mean) | ((uintptr_t)invstd)) & 15) == 0);
+  if (vec0 && norm_cb_ok(n, C, nseg) && seg_off[0] == 0 && seg_off[1] == n) {      // short matrix: one launch (see k_norm_fwd_cb)
+    hipLaunchKernelGGL(k_norm_fwd_cb, dim3(C / 16), dim3(1024), 0, st, x, ldx, n, C, eps, weight, bias, res, ldr, act,
+                       running_mean, running_var, momentum, mean, invstd, y, ldy, (unsigned short*)y_bf16);
+    ES_CHECK_LAUNCH();
+    return 0;
+  }
   const int NCH = norm_chunk_rows(max_seg_rows(s));
   int nchunk = es_cdiv(max_seg_rows(s), NCH);
   if (nchunk < 1) nchunk = 1;
@@ -411,6 +531,89 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply4(const float* __restrict
 #undef NB_ELT
   }
 }
+// one-launch backward for short matrices (see k_norm_fwd_cb): dz = dy * act'(y) in place, per-channel sums of dz and dz * xhat
+// (f32 per thread, f64 across the workgroup, fixed order), parameter gradients (the workgroup is the only writer of its 16
+// channels), then the k_norm_bwd_apply4 expression on the rows the same thread has just written.
+__global__ __launch_bounds__(1024) void k_norm_bwd_cb(float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
+                                                      const float* __restrict__ x, int ldx, int n, int C,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ w, int act, float* dweight, float* dbias,
+                                                      float* __restrict__ dx, int ldo, int accumulate,
+                                                      unsigned short* __restrict__ dxh) {
+  __shared__ double sm[16][4][4];
+  const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2, c = blockIdx.x * 16 + tx * 4;
+  const float4 m = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+  float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+  for (int rb = ty; rb < n; rb += 4 * NCB_TY) {
+    float4 g[4], yv[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int r = rb + u * NCB_TY;
+      int rc = r < n ? r : rb;
+      g[u] = *(const float4*)(dy + (size_t)rc * ldd + c);
+      if (act) yv[u] = *(const float4*)(y + (size_t)rc * ldy + c);
+      xv[u] = *(const float4*)(x + (size_t)rc * ldx + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int r = rb + u * NCB_TY;
+      if (r >= n) continue;
+      float4 gg = g[u];
+      if (act) {
+        float4 yy = yv[u];
+        if (act == 1) {
+          gg.x = yy.x > 0.f ? gg.x : 0.f; gg.y = yy.y > 0.f ? gg.y : 0.f;
+          gg.z = yy.z > 0.f ? gg.z : 0.f; gg.w = yy.w > 0.f ? gg.w : 0.f;
+        } else {
+          gg.x = yy.x > 0.f ? gg.x : gg.x * (yy.x + 1.f); gg.y = yy.y > 0.f ? gg.y : gg.y * (yy.y + 1.f);
+          gg.z = yy.z > 0.f ? gg.z : gg.z * (yy.z + 1.f); gg.w = yy.w > 0.f ? gg.w : gg.w * (yy.w + 1.f);
+        }
+        *(float4*)(dy + (size_t)r * ldd + c) = gg;
+      }
+      float4 xx = xv[u];
+      s.x += gg.x; s.y += gg.y; s.z += gg.z; s.w += gg.w;
+      q.x += gg.x * ((xx.x - m.x) * is.x); q.y += gg.y * ((xx.y - m.y) * is.y);
+      q.z += gg.z * ((xx.z - m.z) * is.z); q.w += gg.w * ((xx.w - m.w) * is.w);
+    }
+  }
+  double a[4] = {s.x, s.y, s.z, s.w}, bq[4] = {q.x, q.y, q.z, q.w};
+  cb_reduce4(a, sm);
+  cb_reduce4(bq, sm);
+  if (ty == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (dweight) dweight[c + i] += (float)bq[i];
+      if (dbias) dbias[c + i] += (float)a[i];
+    }
+  }
+  const float sd[4] = {(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+  const float sq[4] = {(float)bq[0], (float)bq[1], (float)bq[2], (float)bq[3]};
+  const float4 ww = *(const float4*)(w + c);
+  const float inv_n = 1.f / (float)n;
+  for (int rb = ty; rb < n; rb += 4 * NCB_TY) {
+    float4 g[4], xv[4], ov[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int r = rb + u * NCB_TY;
+      int rc = r < n ? r : rb;
+      g[u] = *(const float4*)(dy + (size_t)rc * ldd + c);                       // dz: written above by this very thread
+      xv[u] = *(const float4*)(x + (size_t)rc * ldx + c);
+      ov[u] = accumulate ? *(const float4*)(dx + (size_t)rc * ldo + c) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int r = rb + u * NCB_TY;
+      if (r >= n) continue;
+#define NCB_ELT(xe, ge, oe, me, ie, we, se, qe) \
+      { float xh = ((xe) - (me)) * (ie); float gg = (we) * (ie) * ((ge) - (se) * inv_n - xh * (qe) * inv_n); oe = accumulate ? ((oe) + gg) : gg; }
+      NCB_ELT(xv[u].x, g[u].x, ov[u].x, m.x, is.x, ww.x, sd[0], sq[0]) NCB_ELT(xv[u].y, g[u].y, ov[u].y, m.y, is.y, ww.y, sd[1], sq[1])
+      NCB_ELT(xv[u].z, g[u].z, ov[u].z, m.z, is.z, ww.z, sd[2], sq[2]) NCB_ELT(xv[u].w, g[u].w, ov[u].w, m.w, is.w, ww.w, sd[3], sq[3])
+#undef NCB_ELT
+      *(float4*)(dx + (size_t)r * ldo + c) = ov[u];
+      if (dxh) *(uint2*)(dxh + (size_t)r * C + c) = make_uint2(es_pack_bf16(ov[u].x, ov[u].y), es_pack_bf16(ov[u].z, ov[u].w));
+    }
+  }
+}
 // dy is overwritten with dz (= gradient w.r.t. the pre-activation, which is also the
 // gradient of the residual input).  workspace as in es_norm_fwd plus 2*nseg*C floats.
 extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const float* x, int ldx, int n, int C,
@@ -423,6 +626,17 @@ extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const fl
   const int NCH = norm_chunk_rows(max_seg_rows(s));
   int nchunk = es_cdiv(max_seg_rows(s), NCH);
   if (nchunk < 1) nchunk = 1;
+  {
+    const bool vec0 = ((C & 3) == 0) && ((ldx & 3) == 0) && ((ldd & 3) == 0) && ((ldo & 3) == 0) && ((ldy & 3) == 0) &&
+                      (((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)y) | ((uintptr_t)weight) |
+                         ((uintptr_t)mean) | ((uintptr_t)invstd)) & 15) == 0);
+    if (vec0 && dx != dy && norm_cb_ok(n, C, nseg) && seg_off[0] == 0 && seg_off[1] == n) {
+      hipLaunchKernelGGL(k_norm_bwd_cb, dim3(C / 16), dim3(1024), 0, st, dy, ldd, y, ldy, x, ldx, n, C, mean, invstd, weight, act,
+                         dweight, dbias, dx, ldo, accumulate, (unsigned short*)dx_bf16);
+      ES_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   float* sums = workspace + (size_t)nseg * nchunk * 2 * C;
   hipLaunchKernelGGL(k_norm_bwd_stats, dim3(nchunk, nseg), dim3(256), 0, st, dy, ldd, y, ldy, x,
                      ldx, C, s, nchunk, NCH, mean, invstd, act, workspace);

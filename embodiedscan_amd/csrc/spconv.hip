@@ -37,7 +37,14 @@ static int ES_OPT_DMA_MIN_CIN = 768;       // ... for layers with at least this 
 static int ES_OPT_WGRAD_TR = 1;            // weight-gradient 128 x 128 tile with LDS-DMA staging + ds_read_b64_tr_b16 (k_spconv_wgrad_bf16_tr): run on
                                            // hardware in round 4 (profiles/r4a_*): bit-identical to the register-transposing tile, step -0.2 ms
 static int ES_OPT_ROWGEMM2 = 1;            // second-generation row GEMM (swapped MFMA operands, register epilogue with 16-byte accesses)
+static int ES_OPT_SPLIT_FOLD = 0;           // tap-split launches: partial tiles added by a second launch (0, default) or by the tile's last workgroup
+                                           // inside the launch (1, es_set_option key 16).  MEASURED AND REJECTED as the default (round 4,
+                                           // profiles/r4l_sweep.txt): the in-kernel election needs an agent-scope release fence per workgroup
+                                           // (buffer_wbl2: the partial tiles must reach memory, their readers sit on other XCDs), and hundreds of
+                                           // L2 write-backs inside a streaming kernel cost far more than the 70 reduce launches they replace:
+                                           // mv-3ddet step 30.9 ms against 25.9 (with a seq_cst fence, i.e. + buffer_inv: 32.6).  Kept as a tested option.
 static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
+extern int ES_OPT_NORM_CB_ROWS;          // rowops.hip: one-launch norm for matrices with at most this many rows (key 15)
 extern "C" int es_set_option(int key, int value) {
   if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
   if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }
@@ -52,6 +59,8 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 12) { ES_OPT_RG128_MIN_CIN = value; return 0; }
   if (key == 13) { ES_OPT_ROWGEMM2 = value; return 0; }
   if (key == 14) { ES_OPT_WGRAD_TR = value; return 0; }
+  if (key == 15) { ES_OPT_NORM_CB_ROWS = value; return 0; }
+  if (key == 16) { ES_OPT_SPLIT_FOLD = value; return 0; }
   return -2;
 }
 
@@ -675,6 +684,40 @@ __global__ __launch_bounds__(256) void k_spconv_bf16(const float* __restrict__ X
 // PP = true: ping-pong LDS buffers -- chunk c is computed from buffer c&1 while chunk c+1 is written into the other one, so
 // the loop needs ONE workgroup barrier per 16-MFMA chunk instead of two and the LDS stores overlap the matrix
 // instructions of the current chunk (46 KB LDS per workgroup, still 3 workgroups per CU).
+// Tail of a tap-split launch (round 4: replaces the k_sum_splits launch behind every split convolution -- 70 launches on the
+// dependent chain of an mv-3ddet step): the gridDim.z workgroups of an output tile have written their partial tiles to the
+// workspace [slice][row][col]; the last one to arrive (es_last_block on the tile's ticket) adds them IN SLICE ORDER into Y --
+// the summation order of k_sum_splits4, bit for bit, whichever workgroup happens to be last.  `tickets`: one zero-initialised
+// unsigned int per tile (left at zero); the launcher hands it over through the unused ep_shift argument.
+#define ES_SPLIT_TICKETS 1024
+template <int BNT_>
+__device__ inline void split_tail(const float* ws, unsigned int* tickets, int row0, int n0, int n_out, int Cout,
+                                  float* __restrict__ Y, int ldy, int accumulate) {
+  if (!es_last_block_release_only(tickets + blockIdx.y * gridDim.x + blockIdx.x, gridDim.z)) return;
+  const int split = gridDim.z;
+  constexpr int C4 = BNT_ / 4;
+  const size_t tot = (size_t)n_out * Cout;
+  const bool vec = ((ldy & 3) == 0) && ((((uintptr_t)Y) & 15) == 0);
+  for (int e = threadIdx.x; e < BM * C4; e += blockDim.x) {
+    const int row = row0 + e / C4, col = n0 + (e % C4) * 4;
+    if (row >= n_out) break;
+    const float* p0 = ws + (size_t)row * Cout + col;
+    float4 sum = *(const float4*)p0;
+    for (int z = 1; z < split; ++z) {
+      float4 v = *(const float4*)(p0 + (size_t)z * tot);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    float* y = Y + (size_t)row * ldy + col;
+    if (vec) {
+      if (accumulate) { float4 y0 = *(const float4*)y; sum.x = y0.x + sum.x; sum.y = y0.y + sum.y; sum.z = y0.z + sum.z; sum.w = y0.w + sum.w; }
+      *(float4*)y = sum;
+    } else {
+      y[0] = accumulate ? y[0] + sum.x : sum.x; y[1] = accumulate ? y[1] + sum.y : sum.y;
+      y[2] = accumulate ? y[2] + sum.z : sum.z; y[3] = accumulate ? y[3] + sum.w : sum.w;
+    }
+  }
+}
+
 template <int BNT, bool XH, bool PP>
 __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restrict__ Xv, int ldx,
                                                           const unsigned short* __restrict__ W,
@@ -725,7 +768,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
   }
   __syncthreads();
   // tap split (gridDim.z > 1): launches with too few tiles to fill the chip share the tap list among gridDim.z
-  // workgroups which write their partial sums to a workspace (k_sum_splits adds them in slice order)
+  // workgroups which write their partial tiles to a workspace; the tile's last workgroup adds them in slice order (split_tail)
   const int nTall = nTaps;
   const int tBeg = (int)(((long long)nTall * bz) / gridDim.z);
   const int nT = (int)(((long long)nTall * (bz + 1)) / gridDim.z);
@@ -885,7 +928,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
     for (int nf = 0; nf < NF; ++nf) {
       int col = n0 + nf * 16 + li;
       float bv = bias ? bias[col] : 0.f;
-      float sc = ep_scale ? ep_scale[col] : 1.f, sh = ep_shift ? ep_shift[col] : 0.f;
+      float sc = ep_scale ? ep_scale[col] : 1.f, sh = (ep_shift && gridDim.z == 1) ? ep_shift[col] : 0.f;   // (split: ep_shift = tickets)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = row0 + wv * 32 + mf * 16 + kq * 4 + r;
@@ -919,6 +962,7 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
         }
       }
     }
+  if (gridDim.z > 1 && ep_shift) split_tail<BNT>(ep_res, (unsigned int*)ep_shift, row0, n0, n_out, Cout, Y, ldy, accumulate);
 }
 
 // ------------------------------------------------------------------ LDS-DMA variant of the fast kernel (round 3, late)
@@ -1102,7 +1146,7 @@ __global__ __launch_bounds__(256, (KB == 1 && NBUF == 2) ? 3 : 2) void k_spconv_
     for (int nf = 0; nf < NFW; ++nf) {
       int col = n0 + wc * (BNT / 2) + nf * 16 + li;
       float bv = bias ? bias[col] : 0.f;
-      float sc = ep_scale ? ep_scale[col] : 1.f, sh = ep_shift ? ep_shift[col] : 0.f;
+      float sc = ep_scale ? ep_scale[col] : 1.f, sh = (ep_shift && gridDim.z == 1) ? ep_shift[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = row0 + wr * 64 + mf * 16 + kq * 4 + r;
@@ -1135,6 +1179,7 @@ __global__ __launch_bounds__(256, (KB == 1 && NBUF == 2) ? 3 : 2) void k_spconv_
         }
       }
     }
+  if (gridDim.z > 1 && ep_shift) split_tail<BNT>(ep_res, (unsigned int*)ep_shift, row0, n0, n_out, Cout, Y, ldy, accumulate);
 }
 
 // ------------------------------------------------------------------ K = 1 on the identity map: a streaming row GEMM
@@ -1543,7 +1588,7 @@ __global__ void k_sum_splits4(const float4* __restrict__ ws, int split, size_t t
 extern "C" size_t es_spconv_split_workspace_floats(int n_out, int K, int Cin, int Cout) {
   if (K <= 1 || Cin % HBK != 0 || Cout % 64 != 0 || n_out <= 0) return 0;
   int split = split_factor(n_out, K, Cout);
-  return split > 1 ? (size_t)split * n_out * Cout : 0;
+  return split > 1 ? (size_t)ES_SPLIT_TICKETS + (size_t)split * n_out * Cout : 0;     // [tile tickets | partial tiles]
 }
 
 static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out,
@@ -1606,9 +1651,12 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
   if (fast && !(ep_scale || ep_res || ep_act) && K > 1 && !y_half) {
     // too few workgroups for 256 CUs: split the tap list over gridDim.z (partial sums through the caller's workspace)
     int split = split_factor(n_out, K, Cout);
-    if (split > 1 && ws != nullptr && ws_floats >= (size_t)split * n_out * Cout) {
-      det_split = split;                   // deterministic: partial sums to the workspace, fixed-order reduction below
-      ep_res = ws;
+    const int tiles = (Cout % 128 == 0) ? g128.x * g128.y : g64.x * g64.y;
+    if (split > 1 && ws != nullptr && ws_floats >= (size_t)ES_SPLIT_TICKETS + (size_t)split * n_out * Cout && tiles <= ES_SPLIT_TICKETS &&
+        ((((uintptr_t)ws) & 15) == 0)) {
+      det_split = split;                   // deterministic: partial tiles to the workspace, added in slice order by the tile's last
+      ep_shift = ES_OPT_SPLIT_FOLD ? ws : nullptr;   // workgroup (split_tail); the head of the workspace holds the tile tickets (zero on entry / exit)
+      ep_res = ws + ES_SPLIT_TICKETS;
       ep_act = 7;
       g128.z = g64.z = split;
     }                                      // (without a workspace the launch keeps one workgroup per tile: no f32 atomics)
@@ -1662,15 +1710,16 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
                        nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, x_is_bf16, io);
   }
   ES_CHECK_LAUNCH();
-  if (det_split) {
-    if ((Cout % 4 == 0) && (ldy % 4 == 0) && (((((uintptr_t)ws) | ((uintptr_t)Y)) & 15) == 0)) {
+  if (det_split && !ES_OPT_SPLIT_FOLD) {       // A/B path (es_set_option 16 = 0): the reduction as a second launch
+    const float* part = ws + ES_SPLIT_TICKETS;
+    if ((Cout % 4 == 0) && (ldy % 4 == 0) && (((((uintptr_t)part) | ((uintptr_t)Y)) & 15) == 0)) {
       size_t tot4 = (size_t)n_out * (Cout / 4);
       int g = es_cdiv((long long)tot4, 256);
-      hipLaunchKernelGGL(k_sum_splits4, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, (const float4*)ws, det_split, tot4,
+      hipLaunchKernelGGL(k_sum_splits4, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, (const float4*)part, det_split, tot4,
                          Cout / 4, Y, ldy, accumulate);
     } else {
       int g = es_cdiv((long long)n_out * Cout, 256);
-      hipLaunchKernelGGL(k_sum_splits, dim3(g > 4096 ? 4096 : g), dim3(256), 0, st, ws, det_split, n_out, Cout, Y, ldy, accumulate);
+      hipLaunchKernelGGL(k_sum_splits, dim3(g > 4096 ? 4096 : g), dim3(256), 0, st, part, det_split, n_out, Cout, Y, ldy, accumulate);
     }
     ES_CHECK_LAUNCH();
   }

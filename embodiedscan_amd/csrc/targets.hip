@@ -70,6 +70,7 @@ __device__ inline uint32_t f2ord_t(float f) {
 __device__ inline float ord2f_t(uint32_t u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
+#define TG_CAP 8192
 // per box: best level (fcaf3d_head.py:1622-1638) then the k-th largest masked centerness
 __global__ __launch_bounds__(1024) void k_tg_select(const float* __restrict__ cen, int N, Levels L, int G,
                                                     const int* __restrict__ npos, int assign_thr, int kth,
@@ -102,12 +103,32 @@ __global__ __launch_bounds__(1024) void k_tg_select(const float* __restrict__ ce
   // Most locations are outside the box (value -1): they would all hit one histogram bin (serialised LDS atomics), so
   // they are counted separately: with fewer than k candidates (inside points, value >= 0) the threshold is -1,
   // otherwise the k-th largest lies among the candidates and the -1 values can be ignored.
-  __shared__ unsigned int s_cand;
-  if (threadIdx.x == 0) s_cand = 0;
+  // Round 4: the candidates of a box are few (the locations inside it: hundreds to a few thousand of up to ~10^5 scanned), so the
+  // ONE scan that counts them also collects them in LDS and the four radix passes then run on that array; only a box with more
+  // than TG_CAP candidates falls back to re-scanning global memory per pass (this kernel was 0.25 ms per sample: five scans of
+  // the level by one workgroup per box).  The result is the k-th largest VALUE: the order of collection does not matter.
+  __shared__ unsigned int s_cand, s_live;
+  __shared__ float candS[TG_CAP];
+  if (threadIdx.x == 0) s_cand = s_live = 0;
   __syncthreads();
   {
     unsigned int c = 0;
-    for (int i = lb + threadIdx.x; i < le; i += blockDim.x) c += (cg[i] >= 0.f) ? 1u : 0u;
+    const int lane = threadIdx.x & 63;
+    for (int b0 = lb; b0 < le; b0 += blockDim.x) {
+      const int i = b0 + threadIdx.x;
+      const float v = (i < le) ? cg[i] : -1.f;
+      c += (v >= 0.f) ? 1u : 0u;
+      const bool live = (i < le) && !(v < 0.f);
+      const unsigned long long m = __ballot(live);
+      if (m) {
+        unsigned int base = 0;
+        const int first = __ffsll((long long)m) - 1;
+        if (lane == first) base = atomicAdd(&s_live, (unsigned int)__popcll(m));
+        base = __shfl(base, first, 64);
+        const unsigned int slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        if (live && slot < TG_CAP) candS[slot] = v;
+      }
+    }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cand, c);
   }
@@ -116,16 +137,18 @@ __global__ __launch_bounds__(1024) void k_tg_select(const float* __restrict__ ce
     if (threadIdx.x == 0) thr_out[g] = -1.f;
     return;
   }
+  const bool in_lds = s_live <= TG_CAP;
+  const int n_scan = in_lds ? (int)s_live : (le - lb);
   uint32_t pmask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t prefix = s_prefix;
-    for (int b0 = lb; b0 < le; b0 += blockDim.x) {         // wave-aggregated histogram (see k_topk_mask, rowops.hip)
+    for (int b0 = 0; b0 < n_scan; b0 += blockDim.x) {       // wave-aggregated histogram (see k_topk_mask, rowops.hip)
       const int i = b0 + threadIdx.x;
-      const float v = (i < le) ? cg[i] : -1.f;
+      const float v = (i < n_scan) ? (in_lds ? candS[i] : cg[lb + i]) : -1.f;
       const uint32_t u = f2ord_t(v);
-      const bool live = (i < le) && !(v < 0.f) && ((u & pmask) == prefix);
+      const bool live = (i < n_scan) && !(v < 0.f) && ((u & pmask) == prefix);
       const int d = (int)((u >> shift) & 255);
       unsigned long long m = __ballot(live);
 #pragma unroll

@@ -427,13 +427,15 @@ DET_SPLIT = [os.environ.get('ES_DET_SPLIT', '1') != '0']   # deterministic tap s
 
 def _split_ws(n_out, K, cin, cout, like):
     """workspace for the deterministic tap split of an under-filled bf16 conv launch (size from the library's own rule,
-    es_spconv_split_workspace_floats): (tensor or None, floats)"""
+    es_spconv_split_workspace_floats): (tensor or None, floats).  Its head holds the tile tickets of the in-kernel reduction (zero
+    before and after every launch), so it is the stream's persistent zero-initialised ticket workspace (ticket_ws), not a fresh
+    allocation: the split launches of a stream are ordered, each has read its partial tiles before the next one starts."""
     if not DET_SPLIT[0] or K <= 1 or n_out <= 0:
         return None, 0
     nf = int(hip.raw('es_spconv_split_workspace_floats')(n_out, K, cin, cout))
     if nf == 0:
         return None, 0
-    return torch.empty(nf, dtype=torch.float32, device=like.device), nf
+    return ticket_ws(nf, like)
 
 
 def _fwd_bf16(X, x_is_bf16, ldx, Wp, nbr, n_out, n_in, K, cin, cout, bias_p, Y, ldy, acc, like):

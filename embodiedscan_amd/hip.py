@@ -37,11 +37,6 @@ def parse_header(path=HEADER_PATH):
     return out
 
 
-# Every HIP stream should own a hardware queue: the train step uses up to seven (main, image branch, two weight-gradient streams,
-# H2D copy, next-batch prefetch, RCCL) and ROCm's default of 4 hardware queues serialises streams that share one (bench.py
-# has the measurement).  Effective when this module is imported before the process makes its first HIP call.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
-
 PROTOS = parse_header()
 CONSTS = {k: int(v) for k, v in re.findall(r'#define\s+(ES_\w+)\s+(\d+)', open(HEADER_PATH).read())}
 

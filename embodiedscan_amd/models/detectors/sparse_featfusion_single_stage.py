@@ -121,12 +121,19 @@ class SparseFeatureFusionSingleStage3DDetector:
         weight-independent prefix of train_step(data, ...) issued now.  Returns `data`; hand exactly this object to the next
         train_step().  Optional: train_step() on any other data works as before."""
         if self._pf_stream is None:
-            self._pf_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            self._pf_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('ES_PF_PRIORITY', '-1')))
         st = self._pf_stream
         while len(self._pf_hold) > 1:                          # the step before the last one has long finished on the device
             ev, old = self._pf_hold.pop(0)
             st.wait_event(ev)
             del old
+        # The prefetch is a chain of ~200 small launches with a handful of host round trips -- and so is the 3-D backbone's forward
+        # pass.  Two latency-bound chains interleaved on the chip slow each other several-fold (measured, profiles/r4g_*: 3-D
+        # forward 3.2 -> 10 ms), so the prefetch kernels are held back until the step queued last has finished that stage and
+        # the main stream runs the head's large launches.
+        gate = getattr(self, '_ev_3d_done', None)
+        if gate is not None and os.environ.get('ES_PF_GATE', '1') != '0':
+            st.wait_event(gate)
         self._bind()
         try:
             with torch.cuda.stream(st):
@@ -220,6 +227,9 @@ class SparseFeatureFusionSingleStage3DDetector:
         E.mark('A4 voxelise')
         x = self.backbone_3d(SparseTensor(cs, E.Var(feats, rg=False)))
         E.mark('A5+A6 3-D backbone fwd + maps')
+        if self._pf_stream is not None:                        # next-batch prefetch in use: its kernels start behind this point
+            self._ev_3d_done = torch.cuda.Event()
+            self._ev_3d_done.record(hip.stream_obj())
         self._tape_marks.append(len(E.TAPE.fns))               # end of the 3-D backbone's closures
         metas = [ds.metainfo for ds in batch_data_samples]
         meta_dev = build_fusion_meta(metas, self.coord_type, (H, W), V).to(self.device, non_blocking=True)

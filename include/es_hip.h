@@ -82,8 +82,10 @@ int es_spconv_fwd(const float* X, int ldx, const float* W, const int* nbr, int n
 int es_spconv_fwd_bf16(const void* X, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in,
                        int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, void* stream);
 /* the same with a caller-provided workspace of es_spconv_split_workspace_floats() floats: launches with too few tiles to
- * fill the chip split their tap list over several workgroups; with the workspace the partial sums are reduced in a fixed
- * order (bit-reproducible) instead of f32 atomics into Y */
+ * fill the chip split their tap list over several workgroups, which write partial tiles to the workspace; the LAST workgroup
+ * of every output tile adds them in slice order into Y inside the same launch (round 4; bit-reproducible, no f32 atomics, no
+ * second launch).  The first 1024 floats of the workspace are the tiles' ticket counters: ZERO on entry, zero again on exit --
+ * keep one zero-initialised workspace per stream and reuse it. */
 size_t es_spconv_split_workspace_floats(int n_out, int K, int Cin, int Cout);
 int es_spconv_fwd_bf16_ws(const void* X, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in,
                           int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, float* ws,

@@ -64,12 +64,22 @@ def test_dma_kernel_is_bit_identical_to_the_register_staged_kernel():
                     call('es_spconv_fwd_bf16', P(xh), 1, cin, P(wt), P(nbr) if nbr is not None else 0, n_out, n_in, K, cin, cout,
                          0, wide.data_ptr() + 4 * cout, 2 * cout, 1, st)
                     o.append(wide)
-                    if nf:                           # deterministic tap split through the workspace
-                        ws = torch.empty(nf, device=dev)
-                        y = torch.empty(n_out, cout, device=dev)
-                        call('es_spconv_fwd_bf16_ws', P(xh), 1, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y), cout, 0,
-                             P(ws), nf, st)
-                        o.append(y)
+                    if nf:                           # deterministic tap split through the workspace: reduction by a second launch
+                        for fold in (0, 1):          # (option 16 = 0, default) and by the tile's last workgroup (16 = 1) -- bit-identical
+                            opt(16, fold)
+                            ws = torch.zeros(nf, device=dev)          # (head = tile tickets: zero on entry, left zero)
+                            y = torch.empty(n_out, cout, device=dev)
+                            call('es_spconv_fwd_bf16_ws', P(xh), 1, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y), cout, 0,
+                                 P(ws), nf, st)
+                            if fold:
+                                call('es_spconv_fwd_bf16_ws', P(xh), 1, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y), cout,
+                                     0, P(ws), nf, st)       # the same workspace again: the tickets were left at zero
+                                torch.cuda.synchronize()
+                                assert int(ws[:1024].view(torch.int32).abs().max()) == 0
+                            o.append(y)
+                        opt(16, 0)
+                        torch.cuda.synchronize()
+                        assert torch.equal(o[-1], o[-2]), 'in-kernel split reduction differs from the two-launch reduction'
                     for act, r, rh, yh in ((1, res, 0, 0), (0, None, 0, 0), (3, res, 0, 0), (1, resh, 1, 1), (1, None, 0, 1),
                                            (3, resh, 1, 0)):
                         y = torch.empty(n_out, cout, device=dev, dtype=torch.bfloat16 if yh else torch.float32)
@@ -99,5 +109,6 @@ def test_dma_kernel_is_bit_identical_to_the_register_staged_kernel():
         opt(10, 2)
         opt(11, 768)
         opt(3, 1)
+        opt(16, 0)
     print(f'LDS-DMA conv kernel: {n_checked} outputs identical to the register-staged kernel '
           f'({len(maps)} maps x 7 channel shapes x 2 chunk sizes x up to 9 launch modes)')

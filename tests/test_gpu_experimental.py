@@ -106,7 +106,7 @@ def test_three_buffer_dma_ring_matches_the_register_staged_kernel():
                     opt(11, 0)
                     y = torch.empty(n, cout, device=dev)
                     if nf:
-                        ws = torch.empty(nf, device=dev)
+                        ws = torch.zeros(nf, device=dev)          # (head = tile tickets: zero on entry, left zero)
                         call('es_spconv_fwd_bf16_ws', P(xh), 1, cin, P(wt), P(nbr), n, n, K, cin, cout, P(bias), P(y), cout, 0, P(ws), nf, st)
                     else:
                         call('es_spconv_fwd_bf16', P(xh), 1, cin, P(wt), P(nbr), n, n, K, cin, cout, P(bias), P(y), cout, 0, st)

@@ -71,6 +71,7 @@ main = torch.cuda.current_stream()
 for it in range(6):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     E.HOST_MARKS = []
+    E.MARKS = []
     a = time.perf_counter()
     ev[0].record(main)
     batch = nxt if nxt is not None else make()
@@ -79,18 +80,20 @@ for it in range(6):
     ev[1].record(main)
     b = time.perf_counter()
     hm, E.HOST_MARKS = E.HOST_MARKS, None
+    dm, E.MARKS = E.MARKS, None
     pst = det._pf_stream
     ev[2].record(pst)
     nxt = det.prefetch(make)
     ev[3].record(pst)
     c = time.perf_counter()
-    log.append((a - h0, b - h0, c - h0, ev, [(n, t - h0) for n, t in hm]))
+    log.append((a - h0, b - h0, c - h0, ev, [(n, t - h0) for n, t in hm], dm))
 torch.cuda.synchronize()
-for i, (a, b, c, ev, hm) in enumerate(log):
+for i, (a, b, c, ev, hm, dm) in enumerate(log):
     d = [base.elapsed_time(e) for e in ev]
     print(f'step {i}: HOST train_step {a * 1e3:7.2f} .. {b * 1e3:7.2f} ms, prefetch .. {c * 1e3:7.2f} | DEVICE main stream {d[0]:7.2f} .. {d[1]:7.2f} ms, '
           f'prefetch stream {d[2]:7.2f} .. {d[3]:7.2f}')
     print('        host stage boundaries: ' + ', '.join(f'{n.split()[0]} {t * 1e3:.2f}' for n, t in hm))
+    print('        device stage boundaries (main stream): ' + ', '.join(f'{n.split()[0]} {base.elapsed_time(e):.2f}' for n, e in dm))
 rows = []
 
 for it in range(4):
