@@ -122,4 +122,43 @@ __device__ inline bool es_last_block_release_only(unsigned int* ticket, unsigned
   __syncthreads();
   return es_s_last2 != 0u;
 }
+// The light election (round 4, after profiles/r4q: the grounding step had become 9 ms SLOWER with es_last_block in its small
+// reductions): an agent-scope fence is buffer_wbl2 (+ buffer_inv) on gfx950 -- it writes back / drops the WHOLE L2 of the XCD, i.e.
+// also the tiles of the large kernels running beside this one on other streams.  When the partial results travel through
+// device-scope ATOMIC stores / loads instead of plain ones (es_coh_store / es_coh_load: performed at the memory-side coherence
+// point, never held dirty or stale in an XCD's L2) no cache maintenance is needed at all: wait until this thread's stores have
+// been performed (s_waitcnt), barrier, count the ticket, and the winner reads the partials with coherent loads.
+__device__ inline void es_coh_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline float es_coh_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void es_coh_store_u(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned int es_coh_load_u(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// sum of `count` coherent loads p[0], p[stride], ... IN INDEX ORDER, with 16 loads in flight: a coherent load travels to the memory
+// side (~1-2 us), so a loop that waits for each one before issuing the next serialises 100 partials into 0.2 ms (round 4: that
+// alone made the grounding step 8 ms slower); the order of the additions -- and so the result -- is unchanged.
+__device__ inline float es_coh_sum(const float* p, int count, size_t stride) {
+  float t = 0.f;
+  int b = 0;
+  for (; b + 16 <= count; b += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = es_coh_load(p + (size_t)(b + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += v[u];
+  }
+  for (; b < count; ++b) t += es_coh_load(p + (size_t)b * stride);
+  return t;
+}
+__device__ inline bool es_last_block_light(unsigned int* ticket, unsigned int nblocks) {
+  __shared__ unsigned int es_s_last3;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);                       // vmcnt(0) lgkmcnt(0): every coherent store / atomic of this thread has been performed
+  __syncthreads();
+  if ((threadIdx.x | threadIdx.y | threadIdx.z) == 0) {
+    unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    es_s_last3 = (t == nblocks - 1u) ? 1u : 0u;
+    if (es_s_last3) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return es_s_last3 != 0u;
+}
 #define ES_TICKET_FLOATS 4          // floats reserved at the head of a workspace for the ticket (keeps partials 16-byte aligned)

@@ -177,3 +177,75 @@ extern "C" int es_stem_conv_fwd(const float* x, const float* w, const float* sca
   ES_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------ N4: PointSample on the device (counter-based draws)
+// datasets/transforms/points.py:155-213 draws `np.random.choice(range(n), k, replace=False)` per depth frame and once more over
+// the aggregated cloud: a uniform k-subset in uniform random order.  On the host that is a Fisher-Yates over all ~3e5 valid pixels
+// of every frame -- 52 % of the loader's time per scan (profiles/r3_loader_profile.txt).  Here every element gets a 30-bit key
+// from a counter-based generator (splitmix64 of seed, stream and index: no sequential state, any element in any order), the k
+// LARGEST keys are selected (es_topk_mask_ws on the keys' float encodings: positive finite floats order like their bit patterns;
+// invalid pixels carry -1) and emitted in descending key order (es_sort_u64 on 2^30 - 1 - key).  The same law as the reference's
+// draw, not its numpy stream; oracle/draws.py restates these kernels integer for integer (tests: exact equality + frequencies).
+__device__ inline uint64_t es_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ inline uint32_t es_draw_key(uint64_t seed, uint32_t stream, uint64_t index) {
+  const uint64_t s = seed ^ ((uint64_t)stream * 0x9E3779B97F4A7C15ull);
+  return (uint32_t)(es_splitmix64(s + index * 0xD1B54A32D192ED03ull) >> 34);
+}
+// per (view, pixel): values = the key's float encoding (valid depth) or -1; keys = view << 54 | (2^30 - 1 - key) << 24 | pixel
+__global__ void k_draw_keys(const float* __restrict__ depth, int V, int HW, uint64_t seed, float* __restrict__ values,
+                            int64_t* __restrict__ keys) {
+  const size_t tot = (size_t)V * HW;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    const int v = (int)(e / HW), p = (int)(e - (size_t)v * HW);
+    const uint32_t k = es_draw_key(seed, (uint32_t)v, (uint64_t)p);
+    values[e] = depth[e] != 0.f ? __uint_as_float(k) : -1.f;
+    keys[e] = ((int64_t)v << 54) | ((int64_t)(0x3fffffffu - k) << 24) | (int64_t)p;
+  }
+}
+extern "C" int es_draw_keys(const float* depth, int V, int HW, size_t seed, float* values, int64_t* keys, void* stream) {
+  if (V <= 0 || HW <= 0) return 0;
+  if (V > 256 || HW > (1 << 24)) return -4;
+  int g = es_cdiv((long long)V * HW, 256);
+  hipLaunchKernelGGL(k_draw_keys, dim3(g > 16384 ? 16384 : g), dim3(256), 0, (hipStream_t)stream, depth, V, HW, (uint64_t)seed, values,
+                     keys);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+// the aggregate draw: element j of `stream`: values = key encoding, keys = (2^30 - 1 - key) << 24 | j
+__global__ void k_draw_keys_index(int n, uint64_t seed, uint32_t stream, float* __restrict__ values, int64_t* __restrict__ keys) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t k = es_draw_key(seed, stream, (uint64_t)j);
+  values[j] = __uint_as_float(k);
+  keys[j] = ((int64_t)(0x3fffffffu - k) << 24) | (int64_t)j;
+}
+extern "C" int es_draw_keys_index(int n, size_t seed, int stream_id, float* values, int64_t* keys, void* stream) {
+  if (n <= 0) return 0;
+  if (n > (1 << 24)) return -4;
+  hipLaunchKernelGGL(k_draw_keys_index, dim3(es_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (uint64_t)seed, (uint32_t)stream_id,
+                     values, keys);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+// sorted keys -> (view, pixel) lists; with in_view / in_pix: the low 24 bits index those lists (aggregate draw)
+__global__ void k_draw_unpack(const int64_t* __restrict__ keys, int n, const int* __restrict__ in_view, const int* __restrict__ in_pix,
+                              int* __restrict__ out_view, int* __restrict__ out_pix) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t k = keys[i];
+  const int low = (int)(k & 0xffffff);
+  if (in_view) { out_view[i] = in_view[low]; out_pix[i] = in_pix[low]; }
+  else { out_view[i] = (int)(k >> 54); out_pix[i] = low; }
+}
+extern "C" int es_draw_unpack(const int64_t* keys, int n, const int* in_view, const int* in_pix, int* out_view, int* out_pix,
+                              void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_draw_unpack, dim3(es_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, keys, n, in_view, in_pix, out_view, out_pix);
+  ES_CHECK_LAUNCH();
+  return 0;
+}

@@ -916,6 +916,193 @@ extern "C" int es_topk_mask(const float* values, const int* seg_off, int nseg, i
   return 0;
 }
 
+// ---- the same selection spread over many workgroups (round 4).  k_topk_mask walks a segment with ONE workgroup five times
+// (four 8-bit radix passes + the ordered tie pass): 0.5 - 0.6 ms for the ~10^5 scores per sample of the head's finest level, a single
+// launch on the step's dependent chain.  Here a segment is cut into TKP slices; per radix pass one launch: every workgroup adds the
+// digit histogram of its slice (elements that match the prefix found so far) to the segment's global histogram with INTEGER atomics
+// (exact, order-free), the last workgroup of the segment to arrive walks the 256 buckets, extends the prefix and clears the
+// histogram.  Then the tie pass: per-slice counts of elements equal to the threshold, scanned by the segment's last workgroup,
+// and a final launch writes the mask (ties in ascending row order, like k_topk_mask: bit-identical masks).
+// Workspace (ints; tickets and histograms zero-initialised once and left at zero by every call).  The layout is FIXED for
+// ES_MAX_SEG segments -- [tickets MAX | state MAX x 2 (prefix, remaining) | hist MAX x 256 | eq counts MAX x TKP | eq bases
+// MAX x TKP] -- so that calls with different segment counts can share one workspace (a layout that depended on nseg put the
+// tickets of a 12-segment call onto the leftover state of a 1-segment call: found as a memory fault in round 4).
+#define TKP 32
+#define TK_STATE ES_MAX_SEG
+#define TK_HIST (3 * ES_MAX_SEG)
+#define TK_CNT (TK_HIST + 256 * ES_MAX_SEG)
+#define TK_BASE (TK_CNT + TKP * ES_MAX_SEG)
+#define TK_INTS (TK_BASE + TKP * ES_MAX_SEG)
+__global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ v, Segs segs, int kkeep, int shift, uint32_t pmask,
+                                                   unsigned int* __restrict__ wsp) {
+  const int seg = blockIdx.y, r0 = segs.off[seg], r1 = segs.off[seg + 1], n = r1 - r0;
+  if (kkeep >= n) return;                               // (segment-uniform: every workgroup of the segment leaves)
+  unsigned int* tickets = wsp;
+  unsigned int* state = wsp + TK_STATE + 2 * seg;
+  unsigned int* hist = wsp + TK_HIST + 256 * seg;
+  __shared__ unsigned int lh[256];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t prefix = shift == 24 ? 0u : state[0];
+  const int per = (n + TKP - 1) / TKP, b0 = r0 + blockIdx.x * per, b1 = min(r1, b0 + per);
+  const int lane = threadIdx.x & 63;
+  for (int base = b0; base < b1; base += 256) {         // wave-aggregated histogram (see k_topk_mask)
+    const int i = base + threadIdx.x;
+    const uint32_t u = (i < b1) ? f2ord(v[i]) : 0u;
+    const bool live = (i < b1) && ((u & pmask) == prefix);
+    const int d = (int)((u >> shift) & 255);
+    unsigned long long m = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      unsigned long long bal = __ballot((d >> b) & 1);
+      m &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    if (live && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&lh[d], (unsigned int)__popcll(m));
+  }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+  if (!es_last_block_light(tickets + seg, gridDim.x)) return;      // (everything the workgroups exchange goes through atomics)
+  // the segment's histogram is complete: walk the buckets from the largest digit (one thread; 256 coherent reads)
+  if (threadIdx.x == 0) {
+    unsigned int rem = shift == 24 ? (unsigned int)kkeep : state[1], b = 255;
+    for (;; --b) {
+      unsigned int h = es_coh_load_u(&hist[b]);
+      if (h >= rem) break;
+      rem -= h;
+      if (b == 0) break;
+    }
+    state[0] = prefix | (b << shift);
+    state[1] = rem;                                     // how many to take from the bucket equal to the threshold
+  }
+  __syncthreads();
+  es_coh_store_u(&hist[threadIdx.x], 0u);               // ready for the next pass / the next call
+}
+__global__ __launch_bounds__(256) void k_topk_eqcount(const float* __restrict__ v, Segs segs, int kkeep, unsigned int* __restrict__ wsp) {
+  const int seg = blockIdx.y, r0 = segs.off[seg], r1 = segs.off[seg + 1], n = r1 - r0;
+  if (kkeep >= n) return;
+  unsigned int* tickets = wsp;
+  const uint32_t thr = wsp[TK_STATE + 2 * seg];
+  unsigned int* cnt = wsp + TK_CNT + TKP * seg;
+  unsigned int* basep = wsp + TK_BASE + TKP * seg;
+  const int per = (n + TKP - 1) / TKP, b0 = r0 + blockIdx.x * per, b1 = min(r1, b0 + per);
+  unsigned int c = 0;
+  for (int i = b0 + threadIdx.x; i < b1; i += 256) c += (f2ord(v[i]) == thr) ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  __shared__ unsigned int wc[4];
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) es_coh_store_u(&cnt[blockIdx.x], wc[0] + wc[1] + wc[2] + wc[3]);
+  if (!es_last_block_light(tickets + seg, gridDim.x)) return;
+  if (threadIdx.x == 0) {
+    unsigned int run = 0;
+    for (int b = 0; b < TKP; ++b) {
+      basep[b] = run;
+      run += es_coh_load_u(&cnt[b]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_topk_write(const float* __restrict__ v, Segs segs, int kkeep, const unsigned int* __restrict__ wsp,
+                                                    int* __restrict__ mask) {
+  const int seg = blockIdx.y, r0 = segs.off[seg], r1 = segs.off[seg + 1], n = r1 - r0;
+  const int per = (n + TKP - 1) / TKP, b0 = r0 + blockIdx.x * per, b1 = min(r1, b0 + per);
+  if (kkeep >= n) {
+    for (int i = b0 + threadIdx.x; i < b1; i += 256) mask[i] = 1;
+    return;
+  }
+  const uint32_t thr = wsp[TK_STATE + 2 * seg];
+  const unsigned int take_eq = wsp[TK_STATE + 2 * seg + 1];
+  __shared__ unsigned int s_carry;
+  __shared__ int wsum[4];
+  if (threadIdx.x == 0) s_carry = wsp[TK_BASE + TKP * seg + blockIdx.x];
+  __syncthreads();
+  for (int base = b0; base < b1; base += 256) {         // ordered pass: rank the ties by row
+    const int i = base + threadIdx.x;
+    const uint32_t u = (i < b1) ? f2ord(v[i]) : 0;
+    const int eq = (i < b1) && (u == thr);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = eq;
+    for (int o = 1; o < 64; o <<= 1) {
+      int tt = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += tt;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int bs = (int)s_carry, tot = 0;
+    for (int q = 0; q < 4; ++q) {
+      if (q < w) bs += wsum[q];
+      tot += wsum[q];
+    }
+    if (i < b1) mask[i] = (u > thr) || (eq && (unsigned)(bs + inc - 1) < take_eq);
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += tot;
+    __syncthreads();
+  }
+}
+extern "C" size_t es_topk_mask_workspace_ints(int nseg) { (void)nseg; return (size_t)TK_INTS; }     // (fixed layout, see above)
+extern "C" int es_topk_mask_ws(const float* values, const int* seg_off, int nseg, int k, int* mask, int* workspace,
+                               size_t workspace_ints, void* stream) {
+  if (nseg <= 0 || nseg > ES_MAX_SEG) return nseg > ES_MAX_SEG ? -3 : 0;
+  if (!workspace || workspace_ints < es_topk_mask_workspace_ints(nseg)) return -5;
+  Segs s = make_segs(seg_off, nseg);
+  hipStream_t st = (hipStream_t)stream;
+  bool any = false;
+  for (int i = 0; i < nseg; ++i) any = any || (seg_off[i + 1] - seg_off[i] > k);
+  unsigned int* w = (unsigned int*)workspace;
+  if (any) {
+    uint32_t pmask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      hipLaunchKernelGGL(k_topk_hist, dim3(TKP, nseg), dim3(256), 0, st, values, s, k, shift, pmask, w);
+      pmask |= (255u << shift);
+    }
+    hipLaunchKernelGGL(k_topk_eqcount, dim3(TKP, nseg), dim3(256), 0, st, values, s, k, w);
+  }
+  hipLaunchKernelGGL(k_topk_write, dim3(TKP, nseg), dim3(256), 0, st, values, s, k, w, mask);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients), deterministic, one launch
+// dst[c] (+)= sum_rows g[r, c].  Rounds 1-3 ran every bias gradient as a 1 x C weight-gradient GEMM against a column of ones (an
+// f32 MFMA launch + its slice reduction: 105 launch pairs moving 0.8 GB for 0.4 GFLOP in one grounding step).  Here a workgroup
+// sums a chunk of rows (256, or n / 64 for long matrices: at most 64 chunks; threads over columns x 4 row stripes, fixed order), stores its partial row, and the last workgroup
+// to arrive (es_last_block_light: the partial rows travel through coherent stores / loads, no cache maintenance) adds the partials
+// in chunk order: no float atomics, no second launch.
+#define CS_ROWS 256
+static int colsum_rows(int n) { int r = es_cdiv(n > 0 ? n : 1, 64); r = (r + 3) / 4 * 4; return r < CS_ROWS ? CS_ROWS : r; }   // <= 64 chunks
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int ld, int n, int C, float* __restrict__ dst, int accumulate,
+                                                float* __restrict__ ws, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+  float* part = ws + ES_TICKET_FLOATS + (size_t)blockIdx.x * C;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + tx;
+    float s = 0.f;
+    if (c < C)
+      for (int r = r0 + ty; r < r1; r += 4) s += g[(size_t)r * ld + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) es_coh_store(part + c, (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+    __syncthreads();
+  }
+  if (!es_last_block_light((unsigned int*)ws, gridDim.x)) return;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = es_coh_sum(ws + ES_TICKET_FLOATS + c, (int)gridDim.x, (size_t)C);
+    dst[c] = accumulate ? dst[c] + t : t;
+  }
+}
+extern "C" size_t es_colsum_workspace_floats(int n, int C) { return (size_t)ES_TICKET_FLOATS + (size_t)es_cdiv(n > 0 ? n : 1, colsum_rows(n)) * C; }
+extern "C" int es_colsum(const float* g, int ld, int n, int C, float* dst, int accumulate, float* workspace, size_t workspace_floats,
+                         void* stream) {
+  if (C <= 0) return 0;
+  if (n <= 0) { if (!accumulate) ES_TRY(hipMemsetAsync(dst, 0, (size_t)C * 4, (hipStream_t)stream)); return 0; }
+  if (!workspace || workspace_floats < es_colsum_workspace_floats(n, C)) return -5;
+  const int rpb = colsum_rows(n);
+  hipLaunchKernelGGL(k_colsum, dim3(es_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, g, ld, n, C, dst, accumulate, workspace, rpb);
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
 // row-wise max over channels (prune score = max class logit, fcaf3d_head.py:1131-1134)
 __global__ void k_row_max(const float* __restrict__ x, int ldx, int n, int C, float* __restrict__ out) {
   int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;

@@ -213,9 +213,16 @@ __global__ void k_apply_sorted(const int64_t* __restrict__ keys, const int* __re
   out_keys[i] = keys[p];
   if (src) out_src[i] = src[p];
 }
-// out_keys / out_src = keys / src permuted into Z-curve order (batch major).  scratch: es_sort_scratch_bytes(n).
-extern "C" int es_morton_sort(const int64_t* keys, const int* src, int n, void* scratch, size_t scratch_bytes,
-                              int64_t* out_keys, int* out_src, void* stream) {
+__global__ void k_plain_keys(const int64_t* __restrict__ keys, int n, uint64_t* __restrict__ mk, int* __restrict__ idx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  mk[i] = (uint64_t)keys[i];
+  idx[i] = i;
+}
+// out_keys / out_src = keys / src permuted into Z-curve order (batch major) -- or, morton = false (es_sort_u64), into ascending
+// order of the keys themselves (non-negative, < 2^62; stable).  scratch: es_sort_scratch_bytes(n).
+static int radix_sort(const int64_t* keys, const int* src, int n, void* scratch, size_t scratch_bytes, int64_t* out_keys, int* out_src,
+                      void* stream, bool morton) {
   hipStream_t st = (hipStream_t)stream;
   if (n <= 0) return 0;
   if (es_sort_scratch_bytes(n) > scratch_bytes) return -5;
@@ -230,7 +237,8 @@ extern "C" int es_morton_sort(const int64_t* keys, const int* src, int n, void* 
   int* vb1 = (int*)p;
   int g = es_cdiv(n, 256);
   ES_TRY(hipMemsetAsync(hist, 0, RS_PASSES * 256 * 4, st));
-  hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, st, keys, n, kb0, vb0);
+  if (morton) hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, st, keys, n, kb0, vb0);
+  else hipLaunchKernelGGL(k_plain_keys, dim3(g), dim3(256), 0, st, keys, n, kb0, vb0);
   hipLaunchKernelGGL(k_rs_hist_all, dim3(g > 1024 ? 1024 : g), dim3(256), 0, st, kb0, n, hist);
   hipLaunchKernelGGL(k_rs_plan, dim3(1), dim3(256), 0, st, hist, n, plan);
   for (int pass = 0; pass < RS_PASSES; ++pass) {
@@ -241,4 +249,14 @@ extern "C" int es_morton_sort(const int64_t* keys, const int* src, int n, void* 
   hipLaunchKernelGGL(k_apply_sorted, dim3(g), dim3(256), 0, st, keys, src, vb0, vb1, plan, n, out_keys, out_src);
   ES_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int es_morton_sort(const int64_t* keys, const int* src, int n, void* scratch, size_t scratch_bytes,
+                              int64_t* out_keys, int* out_src, void* stream) {
+  return radix_sort(keys, src, n, scratch, scratch_bytes, out_keys, out_src, stream, true);
+}
+// plain ascending stable sort of non-negative 62-bit keys with an int payload (N4: the random-key order of the device-side
+// PointSample draws, data.hip)
+extern "C" int es_sort_u64(const int64_t* keys, const int* src, int n, void* scratch, size_t scratch_bytes, int64_t* out_keys,
+                           int* out_src, void* stream) {
+  return radix_sort(keys, src, n, scratch, scratch_bytes, out_keys, out_src, stream, false);
 }

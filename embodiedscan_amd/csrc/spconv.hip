@@ -21,9 +21,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static int ES_OPT_PINGPONG = 1;
 static int ES_OPT_WGRAD_HUGE = 1;      // 256 x 256 weight-gradient tile for wide layers (both operands bf16 shadows)
 static int ES_OPT_ROWGEMM = 1;         // streaming row GEMM for K = 1 on the identity map
-static int ES_OPT_WG_BIG_TARGET = 8192;    // workgroups a 128 x 128-tile weight-gradient launch aims for (row slices)
+static int ES_OPT_WG_BIG_TARGET = 2048;    // workgroups a 128 x 128-tile weight-gradient launch aims for (row slices); round 4: 8192 -> 2048
+                                           // (profiles/r4m_sweep.txt: a quarter of the slices = a quarter of the partial-tile traffic, step -0.1 .. -0.35 ms)
 static int ES_OPT_WG_BIG_ROWS = 512;       // ... and the fewest rows a slice may have
-static int ES_OPT_WG_SMALL_TARGET = 4096;  // the same for the 64 x 64 tile
+static int ES_OPT_WG_SMALL_TARGET = 1024;  // the same for the 64 x 64 tile (round 4: 4096 -> 1024; 512 is slower: 26.9 ms)
 static int ES_OPT_WG_CAP_MB = 256;         // workspace of partial tiles per launch (weights <= 8 M floats)
 static int ES_OPT_FWD_SPLIT_WGS = 384;     // forward / dgrad launches with fewer workgroups split their tap list (sweep, session F:
                                            // 192 -> 384 neutral on mv-3ddet, -0.8 ms on the occupancy step; 96: +3.5 / +4.7 ms)

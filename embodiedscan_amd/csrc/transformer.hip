@@ -399,7 +399,7 @@ extern "C" int es_layernorm_fwd(const float* x, const float* res, int n, int C, 
 }
 // dz = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * w;  dw += sum_rows dy * xhat, db += sum_rows dy
 // Parameter gradients (round 4, deterministic): every workgroup stores the partial sums of its slice of rows in the workspace,
-// the last workgroup to arrive (es_last_block) adds them in workgroup order into dw / db -- one writer, fixed order, no float
+// the last workgroup to arrive (es_last_block_light, common.h) adds them in workgroup order into dw / db -- one writer, fixed order, no float
 // atomics (rounds 2-3 used unsafeAtomicAdd here: the grounder's gradients were reproducible to ~1e-6 only).
 #define LN_ROWS_PER_BLOCK 32
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ z, int n, int C,
@@ -454,17 +454,14 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
   }
   __syncthreads();
   float* part = ws + ES_TICKET_FLOATS;                              // [block][2][C]
-  for (int c = threadIdx.x; c < C; c += 256) {
-    part[((size_t)blockIdx.x * 2) * C + c] = sw[0][c] + sw[1][c] + sw[2][c] + sw[3][c];
-    part[((size_t)blockIdx.x * 2 + 1) * C + c] = sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c];
+  for (int c = threadIdx.x; c < C; c += 256) {                       // (coherent stores / loads: see es_last_block_light)
+    es_coh_store(part + ((size_t)blockIdx.x * 2) * C + c, sw[0][c] + sw[1][c] + sw[2][c] + sw[3][c]);
+    es_coh_store(part + ((size_t)blockIdx.x * 2 + 1) * C + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
   }
-  if (!es_last_block((unsigned int*)ws, gridDim.x)) return;
+  if (!es_last_block_light((unsigned int*)ws, gridDim.x)) return;
   for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f, bsum = 0.f;
-    for (unsigned int blk = 0; blk < gridDim.x; ++blk) {
-      a += part[((size_t)blk * 2) * C + c];
-      bsum += part[((size_t)blk * 2 + 1) * C + c];
-    }
+    const float a = es_coh_sum(part + c, (int)gridDim.x, (size_t)2 * C);
+    const float bsum = es_coh_sum(part + C + c, (int)gridDim.x, (size_t)2 * C);
     if (dw) dw[c] += a;
     if (db) db[c] += bsum;
   }
@@ -618,15 +615,12 @@ __global__ __launch_bounds__(256) void k_contrastive_bwd(const float* __restrict
         if (c1 < C) o[c1] += a1;
       }
     }
-    if (threadIdx.x == 0) ws[ES_TICKET_FLOATS + (size_t)b * T + t] = bs;
+    if (threadIdx.x == 0) es_coh_store(ws + ES_TICKET_FLOATS + (size_t)b * T + t, bs);
   }
   if (!reduce) return;
-  if (!es_last_block((unsigned int*)ws, gridDim.x * gridDim.y)) return;
+  if (!es_last_block_light((unsigned int*)ws, gridDim.x * gridDim.y)) return;
   if (dbias && threadIdx.x == 0) {
-    float tot = 0.f;
-    const int nb = gridDim.y * T;
-    for (int e = 0; e < nb; ++e) tot += ws[ES_TICKET_FLOATS + e];
-    dbias[0] += tot;
+    dbias[0] += es_coh_sum(ws + ES_TICKET_FLOATS, (int)(gridDim.y * T), 1);
   }
 }
 extern "C" size_t es_contrastive_bwd_workspace_floats(int B, int T) { return (size_t)ES_TICKET_FLOATS + (size_t)(B > 0 ? B : 1) * T; }

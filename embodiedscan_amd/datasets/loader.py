@@ -51,7 +51,8 @@ class ScanLoader:
     not depend on thread scheduling."""
 
     def __init__(self, dataset, batch_size=4, rank=0, world=1, shuffle=True, seed=0, times=1, num_threads=8, prefetch=16,
-                 pin=True, drop_last=True, workers='thread', slot_bytes=None, worker_timeout=120.0, exact_draws=None):
+                 pin=True, drop_last=True, workers='thread', slot_bytes=None, worker_timeout=120.0, exact_draws=None,
+                 device_draws=None):
         """slot_bytes: size of one shared pinned slot in process mode (None: estimated from the frame headers of every
         source of the dataset -- EmbodiedScan mixes ScanNet / 3RScan / Matterport3D resolutions); a scan that still does
         not fit is decoded by the parent instead of aborting the epoch.  worker_timeout: seconds without any result
@@ -60,6 +61,8 @@ class ScanLoader:
         assert workers in ('thread', 'process')
         if exact_draws is not None:          # None: whatever the dataset's pipeline says (default: the reference's exact stream);
             dataset.pipeline.exact_draws = bool(exact_draws)   # False: O(k) PointSample draws (loading.draw_without_order)
+        if device_draws is not None:         # True: the host only decodes, both PointSample draws run on the GPU (pipeline.device_point_sample)
+            dataset.pipeline.device_draws = bool(device_draws)
         self.dataset, self.batch_size = dataset, batch_size
         self.rank, self.world, self.shuffle, self.seed, self.times = rank, world, shuffle, seed, times
         self.num_threads, self.prefetch, self.pin, self.drop_last = max(1, num_threads), max(1, prefetch), pin, drop_last
@@ -119,6 +122,8 @@ class ScanLoader:
         colour frame and one depth map give that source's frame sizes -- the slots are sized for the largest."""
         probe = pipeline._host_tensors(self.dataset.load_scan(first_idx, self._rng(0)))
         _, need = self._layout(probe)
+        if 'sel_pix' not in probe:            # device-side draws: a scan that falls back to host draws also carries its index arrays
+            need += 8 * int(self.dataset.pipeline.n_points) + 512
         V = int(probe['depth'].shape[0])
         fixed = need - int(probe['depth'].numel()) * 4 - int(probe['img_raw'].numel() if 'img_raw' in probe else probe['img'].numel())
         best = need

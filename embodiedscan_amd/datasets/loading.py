@@ -125,10 +125,16 @@ class ScanPipeline:
 
     def __init__(self, n_images=20, ordered=False, n_points=100000, view_points=None, img_scale=(480, 480),
                  flip=False, flip_h=0.5, flip_v=0.5, rst=False, rot_range=(-0.087266, 0.087266), scale_range=(.9, 1.1),
-                 trans_std=(.1, .1, .1), with_occupancy=False, view_masks=False, point_range=None, exact_draws=True):
+                 trans_std=(.1, .1, .1), with_occupancy=False, view_masks=False, point_range=None, exact_draws=True,
+                 device_draws=False):
         # exact_draws: PointSample replays the reference's RandomState stream pick for pick (parity tests, golden vectors);
         # False: same distribution from O(k) draws (draw_without_order) -- 1.7 x the scans per core
         self.exact_draws = bool(exact_draws)
+        # device_draws (round 4, N4): the host only DECODES; both PointSample draws are made on the GPU from counter-based keys
+        # (pipeline.device_point_sample: the same law, neither numpy stream).  Used when no `replace=True` case of the reference
+        # arises (every frame holds >= view_points valid pixels, V * view_points >= n_points) and no range filter sits between
+        # the two draws; otherwise the scan falls back to the host's O(k) draws.  Overrides exact_draws.
+        self.device_draws = bool(device_draws)
         self.n_images, self.ordered = n_images, ordered
         self.n_points, self.view_points = n_points, view_points if view_points is not None else n_points // 10
         self.img_scale = tuple(img_scale)                      # (w, h) as in mmcv Resize
@@ -197,13 +203,27 @@ class ScanPipeline:
             imgs.append(decode_image(info['img_path'][i]))
             d = decode_depth(info['depth_img_path'][i], info['depth_shift'])
             depths.append(d)
-            pix = sample_pixels(d, self.view_points, rng, self.exact_draws)
-            sel_pix.append(pix)
-            sel_view.append(np.full(len(pix), j, np.int32))
+            if not self.device_draws:
+                pix = sample_pixels(d, self.view_points, rng, self.exact_draws)
+                sel_pix.append(pix)
+                sel_view.append(np.full(len(pix), j, np.int32))
             intr.append(np.asarray(intr_all[i] if isinstance(intr_all, list) else intr_all, np.float32))
             depth_intr.append(np.asarray(dci[i] if isinstance(dci, list) else dci, np.float32))
             extr.append(info['depth2img']['extrinsic'][i])
-        sel_view, sel_pix = np.concatenate(sel_view), np.concatenate(sel_pix)
+        on_device = False
+        if self.device_draws:
+            # the device draws cover the `replace=False` law only: enough valid pixels in every frame, enough aggregated points,
+            # no PointsRangeFilter between the draws -- else the host draws (O(k)) take over for this scan
+            on_device = (self.point_range is None and len(depths) * self.view_points >= self.n_points and
+                         len(depths) <= 256 and all(int(np.count_nonzero(d)) >= self.view_points for d in depths))
+            if not on_device:
+                for j, d in enumerate(depths):
+                    pix = sample_pixels(d, self.view_points, rng, False)
+                    sel_pix.append(pix)
+                    sel_view.append(np.full(len(pix), j, np.int32))
+        if not on_device:
+            sel_view, sel_pix = np.concatenate(sel_view), np.concatenate(sel_pix)
+        draw_seed = int(rng.randint(0, 2 ** 31 - 1)) if on_device else None
         # colour frames and depth maps come at their own native resolutions (e.g. ScanNet 1296x968 jpg, 640x480 png: the
         # reference keeps a separate depth_cam2img for that reason); each kind must be uniform inside a scan because the
         # frames of a kind are stacked, but the two kinds are independent -- depth_to_points uses the depth size, the frame
@@ -215,13 +235,13 @@ class ScanPipeline:
         # PointsRangeFilter sits BETWEEN the aggregation and PointSample(n_points) in the occupancy pipeline
         # (configs/occupancy/mv-occ_...py:121-123, transforms/points.py:246-263): drop the aggregated points outside the
         # range (unless fewer than 100 survive), THEN draw -- so the draw's population is the filtered cloud
-        if self.point_range is not None and len(sel_pix):
+        if self.point_range is not None and not on_device and len(sel_pix):
             keep = points_in_range(depths, depth_intr, extr, sel_view, sel_pix, self.point_range)
             if int(keep.sum()) >= 100:
                 sel_view, sel_pix = sel_view[keep], sel_pix[keep]
         # PointSample(n_points) over the aggregated cloud (points.py:189-206)
-        if len(sel_pix):
-            pick = draw_without_order(rng, len(sel_pix), self.n_points, self.exact_draws)
+        if not on_device and len(sel_pix):
+            pick = draw_without_order(rng, len(sel_pix), self.n_points, self.exact_draws and not self.device_draws)
             sel_view, sel_pix = sel_view[pick], sel_pix[pick]
         aug, aug_meta = draw_augmentation(self.aug, rng)
         H, W = imgs[0].shape[:2]
@@ -241,8 +261,11 @@ class ScanPipeline:
                 meta[k] = info[k]
         meta.update(aug_meta)
         scan = dict(depth=np.stack(depths), img_raw=np.stack(imgs), extrinsic=np.stack(extr).astype(np.float32),
-                    intrinsic=np.stack(depth_intr), sel_view=sel_view.astype(np.int32), sel_pix=sel_pix.astype(np.int32),
-                    gt_boxes=augment_gt_boxes(boxes, aug).numpy(), gt_labels=labels, meta=meta, aug=aug)
+                    intrinsic=np.stack(depth_intr), gt_boxes=augment_gt_boxes(boxes, aug).numpy(), gt_labels=labels, meta=meta, aug=aug)
+        if on_device:
+            scan['draw'] = (draw_seed, int(self.view_points), int(self.n_points))
+        else:
+            scan.update(sel_view=sel_view.astype(np.int32), sel_pix=sel_pix.astype(np.int32))
         if self.with_occupancy and 'gt_occupancy' in ann:
             scan['gt_occupancy'] = ann['gt_occupancy']
             vm = ann.get('visible_occupancy_masks')

@@ -373,11 +373,12 @@ def join_wgrad_streams(final=True):
 _TICKET_WS = {}         # stream handle -> zero-initialised f32 workspace of the last-block reductions queued on that stream
 
 
-def ticket_ws(floats, like):
+def ticket_ws(floats, like, tag=''):
     """(tensor, floats) workspace for a kernel that reduces per-workgroup partials in its last workgroup (csrc/common.h
     es_last_block): its head holds a ticket counter that must be 0 before every launch and is left 0 by every launch, so ONE
-    zero-initialised buffer per stream serves all such launches of the stream (they are ordered); grown on demand."""
-    h = _stream()
+    zero-initialised buffer per stream serves all such launches of the stream (they are ordered); grown on demand.  `tag`: a
+    kernel family that leaves more than the ticket behind (es_topk_mask_ws keeps its selection state there) gets a buffer of its own."""
+    h = (_stream(), tag)
     ws = _TICKET_WS.get(h)
     if ws is None or ws.numel() < floats or ws.device != like.device:
         if ws is not None:
@@ -435,7 +436,7 @@ def _split_ws(n_out, K, cin, cout, like):
     nf = int(hip.raw('es_spconv_split_workspace_floats')(n_out, K, cin, cout))
     if nf == 0:
         return None, 0
-    return ticket_ws(nf, like)
+    return ticket_ws(nf, like, tag='split')
 
 
 def _fwd_bf16(X, x_is_bf16, ldx, Wp, nbr, n_out, n_in, K, cin, cout, bias_p, Y, ldy, acc, like):
@@ -504,19 +505,6 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
     return y
 
 
-_ONES = {}
-
-
-def _ones(n, device):
-    """(>= n, 1) column of ones (cached, grows): the left operand of the bias-gradient GEMM"""
-    t = _ONES.get(device)
-    if t is None or t.shape[0] < n:
-        if t is not None:
-            _KEEP.append(t)
-        t = _ONES[device] = torch.ones((max(n, 1 << 16), 1), dtype=torch.float32, device=device)
-    return t
-
-
 def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, gate=None):
     """wgrad (+ bias grad) and dgrad of a convolution whose output gradient is the row matrix `gy`.
     gate: folded-BN scale of x's producer -- the dgrad launch then also applies that layer's ReLU mask and BN scale
@@ -545,9 +533,20 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         _wgrad('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', sw, P(w.g), P(x.d), _ld(x.d), P(gy),
                _ld(gy), P(nbr), n_out, n_in, K, cin, cout)
     if bias is not None and bias.g is not None:
-        ones = _ones(n_out, x.d.device)
-        _wgrad('es_spconv_wgrad', sw, bias.g.data_ptr() + 4 * bias_from, P(ones), 1, gy.data_ptr() + 4 * bias_from, _ld(gy), 0,
-               n_out, n_out, 1, 1, cout - bias_from)
+        # column sums of gy (round 4: one deterministic launch on the weight-gradient stream; was an f32 GEMM against a column of ones)
+        nb, dst = cout - bias_from, bias.g.data_ptr() + 4 * bias_from
+        key = (sw, 'colsum')
+        ws = _TICKET_WS.get(key)
+        need = int(hip.raw('es_colsum_workspace_floats')(n_out, nb))
+        if ws is None or ws.numel() < need:
+            if ws is not None:
+                _KEEP.append(ws)
+            ws = _TICKET_WS[key] = torch.zeros(max(need, 1 << 16), dtype=torch.float32, device=gy.device)
+            if sw != _stream():                  # the zero fill was queued on the compute stream, AFTER the weight-gradient stream forked:
+                ev = torch.cuda.Event()          # order the fill before the first launch that reads the ticket
+                ev.record(hip.stream_obj())
+                hip._stream_of(sw).wait_event(ev)
+        call('es_colsum', gy.data_ptr() + 4 * bias_from, _ld(gy), n_out, nb, dst, _first_write(dst), P(ws), ws.numel(), sw)
     if need_dx and x.rg and gate is not None:
         assert x.g is None and bf, 'gated dgrad: x must have exactly one consumer'
         x.g, x.gated = torch.empty(x.d.shape, dtype=torch.float32, device=x.d.device), True

@@ -169,7 +169,8 @@ class FCAF3DHeadRotMat:
         s = torch.empty(x.cs.n, dtype=torch.float32, device=x.cs.device)
         call('es_interp_scores', P(score), P(idx), P(w), x.cs.n, P(s), _stream())
         mask = torch.empty(x.cs.n, dtype=torch.int32, device=x.cs.device)
-        call('es_topk_mask', P(s), iarr(off), x.cs.n_batch, int(thr), P(mask), _stream())
+        ws, nws = E.ticket_ws(int(hip.raw('es_topk_mask_workspace_ints')(x.cs.n_batch)), s, tag='topk')
+        call('es_topk_mask_ws', P(s), iarr(off), x.cs.n_batch, int(thr), P(mask), P(ws), nws, _stream())
         kept = [0]                                  # top-k keeps min(n_b, thr) rows of sample b: no row-count read-back
         for b in range(x.cs.n_batch):
             kept.append(kept[-1] + min(off[b + 1] - off[b], thr))

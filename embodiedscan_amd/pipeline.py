@@ -70,8 +70,9 @@ def _host_tensors(scan):
     """the arrays of one raw scan that go to the device.  A scan from the dataset reader carries `img_raw` (decoded frames
     at the file resolution, resized on the device); a synthetic scan carries `img` at the network resolution."""
     mats, aug = scan_matrices(scan)
-    host = dict(depth=torch.from_numpy(scan['depth']), sel_view=torch.from_numpy(scan['sel_view']),
-                sel_pix=torch.from_numpy(scan['sel_pix']), mats=mats, aug=aug)
+    host = dict(depth=torch.from_numpy(scan['depth']), mats=mats, aug=aug)
+    if 'sel_pix' in scan:                    # (absent: the PointSample draws are made on the device, see device_point_sample)
+        host.update(sel_view=torch.from_numpy(scan['sel_view']), sel_pix=torch.from_numpy(scan['sel_pix']))
     if 'img_raw' in scan:
         host['img_raw'] = torch.from_numpy(scan['img_raw'])
     else:
@@ -82,7 +83,7 @@ def _host_tensors(scan):
 def _finish(d, scan):
     d.update(meta=scan['meta'], gt_boxes=torch.as_tensor(scan['gt_boxes']), gt_labels=torch.as_tensor(scan['gt_labels']))
     for k in ('gt_occupancy', 'gt_occupancy_masks', 'visible_occupancy_masks', 'visible_instance_masks', 'point_range',
-              'text', 'tokens_positive'):
+              'text', 'tokens_positive', 'draw'):
         if k in scan:
             d[k] = scan[k]
     return d
@@ -93,7 +94,7 @@ def upload_scan(scan, device):
     d = {k: v.to(device) for k, v in _host_tensors(scan).items()}
     if 'img_raw' in d:
         d['img'] = resize_frames(d.pop('img_raw'), scan['meta']['img_shape'])
-    return _finish(d, scan)
+    return _ensure_draws(_finish(d, scan))
 
 
 def pin_scan(scan, pin=True):
@@ -126,7 +127,74 @@ def upload_into(slot, pinned):
         resize_frames(slot['img_raw'], pinned['meta']['img_shape'], out=slot['img'])
     d = dict(slot)
     d.pop('img_raw', None)
-    return _finish(d, {k: pinned[k] for k in pinned if k not in slot})
+    return _ensure_draws(_finish(d, {k: pinned[k] for k in pinned if k not in slot}))
+
+
+# ------------------------------------------------------------------ N4: PointSample on the device
+_DRAW_WS = {}
+
+
+def device_point_sample(depth, seed, view_points, n_points):
+    """PointSample(num_points=view_points) per depth frame + PointSample(n_points) over the aggregated cloud
+    (datasets/transforms/points.py:155-213, configs/detection/mv-det3d_...py:141-143) ON THE DEVICE, from counter-based keys
+    (csrc/data.hip; the law of the reference's draws, not its numpy stream; oracle/draws.py restates it integer for integer).
+    depth (V, H, W) f32 on the device; every view must hold >= view_points non-zero pixels and V * view_points >= n_points
+    (the host checks both and falls back to host draws otherwise).  -> (sel_view, sel_pix) int32 (n_points,), random order."""
+    from . import hip
+    V, H, W = depth.shape
+    HW, M = H * W, V * view_points
+    dev = depth.device
+    st = torch.cuda.current_stream().cuda_stream
+    i32, i64 = torch.int32, torch.int64
+
+    def topk(values, seg, k, mask):
+        ns = len(seg) - 1
+        key = (st, 'topk')
+        ws = _DRAW_WS.get(key)
+        need = int(hip.raw('es_topk_mask_workspace_ints')(32))
+        if ws is None or ws.device != dev:
+            ws = _DRAW_WS[key] = torch.zeros(need, dtype=i32, device=dev)
+        call('es_topk_mask_ws', values, hip.iarr(seg), ns, k, mask, P(ws), ws.numel(), st)
+
+    def select_sorted(values, keys, n, seg_fn, k_total):
+        """keys of the selected elements (mask from per-segment top-k) in ascending key order -> (k_total,) int64"""
+        mask = torch.empty(n, dtype=i32, device=dev)
+        seg_fn(mask)
+        scratch = torch.empty(n + n // 2048 + 8, dtype=i32, device=dev)
+        sel = torch.empty(k_total, dtype=i64, device=dev)
+        src = torch.empty(k_total, dtype=i32, device=dev)
+        call('es_compact_mask', P(keys), n, P(mask), P(scratch), P(sel), P(src), 0, st)
+        nb = int(hip.raw('es_sort_scratch_bytes')(k_total))
+        sc = torch.empty(nb, dtype=torch.uint8, device=dev)
+        out = torch.empty(k_total, dtype=i64, device=dev)
+        call('es_sort_u64', P(sel), 0, k_total, P(sc), nb, P(out), 0, st)
+        return out
+
+    values = torch.empty(V * HW, dtype=torch.float32, device=dev)
+    keys = torch.empty(V * HW, dtype=i64, device=dev)
+    call('es_draw_keys', P(depth), V, HW, int(seed), P(values), P(keys), st)
+
+    def per_view(mask):
+        for v0 in range(0, V, 32):                         # es_topk_mask_ws: at most ES_MAX_SEG = 32 segments per call
+            nv = min(32, V - v0)
+            topk(values.data_ptr() + 4 * v0 * HW, [i * HW for i in range(nv + 1)], view_points, mask.data_ptr() + 4 * v0 * HW)
+    k1 = select_sorted(values, keys, V * HW, per_view, M)
+    view1, pix1 = torch.empty(M, dtype=i32, device=dev), torch.empty(M, dtype=i32, device=dev)
+    call('es_draw_unpack', P(k1), M, 0, 0, P(view1), P(pix1), st)
+    v2, kk2 = torch.empty(M, dtype=torch.float32, device=dev), torch.empty(M, dtype=i64, device=dev)
+    call('es_draw_keys_index', M, int(seed), 255, P(v2), P(kk2), st)
+    k2 = select_sorted(v2, kk2, M, lambda mask: topk(P(v2), [0, M], n_points, P(mask)), n_points)
+    sel_view, sel_pix = torch.empty(n_points, dtype=i32, device=dev), torch.empty(n_points, dtype=i32, device=dev)
+    call('es_draw_unpack', P(k2), n_points, P(view1), P(pix1), P(sel_view), P(sel_pix), st)
+    return sel_view, sel_pix
+
+
+def _ensure_draws(d):
+    """a scan handed over WITHOUT sel_view / sel_pix (ScanPipeline(device_draws=True)) gets them drawn here, on the stream of the upload"""
+    if 'sel_pix' not in d and d.get('draw') is not None:
+        seed, vp, npts = d['draw']
+        d['sel_view'], d['sel_pix'] = device_point_sample(d['depth'], seed, vp, npts)
+    return d
 
 
 def scan_h2d_bytes(pinned):
@@ -294,7 +362,7 @@ def upload_batch(slot, pinned):
         if 'img_raw' in d:
             d['img'] = resize_frames(d.pop('img_raw'), pinned.extras[i]['meta']['img_shape'])
         d.update(pinned.extras[i])
-        out.append(d)
+        out.append(_ensure_draws(d))
     st = dev.stacked('img')
     if st is not None and out:
         out[0]['_img_stack'] = st

@@ -37,6 +37,17 @@ int es_unique_first(const int64_t* keys, int n, int64_t* tkeys, int* tvals, int 
 size_t es_sort_scratch_bytes(int n);
 int es_morton_sort(const int64_t* keys, const int* src, int n, void* scratch, size_t scratch_bytes, int64_t* out_keys,
                    int* out_src, void* stream);
+/* plain ascending stable sort of non-negative keys < 2^62 with an int payload (same scratch as es_morton_sort) */
+int es_sort_u64(const int64_t* keys, const int* src, int n, void* scratch, size_t scratch_bytes, int64_t* out_keys, int* out_src,
+                void* stream);
+/* N4: PointSample._points_random_sampling on the device (datasets/transforms/points.py:155-213: np.random.choice(range(n), k,
+ * replace=False) per depth frame and over the aggregated cloud, multiview.py:139-169) with counter-based keys; see data.hip.
+ * es_draw_keys: values (V*HW floats: key encodings, -1 for zero-depth pixels) for es_topk_mask_ws with one segment per view, and
+ * 64-bit sort keys (view << 54 | (2^30 - 1 - key) << 24 | pixel); es_draw_keys_index: the same for elements 0..n-1 of a stream;
+ * es_draw_unpack: sorted keys -> (view, pixel) lists (in_view / in_pix non-NULL: the key's low 24 bits index those lists). */
+int es_draw_keys(const float* depth, int V, int HW, size_t seed, float* values, int64_t* keys, void* stream);
+int es_draw_keys_index(int n, size_t seed, int stream_id, float* values, int64_t* keys, void* stream);
+int es_draw_unpack(const int64_t* keys, int n, const int* in_view, const int* in_pix, int* out_view, int* out_pix, void* stream);
 int es_build_table(const int64_t* keys, int n, int64_t* tkeys, int* tvals, int cap, void* stream);
 /* strided output coordinates floor(c / ts) * ts.  mink_resnet.py:58-69,104-108 (stride-2 conv / pool) */
 int es_stride_keys(const int64_t* in_keys, int n, int out_ts, int64_t* out_keys, void* stream);
@@ -185,7 +196,19 @@ int es_row_move(float* dst, int ldd, const float* src, int lds, const int* idx, 
 int es_axpy2d(float* dst, int ldd, const float* src, int lds, int n, int C, float alpha, int op, void* stream);
 int es_interp_scores(const float* score, const int* idx, const float* w, int n, float* out, void* stream);
 /* per-sample top-k keep mask (ties: lower row first).  fcaf3d_head.py:1105-1112 */
+/* bias gradient of a Linear / convolution (the column sums torch autograd takes for `y = x W + b`): dst[c] (+)= sum_r g[r, c],
+ * deterministic (per-chunk partial rows in `workspace`, added in chunk order by the last workgroup; ticket convention of
+ * es_layernorm_bwd: one zero-initialised workspace per stream) */
+size_t es_colsum_workspace_floats(int n, int C);
+int es_colsum(const float* g, int ld, int n, int C, float* dst, int accumulate, float* workspace, size_t workspace_floats, void* stream);
 int es_topk_mask(const float* values, const int* seg_off_host, int nseg, int k, int* mask, void* stream);
+/* the same masks (bit-identical) with every segment spread over 32 workgroups: one launch per radix pass + tie count + mask
+ * write (6 launches of a few microseconds instead of one 0.5 ms single-workgroup launch on the step's dependent chain).
+ * workspace: es_topk_mask_workspace_ints(nseg) ints of its own (not shared with other kernels: the selection state stays in it);
+ * zero-initialise it once -- tickets and histograms are left at zero by every call. */
+size_t es_topk_mask_workspace_ints(int nseg);
+int es_topk_mask_ws(const float* values, const int* seg_off_host, int nseg, int k, int* mask, int* workspace, size_t workspace_ints,
+                    void* stream);
 int es_row_max(const float* x, int ldx, int n, int C, float* out, void* stream);
 /* frozen BatchNorm2d folded to scale/shift + residual + ReLU (mmdet.ResNet, norm_eval=True) */
 int es_bn_fold(const float* w, const float* b, const float* rm, const float* rv, int C, float eps, float* scale,

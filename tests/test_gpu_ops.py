@@ -407,6 +407,44 @@ def test_topk_mask(dev):
         np.testing.assert_array_equal(m[sl], exp)
 
 
+def test_topk_mask_many_workgroups_equals_single_workgroup(dev):
+    """es_topk_mask_ws (round 4: every segment spread over 32 workgroups, one launch per radix pass) against the stable-argsort
+    definition and against es_topk_mask: heavy ties across the threshold (quantised scores), a segment shorter than k (all
+    kept), an empty segment, sizes that are not multiples of the slice; called twice on the same workspace (state is reusable)"""
+    from embodiedscan_amd import hip
+    from embodiedscan_amd.hip import call, P, iarr
+    g = torch.Generator().manual_seed(5)
+    st = torch.cuda.current_stream().cuda_stream
+    seg = [0, 103217, 103217, 104000, 230001, 330001]
+    n = seg[-1]
+    for quant, k in ((0.0, 100000), (0.05, 100000), (0.5, 70000), (0.0, 1)):
+        v = torch.randn(n, generator=g)
+        if quant:
+            v = torch.round(v / quant) * quant + 0.0    # thousands of equal scores around any threshold (+ 0.0: no -0.0, which
+                                                        # the kernels order below +0.0 while argsort treats the two as equal)
+        vd = v.to(dev)
+        ws = torch.zeros(int(hip.raw('es_topk_mask_workspace_ints')(len(seg) - 1)), dtype=torch.int32, device=dev)
+        # a call with ANOTHER segment count first, on the same workspace (a layout that depended on the count once put the tickets
+        # of the second call onto the leftover state of the first: the round-4 memory fault)
+        m0 = torch.zeros(n, dtype=torch.int32, device=dev)
+        call('es_topk_mask_ws', P(vd), iarr([0, n]), 1, max(1, k // 2), P(m0), P(ws), ws.numel(), st)
+        m1 = torch.zeros(n, dtype=torch.int32, device=dev)
+        call('es_topk_mask', P(vd), iarr(seg), len(seg) - 1, k, P(m1), st)
+        for rep in range(2):
+            m2 = torch.full((n,), 7, dtype=torch.int32, device=dev)
+            call('es_topk_mask_ws', P(vd), iarr(seg), len(seg) - 1, k, P(m2), P(ws), ws.numel(), st)
+            torch.cuda.synchronize()
+            assert torch.equal(m1, m2), (quant, k, rep, int((m1 != m2).sum()))
+        m = m2.cpu().numpy().astype(bool)
+        for s_ in range(len(seg) - 1):
+            sl = slice(seg[s_], seg[s_ + 1])
+            kk = min(k, seg[s_ + 1] - seg[s_])
+            order = torch.argsort(v[sl], descending=True, stable=True)[:kk].numpy()
+            exp = np.zeros(seg[s_ + 1] - seg[s_], bool)
+            exp[order] = True
+            np.testing.assert_array_equal(m[sl], exp)
+
+
 def test_get_targets_golden_and_random(dev, golden_dir):
     import os
     from embodiedscan_amd.models.dense_heads import fcaf3d_head as H

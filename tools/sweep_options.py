@@ -63,7 +63,7 @@ def main():
         ms = (time.perf_counter() - t0) / args.steps * 1e3
         print(json.dumps(dict(variant=label, ms_per_step=round(ms, 3))), flush=True)
         return ms
-    defaults = {4: 8192, 5: 512, 6: 4096, 7: 256, 8: 384}
+    defaults = {4: 2048, 5: 512, 6: 1024, 7: 256, 8: 384}
     names = {4: 'wgrad big target', 5: 'wgrad big min rows', 6: 'wgrad small target', 7: 'wgrad ws cap MB', 8: 'fwd split wgs'}
     run('default (first)')
     run('default (again)')
