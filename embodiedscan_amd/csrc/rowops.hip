@@ -1064,10 +1064,10 @@ extern "C" int es_topk_mask_ws(const float* values, const int* seg_off, int nseg
 // ------------------------------------------------------------------ column sums (bias gradients), deterministic, one launch
 // dst[c] (+)= sum_rows g[r, c].  Rounds 1-3 ran every bias gradient as a 1 x C weight-gradient GEMM against a column of ones (an
 // f32 MFMA launch + its slice reduction: 105 launch pairs moving 0.8 GB for 0.4 GFLOP in one grounding step).  Here a workgroup
-// sums a chunk of rows (256, or n / 64 for long matrices: at most 64 chunks; threads over columns x 4 row stripes, fixed order), stores its partial row, and the last workgroup
+// sums a chunk of rows (64, or n / 64 for long matrices: at most 64 chunks; threads over columns x 4 row stripes, fixed order), stores its partial row, and the last workgroup
 // to arrive (es_last_block_light: the partial rows travel through coherent stores / loads, no cache maintenance) adds the partials
 // in chunk order: no float atomics, no second launch.
-#define CS_ROWS 256
+#define CS_ROWS 64
 static int colsum_rows(int n) { int r = es_cdiv(n > 0 ? n : 1, 64); r = (r + 3) / 4 * 4; return r < CS_ROWS ? CS_ROWS : r; }   // <= 64 chunks
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int ld, int n, int C, float* __restrict__ dst, int accumulate,
                                                 float* __restrict__ ws, int rows_per_block) {
@@ -1079,7 +1079,13 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int
     const int c = c0 + tx;
     float s = 0.f;
     if (c < C)
-      for (int r = r0 + ty; r < r1; r += 4) s += g[(size_t)r * ld + c];
+      for (int r = r0 + ty; r < r1; r += 32) {          // 8 rows of this stripe in flight (a load per iteration was 98 us per launch:
+        float v[8];                                     // 256 serialised L2 round trips in 12 workgroups); same order of additions
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (r + 4 * u) < r1 ? g[(size_t)(r + 4 * u) * ld + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < C) es_coh_store(part + c, (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));

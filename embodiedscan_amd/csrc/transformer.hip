@@ -600,14 +600,25 @@ __global__ __launch_bounds__(256) void k_contrastive_bwd(const float* __restrict
     float a0 = 0.f, a1 = 0.f, bs = 0.f;
     const int c0 = threadIdx.x, c1 = threadIdx.x + 256;
     if (t < tl) {
-      for (int i = 0; i < L; ++i) {
-        float d = dl[((size_t)b * L + i) * Tout + t];
-        if (d == 0.f) continue;                          // (uniform across the workgroup)
-        bs += d;
-        d *= inv;
-        const float* vr = v + ((size_t)b * L + i) * C;
-        if (c0 < C) a0 += d * vr[c0];
-        if (c1 < C) a1 += d * vr[c1];
+      for (int i0 = 0; i0 < L; i0 += 8) {                  // 8 rows in flight, added in ascending row order
+        float d[8], x0[8], x1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u;
+          const bool in = i < L;
+          d[u] = in ? dl[((size_t)b * L + i) * Tout + t] : 0.f;
+          const float* vr = v + ((size_t)b * L + (in ? i : 0)) * C;
+          x0[u] = (in && c0 < C) ? vr[c0] : 0.f;
+          x1[u] = (in && c1 < C) ? vr[c1] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (d[u] == 0.f) continue;                       // (uniform across the workgroup)
+          bs += d[u];
+          const float ds = d[u] * inv;
+          a0 += ds * x0[u];
+          a1 += ds * x1[u];
+        }
       }
       if (dtext) {
         float* o = dtext + ((size_t)b * T + t) * C;

@@ -23,6 +23,8 @@ def main():
     ap.add_argument('--seconds', type=float, default=8.0)
     ap.add_argument('--device-workers', type=int, default=64)
     ap.add_argument('--fast-draws', action='store_true', help='O(k) PointSample draws instead of the exact RandomState stream')
+    ap.add_argument('--device-draws', action='store_true', help='the host only decodes; both PointSample draws run on the GPU (round 4)')
+    ap.add_argument('--kinds', default='thread,process')
     args = ap.parse_args()
     import torch
     from embodiedscan_amd import pipeline, synth
@@ -44,14 +46,15 @@ def main():
         out = dict(dataset=dict(scans=len(ds), frames_per_scan=args.frames, files=n_files, MB=round(size / 1e6, 1),
                                 write_s=round(time.time() - t0, 1)),
                    pipeline=dict(n_images=ds.pipeline.n_images, n_points=ds.pipeline.n_points, img_scale=ds.pipeline.img_scale),
-                   host_cores=os.cpu_count(), decode=[])
-        for kind in ('thread', 'process'):
+                   host_cores=os.cpu_count(), draws='device' if args.device_draws else ('host O(k)' if args.fast_draws else 'host exact stream'),
+                   decode=[])
+        for kind in args.kinds.split(','):
             for th in [int(t) for t in args.threads.split(',')]:
                 if kind == 'thread' and th > 16:
                     continue                                  # GIL-bound: more threads do not help (see loader.py)
                 ld = ScanLoader(ds, batch_size=4, shuffle=True, seed=0, times=args.repeat, num_threads=th,
                                 prefetch=min(max(16, 2 * th), 64), pin=dev is not None, workers=kind,
-                                exact_draws=not args.fast_draws)
+                                exact_draws=not args.fast_draws, device_draws=args.device_draws)
                 it = iter(ld)
                 ld.done(next(it))                             # untimed: forks the workers, allocates and pins the slots
                 t = time.time()
@@ -71,7 +74,8 @@ def main():
             # loader -> copy stream (H2D + resize) -> A1-A3 on the compute stream, double-buffered like bench.py
             th = args.device_workers
             ld = ScanLoader(ds, batch_size=4, shuffle=True, seed=0, times=args.repeat * 2, num_threads=th,
-                            prefetch=min(2 * th, 64), pin=True, workers='process')
+                            prefetch=min(2 * th, 64), pin=True, workers='process', exact_draws=not args.fast_draws,
+                            device_draws=args.device_draws)
             it = iter(ld)
             ld.done(next(it))
             copy = torch.cuda.Stream()
