@@ -193,15 +193,17 @@ __global__ __launch_bounds__(256) void k_norm_apply4(const float* __restrict__ x
 // The three-launch pipeline above (row-chunk statistics -> finalize -> apply) is built for long matrices; on the deep levels of
 // the sparse networks (190 .. 12 000 rows x 256 .. 1024 channels: 29 of the 47 norm layers of an mv-3ddet step) each of its
 // launches runs for 4 - 10 us and the two launch boundaries on the step's dependent chain cost more than the kernels.  Here ONE
-// workgroup of 1024 threads owns 16 channels (4 float4 lanes x 256 row stripes) of ALL rows: per-channel statistics need no
+// workgroup of 512 threads owns 16 channels (4 float4 lanes x 128 row stripes) of ALL rows: per-channel statistics need no
 // other workgroup, so statistics, finalize and apply are one launch (backward: statistics + parameter gradients + apply).
 // Statistics: per-thread f32 sums about the first row (a shift that is itself a sample), combined over the 1024 threads in f64
-// in a fixed order (wave shuffles, then 16 wave partials) -- deterministic; var = Q/n - (S/n)^2 in f64 on shifted sums.
+// in a fixed order (wave shuffles, then 8 wave partials) -- deterministic; var = Q/n - (S/n)^2 in f64 on shifted sums.
 // The apply arithmetic is the k_norm_apply4 / k_norm_bwd_apply4 expression, element for element.
 int ES_OPT_NORM_CB_ROWS = 4096;       // es_set_option key 15: matrices with at most this many rows take the one-launch path (0: off).
                                       // Measured on the mv-3ddet step (profiles/r4j_sweep.txt): 4096 -> 26.6 ms, off -> 26.8, 16384 -> 27.3
                                       // (8 .. 16 k rows x 256 channels are only 16 workgroups: too few), 65536 -> 33.1
-#define NCB_TY 256
+int ES_OPT_NORM_CB_BWD = 1;           // es_set_option key 17: the one-launch path for the backward pass too (0: forward only)
+#define NCB_TY 128                     // 512 threads: with 1024 the 128-VGPR budget spilled 26 / 38 registers to scratch (resource guard)
+#define NCB_WAVES 8
 __device__ inline void cb_reduce4(double v[4], double (*sm)[4][4]) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tx = threadIdx.x & 3;
 #pragma unroll
@@ -219,17 +221,17 @@ __device__ inline void cb_reduce4(double v[4], double (*sm)[4][4]) {
   for (int i = 0; i < 4; ++i) {
     double tot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) tot += sm[w][tx][i];
+    for (int w = 0; w < NCB_WAVES; ++w) tot += sm[w][tx][i];
     v[i] = tot;
   }
 }
-__global__ __launch_bounds__(1024) void k_norm_fwd_cb(const float* __restrict__ x, int ldx, int n, int C, float eps,
+__global__ __launch_bounds__(512) void k_norm_fwd_cb(const float* __restrict__ x, int ldx, int n, int C, float eps,
                                                       const float* __restrict__ w, const float* __restrict__ b,
                                                       const float* __restrict__ res, int ldr, int act, float* running_mean,
                                                       float* running_var, float momentum, float* __restrict__ mean,
                                                       float* __restrict__ invstd, float* __restrict__ y, int ldy,
                                                       unsigned short* __restrict__ yh) {
-  __shared__ double sm[16][4][4];
+  __shared__ double sm[NCB_WAVES][4][4];
   const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2, c = blockIdx.x * 16 + tx * 4;
   const float4 k = *(const float4*)(x + c);                                    // row 0: the shift
   float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
@@ -237,8 +239,10 @@ __global__ __launch_bounds__(1024) void k_norm_fwd_cb(const float* __restrict__ 
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      int r = rb + u * NCB_TY;
-      v[u] = r < n ? *(const float4*)(x + (size_t)r * ldx + c) : k;              // (a padding row contributes 0)
+      const int r = rb + u * NCB_TY;
+      const float4 t = *(const float4*)(x + (size_t)(r < n ? r : rb) * ldx + c);
+      v[u].x = r < n ? t.x : k.x; v[u].y = r < n ? t.y : k.y;                   // (a padding row contributes 0; selecting VALUES: a select
+      v[u].z = r < n ? t.z : k.z; v[u].w = r < n ? t.w : k.w;                   //  between the load and `k` itself put k into scratch memory)
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -253,23 +257,18 @@ __global__ __launch_bounds__(1024) void k_norm_fwd_cb(const float* __restrict__ 
   const double inv_n = 1.0 / (double)n;
   const float kk[4] = {k.x, k.y, k.z, k.w};
   float m4[4], is4[4];
-  double var4[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     double ms = a[i] * inv_n, var = bq[i] * inv_n - ms * ms;
     if (var < 0) var = 0;
-    var4[i] = var;
     m4[i] = (float)((double)kk[i] + ms);
     is4[i] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  if (ty == 0) {
-    *(float4*)(mean + c) = make_float4(m4[0], m4[1], m4[2], m4[3]);
-    *(float4*)(invstd + c) = make_float4(is4[0], is4[1], is4[2], is4[3]);
-    if (running_mean && n > 1) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+    if (ty == 0) {
+      mean[c + i] = m4[i];
+      invstd[c + i] = is4[i];
+      if (running_mean && n > 1) {
         running_mean[c + i] = (1.f - momentum) * running_mean[c + i] + momentum * m4[i];
-        running_var[c + i] = (1.f - momentum) * running_var[c + i] + momentum * (float)(var4[i] * n / (n - 1));
+        running_var[c + i] = (1.f - momentum) * running_var[c + i] + momentum * (float)(var * n / (n - 1));
       }
     }
   }
@@ -312,7 +311,7 @@ extern "C" int es_norm_fwd(const float* x, int ldx, int n, int C, const int* seg
                     (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res) | ((uintptr_t)weight) | ((uintptr_t)bias) |
                        ((uintptr_t)mean) | ((uintptr_t)invstd)) & 15) == 0);
   if (vec0 && norm_cb_ok(n, C, nseg) && seg_off[0] == 0 && seg_off[1] == n) {      // short matrix: one launch (see k_norm_fwd_cb)
-    hipLaunchKernelGGL(k_norm_fwd_cb, dim3(C / 16), dim3(1024), 0, st, x, ldx, n, C, eps, weight, bias, res, ldr, act,
+    hipLaunchKernelGGL(k_norm_fwd_cb, dim3(C / 16), dim3(4 * NCB_TY), 0, st, x, ldx, n, C, eps, weight, bias, res, ldr, act,
                        running_mean, running_var, momentum, mean, invstd, y, ldy, (unsigned short*)y_bf16);
     ES_CHECK_LAUNCH();
     return 0;
@@ -534,13 +533,13 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply4(const float* __restrict
 // one-launch backward for short matrices (see k_norm_fwd_cb): dz = dy * act'(y) in place, per-channel sums of dz and dz * xhat
 // (f32 per thread, f64 across the workgroup, fixed order), parameter gradients (the workgroup is the only writer of its 16
 // channels), then the k_norm_bwd_apply4 expression on the rows the same thread has just written.
-__global__ __launch_bounds__(1024) void k_norm_bwd_cb(float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
+__global__ __launch_bounds__(512) void k_norm_bwd_cb(float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
                                                       const float* __restrict__ x, int ldx, int n, int C,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ w, int act, float* dweight, float* dbias,
                                                       float* __restrict__ dx, int ldo, int accumulate,
                                                       unsigned short* __restrict__ dxh) {
-  __shared__ double sm[16][4][4];
+  __shared__ double sm[NCB_WAVES][4][4];
   const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2, c = blockIdx.x * 16 + tx * 4;
   const float4 m = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
   float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
@@ -630,8 +629,8 @@ extern "C" int es_norm_bwd(float* dy, int ldd, const float* y, int ldy, const fl
     const bool vec0 = ((C & 3) == 0) && ((ldx & 3) == 0) && ((ldd & 3) == 0) && ((ldo & 3) == 0) && ((ldy & 3) == 0) &&
                       (((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)y) | ((uintptr_t)weight) |
                          ((uintptr_t)mean) | ((uintptr_t)invstd)) & 15) == 0);
-    if (vec0 && dx != dy && norm_cb_ok(n, C, nseg) && seg_off[0] == 0 && seg_off[1] == n) {
-      hipLaunchKernelGGL(k_norm_bwd_cb, dim3(C / 16), dim3(1024), 0, st, dy, ldd, y, ldy, x, ldx, n, C, mean, invstd, weight, act,
+    if (vec0 && dx != dy && ES_OPT_NORM_CB_BWD && norm_cb_ok(n, C, nseg) && seg_off[0] == 0 && seg_off[1] == n) {
+      hipLaunchKernelGGL(k_norm_bwd_cb, dim3(C / 16), dim3(4 * NCB_TY), 0, st, dy, ldd, y, ldy, x, ldx, n, C, mean, invstd, weight, act,
                          dweight, dbias, dx, ldo, accumulate, (unsigned short*)dx_bf16);
       ES_CHECK_LAUNCH();
       return 0;

@@ -46,6 +46,7 @@ static int ES_OPT_SPLIT_FOLD = 0;           // tap-split launches: partial tiles
                                            // mv-3ddet step 30.9 ms against 25.9 (with a seq_cst fence, i.e. + buffer_inv: 32.6).  Kept as a tested option.
 static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
 extern int ES_OPT_NORM_CB_ROWS;          // rowops.hip: one-launch norm for matrices with at most this many rows (key 15)
+extern int ES_OPT_NORM_CB_BWD;           // ... for the backward pass too (key 17)
 extern "C" int es_set_option(int key, int value) {
   if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
   if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }
@@ -62,6 +63,7 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 14) { ES_OPT_WGRAD_TR = value; return 0; }
   if (key == 15) { ES_OPT_NORM_CB_ROWS = value; return 0; }
   if (key == 16) { ES_OPT_SPLIT_FOLD = value; return 0; }
+  if (key == 17) { ES_OPT_NORM_CB_BWD = value; return 0; }
   return -2;
 }
 

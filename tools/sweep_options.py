@@ -69,7 +69,7 @@ def main():
     run('default (again)')
     if args.variants:
         base = dict(defaults)
-        base.update({10: 2, 11: 768, 12: 0, 14: 1, 15: 4096, 16: 0})
+        base.update({10: 2, 11: 768, 12: 0, 14: 1, 15: 4096, 16: 0, 17: 1})
         for var in args.variants.split(';'):
             kv = [tuple(p.split('=')) for p in var.split(',') if p]
             old = {}
