@@ -1063,11 +1063,12 @@ extern "C" int es_topk_mask_ws(const float* values, const int* seg_off, int nseg
 // ------------------------------------------------------------------ column sums (bias gradients), deterministic, one launch
 // dst[c] (+)= sum_rows g[r, c].  Rounds 1-3 ran every bias gradient as a 1 x C weight-gradient GEMM against a column of ones (an
 // f32 MFMA launch + its slice reduction: 105 launch pairs moving 0.8 GB for 0.4 GFLOP in one grounding step).  Here a workgroup
-// sums a chunk of rows (64, or n / 64 for long matrices: at most 64 chunks; threads over columns x 4 row stripes, fixed order), stores its partial row, and the last workgroup
+// sums a chunk of rows (64, or n / 256 for long matrices: at most 256 chunks; threads over columns x 4 row stripes, fixed order), stores its partial row, and the last workgroup
 // to arrive (es_last_block_light: the partial rows travel through coherent stores / loads, no cache maintenance) adds the partials
 // in chunk order: no float atomics, no second launch.
 #define CS_ROWS 64
-static int colsum_rows(int n) { int r = es_cdiv(n > 0 ? n : 1, 64); r = (r + 3) / 4 * 4; return r < CS_ROWS ? CS_ROWS : r; }   // <= 64 chunks
+static int colsum_rows(int n) { int r = es_cdiv(n > 0 ? n : 1, 256); r = (r + 3) / 4 * 4; return r < CS_ROWS ? CS_ROWS : r; }   // <= 256 chunks
+// (64 chunks were too few for the head's 4e5-row launches: 64 workgroups, 0.64 ms, profiles/r4_single_stream_kernel_stats.txt)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int ld, int n, int C, float* __restrict__ dst, int accumulate,
                                                 float* __restrict__ ws, int rows_per_block) {
   __shared__ float red[4][64];
