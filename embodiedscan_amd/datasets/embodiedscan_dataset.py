@@ -195,11 +195,11 @@ class EmbodiedScanDataset:
         return self.data_list[idx]
 
     # ------------------------------------------------------------------ hand-over to the device path
-    def load_scan(self, idx, rng=None):
+    def load_scan(self, idx, rng=None, alloc=None):
         """decode scan `idx` and draw the pipeline's random decisions -> the raw scan dict of pipeline.pin_scan /
         upload_scan (see loading.ScanPipeline).  rng: numpy RandomState (the reference uses the global np.random stream
-        in the same order of draws)."""
-        return self.pipeline(self.data_list[idx], rng if rng is not None else np.random)
+        in the same order of draws).  alloc: where the frames are decoded into (ScanPipeline.__call__)."""
+        return self.pipeline(self.data_list[idx], rng if rng is not None else np.random, alloc)
 
     def __getitem__(self, idx):
         return self.load_scan(idx)

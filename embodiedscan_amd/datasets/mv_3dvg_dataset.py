@@ -157,10 +157,10 @@ class MultiView3DGroundingDataset(EmbodiedScanDataset):
         del self.scans
         return infos
 
-    def load_scan(self, idx, rng=None):
+    def load_scan(self, idx, rng=None, alloc=None):
         info = dict(self.data_list[idx])
         info.setdefault('sample_idx', info['scan_id'])
-        scan = self.pipeline(info, rng if rng is not None else np.random)
+        scan = self.pipeline(info, rng if rng is not None else np.random, alloc)
         scan['text'] = info['text']
         if 'tokens_positive' in info:
             scan['tokens_positive'] = info['tokens_positive']

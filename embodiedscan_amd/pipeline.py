@@ -70,13 +70,16 @@ def _host_tensors(scan):
     """the arrays of one raw scan that go to the device.  A scan from the dataset reader carries `img_raw` (decoded frames
     at the file resolution, resized on the device); a synthetic scan carries `img` at the network resolution."""
     mats, aug = scan_matrices(scan)
-    host = dict(depth=torch.from_numpy(scan['depth']), mats=mats, aug=aug)
-    if 'sel_pix' in scan:                    # (absent: the PointSample draws are made on the device, see device_point_sample)
-        host.update(sel_view=torch.from_numpy(scan['sel_view']), sel_pix=torch.from_numpy(scan['sel_pix']))
+    # (the two big arrays first: a loader worker decodes straight into its slot and must know their offsets before the small
+    #  arrays -- whose presence depends on the decoded depth -- exist; datasets/loader.py `alloc`)
+    host = dict(depth=torch.from_numpy(scan['depth']))
     if 'img_raw' in scan:
         host['img_raw'] = torch.from_numpy(scan['img_raw'])
     else:
         host['img'] = torch.from_numpy(scan['img'])
+    host.update(mats=mats, aug=aug)
+    if 'sel_pix' in scan:                    # (absent: the PointSample draws are made on the device, see device_point_sample)
+        host.update(sel_view=torch.from_numpy(scan['sel_view']), sel_pix=torch.from_numpy(scan['sel_pix']))
     return host
 
 
