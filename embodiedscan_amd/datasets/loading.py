@@ -30,10 +30,82 @@ def decode_image(path, out=None):
     return out
 
 
+_HOST_LIB = False          # libes_host.so (csrc/host_codec.c, include/es_host.h): False = not looked for yet, None = absent
+
+
+def _host_lib():
+    global _HOST_LIB
+    if _HOST_LIB is False:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'libes_host.so')
+        try:
+            lib = ctypes.CDLL(path)
+            lib.es_png_gray16_to_f32.restype = ctypes.c_int
+            lib.es_png_gray16_to_f32.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+            _HOST_LIB = lib
+        except OSError:
+            _HOST_LIB = None                  # (the generic decoder below yields the same values, more slowly)
+    return _HOST_LIB
+
+
+def _inflate_gray16_png(data):
+    """PNG file bytes -> (H, W, inflated scanlines) when the file is a non-interlaced 16-bit greyscale PNG with intact
+    chunk CRCs, else None (the caller then takes the generic decoder, which also owns the error reporting)."""
+    import struct
+    import zlib
+    if data[:8] != b'\x89PNG\r\n\x1a\n':
+        return None
+    o, n, shape, idat, ended = 8, len(data), None, [], False
+    while o + 12 <= n:
+        ln = int.from_bytes(data[o:o + 4], 'big')
+        ty = data[o + 4:o + 8]
+        if o + 12 + ln > n:
+            return None
+        body = data[o + 8:o + 8 + ln]
+        if zlib.crc32(body, zlib.crc32(ty)) != int.from_bytes(data[o + 8 + ln:o + 12 + ln], 'big'):
+            return None
+        if ty == b'IHDR':
+            if ln != 13 or shape is not None:
+                return None
+            w, h, depth, colour, comp, filt, lace = struct.unpack('>IIBBBBB', body)
+            if (depth, colour, comp, filt, lace) != (16, 0, 0, 0, 0) or w == 0 or h == 0:
+                return None
+            shape = (h, w)
+        elif ty == b'IDAT':
+            idat.append(body)
+        elif ty == b'IEND':
+            ended = True
+            break
+        o += 12 + ln
+    if shape is None or not idat or not ended:
+        return None
+    try:
+        raw = zlib.decompress(b''.join(idat) if len(idat) > 1 else idat[0])
+    except zlib.error:
+        return None
+    if len(raw) != shape[0] * (1 + 2 * shape[1]):
+        return None
+    return shape[0], shape[1], raw
+
+
 def decode_depth(path, depth_shift, out=None):
     """16-bit PNG -> float32 metres: `imfrombytes(flag='unchanged').astype(float32) / depth_shift` (loading.py:68-73).
-    out: float32 destination (see decode_image); the division then converts and writes in one pass (same f32 arithmetic:
-    the integer samples are cast to float32 first, then divided in float32)."""
+    out: float32 destination (see decode_image); a map of another shape comes back as its own array.
+    16-bit greyscale PNGs -- the dataset's depth format -- take the native one-pass path (csrc/host_codec.c: unfilter + byte
+    swap + float conversion + division straight into `out`; zlib inflates); every other file, and every file that path
+    declines, goes through PIL with the same f32 arithmetic (the samples are cast to float32, then divided in float32)."""
+    lib = _host_lib()
+    if lib is not None:
+        with open(path, 'rb') as f:
+            data = f.read()
+        got = _inflate_gray16_png(data)
+        if got is not None:
+            h, w, raw = got
+            dst = out if out is not None and out.shape == (h, w) and out.dtype == np.float32 and out.flags.c_contiguous \
+                else np.empty((h, w), np.float32)
+            if lib.es_png_gray16_to_f32(raw, h, w, float(np.float32(depth_shift)), dst.ctypes.data) == 0:
+                return dst
     from PIL import Image
     with Image.open(path) as im:
         a = np.asarray(im)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--fast-draws', action='store_true', help='O(k) PointSample draws instead of the exact RandomState stream')
     ap.add_argument('--device-draws', action='store_true', help='the host only decodes; both PointSample draws run on the GPU (round 4)')
     ap.add_argument('--kinds', default='thread,process')
+    ap.add_argument('--no-device', action='store_true', help='decode legs only (skip the copy + device resize + A1-A3 leg)')
     args = ap.parse_args()
     import torch
     from embodiedscan_amd import pipeline, synth
@@ -70,7 +71,7 @@ def main():
                 out['decode'].append(dict(workers=kind, n=th, scans=n, scans_per_s=round(n / dt, 2),
                                           ms_per_scan=round(dt / n * 1e3, 1), pinned=bool(b[0]['depth'].is_pinned())))
                 print(out['decode'][-1], file=sys.stderr)
-        if dev is not None:
+        if dev is not None and not args.no_device:
             # loader -> copy stream (H2D + resize) -> A1-A3 on the compute stream, double-buffered like bench.py
             th = args.device_workers
             ld = ScanLoader(ds, batch_size=4, shuffle=True, seed=0, times=args.repeat * 2, num_threads=th,
