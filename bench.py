@@ -605,6 +605,17 @@ def launch_classes(records, mfma_peak, top=6):
     return rows[:top]
 
 
+def _cap_cpu_threads():
+    """the CPU legs use as many threads as the box grants cores (cgroup quota), not as many as it shows logical CPUs: on the
+    GPU boxes (256 shown, 16 granted) torch's default 128 threads time-slice 16 cores; `cores` in the line is this count"""
+    import torch
+    from embodiedscan_amd.datasets.loader import effective_cpus
+    n = min(torch.get_num_threads(), effective_cpus())
+    if n != torch.get_num_threads():
+        torch.set_num_threads(n)
+    return n
+
+
 def other_parity(kind, cfg, det, scan, make, dev, args):
     """losses of ONE scan from the pre-training weights: HIP path vs the CPU oracle's forward (no gradients; the oracle's
     forward+backward is what the primary line's cpu_baseline times).  Tolerance: bf16 5e-2 (grounding: 12 losses over 6
@@ -627,6 +638,7 @@ def other_parity(kind, cfg, det, scan, make, dev, args):
     E.TAPE.clear()
     E.join_wgrad_streams()
     imgs = OM.preprocess_img(torch.from_numpy(scan['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])[None]
+    _cap_cpu_threads()
     t0 = time.perf_counter()
     with torch.no_grad():
         if kind == 'grounding':
@@ -767,6 +779,7 @@ def cpu_baseline(scan, sd0, det, parity_hip, args):
     from oracle import model as OM, pipeline as OP
     names = set(det.arena.grad_dict().keys())
     sd = {k: v.clone().requires_grad_(k in names) for k, v in sd0.items()}
+    _cap_cpu_threads()
     t0 = time.perf_counter()
     pts = [OP.scan_to_points(scan)]
     imgs = OM.preprocess_img(torch.from_numpy(scan['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])[None]

@@ -22,6 +22,30 @@ import torch
 from .. import pipeline
 
 
+def effective_cpus(cgroup_root='/sys/fs/cgroup'):
+    """host cores this process may actually use: the affinity mask capped by the cgroup CPU quota.  (The GPU boxes show 256
+    logical CPUs and grant 16 cores -- `/sys/fs/cgroup/cpu.max` = `1600000 100000`: worker pools and CPU thread pools sized by
+    os.cpu_count() oversubscribe that quota 8-16 x and run SLOWER, profiles/r4z_loader_*.json.)"""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for quota_file, period_file in ((cgroup_root + '/cpu.max', None),
+                                    (cgroup_root + '/cpu/cpu.cfs_quota_us', cgroup_root + '/cpu/cpu.cfs_period_us')):
+        try:
+            if period_file is None:
+                q, per = open(quota_file).read().split()[:2]
+            else:
+                q, per = open(quota_file).read().strip(), open(period_file).read().strip()
+            if q not in ('max', '-1') and int(per) > 0 and int(q) > 0:
+                n = min(n, max(1, int(q) // int(per)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def shard_indices(n, rank=0, world=1, shuffle=True, seed=0, epoch=0, round_up=True, times=1):
     """this rank's scan indices for one epoch (DefaultSampler.__iter__ on a RepeatDataset of `times` repeats)"""
     total = n * times

@@ -505,3 +505,28 @@ def test_grounder_state_dict_carries_the_text_encoder(tmp_path):
         b.load_state_dict(bare, strict=True)
     missing, unexpected = b.load_state_dict(dict(sd, **{'text_encoder.bogus.weight': torch.zeros(1)}), strict=False)
     assert unexpected == ['text_encoder.bogus.weight']
+
+
+def test_effective_cpus_honours_the_cgroup_quota(tmp_path):
+    """the GPU boxes show 256 logical CPUs and grant 16 cores (cpu.max = '1600000 100000'): pools are sized by the grant"""
+    import os
+    from embodiedscan_amd.datasets.loader import effective_cpus
+    have = len(os.sched_getaffinity(0))
+    assert effective_cpus(str(tmp_path / 'absent')) == have
+    v2 = tmp_path / 'v2'
+    v2.mkdir()
+    (v2 / 'cpu.max').write_text('max 100000\n')
+    assert effective_cpus(str(v2)) == have
+    (v2 / 'cpu.max').write_text('150000 100000\n')
+    assert effective_cpus(str(v2)) == 1
+    (v2 / 'cpu.max').write_text('1600000 100000\n')
+    assert effective_cpus(str(v2)) == min(have, 16)
+    v1 = tmp_path / 'v1'
+    (v1 / 'cpu').mkdir(parents=True)
+    (v1 / 'cpu' / 'cpu.cfs_quota_us').write_text('-1\n')
+    (v1 / 'cpu' / 'cpu.cfs_period_us').write_text('100000\n')
+    assert effective_cpus(str(v1)) == have
+    (v1 / 'cpu' / 'cpu.cfs_quota_us').write_text('300000\n')
+    assert effective_cpus(str(v1)) == min(have, 3)
+    (v2 / 'cpu.max').write_text('garbage\n')
+    assert effective_cpus(str(v2)) == have
