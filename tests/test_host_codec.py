@@ -60,6 +60,19 @@ def _depth_like(rng, H, W):
     return d.clip(0, 65535).astype(np.uint16)
 
 
+def _lib():
+    """libes_host.so is a build product (git-ignored): a fresh checkout compiles it here (gcc, one second)"""
+    import os
+    import subprocess
+    from embodiedscan_amd.datasets import loading as L
+    if L._host_lib() is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.check_call(['make', '-C', os.path.join(root, 'embodiedscan_amd', 'csrc'), '../libes_host.so'])
+        L._HOST_LIB = False
+    assert L._host_lib() is not None, 'libes_host.so missing: run `make -C embodiedscan_amd/csrc` (__graft_entry__.build)'
+    return L._host_lib()
+
+
 def _pil(path, shift):
     from PIL import Image
     with Image.open(path) as im:
@@ -68,7 +81,7 @@ def _pil(path, shift):
 
 def test_native_depth_decoder_is_loaded_and_equals_pil_for_every_filter_type(tmp_path):
     from embodiedscan_amd.datasets import loading as L
-    assert L._host_lib() is not None, 'libes_host.so missing: run `make -C embodiedscan_amd/csrc` (__graft_entry__.build)'
+    _lib()
     rng = np.random.default_rng(3)
     n = 0
     for H, W in ((48, 64), (37, 53), (1, 1), (2, 300), (120, 160)):
@@ -96,7 +109,7 @@ def test_native_depth_decoder_declines_what_it_does_not_own(tmp_path, monkeypatc
     from PIL import Image
     from embodiedscan_amd.datasets import loading as L
     calls = []
-    lib = L._host_lib()
+    lib = _lib()
     real = lib.es_png_gray16_to_f32
 
     class Spy:
@@ -154,7 +167,7 @@ def test_scan_pipeline_is_identical_with_and_without_the_native_decoder(tmp_path
             dict(type='AggregateMultiViewPoints', coord_type='DEPTH'), dict(type='PointSample', num_points=600),
             dict(type='Pack3DDetInputs', keys=['img', 'points', 'gt_bboxes_3d', 'gt_labels_3d'])]
     ds = EmbodiedScanDataset(root, 'embodiedscan_infos_train.pkl', metainfo=dict(classes=names), pipeline=pipe)
-    assert L._host_lib() is not None
+    _lib()
     a = ds.load_scan(0, np.random.RandomState(4))
     monkeypatch.setattr(L, '_HOST_LIB', None)
     b = ds.load_scan(0, np.random.RandomState(4))
