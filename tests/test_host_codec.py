@@ -174,3 +174,47 @@ def test_scan_pipeline_is_identical_with_and_without_the_native_decoder(tmp_path
     for k in ('depth', 'img_raw', 'sel_view', 'sel_pix', 'extrinsic', 'intrinsic', 'gt_boxes'):
         assert np.array_equal(a[k], b[k]), k
     assert a['depth'].dtype == np.float32 and a['depth'].flags.c_contiguous
+
+
+def test_depth_decoder_same_values_through_libdeflate_zlib_and_from_many_threads(tmp_path, monkeypatch):
+    """the inflate step runs through libdeflate when the system has it, python's zlib otherwise; the loader's thread workers
+    decode concurrently (per-thread decompressor and scratch) -- always the same float32 maps"""
+    import threading
+    from embodiedscan_amd.datasets import loading as L
+    _lib()
+    rng = np.random.default_rng(11)
+    files = []
+    for i, (H, W) in enumerate(((96, 128), (96, 128), (50, 70), (120, 160))):
+        img = _depth_like(rng, H, W)
+        p = str(tmp_path / f'd{i}.png')
+        _write_png16(p, img, list(rng.integers(0, 5, H)), idat_split=1 + i % 3)
+        files.append((p, img.astype(np.float32) / np.float32(1000.0)))
+    with_deflate = [L.decode_depth(p, 1000.0) for p, _ in files]
+    has = L._DEFLATE_LIB is not None
+    for (p, want), got in zip(files, with_deflate):
+        assert np.array_equal(got, want)
+    errors = []
+
+    def work(seed):
+        order = np.random.default_rng(seed).permutation(len(files) * 25) % len(files)
+        for k in order:
+            p, want = files[k]
+            if not np.array_equal(L.decode_depth(p, 1000.0), want):
+                errors.append((seed, p))
+    threads = [threading.Thread(target=work, args=(s,)) for s in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    monkeypatch.setattr(L, '_DEFLATE_LIB', None)                     # the zlib fallback
+    for p, want in files:
+        assert np.array_equal(L.decode_depth(p, 1000.0), want)
+    # a truncated stream is declined by either inflater (the generic decoder then reports the file)
+    import zlib
+    z = zlib.compress(b'x' * 1000)
+    assert L._inflate(z, 999) is None and L._inflate(z[:-6], 1000) is None
+    monkeypatch.setattr(L, '_DEFLATE_LIB', False)
+    assert L._inflate(z, 999) is None and L._inflate(z[:-6], 1000) is None
+    assert bytes(L._inflate(z, 1000)[:1000]) == b'x' * 1000
+    print('libdeflate present:', has)
