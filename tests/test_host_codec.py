@@ -84,8 +84,8 @@ def test_native_depth_decoder_is_loaded_and_equals_pil_for_every_filter_type(tmp
     _lib()
     rng = np.random.default_rng(3)
     n = 0
-    for H, W in ((48, 64), (37, 53), (1, 1), (2, 300), (120, 160)):
-        img = _depth_like(rng, H, W) if H > 2 else rng.integers(0, 65536, (H, W)).astype(np.uint16)
+    for H, W in ((48, 64), (37, 53), (1, 1), (2, 300), (120, 160), (5, 2), (4, 3), (3, 1), (7, 4)):
+        img = _depth_like(rng, H, W) if H > 2 and W > 8 else rng.integers(0, 65536, (H, W)).astype(np.uint16)
         cases = [[t] * H for t in range(5)] + [list(rng.integers(0, 5, H)) for _ in range(3)]
         for types in cases:
             for split in (1, 3):
