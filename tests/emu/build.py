@@ -1,0 +1,54 @@
+"""TEST INFRASTRUCTURE ONLY.  Builds tests/emu/_build/libes_emu_test.so: the kernel sources of embodiedscan_amd/csrc compiled
+for x86 against the emulation shim (tests/emu/hip/hip_runtime.h) -- the same C ABI as libes_hip.so, operating on host
+pointers, every launch executed by the fiber scheduler of emu_runtime.cpp.  The product never loads it.
+
+The only source transformations: an occupancy attribute of the device compiler is dropped, the five `asm volatile("s_waitcnt ...")` statements of spconv.hip become no-ops (x86 cannot
+assemble them; the emulated LDS-DMA completes at issue) and the relative include of the public header is redirected.
+    python tests/emu/build.py [file.hip ...]        (default: spconv.hip rowops.hip)"""
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'embodiedscan_amd', 'csrc')
+OUT = os.path.join(HERE, '_build')
+CLANG = os.environ.get('ES_EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
+DEFAULT = ('spconv.hip', 'rowops.hip')
+
+
+def transform(text):
+    text = re.sub(r'asm volatile\("s_waitcnt [^"]*"\s*::[^;]*\);', 'ES_EMU_WAITCNT();', text)
+    text = re.sub(r'__attribute__\(\(amdgpu_waves_per_eu\(\d+\)\)\)', '', text)       # (an occupancy hint of the device compiler)
+    return text.replace('#include "../../include/es_hip.h"', '#include "es_hip.h"')
+
+
+def build(files=DEFAULT, force=False):
+    os.makedirs(OUT, exist_ok=True)
+    lib = os.path.join(OUT, 'libes_emu_test.so')
+    srcs = [os.path.join(CSRC, f) for f in files] + [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'es_hip.h'),
+                                                     os.path.join(HERE, 'hip', 'hip_runtime.h'), os.path.join(HERE, 'emu_runtime.cpp'),
+                                                     os.path.abspath(__file__)]
+    if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
+        return lib
+    flags = ['-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-w', '-I', HERE, '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
+             '-ffp-contract=off']
+    objs = []
+    for f in files:
+        gen = os.path.join(OUT, f.replace('.hip', '_emu.cpp'))
+        with open(os.path.join(CSRC, f)) as fh:
+            text = transform(fh.read())
+        with open(gen, 'w') as fh:
+            fh.write(text)
+        obj = gen.replace('.cpp', '.o')
+        subprocess.check_call([CLANG] + flags + ['-c', gen, '-o', obj])
+        objs.append(obj)
+    rt = os.path.join(OUT, 'emu_runtime.o')
+    subprocess.check_call([CLANG] + flags + ['-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', rt])
+    subprocess.check_call([CLANG, '-shared', '-fPIC'] + objs + [rt, '-o', lib])
+    return lib
+
+
+if __name__ == '__main__':
+    print(build(tuple(sys.argv[1:]) or DEFAULT, force=True))

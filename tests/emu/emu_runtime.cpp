@@ -1,0 +1,193 @@
+// TEST INFRASTRUCTURE ONLY: the fiber scheduler behind tests/emu/hip/hip_runtime.h (see there).  One OS thread; the threads of
+// a workgroup are ucontext fibers run round-robin; a fiber gives up the processor only at __syncthreads and at wave operations.
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <ucontext.h>
+#include <string>
+#include <vector>
+
+namespace emu {
+
+struct Wave {
+  unsigned char xchg[2][64 * 64];      // two exchange areas (operation k uses k & 1): a lane that has left operation k may already
+                                       // deposit for k + 1 while a slower lane still reads k
+  long long released = 0;              // wave operations completed so far
+  int arrived = 0;                     // lanes waiting in operation number `released`
+  int alive = 0;
+  unsigned long long live_mask = 0;
+};
+
+struct Fiber {
+  ucontext_t ctx;
+  uint3 tid;
+  int lane = 0, wave = 0;
+  bool done = false;
+  int wait = 0;                        // 0 runnable, 1 block barrier, 2 wave operation
+  long long wait_gen = 0;              // barrier generation / wave operation number waited for
+  long long wave_ops = 0;              // wave operations this lane has entered
+};
+
+Fiber* g_cur = nullptr;
+dim3 g_block_idx, g_block_dim, g_grid_dim;
+static ucontext_t g_sched;
+static std::vector<Fiber> g_fibers;
+static std::vector<Wave> g_waves;
+static long long g_bar_gen = 0;
+static int g_bar_arrived = 0, g_alive = 0;
+static const std::function<void()>* g_body = nullptr;
+static unsigned char* g_stacks = nullptr;
+static size_t g_stack_cap = 0;
+static const size_t STACK = 192 * 1024;
+
+const uint3& tid() { return g_cur->tid; }
+int lane() { return g_cur->lane; }
+unsigned long long wave_live_mask() { return g_waves[g_cur->wave].live_mask; }
+
+static void yield() { swapcontext(&g_cur->ctx, &g_sched); }
+
+void block_barrier() {
+  Fiber* f = g_cur;
+  if (++g_bar_arrived == g_alive) {      // last one in: release everybody
+    g_bar_arrived = 0;
+    ++g_bar_gen;
+    return;
+  }
+  f->wait = 1;
+  f->wait_gen = g_bar_gen;
+  yield();
+}
+
+const unsigned char* wave_exchange(const void* mine, int bytes) {
+  Fiber* f = g_cur;
+  Wave& w = g_waves[f->wave];
+  const long long op = f->wave_ops++;
+  if (op != w.released) {
+    fprintf(stderr, "emu: lane %d of wave %d enters wave operation %lld while the wave is at %lld (divergent wave operations)\n",
+            f->lane, f->wave, op, w.released);
+    abort();
+  }
+  unsigned char* area = w.xchg[op & 1];
+  memcpy(area + 64 * f->lane, mine, (size_t)bytes);
+  if (++w.arrived == w.alive) {
+    w.arrived = 0;
+    ++w.released;
+    return area;
+  }
+  f->wait = 2;
+  f->wait_gen = op;
+  yield();
+  return area;
+}
+
+static void trampoline() {
+  (*g_body)();
+  Fiber* f = g_cur;
+  f->done = true;
+  // a thread that has left no longer takes part in barriers / wave operations: release what now only waited for it
+  --g_alive;
+  Wave& w = g_waves[f->wave];
+  --w.alive;
+  w.live_mask &= ~(1ull << f->lane);
+  if (g_alive > 0 && g_bar_arrived == g_alive) {
+    g_bar_arrived = 0;
+    ++g_bar_gen;
+  }
+  if (w.alive > 0 && w.arrived == w.alive) {
+    w.arrived = 0;
+    ++w.released;
+  }
+  swapcontext(&f->ctx, &g_sched);
+}
+
+static bool runnable(const Fiber& f) {
+  if (f.done) return false;
+  if (f.wait == 0) return true;
+  if (f.wait == 1) return g_bar_gen > f.wait_gen;
+  return g_waves[f.wave].released > f.wait_gen;
+}
+
+static std::string g_log;
+
+void launch(const char* name, dim3 grid, dim3 block, const std::function<void()>& body) {
+  const int nt = (int)(block.x * block.y * block.z);
+  if (nt <= 0 || grid.x * (size_t)grid.y * grid.z == 0) return;
+  if (g_log.size() < (1u << 20)) {
+    char tmp[96];
+    snprintf(tmp, sizeof tmp, " grid=(%u,%u,%u) block=%d\n", grid.x, grid.y, grid.z, nt);
+    g_log += name;
+    g_log += tmp;
+  }
+  if (g_cur != nullptr) {
+    fprintf(stderr, "emu: nested launch\n");
+    abort();
+  }
+  if ((size_t)nt * STACK > g_stack_cap) {
+    if (g_stacks) munmap(g_stacks, g_stack_cap);
+    g_stack_cap = (size_t)nt * STACK;
+    g_stacks = (unsigned char*)mmap(nullptr, g_stack_cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (g_stacks == MAP_FAILED) {
+      perror("emu: mmap");
+      abort();
+    }
+  }
+  g_block_dim = block;
+  g_grid_dim = grid;
+  g_body = &body;
+  const int nw = (nt + 63) / 64;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        g_block_idx = dim3(bx, by, bz);
+        g_fibers.assign((size_t)nt, Fiber());
+        g_waves.assign((size_t)nw, Wave());
+        g_bar_gen = 0;
+        g_bar_arrived = 0;
+        g_alive = nt;
+        for (int t = 0; t < nt; ++t) {
+          Fiber& f = g_fibers[(size_t)t];
+          f.tid = uint3{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+          f.lane = t & 63;
+          f.wave = t >> 6;
+          g_waves[(size_t)f.wave].alive++;
+          g_waves[(size_t)f.wave].live_mask |= 1ull << f.lane;
+          getcontext(&f.ctx);
+          f.ctx.uc_stack.ss_sp = g_stacks + (size_t)t * STACK;
+          f.ctx.uc_stack.ss_size = STACK;
+          f.ctx.uc_link = nullptr;
+          makecontext(&f.ctx, trampoline, 0);
+        }
+        int done = 0;
+        while (done < nt) {
+          bool progressed = false;
+          for (int t = 0; t < nt; ++t) {
+            Fiber& f = g_fibers[(size_t)t];
+            if (!runnable(f)) continue;
+            f.wait = 0;
+            g_cur = &f;
+            swapcontext(&g_sched, &f.ctx);
+            g_cur = nullptr;
+            progressed = true;
+            if (f.done) ++done;
+          }
+          if (!progressed) {
+            fprintf(stderr, "emu: deadlock in block (%u, %u, %u): %d of %d threads finished; the rest wait at a barrier / wave "
+                    "operation the others never reach (divergent __syncthreads or a partial-wave shuffle)\n", bx, by, bz, done, nt);
+            abort();
+          }
+        }
+      }
+  g_body = nullptr;
+}
+
+}  // namespace emu
+
+// the launches since the last call, one per line ("<kernel expression> grid=(x,y,z) block=n"): lets a test assert WHICH kernel
+// a dispatch function chose; returns the number of bytes written (truncated to cap - 1) and clears the log
+extern "C" int es_emu_take_launch_log(char* buf, int cap) {
+  int n = (int)emu::g_log.size();
+  if (n > cap - 1) n = cap - 1;
+  if (n > 0) memcpy(buf, emu::g_log.data(), (size_t)n);
+  if (cap > 0) buf[n > 0 ? n : 0] = 0;
+  emu::g_log.clear();
+  return n;
+}

@@ -1,0 +1,234 @@
+"""Kernel LOGIC on the CPU (tests/emu): the sources of embodiedscan_amd/csrc/{spconv,rowops}.hip compiled for x86 against an
+emulation of the CDNA execution model (fibers per workgroup, wave rendezvous for shuffles / ballots / MFMA fragments, LDS-DMA,
+the transposed LDS read) and driven through the SAME C ABI with host pointers.  What this pins without a GPU: tile indexing,
+neighbour-map gathers, tap compaction and tap split, LDS swizzles, fragment layouts, epilogues, the norm pipelines' chunking and
+their one-launch variants -- against numpy evaluations of the same arithmetic (bf16-rounded operands, f64 sums).  What it cannot
+pin: anything about timing or the memory model (the emulator is more permissive than the hardware) -- the GPU suite does that.
+The emulated library is test infrastructure: the product binds libes_hip.so only (embodiedscan_amd/hip.py) and has no CPU path."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+
+
+@pytest.fixture(scope='module')
+def emu():
+    import build as emu_build
+    from embodiedscan_amd import hip
+    lib = ctypes.CDLL(emu_build.build())
+    fns = {}
+    for name, (ret, at, _) in hip.PROTOS.items():
+        f = getattr(lib, name, None)
+        if f is not None:                      # (only the sources listed in tests/emu/build.py are part of the emulated library)
+            f.restype, f.argtypes = ret, at
+            fns[name] = f
+
+    def call(name, *args):
+        rc = fns[name](*args)
+        assert rc == 0, (name, rc)
+
+    def launches():
+        """kernel expressions launched since the last call"""
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.es_emu_take_launch_log(buf, len(buf))
+        return [ln.split(' grid=')[0] for ln in buf.value.decode().splitlines()]
+    call.fns, call.launches = fns, launches
+    return call
+
+
+def P(a):
+    return a.ctypes.data if a is not None else 0
+
+
+def bf16_round(x):
+    """f32 -> nearest-even bf16, returned as f32 (the conversion every kernel uses: v_cvt_pk_bf16_f32)"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def bf16_bits(x):
+    return (bf16_round(x).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def _map(rng, n_out, n_in, K, fill):
+    nbr = np.full((n_out, K), -1, np.int32)
+    m = rng.random((n_out, K)) < fill
+    nbr[m] = rng.integers(0, n_in, int(m.sum()))
+    return nbr
+
+
+def _conv_ref(xb, wb, nbr, bias):
+    """f64 evaluation on the bf16-rounded operands: xb (n_in, Cin), wb (K, Cin, Cout)"""
+    n_out, K = nbr.shape
+    y = np.zeros((n_out, wb.shape[2]), np.float64)
+    for k in range(K):
+        rows = np.flatnonzero(nbr[:, k] >= 0)
+        if len(rows):
+            y[rows] += xb[nbr[rows, k]].astype(np.float64) @ wb[k].astype(np.float64)
+    return y + (bias.astype(np.float64) if bias is not None else 0)
+
+
+def test_weight_cast_layouts(emu):
+    rng = np.random.default_rng(0)
+    K, A, B = 3, 40, 72
+    w = rng.standard_normal((K, A, B)).astype(np.float32)
+    nat = np.zeros((K, A, B), np.uint16)
+    tr = np.zeros((K, B, A), np.uint16)
+    emu('es_cast_weight_bf16', P(w), K, A, B, P(nat), P(tr), 0)
+    assert np.array_equal(nat, bf16_bits(w)) and np.array_equal(tr, bf16_bits(w).transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize('dma', [0, 2])
+def test_sparse_conv_forward_on_the_emulated_matrix_cores(emu, dma):
+    """27-tap gather convolution, bf16 rows: the register-staged ping-pong kernel (option 10 = 0) and the LDS-DMA kernel with
+    64-channel chunks (10 = 2, every width) against f64 on the rounded operands; a ragged last row tile, absent neighbours, a
+    tap that no row of a tile uses (tap compaction), and an under-filled launch that splits its taps through the workspace"""
+    rng = np.random.default_rng(1 + dma)
+    emu('es_set_option', 10, dma)
+    emu('es_set_option', 11, 0)
+    try:
+        for n_out, n_in, K, cin, cout, fill in ((300, 280, 27, 64, 128, 0.3), (130, 130, 27, 128, 64, 0.5), (77, 90, 8, 64, 64, 0.9)):
+            nbr = _map(rng, n_out, n_in, K, fill)
+            nbr[:, 5 % K] = -1                                   # a tap nobody uses
+            x = rng.standard_normal((n_in, cin)).astype(np.float32)
+            w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+            bias = rng.standard_normal(cout).astype(np.float32)
+            xh = bf16_bits(x)
+            wt = np.zeros((K, cout, cin), np.uint16)
+            wn = np.zeros((K, cin, cout), np.uint16)
+            emu('es_cast_weight_bf16', P(w), K, cin, cout, P(wn), P(wt), 0)
+            want = _conv_ref(bf16_round(x), bf16_round(w), nbr, bias)
+            scale = np.abs(want).max()
+            y = np.full((n_out, cout), np.nan, np.float32)
+            emu.launches()
+            emu('es_spconv_fwd_bf16', P(xh), 1, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y), cout, 0, 0)
+            ran = emu.launches()
+            assert any(('k_spconv_bf16_dma' if dma else 'k_spconv_bf16_fast') in k for k in ran), ran
+            err = np.abs(y - want).max() / scale
+            assert err < 2e-6, (n_out, cin, cout, err)
+            # f32 rows (converted while staged) through the same entry point: only the register-staged kernels take them
+            y2 = np.full((n_out, cout), np.nan, np.float32)
+            emu('es_spconv_fwd_bf16', P(x), 0, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y2), cout, 0, 0)
+            assert np.abs(y2 - want).max() / scale < 2e-6
+            # tap split through the workspace (+ the second launch that adds the slices): same sums
+            nf = int(emu.fns['es_spconv_split_workspace_floats'](n_out, K, cin, cout))
+            if nf:
+                ws = np.zeros(nf, np.float32)
+                y3 = np.full((n_out, cout), np.nan, np.float32)
+                emu('es_spconv_fwd_bf16_ws', P(xh), 1, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y3), cout, 0, P(ws), nf, 0)
+                assert np.abs(y3 - want).max() / scale < 2e-6
+                assert not ws[:1024].view(np.int32).any()        # the tile tickets are left at zero
+    finally:
+        emu('es_set_option', 10, 2)
+        emu('es_set_option', 11, 768)
+
+
+def test_row_gemm_with_fused_epilogue(emu):
+    """K = 1 on the identity map (every 1x1 convolution / Linear layer): both row-GEMM generations, affine + residual + ReLU"""
+    rng = np.random.default_rng(7)
+    n, cin, cout = 333, 64, 128
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    wt = np.zeros((1, cout, cin), np.uint16)
+    wn = np.zeros((1, cin, cout), np.uint16)
+    emu('es_cast_weight_bf16', P(w), 1, cin, cout, P(wn), P(wt), 0)
+    scale, shift = (rng.random(cout) + 0.5).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, cout)).astype(np.float32)
+    lin = bf16_round(x).astype(np.float64) @ bf16_round(w)[0].astype(np.float64)
+    want = np.maximum(lin * scale + shift + res, 0)
+    for gen2 in (1, 0):
+        emu('es_set_option', 13, gen2)
+        y = np.full((n, cout), np.nan, np.float32)
+        emu('es_spconv_fwd_bf16_affine', P(x), cin, P(wt), 0, n, n, 1, cin, cout, P(scale), P(shift), P(res), cout, 1, P(y), cout, 0)
+        assert np.abs(y - want).max() / np.abs(want).max() < 2e-6, gen2
+    emu('es_set_option', 13, 1)
+
+
+def test_weight_gradient_tiles(emu):
+    """dW[k] = X[nbr[:, k]]^T dY through the bf16 weight-gradient kernels (64 x 64 tile, 128 x 128 tile, and the LDS-DMA +
+    transposed-read tile whose lane mapping was probed on the GPU) -- row slices through the workspace included"""
+    rng = np.random.default_rng(11)
+    for n_out, n_in, K, cin, cout, tr in ((700, 650, 27, 64, 64, 0), (900, 900, 8, 128, 128, 0), (900, 900, 8, 128, 128, 1)):
+        emu('es_set_option', 14, tr)
+        nbr = _map(rng, n_out, n_in, K, 0.4)
+        x = rng.standard_normal((n_in, cin)).astype(np.float32)
+        dy = rng.standard_normal((n_out, cout)).astype(np.float32)
+        xb, gb = bf16_round(x), bf16_round(dy)
+        want = np.zeros((K, cin, cout), np.float64)
+        for k in range(K):
+            rows = np.flatnonzero(nbr[:, k] >= 0)
+            want[k] = xb[nbr[rows, k]].astype(np.float64).T @ gb[rows].astype(np.float64)
+        xh, gh = bf16_bits(x), bf16_bits(dy)
+        nf = int(emu.fns['es_spconv_wgrad_workspace_floats'](1, P(xh), 1, cin, P(gh), 1, cout, n_out, n_in, K, cin, cout))
+        ws = np.zeros(max(nf, 1), np.float32)
+        dw = np.zeros((K, cin, cout), np.float32)
+        emu.launches()
+        emu('es_spconv_wgrad_bf16_src', P(xh), 1, cin, P(gh), 1, cout, P(nbr), n_out, n_in, K, cin, cout, P(dw), 0, P(ws) if nf else 0,
+            nf, 0)
+        ran = emu.launches()
+        kind = 'k_spconv_wgrad_bf16_tr' if tr else ('k_spconv_wgrad_bf16_big' if cin == 128 else 'k_spconv_wgrad_bf16<')
+        assert any(kind in k for k in ran), (kind, ran)
+        err = np.abs(dw - want).max() / np.abs(want).max()
+        assert err < 3e-6, (cin, cout, tr, err)
+    emu('es_set_option', 14, 1)
+
+
+@pytest.mark.parametrize('n', [300, 5000])
+def test_norm_forward_backward(emu, n):
+    """batch norm (train mode) + ReLU: n = 300 takes the one-launch column-block kernels, n = 5000 the chunked statistics ->
+    finalize -> apply pipeline; forward values, saved statistics, bf16 shadow, and the backward pass (dx, dweight, dbias)"""
+    rng = np.random.default_rng(n)
+    C = 64
+    x = (rng.standard_normal((n, C)) * 2 + 3).astype(np.float32)
+    w, b = (rng.random(C) + 0.5).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    seg = np.array([0, n], np.int32)
+    mean, invstd = np.zeros(C, np.float32), np.zeros(C, np.float32)
+    nws = int(emu.fns['es_norm_workspace_floats'](n, C, P(seg), 1))
+    ws = np.zeros(max(nws, 1), np.float32)
+    y = np.full((n, C), np.nan, np.float32)
+    yh = np.zeros((n, C), np.uint16)
+    rm, rv = np.zeros(C, np.float32), np.ones(C, np.float32)
+    emu.launches()
+    emu('es_norm_fwd', P(x), C, n, C, P(seg), 1, 1e-5, P(w), P(b), 0, 0, 1, P(rm), P(rv), 0.1, P(mean), P(invstd), P(ws), P(y), C,
+        P(yh), 0)
+    assert emu.launches() == (['k_norm_fwd_cb'] if n <= 4096 else ['k_norm_stats', 'k_norm_finalize', 'k_norm_apply4'])
+    x64 = x.astype(np.float64)
+    m, v = x64.mean(0), x64.var(0)
+    want = np.maximum((x64 - m) / np.sqrt(v + 1e-5) * w + b, 0)
+    assert np.abs(mean - m).max() < 1e-5 and np.abs(invstd * np.sqrt(v + 1e-5) - 1).max() < 1e-5
+    assert np.abs(y - want).max() < 2e-5
+    assert np.array_equal(yh, bf16_bits(y))
+    assert np.abs(rm - 0.1 * m).max() < 1e-5 and np.abs(rv - (0.9 + 0.1 * v * n / (n - 1))).max() < 1e-4
+    # backward: dy through ReLU, then the batch-norm backward of train mode
+    dy = rng.standard_normal((n, C)).astype(np.float32)
+    dz = np.where(want > 0, dy.astype(np.float64), 0.0)
+    xhat = (x64 - m) / np.sqrt(v + 1e-5)
+    dwt, dbt = (dz * xhat).sum(0), dz.sum(0)
+    dxt = (dz - dbt / n - xhat * dwt / n) * w / np.sqrt(v + 1e-5)
+    proto = emu.fns['es_norm_bwd'].argtypes
+    assert len(proto) >= 10
+    dyc = dy.copy()
+    dx, dw, db = np.full((n, C), np.nan, np.float32), np.zeros(C, np.float32), np.zeros(C, np.float32)
+    _norm_bwd(emu, dyc, y, x, n, C, seg, w, mean, invstd, ws, dw, db, dx)
+    assert np.abs(dw - dwt).max() / np.abs(dwt).max() < 2e-5 and np.abs(db - dbt).max() / np.abs(dbt).max() < 2e-5
+    assert np.abs(dx - dxt).max() / np.abs(dxt).max() < 2e-5
+
+
+def _norm_bwd(emu, dy, y, x, n, C, seg, w, mean, invstd, ws, dw, db, dx):
+    """es_norm_bwd by argument NAME (the header is the contract; this keeps the test readable if it grows an argument)"""
+    from embodiedscan_amd import hip
+    names = hip.PROTOS['es_norm_bwd'][2]
+    # (backward workspace = the forward one + 2 * nseg * C floats for the reduced sums, as engine.batch_norm sizes it)
+    wsb = np.zeros(int(emu.fns['es_norm_workspace_floats'](n, C, P(seg), 1)) + 2 * C, np.float32)
+    val = dict(dy=P(dy), ldd=C, y=P(y), ldy=C, x=P(x), ldx=C, n=n, C=C, seg_off_host=P(seg), seg_off=P(seg), nseg=1, weight=P(w),
+               mean=P(mean), invstd=P(invstd), act=1, dweight=P(dw), dbias=P(db), accumulate=0, workspace=P(wsb), dx=P(dx), ldo=C,
+               dx_bf16=0, stream=0)
+    missing = [a for a in names if a not in val]
+    assert not missing, f'es_norm_bwd arguments this test does not know: {missing}'
+    emu('es_norm_bwd', *[val[a] for a in names])
