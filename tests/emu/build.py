@@ -2,9 +2,10 @@
 for x86 against the emulation shim (tests/emu/hip/hip_runtime.h) -- the same C ABI as libes_hip.so, operating on host
 pointers, every launch executed by the fiber scheduler of emu_runtime.cpp.  The product never loads it.
 
-The only source transformations: an occupancy attribute of the device compiler is dropped, the five `asm volatile("s_waitcnt ...")` statements of spconv.hip become no-ops (x86 cannot
+The only source transformations: an occupancy attribute of the device compiler is dropped, `extern __shared__ T x[]` becomes a
+pointer to the launch's dynamic-LDS buffer, the five `asm volatile("s_waitcnt ...")` statements of spconv.hip become no-ops (x86 cannot
 assemble them; the emulated LDS-DMA completes at issue) and the relative include of the public header is redirected.
-    python tests/emu/build.py [file.hip ...]        (default: spconv.hip rowops.hip)"""
+    python tests/emu/build.py [file.hip ...]        (default: every source of the Makefile)"""
 import os
 import re
 import subprocess
@@ -15,11 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'embodiedscan_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 CLANG = os.environ.get('ES_EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
-DEFAULT = ('spconv.hip', 'rowops.hip')
+DEFAULT = ('coords.hip', 'sort.hip', 'spconv.hip', 'rowops.hip', 'fusion.hip', 'targets.hip', 'losses.hip', 'optim.hip', 'data.hip',
+           'predict.hip', 'dense.hip', 'occ.hip', 'transformer.hip', 'ground.hip')
 
 
 def transform(text):
     text = re.sub(r'asm volatile\("s_waitcnt [^"]*"\s*::[^;]*\);', 'ES_EMU_WAITCNT();', text)
+    text = re.sub(r'extern\s+__shared__\s+([\w ]+?)\s+(\w+)\[\];', r'\1* \2 = (\1*)emu::dyn_shared();', text)    # dynamic LDS
     text = re.sub(r'__attribute__\(\(amdgpu_waves_per_eu\(\d+\)\)\)', '', text)       # (an occupancy hint of the device compiler)
     return text.replace('#include "../../include/es_hip.h"', '#include "es_hip.h"')
 
@@ -34,18 +37,20 @@ def build(files=DEFAULT, force=False):
         return lib
     flags = ['-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-w', '-I', HERE, '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
              '-ffp-contract=off']
-    objs = []
+    jobs = []
     for f in files:
         gen = os.path.join(OUT, f.replace('.hip', '_emu.cpp'))
         with open(os.path.join(CSRC, f)) as fh:
             text = transform(fh.read())
         with open(gen, 'w') as fh:
             fh.write(text)
-        obj = gen.replace('.cpp', '.o')
-        subprocess.check_call([CLANG] + flags + ['-c', gen, '-o', obj])
-        objs.append(obj)
+        jobs.append((gen, gen.replace('.cpp', '.o')))
     rt = os.path.join(OUT, 'emu_runtime.o')
-    subprocess.check_call([CLANG] + flags + ['-c', os.path.join(HERE, 'emu_runtime.cpp'), '-o', rt])
+    jobs.append((os.path.join(HERE, 'emu_runtime.cpp'), rt))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:       # (the compiler processes run in parallel)
+        list(ex.map(lambda j: subprocess.check_call([CLANG] + flags + ['-c', j[0], '-o', j[1]]), jobs))
+    objs = [o for _, o in jobs[:-1]]
     subprocess.check_call([CLANG, '-shared', '-fPIC'] + objs + [rt, '-o', lib])
     return lib
 

@@ -107,8 +107,11 @@ static bool runnable(const Fiber& f) {
 }
 
 static std::string g_log;
+static std::vector<unsigned char> g_dyn;
+void* dyn_shared() { return g_dyn.data(); }
 
-void launch(const char* name, dim3 grid, dim3 block, const std::function<void()>& body) {
+void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()>& body) {
+  if (g_dyn.size() < dyn_shared_bytes + 64) g_dyn.resize(dyn_shared_bytes + 64);
   const int nt = (int)(block.x * block.y * block.z);
   if (nt <= 0 || grid.x * (size_t)grid.y * grid.z == 0) return;
   if (g_log.size() < (1u << 20)) {

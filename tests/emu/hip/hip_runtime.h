@@ -56,6 +56,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 #define hipMemcpyDeviceToDevice 3
 #define hipMemcpyDeviceToHost 2
 #define hipMemcpyHostToDevice 1
@@ -66,7 +68,8 @@ extern Fiber* g_cur;
 extern dim3 g_block_idx, g_block_dim, g_grid_dim;
 const uint3& tid();
 int lane();
-void launch(const char* name, dim3 grid, dim3 block, const std::function<void()>& body);
+void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()>& body);
+void* dyn_shared();      // the launch's dynamic LDS (`extern __shared__ T name[]` is rewritten to `T* name = (T*)emu::dyn_shared()`)
 void block_barrier();
 // wave rendezvous: every live lane of the wave deposits `bytes` bytes; returns the wave's exchange area (64 slots of 64 bytes)
 // valid until the lane's next wave operation
@@ -79,7 +82,7 @@ unsigned long long wave_live_mask();
 #define blockDim (emu::g_block_dim)
 #define gridDim (emu::g_grid_dim)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  emu::launch(#kernel, dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+  emu::launch(#kernel, dim3(grid), dim3(block), (size_t)(shmem), [=]() { kernel(__VA_ARGS__); })
 
 static inline void __syncthreads() { emu::block_barrier(); }
 static inline void __threadfence() {}
@@ -109,6 +112,17 @@ static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T>
 static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 
+// IEEE single operations that must not be contracted into FMAs (integer decisions depend on them): plain operators here, the
+// emulated build is compiled with -ffp-contract=off
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fsub_rn(float a, float b) { return a - b; }
+static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
+#define __expf(x) expf(x)          // (fast-math intrinsics of the device: the tolerances of the callers' tests cover the difference)
+#define __logf(x) logf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+template <class T>
+static inline T unsafeAtomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
