@@ -232,3 +232,111 @@ def _norm_bwd(emu, dy, y, x, n, C, seg, w, mean, invstd, ws, dw, db, dx):
     missing = [a for a in names if a not in val]
     assert not missing, f'es_norm_bwd arguments this test does not know: {missing}'
     emu('es_norm_bwd', *[val[a] for a in names])
+
+
+def test_radix_sort_and_topk_and_column_sums(emu):
+    """the hand-written LSD radix sort (stable, int payload), the per-segment top-k mask -- single-workgroup kernel and the
+    multi-workgroup histogram / election variant on one shared workspace with changing segment counts -- and the deterministic
+    column sums with their last-workgroup election"""
+    rng = np.random.default_rng(21)
+    for n in (1, 77, 5000, 70000):
+        keys = rng.integers(0, 1 << 40, n).astype(np.int64)
+        keys[rng.integers(0, n, n // 3)] = keys[0]                      # duplicates: stability matters
+        src = np.arange(n, dtype=np.int32)[::-1].copy()
+        nb = int(emu.fns['es_sort_scratch_bytes'](n))
+        scratch = np.zeros(nb + 64, np.uint8)
+        ok, os_ = np.zeros(n, np.int64), np.zeros(n, np.int32)
+        emu('es_sort_u64', P(keys), P(src), n, P(scratch), nb, P(ok), P(os_), 0)
+        order = np.argsort(keys, kind='stable')
+        assert np.array_equal(ok, keys[order]) and np.array_equal(os_, src[order]), n
+    nw = int(emu.fns['es_topk_mask_workspace_ints'](1))
+    ws = np.zeros(nw, np.int32)                                        # ONE workspace for every call below (fixed layout)
+    for seg_sizes, k in (((3000,), 1000), ((50, 0, 1200, 999), 300), ((40000,), 10000), ((5,), 10)):
+        off = np.concatenate([[0], np.cumsum(seg_sizes)]).astype(np.int32)
+        n = int(off[-1])
+        v = rng.standard_normal(n).astype(np.float32)
+        v[rng.integers(0, n, n // 4)] = v[0]                            # ties: the lower index wins
+        v[rng.integers(0, n, 5)] = -0.0
+        want = np.zeros(n, np.int32)
+        for s in range(len(seg_sizes)):
+            a, b = off[s], off[s + 1]
+            idx = np.lexsort((np.arange(b - a), -v[a:b].astype(np.float64)))[:k]
+            want[a + idx] = 1
+        m1, m2 = np.full(n, -1, np.int32), np.full(n, -1, np.int32)
+        emu('es_topk_mask', P(v), P(off), len(seg_sizes), k, P(m1), 0)
+        emu('es_topk_mask_ws', P(v), P(off), len(seg_sizes), k, P(m2), P(ws), nw, 0)
+        assert np.array_equal(m1, want), (seg_sizes, k)
+        assert np.array_equal(m2, want), (seg_sizes, k)
+    for n, C in ((1, 8), (700, 64), (20000, 24), (100000, 4)):
+        g = rng.standard_normal((n, C + 4)).astype(np.float32)[:, :C]   # strided rows
+        ld = g.strides[0] // 4
+        nf = int(emu.fns['es_colsum_workspace_floats'](n, C))
+        w = np.zeros(nf, np.float32)
+        dst = np.full(C, 7.0, np.float32)
+        emu('es_colsum', P(g), ld, n, C, P(dst), 1, P(w), nf, 0)
+        emu('es_colsum', P(g), ld, n, C, P(dst), 1, P(w), nf, 0)        # same workspace again: the ticket was left at zero
+        want = 7.0 + 2 * g.astype(np.float64).sum(0)
+        assert np.abs(dst - want).max() <= 2e-6 * np.abs(g).sum(0).max(), (n, C)
+        assert not w[:4].view(np.int32).any()
+
+
+def test_layernorm_and_attention(emu):
+    rng = np.random.default_rng(31)
+    n, C = 700, 256
+    x, res = rng.standard_normal((n, C)).astype(np.float32), rng.standard_normal((n, C)).astype(np.float32)
+    w, b = (rng.random(C) + 0.5).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    y, z = np.zeros((n, C), np.float32), np.zeros((n, C), np.float32)
+    mean, rstd = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    emu('es_layernorm_fwd', P(x), P(res), n, C, P(w), P(b), 1e-5, P(y), P(z), P(mean), P(rstd), 0)
+    z64 = x.astype(np.float64) + res
+    m, v = z64.mean(1, keepdims=True), z64.var(1, keepdims=True)
+    xh = (z64 - m) / np.sqrt(v + 1e-5)
+    assert np.abs(y - (xh * w + b)).max() < 1e-5 and np.array_equal(z, (x + res))
+    dy = rng.standard_normal((n, C)).astype(np.float32)
+    nf = int(emu.fns['es_layernorm_bwd_workspace_floats'](n, C))
+    ws = np.zeros(nf, np.float32)
+    dz, dw, db = np.zeros((n, C), np.float32), np.zeros(C, np.float32), np.zeros(C, np.float32)
+    for _ in range(2):                                                  # dw / db accumulate (+=); the workspace is reused
+        emu('es_layernorm_bwd', P(dy), P(z), n, C, P(w), P(mean), P(rstd), P(dz), 0, P(dw), P(db), P(ws), nf, 0)
+    g = dy.astype(np.float64) * w
+    dzt = (g - g.mean(1, keepdims=True) - xh * (g * xh).mean(1, keepdims=True)) / np.sqrt(v + 1e-5)
+    assert np.abs(dz - dzt).max() < 2e-5
+    assert np.abs(dw - 2 * (dy * xh).sum(0)).max() < 1e-3 and np.abs(db - 2 * dy.astype(np.float64).sum(0)).max() < 1e-3
+    assert not ws[:4].view(np.int32).any()
+    # attention core: head_dim 32, prefix key masks, both matrix-core types
+    B, H, Lq, Lk = 2, 4, 70, 150
+    D = 32 * H
+    Q, K, V = (rng.standard_normal((B * L, D)).astype(np.float32) for L in (Lq, Lk, Lk))
+    klen = np.array([Lk, 37], np.int32)
+    want = np.zeros((B * Lq, D))
+    for bb in range(B):
+        for h in range(H):
+            q = Q[bb * Lq:(bb + 1) * Lq, 32 * h:32 * h + 32].astype(np.float64)
+            k = K[bb * Lk:bb * Lk + klen[bb], 32 * h:32 * h + 32].astype(np.float64)
+            vv = V[bb * Lk:bb * Lk + klen[bb], 32 * h:32 * h + 32].astype(np.float64)
+            s = q @ k.T / np.sqrt(32.0)
+            p = np.exp(s - s.max(1, keepdims=True))
+            want[bb * Lq:(bb + 1) * Lq, 32 * h:32 * h + 32] = (p / p.sum(1, keepdims=True)) @ vv
+    for bf16, tol in ((0, 2e-5), (1, 2e-2)):
+        O, lse = np.zeros((B * Lq, D), np.float32), np.zeros((B, H, Lq), np.float32)
+        emu('es_attn_fwd', P(Q), D, P(K), D, P(V), D, B, H, Lq, Lk, P(klen), P(O), D, P(lse), bf16, 0)
+        assert np.abs(O - want).max() < tol * max(1.0, np.abs(want).max()), (bf16, np.abs(O - want).max())
+
+
+def test_device_point_sample_keys_follow_the_restated_generator(emu):
+    """es_draw_keys (N4, counter-based PointSample draws) against oracle/draws.py: key per pixel, -1 for zero depth, the 64-bit
+    sort key layout view << 54 | (2^30 - 1 - key) << 24 | pixel"""
+    from oracle import draws as OD
+    rng = np.random.default_rng(41)
+    V, HW, seed = 3, 5000, 123456789
+    depth = rng.random((V, HW)).astype(np.float32)
+    depth[rng.random((V, HW)) < 0.2] = 0
+    values, keys = np.zeros((V, HW), np.float32), np.zeros((V, HW), np.int64)
+    emu('es_draw_keys', P(depth), V, HW, seed, P(values), P(keys), 0)
+    pix = np.arange(HW, dtype=np.int64)
+    for v in range(V):
+        k30 = OD.key30(seed, v, pix)
+        ok = depth[v] != 0
+        assert np.all(values[v][~ok] == -1)
+        assert np.array_equal(keys[v][ok], (np.int64(v) << 54) | ((np.int64((1 << 30) - 1) - k30[ok]) << 24) | pix[ok])
+        assert np.array_equal(np.argsort(-values[v][ok].astype(np.float64), kind='stable'), np.argsort(-k30[ok], kind='stable'))
