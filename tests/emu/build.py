@@ -3,8 +3,8 @@ for x86 against the emulation shim (tests/emu/hip/hip_runtime.h) -- the same C A
 pointers, every launch executed by the fiber scheduler of emu_runtime.cpp.  The product never loads it.
 
 The only source transformations: an occupancy attribute of the device compiler is dropped, `extern __shared__ T x[]` becomes a
-pointer to the launch's dynamic-LDS buffer, the five `asm volatile("s_waitcnt ...")` statements of spconv.hip become no-ops (x86 cannot
-assemble them; the emulated LDS-DMA completes at issue) and the relative include of the public header is redirected.
+pointer to the launch's dynamic-LDS buffer, the five `asm volatile("s_waitcnt ...")` statements of spconv.hip become calls that retire
+the emulated LDS-DMA queue (x86 cannot assemble them) and the relative include of the public header is redirected.
     python tests/emu/build.py [file.hip ...]        (default: every source of the Makefile)"""
 import os
 import re
@@ -21,7 +21,10 @@ DEFAULT = ('coords.hip', 'sort.hip', 'spconv.hip', 'rowops.hip', 'fusion.hip', '
 
 
 def transform(text):
-    text = re.sub(r'asm volatile\("s_waitcnt [^"]*"\s*::[^;]*\);', 'ES_EMU_WAITCNT();', text)
+    text = re.sub(r'asm volatile\("s_waitcnt vmcnt\(%0\)"\s*::\s*"n"\((\w+)\)\s*:\s*"memory"\);', r'ES_EMU_WAITCNT_VM(\1);', text)
+    text = re.sub(r'asm volatile\("s_waitcnt vmcnt\((\d+)\)"\s*:::\s*"memory"\);', r'ES_EMU_WAITCNT_VM(\1);', text)
+    text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(\d+\)"\s*:::\s*"memory"\);', 'ES_EMU_WAITCNT_NONE();', text)
+    assert 'asm volatile' not in text, 'an inline-asm statement the emulation build does not know'
     text = re.sub(r'extern\s+__shared__\s+([\w ]+?)\s+(\w+)\[\];', r'\1* \2 = (\1*)emu::dyn_shared();', text)    # dynamic LDS
     text = re.sub(r'__attribute__\(\(amdgpu_waves_per_eu\(\d+\)\)\)', '', text)       # (an occupancy hint of the device compiler)
     return text.replace('#include "../../include/es_hip.h"', '#include "es_hip.h"')
@@ -32,6 +35,7 @@ def build(files=DEFAULT, force=False):
     lib = os.path.join(OUT, 'libes_emu_test.so')
     srcs = [os.path.join(CSRC, f) for f in files] + [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'es_hip.h'),
                                                      os.path.join(HERE, 'hip', 'hip_runtime.h'), os.path.join(HERE, 'emu_runtime.cpp'),
+                                                     os.path.join(HERE, 'selftest_kernels.cpp'),
                                                      os.path.abspath(__file__)]
     if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
         return lib
@@ -45,6 +49,7 @@ def build(files=DEFAULT, force=False):
         with open(gen, 'w') as fh:
             fh.write(text)
         jobs.append((gen, gen.replace('.cpp', '.o')))
+    jobs.append((os.path.join(HERE, 'selftest_kernels.cpp'), os.path.join(OUT, 'selftest_kernels.o')))
     rt = os.path.join(OUT, 'emu_runtime.o')
     jobs.append((os.path.join(HERE, 'emu_runtime.cpp'), rt))
     from concurrent.futures import ThreadPoolExecutor

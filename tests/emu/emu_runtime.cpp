@@ -17,6 +17,8 @@ struct Wave {
   unsigned long long live_mask = 0;
 };
 
+struct Dma { void* dst; const void* src; int bytes; };
+
 struct Fiber {
   ucontext_t ctx;
   uint3 tid;
@@ -25,6 +27,7 @@ struct Fiber {
   int wait = 0;                        // 0 runnable, 1 block barrier, 2 wave operation
   long long wait_gen = 0;              // barrier generation / wave operation number waited for
   long long wave_ops = 0;              // wave operations this lane has entered
+  std::vector<Dma> dma;                // lazy mode: LDS-DMA pieces issued and not yet retired (oldest first)
 };
 
 Fiber* g_cur = nullptr;
@@ -44,6 +47,23 @@ int lane() { return g_cur->lane; }
 unsigned long long wave_live_mask() { return g_waves[g_cur->wave].live_mask; }
 
 static void yield() { swapcontext(&g_cur->ctx, &g_sched); }
+
+static int g_dma_lazy = 0;
+void dma_issue(void* dst, const void* src, int bytes) {
+  if (!g_dma_lazy) {
+    memcpy(dst, src, (size_t)bytes);
+    return;
+  }
+  g_cur->dma.push_back(Dma{dst, src, bytes});
+}
+void waitcnt_vm(int n) {
+  std::vector<Dma>& q = g_cur->dma;
+  const size_t keep = n < 0 ? 0 : (size_t)n;
+  if (q.size() <= keep) return;
+  const size_t retire = q.size() - keep;
+  for (size_t i = 0; i < retire; ++i) memcpy(q[i].dst, q[i].src, (size_t)q[i].bytes);
+  q.erase(q.begin(), q.begin() + (long)retire);
+}
 
 void block_barrier() {
   Fiber* f = g_cur;
@@ -81,6 +101,7 @@ const unsigned char* wave_exchange(const void* mine, int bytes) {
 
 static void trampoline() {
   (*g_body)();
+  waitcnt_vm(0);                        // (s_endpgm waits for outstanding memory operations)
   Fiber* f = g_cur;
   f->done = true;
   // a thread that has left no longer takes part in barriers / wave operations: release what now only waited for it
@@ -108,6 +129,12 @@ static bool runnable(const Fiber& f) {
 
 static std::string g_log;
 static std::vector<unsigned char> g_dyn;
+// Order in which the runnable threads of a workgroup get the processor between synchronisation points: 0 ascending, 1 descending,
+// 2 random.  A kernel whose result depends on it is missing a barrier (or races on LDS / global memory inside a workgroup):
+// the tests run every kernel under several orders and require identical results.
+static int g_order = 0;
+static unsigned long long g_rng = 1;
+static std::vector<int> g_perm;
 void* dyn_shared() { return g_dyn.data(); }
 
 void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()>& body) {
@@ -142,6 +169,8 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
       for (unsigned bx = 0; bx < grid.x; ++bx) {
         g_block_idx = dim3(bx, by, bz);
         g_fibers.assign((size_t)nt, Fiber());
+        g_perm.resize((size_t)nt);
+        for (int t = 0; t < nt; ++t) g_perm[(size_t)t] = t;
         g_waves.assign((size_t)nw, Wave());
         g_bar_gen = 0;
         g_bar_arrived = 0;
@@ -162,7 +191,14 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
         int done = 0;
         while (done < nt) {
           bool progressed = false;
-          for (int t = 0; t < nt; ++t) {
+          if (g_order == 2) {                                      // a fresh random order of the fibers in every scheduling round
+            for (int i = nt - 1; i > 0; --i) {
+              g_rng = g_rng * 6364136223846793005ull + 1442695040888963407ull;
+              std::swap(g_perm[(size_t)i], g_perm[(size_t)((g_rng >> 33) % (unsigned long long)(i + 1))]);
+            }
+          }
+          for (int q = 0; q < nt; ++q) {
+            const int t = g_order == 0 ? q : (g_order == 1 ? nt - 1 - q : g_perm[(size_t)q]);
             Fiber& f = g_fibers[(size_t)t];
             if (!runnable(f)) continue;
             f.wait = 0;
@@ -183,6 +219,13 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
 }
 
 }  // namespace emu
+
+extern "C" void es_emu_set_dma_mode(int lazy) { emu::g_dma_lazy = lazy; }
+
+extern "C" void es_emu_set_schedule(int order, unsigned long long seed) {
+  emu::g_order = order;
+  emu::g_rng = seed * 2 + 1;
+}
 
 // the launches since the last call, one per line ("<kernel expression> grid=(x,y,z) block=n"): lets a test assert WHICH kernel
 // a dispatch function chose; returns the number of bytes written (truncated to cap - 1) and clears the log

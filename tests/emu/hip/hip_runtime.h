@@ -69,7 +69,12 @@ extern dim3 g_block_idx, g_block_dim, g_grid_dim;
 const uint3& tid();
 int lane();
 void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, const std::function<void()>& body);
-void* dyn_shared();      // the launch's dynamic LDS (`extern __shared__ T name[]` is rewritten to `T* name = (T*)emu::dyn_shared()`)
+void* dyn_shared();
+// LDS-DMA pieces of the calling lane.  Mode 0 (eager): the copy happens at issue.  Mode 1 (lazy): it is queued and happens as
+// LATE as the program allows -- when an s_waitcnt vmcnt(n) retires it (oldest first, until n remain) or the thread ends: a
+// kernel that reads a tile before waiting for it sees stale LDS and fails its parity test
+void dma_issue(void* lds_dst, const void* src, int bytes);
+void waitcnt_vm(int n);      // the launch's dynamic LDS (`extern __shared__ T name[]` is rewritten to `T* name = (T*)emu::dyn_shared()`)
 void block_barrier();
 // wave rendezvous: every live lane of the wave deposits `bytes` bytes; returns the wave's exchange area (64 slots of 64 bytes)
 // valid until the lane's next wave operation
@@ -87,9 +92,10 @@ unsigned long long wave_live_mask();
 static inline void __syncthreads() { emu::block_barrier(); }
 static inline void __threadfence() {}
 #define __builtin_amdgcn_s_barrier() emu::block_barrier()
-#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) emu::waitcnt_vm(0)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-#define ES_EMU_WAITCNT(...) ((void)0)
+#define ES_EMU_WAITCNT_VM(n) emu::waitcnt_vm((n))     // build.py: asm volatile("s_waitcnt vmcnt(n)") -> this
+#define ES_EMU_WAITCNT_NONE() ((void)0)               // ... lgkmcnt-only waits: LDS reads are synchronous here
 
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
@@ -229,7 +235,7 @@ static inline emu_f32x4 emu_mfma_16x16x4_f32(float a, float b, emu_f32x4 c) {
 // LDS-DMA: the LDS operand is the wave-uniform base, lane l lands at base + size * l
 template <class G, class L>
 static inline void emu_global_load_lds(G g, L lds, int size, int offset, int) {
-  memcpy((unsigned char*)(uintptr_t)lds + offset + (size_t)size * emu::lane(), (const void*)(uintptr_t)g, (size_t)size);
+  emu::dma_issue((unsigned char*)(uintptr_t)lds + offset + (size_t)size * emu::lane(), (const void*)(uintptr_t)g, size);
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((g), (l), (size), (off), (aux))
 

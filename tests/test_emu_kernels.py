@@ -16,11 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
 
 
-@pytest.fixture(scope='module')
-def emu():
+@pytest.fixture(scope='module', params=['ascending', 'descending', 'random'])
+def emu(request):
+    """the emulated library under one of three thread schedules: between two synchronisation points the threads of a workgroup
+    run in ascending, descending or random order -- a kernel that is missing a barrier gives different results under them"""
     import build as emu_build
     from embodiedscan_amd import hip
     lib = ctypes.CDLL(emu_build.build())
+    lib.es_emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_ulonglong]
+    lib.es_emu_set_schedule(['ascending', 'descending', 'random'].index(request.param), 12345)
     fns = {}
     for name, (ret, at, _) in hip.PROTOS.items():
         f = getattr(lib, name, None)
@@ -37,8 +41,35 @@ def emu():
         buf = ctypes.create_string_buffer(1 << 16)
         lib.es_emu_take_launch_log(buf, len(buf))
         return [ln.split(' grid=')[0] for ln in buf.value.decode().splitlines()]
-    call.fns, call.launches = fns, launches
+    call.fns, call.launches, call.lib, call.schedule = fns, launches, lib, request.param
     return call
+
+
+def test_the_emulator_catches_a_missing_wait_and_a_missing_barrier(emu):
+    """the two failure classes the emulator exists to catch, on deliberately breakable kernels (tests/emu/selftest_kernels.cpp):
+    LDS read before its LDS-DMA was waited for (seen with late DMA delivery), LDS exchange without a barrier (seen under at
+    least one thread schedule); the correct variants pass under every mode"""
+    lib = emu.lib
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, 3 * 4096).astype(np.uint8)
+    src[src == 0xEE] = 1
+    for lazy in (0, 1):
+        lib.es_emu_set_dma_mode(lazy)
+        for wait in (1, 0):
+            dst = np.zeros_like(src)
+            lib.es_emu_selftest_dma(ctypes.c_void_p(P(src)), ctypes.c_void_p(P(dst)), 3, wait)
+            good = np.array_equal(dst, src)
+            assert good == (wait == 1 or lazy == 0), (lazy, wait)          # the missing wait is invisible with eager delivery,
+    lib.es_emu_set_dma_mode(0)                                             # caught with late delivery
+    a = rng.integers(0, 1000, 2 * 256).astype(np.int32)
+    want = np.concatenate([np.roll(a[i:i + 256], -1) + np.roll(a[i:i + 256], 1) for i in (0, 256)])
+    for barrier in (1, 0):
+        out = np.zeros_like(a)
+        lib.es_emu_selftest_barrier(ctypes.c_void_p(P(a)), ctypes.c_void_p(P(out)), 2, barrier)
+        if barrier:
+            assert np.array_equal(out, want)
+        else:
+            assert not np.array_equal(out, want), emu.schedule             # every schedule runs SOME reader before its writer
 
 
 def P(a):
@@ -84,7 +115,7 @@ def test_weight_cast_layouts(emu):
     assert np.array_equal(nat, bf16_bits(w)) and np.array_equal(tr, bf16_bits(w).transpose(0, 2, 1))
 
 
-@pytest.mark.parametrize('dma', [0, 2])
+@pytest.mark.parametrize('dma', [0, 1, 2, 3])
 def test_sparse_conv_forward_on_the_emulated_matrix_cores(emu, dma):
     """27-tap gather convolution, bf16 rows: the register-staged ping-pong kernel (option 10 = 0) and the LDS-DMA kernel with
     64-channel chunks (10 = 2, every width) against f64 on the rounded operands; a ragged last row tile, absent neighbours, a
@@ -93,7 +124,8 @@ def test_sparse_conv_forward_on_the_emulated_matrix_cores(emu, dma):
     emu('es_set_option', 10, dma)
     emu('es_set_option', 11, 0)
     try:
-        for n_out, n_in, K, cin, cout, fill in ((300, 280, 27, 64, 128, 0.3), (130, 130, 27, 128, 64, 0.5), (77, 90, 8, 64, 64, 0.9)):
+        for lazy, (n_out, n_in, K, cin, cout, fill) in [(lz, c) for lz in ((0, 1) if dma else (0,)) for c in ((300, 280, 27, 64, 128, 0.3), (130, 130, 27, 128, 64, 0.5), (77, 90, 8, 64, 64, 0.9))]:
+            emu.lib.es_emu_set_dma_mode(lazy)                       # LDS-DMA delivered at issue / as late as the waits allow
             nbr = _map(rng, n_out, n_in, K, fill)
             nbr[:, 5 % K] = -1                                   # a tap nobody uses
             x = rng.standard_normal((n_in, cin)).astype(np.float32)
@@ -125,6 +157,7 @@ def test_sparse_conv_forward_on_the_emulated_matrix_cores(emu, dma):
                 assert np.abs(y3 - want).max() / scale < 2e-6
                 assert not ws[:1024].view(np.int32).any()        # the tile tickets are left at zero
     finally:
+        emu.lib.es_emu_set_dma_mode(0)
         emu('es_set_option', 10, 2)
         emu('es_set_option', 11, 768)
 
@@ -154,7 +187,10 @@ def test_weight_gradient_tiles(emu):
     """dW[k] = X[nbr[:, k]]^T dY through the bf16 weight-gradient kernels (64 x 64 tile, 128 x 128 tile, and the LDS-DMA +
     transposed-read tile whose lane mapping was probed on the GPU) -- row slices through the workspace included"""
     rng = np.random.default_rng(11)
-    for n_out, n_in, K, cin, cout, tr in ((700, 650, 27, 64, 64, 0), (900, 900, 8, 128, 128, 0), (900, 900, 8, 128, 128, 1)):
+    for n_out, n_in, K, cin, cout, tr in ((700, 650, 27, 64, 64, 0), (900, 900, 8, 128, 128, 0), (900, 900, 8, 128, 128, 1),
+                                          (900, 900, 8, 128, 128, 2)):
+        emu.lib.es_emu_set_dma_mode(1 if tr == 2 else 0)            # the transposed-read tile stages by LDS-DMA: also with late delivery
+        tr = min(tr, 1)
         emu('es_set_option', 14, tr)
         nbr = _map(rng, n_out, n_in, K, 0.4)
         x = rng.standard_normal((n_in, cin)).astype(np.float32)
@@ -176,6 +212,7 @@ def test_weight_gradient_tiles(emu):
         assert any(kind in k for k in ran), (kind, ran)
         err = np.abs(dw - want).max() / np.abs(want).max()
         assert err < 3e-6, (cin, cout, tr, err)
+    emu.lib.es_emu_set_dma_mode(0)
     emu('es_set_option', 14, 1)
 
 
