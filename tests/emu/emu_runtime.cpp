@@ -9,10 +9,11 @@
 namespace emu {
 
 struct Wave {
-  unsigned char xchg[2][64 * 64];      // two exchange areas (operation k uses k & 1): a lane that has left operation k may already
-                                       // deposit for k + 1 while a slower lane still reads k
-  long long released = 0;              // wave operations completed so far
-  int arrived = 0;                     // lanes waiting in operation number `released`
+  unsigned char deposit[64 * 64];      // operands of the lanes currently waiting in a wave operation (one 64-byte slot per lane)
+  unsigned char snap[2][64 * 64];      // what a released group reads: the deposit area at the moment of its release (two of them:
+                                       // a released lane may deposit for its NEXT operation while a slower lane of the group still reads)
+  unsigned long long snap_mask[2] = {0, 0};   // lanes that took part in that release (EXEC mask of the operation)
+  long long gen = 0;                   // releases so far
   int alive = 0;
   unsigned long long live_mask = 0;
 };
@@ -24,9 +25,10 @@ struct Fiber {
   uint3 tid;
   int lane = 0, wave = 0;
   bool done = false;
-  int wait = 0;                        // 0 runnable, 1 block barrier, 2 wave operation
-  long long wait_gen = 0;              // barrier generation / wave operation number waited for
-  long long wave_ops = 0;              // wave operations this lane has entered
+  int wait = 0;                        // 0 runnable, 1 block barrier, 2 wave operation (not yet released)
+  long long wait_gen = 0;              // barrier generation waited for
+  const void* site = nullptr;          // wave operation: the call site this lane waits at
+  int snap = 0;                        // ... and, once released, which snapshot it reads
   std::vector<Dma> dma;                // lazy mode: LDS-DMA pieces issued and not yet retired (oldest first)
 };
 
@@ -44,7 +46,6 @@ static const size_t STACK = 192 * 1024;
 
 const uint3& tid() { return g_cur->tid; }
 int lane() { return g_cur->lane; }
-unsigned long long wave_live_mask() { return g_waves[g_cur->wave].live_mask; }
 
 static void yield() { swapcontext(&g_cur->ctx, &g_sched); }
 
@@ -77,26 +78,60 @@ void block_barrier() {
   yield();
 }
 
-const unsigned char* wave_exchange(const void* mine, int bytes) {
+// Wave operations under divergence.  The hardware runs a wave in lockstep under an EXEC mask: lanes that skipped a branch do not
+// take part in the shuffles inside it (a quad reduction inside `if (active)` is legal when the four lanes of a quad agree).  Here
+// every lane is a fiber, so the lanes inside the branch wait at ITS call site while the others run ahead to a later one.  Rule:
+// when every live lane of the wave waits at the same site, they are released together (the common case); when every live lane
+// is blocked but at DIFFERENT sites, the group at the lowest code address goes first with only its lanes active (structured
+// code lays the body of a branch / loop out before what follows it) -- reads from a lane outside the group return zeros.
+static void release_group(Wave& w, int wave_index, const void* site) {
+  const int idx = (int)(w.gen & 1);
+  memcpy(w.snap[idx], w.deposit, sizeof w.deposit);
+  unsigned long long mask = 0;
+  for (int l = 0; l < 64; ++l) {
+    const size_t t = (size_t)wave_index * 64 + (size_t)l;
+    if (t >= g_fibers.size()) break;
+    Fiber& f = g_fibers[t];
+    if (!f.done && f.wait == 2 && f.site == site) {
+      f.wait = 0;
+      f.snap = idx;
+      mask |= 1ull << l;
+    }
+  }
+  for (int l = 0; l < 64; ++l)
+    if (!((mask >> l) & 1ull)) memset(w.snap[idx] + 64 * l, 0, 64);
+  w.snap_mask[idx] = mask;
+  ++w.gen;
+}
+
+// all = true: only if every live lane of the wave waits in a wave operation; false (the scheduler found nothing runnable): also
+// when the other live lanes are stuck elsewhere.  Returns whether a group was released.
+static bool try_release(int wave_index, bool all) {
+  Wave& w = g_waves[(size_t)wave_index];
+  const void* lowest = nullptr;
+  int waiting = 0;
+  for (int l = 0; l < 64; ++l) {
+    const size_t t = (size_t)wave_index * 64 + (size_t)l;
+    if (t >= g_fibers.size()) break;
+    const Fiber& f = g_fibers[t];
+    if (f.done || f.wait != 2) continue;
+    ++waiting;
+    if (lowest == nullptr || (uintptr_t)f.site < (uintptr_t)lowest) lowest = f.site;
+  }
+  if (waiting == 0 || (all && waiting != w.alive)) return false;
+  release_group(w, wave_index, lowest);
+  return true;
+}
+
+WaveView wave_exchange(const void* site, const void* mine, int bytes) {
   Fiber* f = g_cur;
-  Wave& w = g_waves[f->wave];
-  const long long op = f->wave_ops++;
-  if (op != w.released) {
-    fprintf(stderr, "emu: lane %d of wave %d enters wave operation %lld while the wave is at %lld (divergent wave operations)\n",
-            f->lane, f->wave, op, w.released);
-    abort();
-  }
-  unsigned char* area = w.xchg[op & 1];
-  memcpy(area + 64 * f->lane, mine, (size_t)bytes);
-  if (++w.arrived == w.alive) {
-    w.arrived = 0;
-    ++w.released;
-    return area;
-  }
+  Wave& w = g_waves[(size_t)f->wave];
+  memcpy(w.deposit + 64 * f->lane, mine, (size_t)bytes);
   f->wait = 2;
-  f->wait_gen = op;
-  yield();
-  return area;
+  f->site = site;
+  try_release(f->wave, true);
+  if (f->wait == 2) yield();
+  return WaveView{w.snap[f->snap], w.snap_mask[f->snap]};
 }
 
 static void trampoline() {
@@ -113,10 +148,7 @@ static void trampoline() {
     g_bar_arrived = 0;
     ++g_bar_gen;
   }
-  if (w.alive > 0 && w.arrived == w.alive) {
-    w.arrived = 0;
-    ++w.released;
-  }
+  if (w.alive > 0) try_release(f->wave, true);
   swapcontext(&f->ctx, &g_sched);
 }
 
@@ -124,7 +156,7 @@ static bool runnable(const Fiber& f) {
   if (f.done) return false;
   if (f.wait == 0) return true;
   if (f.wait == 1) return g_bar_gen > f.wait_gen;
-  return g_waves[f.wave].released > f.wait_gen;
+  return false;                        // (a lane in a wave operation is made runnable by release_group)
 }
 
 static std::string g_log;
@@ -208,7 +240,9 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
             progressed = true;
             if (f.done) ++done;
           }
-          if (!progressed) {
+          if (!progressed) {                                       // divergent wave operations: let the earliest group go
+            for (int wv = 0; wv < nw; ++wv) progressed = try_release(wv, false) || progressed;
+            if (progressed) continue;
             fprintf(stderr, "emu: deadlock in block (%u, %u, %u): %d of %d threads finished; the rest wait at a barrier / wave "
                     "operation the others never reach (divergent __syncthreads or a partial-wave shuffle)\n", bx, by, bz, done, nt);
             abort();

@@ -76,10 +76,11 @@ void* dyn_shared();
 void dma_issue(void* lds_dst, const void* src, int bytes);
 void waitcnt_vm(int n);      // the launch's dynamic LDS (`extern __shared__ T name[]` is rewritten to `T* name = (T*)emu::dyn_shared()`)
 void block_barrier();
-// wave rendezvous: every live lane of the wave deposits `bytes` bytes; returns the wave's exchange area (64 slots of 64 bytes)
-// valid until the lane's next wave operation
-const unsigned char* wave_exchange(const void* mine, int bytes);
-unsigned long long wave_live_mask();
+// wave rendezvous at call site `site`: the lane deposits `bytes` (<= 64) bytes and waits for the lanes that execute the same
+// operation with it; returns their operands (64 slots of 64 bytes; zeros for lanes that do not take part) and the mask of the
+// participating lanes, valid until the lane's next wave operation.  Divergence: see emu_runtime.cpp.
+struct WaveView { const unsigned char* slots; unsigned long long mask; };
+WaveView wave_exchange(const void* site, const void* mine, int bytes);
 }  // namespace emu
 
 #define threadIdx (emu::tid())
@@ -143,46 +144,48 @@ static inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
 static inline long long min(long long a, int b) { return a < b ? a : b; }
 static inline long long max(long long a, int b) { return a > b ? a : b; }
 
+// Every wave operation below is a NON-inlined function: its return address identifies the call site in the kernel, which is
+// what lanes rendezvous on (emu_runtime.cpp).
+#define ES_EMU_WAVEOP __attribute__((noinline))
 template <class T>
-static inline T __shfl(T v, int src, int width = 64) {
+ES_EMU_WAVEOP T __shfl(T v, int src, int width = 64) {
   static_assert(sizeof(T) <= 64, "exchange slot");
-  const unsigned char* x = emu::wave_exchange(&v, (int)sizeof(T));
+  const emu::WaveView x = emu::wave_exchange(__builtin_return_address(0), &v, (int)sizeof(T));
   const int l = emu::lane(), base = l & ~(width - 1);
   T r;
-  memcpy(&r, x + 64 * (base + (src & (width - 1))), sizeof(T));
+  memcpy(&r, x.slots + 64 * (base + (src & (width - 1))), sizeof(T));
   return r;
 }
 template <class T>
-static inline T __shfl_xor(T v, int mask, int width = 64) {
-  const unsigned char* x = emu::wave_exchange(&v, (int)sizeof(T));
+ES_EMU_WAVEOP T __shfl_xor(T v, int mask, int width = 64) {
+  const emu::WaveView x = emu::wave_exchange(__builtin_return_address(0), &v, (int)sizeof(T));
   const int l = emu::lane(), src = l ^ mask;
   T r = v;
-  if ((src & ~(width - 1)) == (l & ~(width - 1))) memcpy(&r, x + 64 * src, sizeof(T));
+  if ((src & ~(width - 1)) == (l & ~(width - 1))) memcpy(&r, x.slots + 64 * src, sizeof(T));
   return r;
 }
 template <class T>
-static inline T __shfl_up(T v, unsigned delta, int width = 64) {
-  const unsigned char* x = emu::wave_exchange(&v, (int)sizeof(T));
+ES_EMU_WAVEOP T __shfl_up(T v, unsigned delta, int width = 64) {
+  const emu::WaveView x = emu::wave_exchange(__builtin_return_address(0), &v, (int)sizeof(T));
   const int l = emu::lane(), src = l - (int)delta;
   T r = v;
-  if (src >= (l & ~(width - 1))) memcpy(&r, x + 64 * src, sizeof(T));
+  if (src >= (l & ~(width - 1))) memcpy(&r, x.slots + 64 * src, sizeof(T));
   return r;
 }
 template <class T>
-static inline T __shfl_down(T v, unsigned delta, int width = 64) {
-  const unsigned char* x = emu::wave_exchange(&v, (int)sizeof(T));
+ES_EMU_WAVEOP T __shfl_down(T v, unsigned delta, int width = 64) {
+  const emu::WaveView x = emu::wave_exchange(__builtin_return_address(0), &v, (int)sizeof(T));
   const int l = emu::lane(), src = l + (int)delta;
   T r = v;
-  if (src < (l & ~(width - 1)) + width) memcpy(&r, x + 64 * src, sizeof(T));
+  if (src < (l & ~(width - 1)) + width) memcpy(&r, x.slots + 64 * src, sizeof(T));
   return r;
 }
-static inline unsigned long long __ballot(int pred) {
+ES_EMU_WAVEOP static unsigned long long __ballot(int pred) {
   const unsigned char p = pred ? 1 : 0;
-  const unsigned char* x = emu::wave_exchange(&p, 1);
-  const unsigned long long live = emu::wave_live_mask();
+  const emu::WaveView x = emu::wave_exchange(__builtin_return_address(0), &p, 1);
   unsigned long long m = 0;
   for (int l = 0; l < 64; ++l)
-    if (((live >> l) & 1ull) && x[64 * l]) m |= 1ull << l;
+    if (((x.mask >> l) & 1ull) && x.slots[64 * l]) m |= 1ull << l;
   return m;
 }
 
@@ -196,11 +199,11 @@ static inline float emu_bf16_to_f32(__bf16 h) {
 }
 // D = A (16 x 32) * B (32 x 16) + C; products of bf16 values are exact in f32, the sum is taken in double and rounded once
 // (the hardware's internal order is not specified; the parity tolerances of the tests are what both must meet)
-static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
+ES_EMU_WAVEOP static emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
   struct Slot { __bf16 a[8]; __bf16 b[8]; } mine;
   memcpy(mine.a, &a, 16);
   memcpy(mine.b, &b, 16);
-  const unsigned char* x = emu::wave_exchange(&mine, (int)sizeof(Slot));
+  const unsigned char* x = emu::wave_exchange(__builtin_return_address(0), &mine, (int)sizeof(Slot)).slots;
   const int l = emu::lane(), j = l & 15, i0 = 4 * (l >> 4);
   emu_f32x4 d = c;
   for (int r = 0; r < 4; ++r) {
@@ -217,9 +220,9 @@ static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32_bf16((a), (b), (c))
 // exact-f32 tile: A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16]
-static inline emu_f32x4 emu_mfma_16x16x4_f32(float a, float b, emu_f32x4 c) {
+ES_EMU_WAVEOP static emu_f32x4 emu_mfma_16x16x4_f32(float a, float b, emu_f32x4 c) {
   struct Slot { float a, b; } mine = {a, b};
-  const unsigned char* x = emu::wave_exchange(&mine, (int)sizeof(Slot));
+  const unsigned char* x = emu::wave_exchange(__builtin_return_address(0), &mine, (int)sizeof(Slot)).slots;
   const int l = emu::lane(), j = l & 15, i0 = 4 * (l >> 4);
   emu_f32x4 d = c;
   for (int r = 0; r < 4; ++r) {
@@ -243,9 +246,9 @@ static inline void emu_global_load_lds(G g, L lds, int size, int offset, int) {
 // address of the 8 bytes at block row (i >> 2), block columns 4 (i & 3) ..; it receives column i of rows 0 .. 3
 typedef short emu_s16x4 __attribute__((ext_vector_type(4)));
 template <class P>
-static inline emu_s16x4 emu_ds_read_tr16_b64(P p) {
+ES_EMU_WAVEOP emu_s16x4 emu_ds_read_tr16_b64(P p) {
   const uintptr_t mine = (uintptr_t)p;
-  const unsigned char* x = emu::wave_exchange(&mine, (int)sizeof(mine));
+  const unsigned char* x = emu::wave_exchange(__builtin_return_address(0), &mine, (int)sizeof(mine)).slots;
   const int l = emu::lane(), g = l & ~15, i = l & 15;
   emu_s16x4 r;
   for (int row = 0; row < 4; ++row) {

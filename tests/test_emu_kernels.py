@@ -16,10 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
 
 
-@pytest.fixture(scope='module', params=['ascending', 'descending', 'random'])
+@pytest.fixture(scope='module', params=['descending', 'random'])
 def emu(request):
-    """the emulated library under one of three thread schedules: between two synchronisation points the threads of a workgroup
-    run in ascending, descending or random order -- a kernel that is missing a barrier gives different results under them"""
+    """the emulated library under two thread schedules: between two synchronisation points the threads of a workgroup run in
+    descending or random order (tests/test_emu_product.py runs ascending) -- a kernel that is missing a barrier gives different
+    results under them"""
     import build as emu_build
     from embodiedscan_amd import hip
     lib = ctypes.CDLL(emu_build.build())
@@ -276,7 +277,7 @@ def test_radix_sort_and_topk_and_column_sums(emu):
     multi-workgroup histogram / election variant on one shared workspace with changing segment counts -- and the deterministic
     column sums with their last-workgroup election"""
     rng = np.random.default_rng(21)
-    for n in (1, 77, 5000, 70000):
+    for n in (1, 77, 5000, 30000):
         keys = rng.integers(0, 1 << 40, n).astype(np.int64)
         keys[rng.integers(0, n, n // 3)] = keys[0]                      # duplicates: stability matters
         src = np.arange(n, dtype=np.int32)[::-1].copy()
@@ -288,7 +289,7 @@ def test_radix_sort_and_topk_and_column_sums(emu):
         assert np.array_equal(ok, keys[order]) and np.array_equal(os_, src[order]), n
     nw = int(emu.fns['es_topk_mask_workspace_ints'](1))
     ws = np.zeros(nw, np.int32)                                        # ONE workspace for every call below (fixed layout)
-    for seg_sizes, k in (((3000,), 1000), ((50, 0, 1200, 999), 300), ((40000,), 10000), ((5,), 10)):
+    for seg_sizes, k in (((3000,), 1000), ((50, 0, 1200, 999), 300), ((20000,), 5000), ((5,), 10)):
         off = np.concatenate([[0], np.cumsum(seg_sizes)]).astype(np.int32)
         n = int(off[-1])
         v = rng.standard_normal(n).astype(np.float32)

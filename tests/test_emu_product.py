@@ -1,0 +1,108 @@
+"""The GPU suite's own kernel-level parity tests, run in the CPU suite: the product's HOST layer (embodiedscan_amd/sparse.py,
+the head's target assignment, the fusion meta tables ...) drives the kernel sources under the CDNA emulator of tests/emu
+instead of libes_hip.so, on CPU tensors.  The test BODIES are the ones of tests/test_gpu_*.py, imported and called unchanged --
+what the MI355X must satisfy at round end is checked here first, bit-exact integer work included (voxelisation, kernel / stride
+/ generative / union maps, target assignment against the reference's own output).
+How: a test-only fixture swaps the ctypes table of embodiedscan_amd.hip for the emulated library's (same C ABI), pins the
+stream handle to 0 and gives torch.cuda's synchronisation calls no-op stand-ins.  Nothing of this exists outside the fixture:
+the product binds libes_hip.so and has no CPU path."""
+import ctypes
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+class _ListAsDict:
+    """monkeypatch.setitem for a one-element list (the engine's mutable flags)"""
+
+    def __init__(self, lst):
+        self.lst = lst
+
+    def get(self, k, default=None):
+        return self.lst[k]
+
+    def __setitem__(self, k, v):
+        self.lst[k] = v
+
+    def __delitem__(self, k):
+        pass
+
+
+@pytest.fixture
+def emulated(monkeypatch):
+    import build as emu_build
+    from embodiedscan_amd import hip, sparse
+    lib = ctypes.CDLL(emu_build.build())
+    fns = {}
+    for name, (ret, at, _) in hip.PROTOS.items():
+        f = getattr(lib, name)
+        f.restype, f.argtypes = ret, at
+        fns[name] = f
+    monkeypatch.setattr(hip, '_fn', fns)
+    monkeypatch.setattr(hip, '_STREAM', [0])
+    stream = types.SimpleNamespace(cuda_stream=0, synchronize=lambda: None, wait_event=lambda e: None, wait_stream=lambda s: None)
+    monkeypatch.setattr(hip, '_STREAM_OBJ', [stream])
+    monkeypatch.setattr(hip, 'refresh_stream', lambda: 0)
+    monkeypatch.setattr(sparse, 'read_ints', lambda t: [int(v) for v in t.reshape(-1).tolist()])
+    monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a, **k: stream)
+    # the engine's single-stream schedule (what ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0 ES_GRAPHS=0 select on the GPU)
+    from embodiedscan_amd import engine as E
+    for flag in (E.TWO_STREAMS, E.WGRAD_ASYNC, E.GRAPHS):
+        monkeypatch.setitem(_ListAsDict(flag), 0, False)
+    return torch.device('cpu')
+
+
+def test_voxelise_and_every_coordinate_map_bit_exact(emulated):
+    import test_gpu_ops as T
+    T.test_voxelize_and_maps_bit_exact(emulated)
+
+
+def test_strided_chain(emulated):
+    import test_gpu_ops as T
+    T.test_strided_chain_one_round_trip_equals_the_level_by_level_chain(emulated)
+
+
+def test_union_add_gather_topk(emulated):
+    import test_gpu_ops as T
+    T.test_union_add_and_gather(emulated)
+    T.test_topk_mask(emulated)
+
+
+def test_target_assignment_against_the_reference_output(emulated, golden_dir):
+    import test_gpu_ops as T
+    T.test_get_targets_golden_and_random(emulated, golden_dir)
+
+
+def test_row_gemm_bit_identical_to_the_general_kernel(emulated):
+    import test_gpu_ops as T
+    T.test_rowgemm_matches_general_kernel(emulated)
+
+
+@pytest.mark.parametrize('bf16,tol', [(0, 2e-5), (1, 2e-2)])
+def test_attention_forward_backward_vs_torch(emulated, bf16, tol):
+    import test_gpu_grounding as T
+    T.test_attention_fwd_bwd_vs_torch(emulated, bf16, tol)
+
+
+def test_grounding_head_kernels_vs_torch_and_reference(emulated):
+    """LayerNorm / ContrastiveEmbed / box decode / sorted top-k vs torch, the FCAF coder vs the reference's golden, rotated 3-D
+    IoU vs the oracle, Hungarian matching identical to scipy on the reference's cost matrices + both losses and their gradients
+    vs the reference's own outputs (the quad reductions inside divergent branches exercise the emulator's EXEC-mask model)"""
+    import test_gpu_grounding as T
+    T.test_layernorm_contrastive_decode_topk_vs_torch(emulated)
+    T.test_fcaf_box_coder_vs_reference(emulated)
+    T.test_box3d_iou_vs_oracle(emulated)
+    T.test_matching_and_losses_vs_reference(emulated)
+
+
+def test_occupancy_targets_and_losses_vs_reference(emulated):
+    import test_gpu_occ as T
+    T.test_occ_targets_and_losses_vs_reference(emulated)
