@@ -30,9 +30,10 @@ def transform(text):
     return text.replace('#include "../../include/es_hip.h"', '#include "es_hip.h"')
 
 
-def build(files=DEFAULT, force=False):
+def build(files=DEFAULT, force=False, lib_name='libes_emu_test.so'):
+    """files: sources relative to embodiedscan_amd/csrc (sub-directories allowed: 'next/x.hip')"""
     os.makedirs(OUT, exist_ok=True)
-    lib = os.path.join(OUT, 'libes_emu_test.so')
+    lib = os.path.join(OUT, lib_name)
     srcs = [os.path.join(CSRC, f) for f in files] + [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'es_hip.h'),
                                                      os.path.join(HERE, 'hip', 'hip_runtime.h'), os.path.join(HERE, 'emu_runtime.cpp'),
                                                      os.path.join(HERE, 'selftest_kernels.cpp'),
@@ -43,14 +44,14 @@ def build(files=DEFAULT, force=False):
              '-ffp-contract=off']
     jobs = []
     for f in files:
-        gen = os.path.join(OUT, f.replace('.hip', '_emu.cpp'))
+        gen = os.path.join(OUT, lib_name.replace('.so', '_') + f.replace('/', '_').replace('.hip', '_emu.cpp'))
         with open(os.path.join(CSRC, f)) as fh:
             text = transform(fh.read())
         with open(gen, 'w') as fh:
             fh.write(text)
         jobs.append((gen, gen.replace('.cpp', '.o')))
-    jobs.append((os.path.join(HERE, 'selftest_kernels.cpp'), os.path.join(OUT, 'selftest_kernels.o')))
-    rt = os.path.join(OUT, 'emu_runtime.o')
+    jobs.append((os.path.join(HERE, 'selftest_kernels.cpp'), os.path.join(OUT, lib_name.replace('.so', '_selftest.o'))))
+    rt = os.path.join(OUT, lib_name.replace('.so', '_runtime.o'))
     jobs.append((os.path.join(HERE, 'emu_runtime.cpp'), rt))
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:       # (the compiler processes run in parallel)

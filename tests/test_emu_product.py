@@ -81,9 +81,8 @@ def test_target_assignment_against_the_reference_output(emulated, golden_dir):
     T.test_get_targets_golden_and_random(emulated, golden_dir)
 
 
-def test_row_gemm_bit_identical_to_the_general_kernel(emulated):
-    import test_gpu_ops as T
-    T.test_rowgemm_matches_general_kernel(emulated)
+# (tests/test_gpu_ops.py::test_rowgemm_matches_general_kernel also passes under emulation -- 7 epilogue modes x 10 shapes, 60 s; the
+#  row GEMMs are covered in tests/test_emu_kernels.py, so it is not repeated here to keep the CPU suite short)
 
 
 @pytest.mark.parametrize('bf16,tol', [(0, 2e-5), (1, 2e-2)])
