@@ -208,12 +208,12 @@ __global__ __launch_bounds__(BMT * 2, (BMT == 128 && KB == 1) ? 3 : 2) void k_sp
 
 // Same operand contract as the fast path of es_spconv_fwd_bf16_io (bf16 rows Xh with ldx in elements, W = the transposed bf16
 // copy [K][Cout][Cin], nbr (n_out, K) or NULL for the identity map).  rows = 256 or 128 (128: the shipped tile through this
-// template, for A/B runs); chunk = 1 or 2 (32 / 64 channels).  Requires Cin % (32 * chunk) == 0, Cout % 64 == 0, ldx % 8 == 0,
+// template, for A/B runs); cols = 0 (128 when C_out % 128 == 0, else 64) or 256; chunk = 1 or 2 (32 / 64 channels).  Requires Cin % (32 * chunk) == 0, Cout % 64 == 0, ldx % 8 == 0,
 // 16-byte aligned rows; returns -4 for a shape it does not take.
 extern "C" int es_next_spconv_fwd_bf16_tile(const void* Xh_, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in, int K,
                                             int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate,
                                             const float* ep_scale, const float* ep_shift, const float* ep_res, int ep_ldr, int ep_act,
-                                            int io, int rows, int chunk, void* stream) {
+                                            int io, int rows, int cols, int chunk, void* stream) {
   const unsigned short* Xh = (const unsigned short*)Xh_;
   const unsigned short* Wh = (const unsigned short*)W_bf16;
   hipStream_t st = (hipStream_t)stream;
@@ -226,7 +226,10 @@ extern "C" int es_next_spconv_fwd_bf16_tile(const void* Xh_, int ldx, const void
 #define T256_LAUNCH(BMT_, BNT_, KB_)                                                                                          \
   hipLaunchKernelGGL((k_spconv_bf16_dma_t<BMT_, BNT_, KB_>), dim3(es_cdiv(n_out, BMT_), Cout / BNT_), dim3(BMT_ * 2), 0, st, Xh, ldx, \
                      Wh, nbr, n_out, n_in, K, Cin, Cout, bias, Y, ldy, accumulate, ep_scale, ep_shift, ep_res, ep_ldr, ep_act, io)
-  if (rows == 256) {
+  if (rows == 256 && cols == 256) {                              // the dense occupancy neck (768 / 1536 / 3072 channels): 64 x 128 wave
+    if (Cout % 256 != 0) return -4;                               // tiles, 12 fragment reads per 32 MFMAs, 0.125 pieces per MFMA;
+    if (chunk == 2) T256_LAUNCH(256, 256, 2); else T256_LAUNCH(256, 256, 1);   // 158.7 KB of LDS at 64-channel chunks
+  } else if (rows == 256) {
     if (wide) { if (chunk == 2) T256_LAUNCH(256, 128, 2); else T256_LAUNCH(256, 128, 1); }
     else T256_LAUNCH(256, 64, 2);
   } else {
