@@ -1,6 +1,6 @@
 """The GPU suite's own kernel-level parity tests, run in the CPU suite: the product's HOST layer (embodiedscan_amd/sparse.py,
 the head's target assignment, the fusion meta tables ...) drives the kernel sources under the CDNA emulator of tests/emu
-instead of libes_hip.so, on CPU tensors.  The test BODIES are the ones of tests/test_gpu_*.py, imported and called unchanged --
+instead of libes_hip.so, on CPU tensors (random thread schedule, late LDS-DMA delivery: the strictest modes).  The test BODIES are the ones of tests/test_gpu_*.py, imported and called unchanged --
 what the MI355X must satisfy at round end is checked here first, bit-exact integer work included (voxelisation, kernel / stride
 / generative / union maps, target assignment against the reference's own output).
 How: a test-only fixture swaps the ctypes table of embodiedscan_amd.hip for the emulated library's (same C ABI), pins the
@@ -45,6 +45,10 @@ def emulated(monkeypatch):
         f = getattr(lib, name)
         f.restype, f.argtypes = ret, at
         fns[name] = f
+    # thread schedule between synchronisation points / LDS-DMA delivery (tests/emu): ES_EMU_SCHEDULE=0|1|2, ES_EMU_LAZY_DMA=0|1
+    lib.es_emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_ulonglong]
+    lib.es_emu_set_schedule(int(os.environ.get('ES_EMU_SCHEDULE', '2')), 777)
+    lib.es_emu_set_dma_mode(int(os.environ.get('ES_EMU_LAZY_DMA', '1')))
     monkeypatch.setattr(hip, '_fn', fns)
     monkeypatch.setattr(hip, '_STREAM', [0])
     stream = types.SimpleNamespace(cuda_stream=0, synchronize=lambda: None, wait_event=lambda e: None, wait_stream=lambda s: None)
