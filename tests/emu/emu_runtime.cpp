@@ -49,8 +49,11 @@ int lane() { return g_cur->lane; }
 
 static void yield() { swapcontext(&g_cur->ctx, &g_sched); }
 
+static double g_count[3] = {0, 0, 0};        // per-LANE events: MFMA, LDS-DMA piece, barrier (divide by 64 for wave instructions)
+void count_mfma() { g_count[0] += 1; }
 static int g_dma_lazy = 0;
 void dma_issue(void* dst, const void* src, int bytes) {
+  g_count[1] += 1;
   if (!g_dma_lazy) {
     memcpy(dst, src, (size_t)bytes);
     return;
@@ -68,6 +71,7 @@ void waitcnt_vm(int n) {
 
 void block_barrier() {
   Fiber* f = g_cur;
+  g_count[2] += 1;
   if (++g_bar_arrived == g_alive) {      // last one in: release everybody
     g_bar_arrived = 0;
     ++g_bar_gen;
@@ -253,6 +257,15 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
 }
 
 }  // namespace emu
+
+// wave-level work of the launches since the last call: out[0] MFMA instructions, out[1] LDS-DMA instructions (1 KiB pieces),
+// out[2] barrier arrivals of waves -- the static work model of a kernel (staging pieces per MFMA)
+extern "C" void es_emu_take_counters(double* out) {
+  for (int i = 0; i < 3; ++i) {
+    out[i] = emu::g_count[i] / 64.0;
+    emu::g_count[i] = 0;
+  }
+}
 
 extern "C" void es_emu_set_dma_mode(int lazy) { emu::g_dma_lazy = lazy; }
 

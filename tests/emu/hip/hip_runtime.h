@@ -74,6 +74,7 @@ void* dyn_shared();
 // LATE as the program allows -- when an s_waitcnt vmcnt(n) retires it (oldest first, until n remain) or the thread ends: a
 // kernel that reads a tile before waiting for it sees stale LDS and fails its parity test
 void dma_issue(void* lds_dst, const void* src, int bytes);
+void count_mfma();       // (work counters of the launches since es_emu_take_counters: MFMA / LDS-DMA wave instructions, barriers)
 void waitcnt_vm(int n);      // the launch's dynamic LDS (`extern __shared__ T name[]` is rewritten to `T* name = (T*)emu::dyn_shared()`)
 void block_barrier();
 // wave rendezvous at call site `site`: the lane deposits `bytes` (<= 64) bytes and waits for the lanes that execute the same
@@ -201,6 +202,7 @@ static inline float emu_bf16_to_f32(__bf16 h) {
 // (the hardware's internal order is not specified; the parity tolerances of the tests are what both must meet)
 ES_EMU_WAVEOP static emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
   struct Slot { __bf16 a[8]; __bf16 b[8]; } mine;
+  emu::count_mfma();
   memcpy(mine.a, &a, 16);
   memcpy(mine.b, &b, 16);
   const unsigned char* x = emu::wave_exchange(__builtin_return_address(0), &mine, (int)sizeof(Slot)).slots;
@@ -222,6 +224,7 @@ ES_EMU_WAVEOP static emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b
 // exact-f32 tile: A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16]
 ES_EMU_WAVEOP static emu_f32x4 emu_mfma_16x16x4_f32(float a, float b, emu_f32x4 c) {
   struct Slot { float a, b; } mine = {a, b};
+  emu::count_mfma();
   const unsigned char* x = emu::wave_exchange(__builtin_return_address(0), &mine, (int)sizeof(Slot)).slots;
   const int l = emu::lane(), j = l & 15, i0 = 4 * (l >> 4);
   emu_f32x4 d = c;

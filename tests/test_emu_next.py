@@ -131,3 +131,30 @@ def test_256_row_tile_fits_gfx950():
     assert wide['LDS Size'] <= 160 * 1024 and wide['VGPRs'] + wide.get('AGPRs', 0) <= 256      # one 8-wave workgroup per CU: 2 waves per SIMD
     mid = next(r for n, r in kernels.items() if 'ILi256ELi128ELi1E' in n)
     assert mid['LDS Size'] <= 80 * 1024 and mid['VGPRs'] <= 128       # two workgroups = 16 waves per CU need <= 128 VGPRs
+
+
+def test_staging_work_per_mfma_of_the_tiles(lib):
+    """the work model behind the 256-row tile (DESIGN.md "Next round" 1), counted by the emulator on one 27-tap 128 -> 128 layer:
+    LDS-DMA pieces per MFMA = 16 (M + N) / (M N) -- 0.25 for the shipped 128 x 128 tile, 0.1875 at 256 x 128 -- and half the
+    barriers per MFMA"""
+    from test_emu_kernels import P, _map, bf16_bits
+    rng = np.random.default_rng(8)
+    n, K, c = 512, 27, 128
+    nbr = _map(rng, n, n, K, 1.0)                       # every neighbour present: no tile skips a tap
+    xh = bf16_bits(rng.standard_normal((n, c)).astype(np.float32))
+    w = rng.standard_normal((K, c, c)).astype(np.float32)
+    wt, wn = np.zeros((K, c, c), np.uint16), np.zeros((K, c, c), np.uint16)
+    lib.es_cast_weight_bf16(P(w), K, c, c, P(wn), P(wt), 0)
+    y = np.zeros((n, c), np.float32)
+    cnt = (ctypes.c_double * 3)()
+    got = {}
+    for rows in (128, 256):
+        lib.es_emu_take_counters(cnt)
+        assert lib.es_next_spconv_fwd_bf16_tile(P(xh), c, P(wt), P(nbr), n, n, K, c, c, 0, P(y), c, 0, 0, 0, 0, 0, 0, 0, rows, 0, 2, 0) == 0
+        lib.es_emu_take_counters(cnt)
+        got[rows] = (cnt[0], cnt[1], cnt[2])
+    for rows, (mfma, dma, bar) in got.items():
+        assert mfma == n // 16 * (c // 16) * K * (c // 32)                      # the same arithmetic either way
+        assert abs(dma / mfma - 16 * (rows + 128) / (rows * 128)) < 1e-9, (rows, dma / mfma)
+    assert got[256][2] / got[128][2] < 1.05                                     # barrier arrivals of waves: as many waves arrive half as often
+    print({r: dict(mfma=v[0], dma_pieces=v[1], pieces_per_mfma=round(v[1] / v[0], 4), wave_barrier_arrivals=v[2]) for r, v in got.items()})
