@@ -1,8 +1,7 @@
 // TEST INFRASTRUCTURE ONLY: the fiber scheduler behind tests/emu/hip/hip_runtime.h (see there).  One OS thread; the threads of
-// a workgroup are ucontext fibers run round-robin; a fiber gives up the processor only at __syncthreads and at wave operations.
+// a workgroup are fibers run round-robin; a fiber gives up the processor only at __syncthreads and at wave operations.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
-#include <ucontext.h>
 #include <string>
 #include <vector>
 
@@ -20,8 +19,35 @@ struct Wave {
 
 struct Dma { void* dst; const void* src; int bytes; };
 
+// Context switch between fibers: callee-saved registers + stack pointer, no signal-mask system calls (ucontext's swapcontext
+// makes two per switch: a kernel of 10^5 threads spent its time there).  x86-64 System V only -- this is test infrastructure
+// for the build container.
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_switch,.-emu_switch
+)");
+
 struct Fiber {
-  ucontext_t ctx;
+  void* sp = nullptr;                  // saved stack pointer while the fiber is not running
   uint3 tid;
   int lane = 0, wave = 0;
   bool done = false;
@@ -34,7 +60,7 @@ struct Fiber {
 
 Fiber* g_cur = nullptr;
 dim3 g_block_idx, g_block_dim, g_grid_dim;
-static ucontext_t g_sched;
+static void* g_sched_sp = nullptr;
 static std::vector<Fiber> g_fibers;
 static std::vector<Wave> g_waves;
 static long long g_bar_gen = 0;
@@ -47,7 +73,7 @@ static const size_t STACK = 192 * 1024;
 const uint3& tid() { return g_cur->tid; }
 int lane() { return g_cur->lane; }
 
-static void yield() { swapcontext(&g_cur->ctx, &g_sched); }
+static void yield() { emu_switch(&g_cur->sp, g_sched_sp); }
 
 static double g_count[3] = {0, 0, 0};        // per-LANE events: MFMA, LDS-DMA piece, barrier (divide by 64 for wave instructions)
 void count_mfma() { g_count[0] += 1; }
@@ -153,7 +179,8 @@ static void trampoline() {
     ++g_bar_gen;
   }
   if (w.alive > 0) try_release(f->wave, true);
-  swapcontext(&f->ctx, &g_sched);
+  emu_switch(&f->sp, g_sched_sp);
+  abort();                             // (a finished fiber is never resumed)
 }
 
 static bool runnable(const Fiber& f) {
@@ -218,11 +245,13 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
           f.wave = t >> 6;
           g_waves[(size_t)f.wave].alive++;
           g_waves[(size_t)f.wave].live_mask |= 1ull << f.lane;
-          getcontext(&f.ctx);
-          f.ctx.uc_stack.ss_sp = g_stacks + (size_t)t * STACK;
-          f.ctx.uc_stack.ss_size = STACK;
-          f.ctx.uc_link = nullptr;
-          makecontext(&f.ctx, trampoline, 0);
+          // initial frame: six callee-saved slots, then the address emu_switch "returns" to; the entry point then sees the
+          // stack as after a call (rsp = 8 mod 16)
+          void** top = (void**)(g_stacks + (size_t)(t + 1) * STACK);
+          top[-1] = nullptr;
+          top[-2] = (void*)&trampoline;
+          for (int i = 3; i <= 8; ++i) top[-i] = nullptr;
+          f.sp = (void*)(top - 8);
         }
         int done = 0;
         while (done < nt) {
@@ -239,7 +268,7 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
             if (!runnable(f)) continue;
             f.wait = 0;
             g_cur = &f;
-            swapcontext(&g_sched, &f.ctx);
+            emu_switch(&g_sched_sp, f.sp);
             g_cur = nullptr;
             progressed = true;
             if (f.done) ++done;

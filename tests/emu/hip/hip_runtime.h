@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE ONLY (tests/emu): a host-side stand-in for <hip/hip_runtime.h> that lets the kernel SOURCES of
 // embodiedscan_amd/csrc be compiled for x86 (amdclang++ in host mode: it understands ext_vector_type, __bf16,
 // __builtin_convertvector like the device compiler does) and executed on the CPU with the CDNA execution model emulated:
-//   * a workgroup = blockDim fibers (ucontext) in ONE OS thread, workgroups run one after the other -> `__shared__` = static;
+//   * a workgroup = blockDim fibers (own stacks, a 15-instruction context switch) in ONE OS thread, workgroups run one after the
+//     other -> `__shared__` = static;
 //   * __syncthreads / s_barrier = a fiber barrier over the workgroup's live threads;
 //   * wave operations (__shfl*, __ballot, MFMA) = a rendezvous of the wave's 64 lanes with the operands exchanged through a
 //     per-wave buffer; v_mfma_f32_16x16x32_bf16 / 16x16x4f32 are evaluated from the lanes' fragments with the operand layout
