@@ -222,6 +222,8 @@ void launch(const char* name, dim3 grid, dim3 block, size_t dyn_shared_bytes, co
       perror("emu: mmap");
       abort();
     }
+    for (int t = 0; t < nt; ++t)        // a guard page at the low end of every stack: an overflow faults instead of corrupting a neighbour
+      mprotect(g_stacks + (size_t)t * STACK, 4096, PROT_NONE);
   }
   g_block_dim = block;
   g_grid_dim = grid;
