@@ -202,20 +202,22 @@ static inline float emu_bf16_to_f32(__bf16 h) {
 // D = A (16 x 32) * B (32 x 16) + C; products of bf16 values are exact in f32, the sum is taken in double and rounded once
 // (the hardware's internal order is not specified; the parity tolerances of the tests are what both must meet)
 ES_EMU_WAVEOP static emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
-  struct Slot { __bf16 a[8]; __bf16 b[8]; } mine;
+  struct Slot { float a[8]; float b[8]; } mine;              // the lane's fragments, widened once (bf16 -> f32 is exact)
   emu::count_mfma();
-  memcpy(mine.a, &a, 16);
-  memcpy(mine.b, &b, 16);
+  for (int t = 0; t < 8; ++t) {
+    mine.a[t] = emu_bf16_to_f32(a[t]);
+    mine.b[t] = emu_bf16_to_f32(b[t]);
+  }
   const unsigned char* x = emu::wave_exchange(__builtin_return_address(0), &mine, (int)sizeof(Slot)).slots;
   const int l = emu::lane(), j = l & 15, i0 = 4 * (l >> 4);
   emu_f32x4 d = c;
   for (int r = 0; r < 4; ++r) {
     const int i = i0 + r;
     double s = 0;
-    for (int k = 0; k < 32; ++k) {
-      const Slot* sa = (const Slot*)(x + 64 * (i + 16 * (k >> 3)));
-      const Slot* sb = (const Slot*)(x + 64 * (j + 16 * (k >> 3)));
-      s += (double)emu_bf16_to_f32(sa->a[k & 7]) * (double)emu_bf16_to_f32(sb->b[k & 7]);
+    for (int kc = 0; kc < 4; ++kc) {                         // k = 8 kc + t lives in lane (row or column) + 16 kc, element t
+      const Slot* sa = (const Slot*)(x + 64 * (i + 16 * kc));
+      const Slot* sb = (const Slot*)(x + 64 * (j + 16 * kc));
+      for (int t = 0; t < 8; ++t) s += (double)(sa->a[t] * sb->b[t]);     // (a product of two bf16 values is exact in f32)
     }
     d[r] = (float)((double)c[r] + s);
   }
