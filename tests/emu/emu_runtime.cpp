@@ -13,6 +13,7 @@ struct Wave {
                                        // a released lane may deposit for its NEXT operation while a slower lane of the group still reads)
   unsigned long long snap_mask[2] = {0, 0};   // lanes that took part in that release (EXEC mask of the operation)
   long long gen = 0;                   // releases so far
+  int waiting = 0;                     // lanes currently waiting in a wave operation (not yet released)
   int alive = 0;
   unsigned long long live_mask = 0;
 };
@@ -126,6 +127,7 @@ static void release_group(Wave& w, int wave_index, const void* site) {
       f.wait = 0;
       f.snap = idx;
       mask |= 1ull << l;
+      --w.waiting;
     }
   }
   for (int l = 0; l < 64; ++l)
@@ -159,7 +161,7 @@ WaveView wave_exchange(const void* site, const void* mine, int bytes) {
   memcpy(w.deposit + 64 * f->lane, mine, (size_t)bytes);
   f->wait = 2;
   f->site = site;
-  try_release(f->wave, true);
+  if (++w.waiting == w.alive) try_release(f->wave, true);      // (the scan over the lanes only when everybody has arrived)
   if (f->wait == 2) yield();
   return WaveView{w.snap[f->snap], w.snap_mask[f->snap]};
 }
@@ -178,7 +180,7 @@ static void trampoline() {
     g_bar_arrived = 0;
     ++g_bar_gen;
   }
-  if (w.alive > 0) try_release(f->wave, true);
+  if (w.alive > 0 && w.waiting == w.alive) try_release(f->wave, true);
   emu_switch(&f->sp, g_sched_sp);
   abort();                             // (a finished fiber is never resumed)
 }
