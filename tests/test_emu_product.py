@@ -159,10 +159,15 @@ def test_tape_level_operators_forward_and_backward(emulated, golden_dir):
     """engine-level (autograd tape) tests of the GPU suite in exact-f32 mode: generative transposed convolution + batch norm +
     max pooling forward AND backward against the oracle's autograd, the occupancy neck (dense 3-D convolutions, transposed
     up-convolution) against the reference module's golden output and gradients, the FPN against the oracle.
-    (tests/test_gpu_ops.py::test_spconv_fwd_bwd -- convolution forward, data and weight gradients vs autograd -- also passes
-    here, at 2 min per shape: run it with `-k` when touching those kernels.)"""
+    (tests/test_gpu_ops.py::test_spconv_fwd_bwd -- convolution forward, data and weight gradients vs autograd -- runs below for its
+    strided K = 1 shape; the 27-tap shapes also pass, at 1 - 2 min each under the random schedule.)"""
     import test_gpu_occ as TO
     import test_gpu_ops as T
     T.test_gen_transpose_norm_pool(emulated)
     TO.test_imvoxel_neck_vs_reference(emulated)
     TO.test_fpn_vs_oracle(emulated)
+
+
+def test_convolution_forward_data_and_weight_gradients_vs_autograd(emulated):
+    import test_gpu_ops as T
+    T.test_spconv_fwd_bwd(emulated, 64, 128, 1, 2)
