@@ -40,7 +40,7 @@ def build(files=DEFAULT, force=False, lib_name='libes_emu_test.so'):
                                                      os.path.abspath(__file__)]
     if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
         return lib
-    flags = ['-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-w', '-I', HERE, '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
+    flags = ['-x', 'c++', '-std=c++17', '-O1', '-fPIC', '-w', '-I', HERE, '-I', CSRC, '-I', os.path.join(ROOT, 'include'),
              '-ffp-contract=off']
     jobs = []
     for f in files:

@@ -5,6 +5,8 @@ CDNA emulator of tests/emu, on CPU tensors, and the result is compared with the 
                                           projection fusion, FCAF3D head with pruning, target assignment, losses  (~10 min)
     python tools/emu_audit.py train       tests/test_gpu_model.py::test_train_step_parity on a small batch: forward AND backward,
                                           integer outputs bit exact, every parameter gradient against the f64-calibrated oracle
+    python tools/emu_audit.py predict     mode='predict' end to end (eval-mode norms, score top-k, decode, multi-class rotated NMS):
+                                          detections identical to the oracle's
     python tools/emu_audit.py grounder    tests/test_gpu_grounding.py::test_grounder_train_step_vs_oracle[f32]: queries and
                                           Hungarian assignments identical, logits, 12 losses, 245 gradients
 
@@ -102,6 +104,49 @@ def train():
           f'emulation: PASSED in {time.time() - t0:.0f} s')
 
 
+def predict():
+    """mode='predict'  end to end: eval-mode norm layers, score / top-k selection, box decoding, multi-class rotated
+    NMS -- detections identical to the oracle's (the body of tests/test_gpu_predict.py::test_predict_end_to_end on smaller scans)"""
+    import numpy as np
+    import torch
+    dev = emulate()
+    from embodiedscan_amd import engine as E, pipeline
+    from embodiedscan_amd.config import build_detector
+    from embodiedscan_amd.synth import make_scan
+    from oracle import model as OM
+    det = build_detector(os.path.join(ROOT, 'configs/mv_3ddet.py'), device=dev, seed=0).to(dev)
+    det.bbox_head.test_cfg = dict(nms_pre=300, iou_thr=0.5, score_thr=0.09)
+    g = torch.Generator().manual_seed(2)
+    sd = {k: v.cpu() for k, v in det.state_dict().items()}
+    for k in sd:
+        if k.endswith('running_var'):
+            sd[k] = torch.rand(sd[k].shape, generator=g) * 0.5 + 0.75
+        if k.endswith('running_mean'):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.05
+    det.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    scans = [make_scan(s, n_views=2, height=60, width=80, img_size=(64, 64), n_points=2500, n_boxes=5) for s in (31, 32)]
+    batch = pipeline.make_batch([pipeline.upload_scan(s, dev) for s in scans])
+    pts_host = [p.cpu() for p in batch['inputs']['points']]
+    t0 = time.time()
+    data = det.data_preprocessor(batch, False)
+    out = det.forward(data['inputs'], data['data_samples'], mode='predict')
+    dt = time.time() - t0
+    assert det.training and E.TAPE.enabled
+    imgs = torch.stack([OM.preprocess_img(torch.from_numpy(s['img']), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])
+                        for s in scans])
+    ref = OM.detector_predict(sd, pts_host, imgs, [s['meta'] for s in scans], nms_pre=300, score_thr=0.09, iou_thr=0.5)
+    n_det = 0
+    for ds, (rb, rs, rl) in zip(out, ref):
+        pr = ds.pred_instances_3d
+        print(f'detections: emulated kernels {len(pr.scores_3d)} oracle {len(rs)}')
+        assert len(pr.scores_3d) == len(rs)
+        np.testing.assert_array_equal(pr.labels_3d.cpu().numpy(), rl.numpy())
+        np.testing.assert_allclose(pr.scores_3d.cpu().numpy(), rs.numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(pr.bboxes_3d.tensor.cpu().numpy(), rb.numpy(), rtol=3e-4, atol=2e-4)
+        n_det += len(rs)
+    print(f'predict (2 scans, {n_det} detections: labels identical, scores 2e-5, boxes 3e-4 vs the oracle) under emulation: PASSED in {dt:.0f} s')
+
+
 def grounder():
     dev = emulate()
     import test_gpu_grounding as T
@@ -112,4 +157,4 @@ def grounder():
 
 
 if __name__ == '__main__':
-    {'forward': forward, 'train': train, 'grounder': grounder}[sys.argv[1] if len(sys.argv) > 1 else 'forward']()
+    {'forward': forward, 'train': train, 'grounder': grounder, 'predict': predict}[sys.argv[1] if len(sys.argv) > 1 else 'forward']()
