@@ -26,7 +26,8 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
 ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_fwd_bf16_io',
-          'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src'}
+          'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src', 'es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16'}
+DENSE = ('es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16')   # round 5: the dense-volume engine (csrc/dconv.hip), geometry instead of a map
 FWD_X = ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_io')     # (X, x_half, ldx, W, nbr, n_out, n_in, K, Cin, Cout, ...)
 SCATTER = {'es_voxel_keys', 'es_unique_first', 'es_morton_sort', 'es_stride_keys', 'es_kernel_map', 'es_inverse_map',
            'es_union_plan', 'es_point_sample_fwd', 'es_point_sample_bwd', 'es_depth_to_points'}
@@ -592,7 +593,9 @@ def launch_classes(records, mfma_peak, top=6):
         if name not in ENGINE:
             continue
         nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
-        kind = 'wgrad' if name.startswith('es_spconv_wgrad') else 'fwd/dgrad'
+        kind = 'wgrad' if (name.startswith('es_spconv_wgrad') or name == 'es_dconv_wgrad_bf16') else 'fwd/dgrad'
+        if name in DENSE:
+            kind += ' dense'
         key = f'{kind} K={K} {cin}->{cout}'
         groups.setdefault(key, []).append(r)
     rows = []
@@ -670,11 +673,29 @@ def other_parity(kind, cfg, det, scan, make, dev, args):
     return parity, base
 
 
+def dense_info(name, a):
+    """(n_out, n_in, K, cin, cout, valid (output, tap) pairs) of a dense-engine launch, in the convention of the map launches
+    (the data gradient is a forward launch over the input voxels with the channel roles swapped)"""
+    geom = list(a[3] if name == 'es_dconv_fwd_bf16' else a[4])
+    B, X, Y, Z, ks, st, pad = geom
+    o = lambda d: (d + 2 * pad - ks) // st + 1
+    ax = lambda d: sum(1 for q in range(o(d)) for k in range(ks) if 0 <= q * st - pad + k < d)
+    pairs = float(B) * ax(X) * ax(Y) * ax(Z)
+    n_in, n_out = B * X * Y * Z, B * o(X) * o(Y) * o(Z)
+    cin, cout = a[5], a[6]
+    if name == 'es_dconv_fwd_bf16' and a[4] == 1:
+        return n_in, n_out, ks ** 3, cout, cin, pairs
+    return n_out, n_in, ks ** 3, cin, cout, pairs
+
+
 def resolve_pairs(hip, records):
     """map pointer -> pair counter while the maps are still alive"""
     out = []
     for name, e0, e1, a in records:
         key = None
+        if name in DENSE:
+            out.append((name, e0, e1, a, dense_info(name, a)[5]))
+            continue
         if name == 'es_spconv_wgrad_bf16_src':
             key = a[6]
         elif name in ENGINE:
@@ -684,6 +705,9 @@ def resolve_pairs(hip, records):
 
 
 def engine_args(name, a):
+    if name in DENSE:
+        n_out, n_in, K, cin, cout, _ = dense_info(name, a)
+        return 1, n_out, n_in, K, cin, cout
     if name == 'es_spconv_wgrad_bf16_src':      # (X, x_half, ldx, dY, dy_half, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream)
         return a[6], a[7], a[8], a[9], a[10], a[11]
     if name in FWD_X:
@@ -702,8 +726,11 @@ def engine_totals(records, mfma_peak):
         ms += e0.elapsed_time(e1)
         n += 1
         nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
-        pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
-        wgrad = name.startswith('es_spconv_wgrad')
+        if isinstance(pairs_dev, float):
+            pairs = pairs_dev
+        else:
+            pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
+        wgrad = name.startswith('es_spconv_wgrad') or name == 'es_dconv_wgrad_bf16' 
         wb = 2 if ('bf16' in name and not wgrad) else 4
         f = 2.0 * pairs * cin * cout
         pb = pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wb
@@ -713,7 +740,9 @@ def engine_totals(records, mfma_peak):
         bx = by = 4.0
         if name == 'es_spconv_wgrad_bf16_src':
             bx, by = (2.0 if a[1] else 4.0), (2.0 if a[4] else 4.0)
-        elif name in FWD_X and a[1]:
+        elif name == 'es_dconv_wgrad_bf16':
+            bx = by = 2.0
+        elif name in DENSE or (name in FWD_X and a[1]):
             bx = 2.0
         if name == 'es_spconv_fwd_bf16_io' and a[17]:           # bf16 activation rows written by the image backbone
             by = 2.0

@@ -475,15 +475,69 @@ def _grad_target(v, shape_like):
     return v.g, 1
 
 
+
+# ------------------------------------------------------------------ dense-volume convolutions (round 5, csrc/dconv.hip)
+# nn.Conv3d on a dense (B, X, Y, Z) grid by address arithmetic: no neighbour map.  `dense` = (B, X, Y, Z, ksize, stride, pad) of the
+# INPUT grid; a convolution that passes it runs on the dense engine wherever the library takes the shape (bf16 mode, reduction
+# channels % 64, output channels % 256; the data gradient for stride 1) and falls back to the map kernels elsewhere -- `maps` is then
+# a callable returning (nbr, inv), so the maps of a layer the dense engine covers completely are never built.
+DENSE = [os.environ.get('ES_DENSE', '1') != '0']
+_DC_WS = {}             # stream handle -> persistent workspace of the partial tiles of split dense launches
+
+
+def _dense_geom(dense):
+    return iarr(dense) if dense is not None else None
+
+
+def dense_ok(dense, mode, cin, cout):
+    return bool(DENSE[0] and dense is not None and PRECISION[0] == 'bf16' and
+                hip.raw('es_dconv_supported')(_dense_geom(dense), mode, cin, cout) == 1)
+
+
+def _dense_launch(Xh, ldx, Wp, dense, mode, cin, cout, Y, ldy, acc, like):
+    g = _dense_geom(dense)
+    need = int(hip.raw('es_dconv_workspace_floats')(g, mode, cin, cout))
+    s = _stream()
+    ws = None
+    if need:
+        ws = _DC_WS.get(s)
+        if ws is None or ws.numel() < need or ws.device != like.device:
+            if ws is not None:
+                _KEEP.append(ws)                 # launches already queued on this stream may still use the old buffer
+            ws = _DC_WS[s] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=like.device)
+    call('es_dconv_fwd_bf16', Xh, ldx, Wp, g, mode, cin, cout, Y, ldy, acc, P(ws), ws.numel() if ws is not None else 0, s)
+
+
+class _Maps:
+    """(nbr, inv) of a convolution, built on first use"""
+    __slots__ = ('fn', 'val')
+
+    def __init__(self, fn):
+        self.fn, self.val = fn, None
+
+    def get(self):
+        if self.val is None:
+            self.val = self.fn()
+        return self.val
+
+
 # ------------------------------------------------------------------ convolution
-def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
+def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0, dense=None, maps=None):
     """y[j] = sum_k x[nbr[j,k]] @ w[k] (+bias).  w.d: (K,Cin,Cout).  nbr None -> identity (K=1).
-    bias_from: first output column whose bias is trainable (earlier columns keep a zero bias)."""
+    bias_from: first output column whose bias is trainable (earlier columns keep a zero bias).
+    dense / maps: see "dense-volume convolutions" above (nbr / inv are then taken from maps() where a map kernel runs)."""
     K, cin, cout = w.d.shape
     n_in = x.d.shape[0]
     y = Var(empty((n_out, cout), x.d))
     bf = PRECISION[0] == 'bf16' and cin >= 16
-    if bf and SHADOW[0] and _ld(x.d) == cin and _use_shadow(n_in, cin, K, cin, cout):
+    if maps is not None:
+        maps = _Maps(maps) if not isinstance(maps, _Maps) else maps
+    dn = dense if (bf and bias is None and _ld(x.d) == cin and dense_ok(dense, 0, cin, cout)) else None
+    if dn is None and maps is not None:
+        nbr, inv = maps.get()
+    if dn is not None:
+        _dense_launch(P(x.shadow()), cin, P(w.bf16()[1]), dn, 0, cin, cout, P(y.d), cout, 0, x.d)
+    elif bf and SHADOW[0] and _ld(x.d) == cin and _use_shadow(n_in, cin, K, cin, cout):
         _fwd_bf16(P(x.shadow()), 1, cin, P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0, P(y.d),
                   cout, 0, x.d)
     elif bf:
@@ -498,14 +552,14 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0):
             return
         if DEBUG_GRADS is not None:
             DEBUG_GRADS[id(y)] = y.g.clone()
-        _conv_backward(x, w, nbr, inv, n_out, y, y.g, bias, bias_from, need_dx, bf)
+        _conv_backward(x, w, nbr, inv, n_out, y, y.g, bias, bias_from, need_dx, bf, dense=dense, maps=maps)
     TAPE.add(bwd)
     x.fresh = False
     y.fresh = True
     return y
 
 
-def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, gate=None):
+def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, gate=None, dense=None, maps=None):
     """wgrad (+ bias grad) and dgrad of a convolution whose output gradient is the row matrix `gy`.
     gate: folded-BN scale of x's producer -- the dgrad launch then also applies that layer's ReLU mask and BN scale
     (x is its only consumer), leaving x.g as the gradient of the producer's raw conv output."""
@@ -513,6 +567,12 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     n_in = x.d.shape[0]
     s = _stream()
     rec = None
+    # dense engine: weight gradient / data gradient by address arithmetic where the library takes the shape
+    dn_ok = bf and dense is not None and gate is None and _ld(gy) == cout and _ld(x.d) == cin and WGRAD_BF16[0]
+    dn_w = dense if (dn_ok and w.g is not None and dense_ok(dense, 2, cin, cout)) else None
+    dn_d = dense if (dn_ok and need_dx and x.rg and dense_ok(dense, 1, cin, cout)) else None
+    if maps is not None and (DEBUG_CONV is not None or (w.g is not None and dn_w is None) or (need_dx and x.rg and dn_d is None)):
+        nbr, inv = maps.get()
     if DEBUG_CONV is not None:
         rec = dict(x=x.d, w=w, nbr=nbr, n_out=n_out, gy=gy.clone(), bf=bool(bf), gate=gate, need_dx=bool(need_dx and x.rg),
                    before=(x.g.clone() if (x.g is not None and need_dx and x.rg) else None), bias=bias, bias_from=bias_from)
@@ -520,12 +580,17 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     # bf16 shadow of the output gradient: gather source of the data-gradient launch and, with the input's shadow from
     # the forward pass, of the weight-gradient launch (made here, before the weight-gradient stream forks)
     gh = None
-    if (bf and cout >= 16 and SHADOW[0] and need_dx and x.rg and gate is None and _ld(gy) == cout
+    if dn_w is not None or dn_d is not None or (
+            bf and cout >= 16 and SHADOW[0] and need_dx and x.rg and gate is None and _ld(gy) == cout
             and _use_shadow(n_out, cout, K, cout, cin)):
         gh = y.grad_shadow() if gy is y.g else _cast_rows(gy)
+    if dn_w is not None:
+        x.shadow()                               # (made by the forward launch; never on the weight-gradient stream)
     if w.g is not None or (bias is not None and bias.g is not None):
         sw = _wgrad_stream(gy, x.d, gh, x.dh)
-    if w.g is not None and bf and WGRAD_BF16[0] and SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None):
+    if dn_w is not None:
+        call('es_dconv_wgrad_bf16', P(x.dh), cin, P(gh), cout, _dense_geom(dn_w), cin, cout, P(w.g), _first_write(P(w.g)), sw)
+    elif w.g is not None and bf and WGRAD_BF16[0] and SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None):
         xs, ys = x.dh if x.dh is not None else x.d, gh if gh is not None else gy
         _wgrad('es_spconv_wgrad_bf16_src', sw, P(w.g), P(xs), int(x.dh is not None), _ld(xs), P(ys), int(gh is not None), _ld(ys),
                P(nbr), n_out, n_in, K, cin, cout)
@@ -558,7 +623,9 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
                  P(x.d), _ld(x.d), 3, P(x.g), _ld(x.g), s)
     elif need_dx and x.rg:
         g, acc = _grad_target(x, x.d)
-        if gh is not None:
+        if dn_d is not None:
+            _dense_launch(P(gh), cout, P(w.bf16()[0]), dn_d, 1, cin, cout, P(g), _ld(g), acc, gh)
+        elif gh is not None:
             _fwd_bf16(P(gh), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc, gh)
         elif bf and cout >= 16:
             _fwd_bf16(P(gy), 0, _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc, gy)

@@ -106,9 +106,13 @@ class IndoorImVoxelNeck:
             self.grids[key] = VolumeGrid(B, dims[0], dims[1], dims[2], dev)
         return self.grids[key]
 
-    def _conv3(self, x, w, g):
-        nbr, inv, n_out, _ = g.conv_map(3, 1, 1)
-        return E.conv(x, w, nbr, inv, n_out)
+    def _conv3(self, x, w, g, stride=1):
+        """nn.Conv3d(k=3, stride, pad=1): the dense engine (address arithmetic, csrc/dconv.hip) where it takes the shape, the
+        neighbour-map kernels elsewhere (the maps are only built if a launch needs them)"""
+        o = lambda d: (d + 2 - 3) // stride + 1
+        n_out = g.B * o(g.X) * o(g.Y) * o(g.Z)
+        return E.conv(x, w, None, None, n_out, dense=(g.B, g.X, g.Y, g.Z, 3, stride, 1),
+                      maps=lambda: g.conv_map(3, stride, 1)[:2])
 
     def _res(self, x, blk, g, B):
         """ResModule (imvoxel_neck.py:112-143)"""
@@ -117,8 +121,9 @@ class IndoorImVoxelNeck:
             o = self._conv3(x, blk['conv1'], g)
             g_out, idt = g, x
         else:
-            nbr, inv, n_out, dims = g.conv_map(3, blk['stride'], 1)
-            o = E.conv(x, blk['conv1'], nbr, inv, n_out)
+            st = blk['stride']
+            dims = tuple((d + 2 - 3) // st + 1 for d in (g.X, g.Y, g.Z))
+            o = self._conv3(x, blk['conv1'], g, stride=st)
             g_out = self._grid(B, dims, x.d.device)
             dn, di, n_d, ddims = g.conv_map(1, blk['stride'], 0)
             assert ddims == dims

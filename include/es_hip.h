@@ -427,6 +427,28 @@ int es_box_cd_pairs(const float* pred, const int* q2g, int B, int Q, const float
 /* per-sample indices of the k largest values, descending, ties by lower row; segment length <= 8192 */
 int es_topk_sorted(const float* vals, int B, int L, const int* vlen_dev, int k, int* idx, void* stream);
 
+/* ---- dense-volume convolution (occupancy neck; round 5, csrc/dconv.hip) ------------------------------------------------
+ * nn.Conv3d(k, stride, pad) of IndoorImVoxelNeck on channels-last bf16 rows by ADDRESS ARITHMETIC (no neighbour map):
+ * embodiedscan/models/necks/imvoxel_neck.py:78-143 (ResModule.conv1 / conv2, _make_block, _make_up_block).
+ * geom_host: 7 host ints {B, X, Y, Z (input grid), ksize, stride, pad}; rows of a grid are ((b*X + x)*Y + y)*Z + z.
+ * mode 0 forward: Xh (B*X*Y*Z x ldx) bf16 rows, W_bf16 = the [K][Cout][Cin] copy, Y (B*Xo*Yo*Zo x ldy) f32.
+ * mode 1 data gradient of a stride-1 convolution: Xh = bf16 rows of the output gradient, W_bf16 = the natural
+ * [K][Cin][Cout] copy, Y = the input gradient (B*X*Y*Z x ldy).  accumulate 1: Y += result.  Launches that would leave the
+ * chip under-filled split their reduction over several workgroups per tile; the partial tiles go through `ws`
+ * (es_dconv_workspace_floats; 0 = not needed) and are added in slice order (bit-reproducible).  -4: shape not taken
+ * (es_dconv_supported: reduction channels % 64, output channels % 256; weight gradient: both % 256). */
+int es_dconv_supported(const int* geom_host, int mode, int Cin, int Cout);
+size_t es_dconv_workspace_floats(const int* geom_host, int mode, int Cin, int Cout);
+int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, const int* geom_host, int mode, int Cin, int Cout, float* Y,
+                      int ldy, int accumulate, float* ws, size_t ws_floats, void* stream);
+/* dW[K][Cin][Cout] (f32) = (accumulate ? dW : 0) + sum over output voxels j of X[src(j, k)]^T . dY[j]; Xh / dYh bf16 rows of the
+ * input / of the output gradient.  One workgroup per (tap, 256 x 256 tile): every element is written once, no atomics. */
+int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int Cin, int Cout, float* dW,
+                        int accumulate, void* stream);
+/* tuning switches of the dense engine (A/B runs): 20 row tile (0 auto, 256, 320), 21 loop order (1 chunk outer / tap inner),
+ * 22 slices per tile (0 auto) */
+int es_dconv_set_option(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif

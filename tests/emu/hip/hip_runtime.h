@@ -137,6 +137,7 @@ static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4);
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }

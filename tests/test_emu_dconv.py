@@ -1,0 +1,184 @@
+"""The dense-volume convolution engine (embodiedscan_amd/csrc/dconv.hip: address-arithmetic implicit GEMM, 256 / 320-row tiles,
+LDS-DMA staging, transposed LDS reads in the weight gradient) under the CDNA emulator of tests/emu: forward, stride-1 data
+gradient and weight gradient against f64 evaluations of nn.Conv3d's arithmetic on the bf16-rounded operands -- ragged row
+tiles, every border case of a small volume, stride 2, batch > 1, both loop orders, forced slice counts (partial tiles through
+the workspace), accumulation into the output -- under two thread schedules and with late LDS-DMA delivery.  TEST
+INFRASTRUCTURE: the product binds libes_hip.so only."""
+import numpy as np
+import pytest
+
+from test_emu_kernels import P, bf16_bits, bf16_round, emu  # noqa: F401  (the fixture)
+
+
+def _conv3d_ref(xb, wb, B, X, Y, Z, ks, st, pad):
+    """f64 nn.Conv3d on channels-last rows: xb (B*X*Y*Z, Cin), wb (K, Cin, Cout), taps ordered (kx, ky, kz)"""
+    o = lambda d: (d + 2 * pad - ks) // st + 1
+    Xo, Yo, Zo = o(X), o(Y), o(Z)
+    cin, cout = wb.shape[1], wb.shape[2]
+    xv = np.zeros((B, X + 2 * pad, Y + 2 * pad, Z + 2 * pad, cin))
+    xv[:, pad:pad + X, pad:pad + Y, pad:pad + Z] = xb.reshape(B, X, Y, Z, cin)
+    y = np.zeros((B, Xo, Yo, Zo, cout))
+    for kx in range(ks):
+        for ky in range(ks):
+            for kz in range(ks):
+                sl = xv[:, kx:kx + st * Xo:st, ky:ky + st * Yo:st, kz:kz + st * Zo:st]
+                y += sl @ wb[(kx * ks + ky) * ks + kz].astype(np.float64)
+    return y.reshape(-1, cout), (Xo, Yo, Zo)
+
+
+def _geom(B, X, Y, Z, ks, st, pad):
+    return np.array([B, X, Y, Z, ks, st, pad], np.int32)
+
+
+CASES = [  # B, X, Y, Z, stride, Cin, Cout
+    (1, 7, 6, 5, 1, 64, 256),        # 210 rows: one ragged tile, every border case
+    (2, 9, 8, 5, 1, 128, 256),       # 720 rows: several tiles, batch boundary inside a tile
+    (1, 10, 8, 6, 2, 64, 256),       # stride 2: 5 x 4 x 3 output voxels
+]
+
+
+@pytest.mark.parametrize('lazy', [0, 1])
+def test_dense_forward_and_data_gradient(emu, lazy):
+    rng = np.random.default_rng(21 + lazy)
+    emu.lib.es_emu_set_dma_mode(lazy)
+    try:
+        for ci, (B, X, Y, Z, st, cin, cout) in enumerate(CASES if not lazy else CASES[:2]):
+            g = _geom(B, X, Y, Z, 3, st, 1)
+            assert emu.fns['es_dconv_supported'](P(g), 0, cin, cout) == 1
+            x = rng.standard_normal((B * X * Y * Z, cin)).astype(np.float32)
+            w = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+            wt, wn = np.zeros((27, cout, cin), np.uint16), np.zeros((27, cin, cout), np.uint16)
+            emu('es_cast_weight_bf16', P(w), 27, cin, cout, P(wn), P(wt), 0)
+            want, (Xo, Yo, Zo) = _conv3d_ref(bf16_round(x), bf16_round(w), B, X, Y, Z, 3, st, 1)
+            M = B * Xo * Yo * Zo
+            scale = np.abs(want).max()
+            xh = bf16_bits(x)
+            variants = [(0, 1, 0), (256, 0, 0), (320, 1, 3)] if not lazy else [(320, 1, 0), (256, 1, 2)]
+            for rows, order, split in variants:
+                emu('es_dconv_set_option', 20, rows)
+                emu('es_dconv_set_option', 21, order)
+                emu('es_dconv_set_option', 22, split)
+                nf = int(emu.fns['es_dconv_workspace_floats'](P(g), 0, cin, cout))
+                assert (nf > 0) == (split > 1) or split == 0
+                ws = np.full(max(nf, 4), np.nan, np.float32)
+                y = np.full((M, cout), np.nan, np.float32)
+                emu.launches()
+                emu('es_dconv_fwd_bf16', P(xh), cin, P(wt), P(g), 0, cin, cout, P(y), cout, 0, P(ws), nf, 0)
+                ran = emu.launches()
+                assert any('k_dconv' in k for k in ran), ran
+                err = np.abs(y - want).max() / scale
+                assert err < 2e-6, (ci, rows, order, split, err)
+            # accumulate into Y
+            y2 = np.ones((M, cout), np.float32)
+            emu('es_dconv_fwd_bf16', P(xh), cin, P(wt), P(g), 0, cin, cout, P(y2), cout, 1, P(ws), nf, 0)
+            assert np.abs(y2 - 1 - want).max() / scale < 2e-6
+            if st != 1 or cin % 256:
+                continue
+            # data gradient of the stride-1 convolution: dX = conv(dY, flipped taps, W^T); reference = the adjoint identity
+            dy = rng.standard_normal((M, cout)).astype(np.float32)
+            dyb = bf16_round(dy)
+            wf = bf16_round(w)[::-1].transpose(0, 2, 1)                  # (K, Cout, Cin), taps mirrored
+            want_dx, _ = _conv3d_ref(dyb, wf, B, X, Y, Z, 3, 1, 1)
+            emu('es_dconv_set_option', 20, 0); emu('es_dconv_set_option', 21, 1); emu('es_dconv_set_option', 22, 0)
+            nf = int(emu.fns['es_dconv_workspace_floats'](P(g), 1, cin, cout))
+            ws = np.zeros(max(nf, 4), np.float32)
+            dx = np.full((B * X * Y * Z, cin), np.nan, np.float32)
+            dyh = bf16_bits(dy)
+            emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx), cin, 0, P(ws), nf, 0)
+            assert np.abs(dx - want_dx).max() / np.abs(want_dx).max() < 2e-6
+    finally:
+        emu.lib.es_emu_set_dma_mode(0)
+        for k in (20, 22):
+            emu('es_dconv_set_option', k, 0)
+        emu('es_dconv_set_option', 21, 1)
+
+
+@pytest.mark.parametrize('lazy', [0, 1])
+def test_dense_weight_gradient(emu, lazy):
+    rng = np.random.default_rng(31 + lazy)
+    emu.lib.es_emu_set_dma_mode(lazy)
+    try:
+        for B, X, Y, Z, st in ((1, 6, 5, 5, 1), (2, 6, 6, 4, 2)) if not lazy else ((1, 5, 5, 4, 1),):
+            cin = cout = 256
+            g = _geom(B, X, Y, Z, 3, st, 1)
+            assert emu.fns['es_dconv_supported'](P(g), 2, cin, cout) == 1
+            o = lambda d: (d + 2 - 3) // st + 1
+            Xo, Yo, Zo = o(X), o(Y), o(Z)
+            M = B * Xo * Yo * Zo
+            x = rng.standard_normal((B * X * Y * Z, cin)).astype(np.float32)
+            dy = rng.standard_normal((M, cout)).astype(np.float32)
+            xb, gb = bf16_round(x).astype(np.float64), bf16_round(dy).astype(np.float64)
+            xv = np.zeros((B, X + 2, Y + 2, Z + 2, cin))
+            xv[:, 1:1 + X, 1:1 + Y, 1:1 + Z] = xb.reshape(B, X, Y, Z, cin)
+            want = np.zeros((27, cin, cout))
+            for kx in range(3):
+                for ky in range(3):
+                    for kz in range(3):
+                        sl = xv[:, kx:kx + st * Xo:st, ky:ky + st * Yo:st, kz:kz + st * Zo:st].reshape(M, cin)
+                        want[(kx * 3 + ky) * 3 + kz] = sl.T @ gb
+            dw = np.full((27, cin, cout), np.nan, np.float32)
+            xh, dyh = bf16_bits(x), bf16_bits(dy)                        # (kept alive: P() of a temporary would dangle)
+            emu.launches()
+            emu('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, P(g), cin, cout, P(dw), 0, 0)
+            assert any('k_dconv_wgrad' in k for k in emu.launches())
+            scale = np.abs(want).max()
+            assert np.abs(dw - want).max() / scale < 2e-6, (B, X, Y, Z, st)
+            dw2 = np.ones((27, cin, cout), np.float32)
+            emu('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, P(g), cin, cout, P(dw2), 1, 0)
+            assert np.abs(dw2 - 1 - want).max() / scale < 2e-6
+    finally:
+        emu.lib.es_emu_set_dma_mode(0)
+
+
+from test_emu_product import emulated, _ListAsDict  # noqa: E402,F401  (the fixture that puts the product's host layer on the emulator)
+
+
+def _launch_log():
+    import ctypes
+    import build as emu_build
+    lib = ctypes.CDLL(emu_build.build())
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.es_emu_take_launch_log(buf, len(buf))
+    return buf.value.decode()
+
+
+def test_engine_dense_path_equals_map_path_through_the_tape(emulated, monkeypatch):
+    """engine.conv(dense=..., maps=...) in bf16 mode: forward, data gradient (accumulating into an existing gradient) and weight
+    gradient through the tape on the dense engine against the same calls on the neighbour-map kernels (ES_DENSE off) -- the
+    host-side dispatch of the occupancy neck (IndoorImVoxelNeck._conv3), stride 1 and 2, on the emulated library."""
+    import torch
+    from embodiedscan_amd import engine as E, hip
+    from embodiedscan_amd.models.necks.imvoxel_neck import VolumeGrid
+    dev = emulated
+    monkeypatch.setitem(_ListAsDict(E.PRECISION), 0, 'bf16')
+    gen = torch.Generator().manual_seed(4)
+    for B, X, Y, Z, st, cin, cout in ((1, 6, 5, 4, 1, 256, 256), (1, 8, 6, 4, 2, 256, 256)):
+        grid = VolumeGrid(B, X, Y, Z, dev)
+        o = lambda d: (d + 2 - 3) // st + 1
+        n_out = B * o(X) * o(Y) * o(Z)
+        xd = torch.randn(B * X * Y * Z, cin, generator=gen)
+        wd = torch.randn(27, cin, cout, generator=gen) / (27 * cin) ** 0.5
+        gy = torch.randn(n_out, cout, generator=gen)
+        res = {}
+        for dense_on in (True, False):
+            monkeypatch.setitem(_ListAsDict(E.DENSE), 0, dense_on)
+            x = E.Var(xd.clone())
+            x.g = torch.ones_like(xd)                                  # an existing gradient: the data-gradient launch accumulates
+            w = E.Param(wd.clone(), torch.zeros_like(wd))
+            w.bf_n, w.bf_t = torch.empty((27, cin, cout), dtype=torch.bfloat16), torch.empty((27, cout, cin), dtype=torch.bfloat16)
+            hip.call('es_cast_weight_bf16', hip.P(w.d), 27, cin, cout, hip.P(w.bf_n), hip.P(w.bf_t), 0)
+            w.bf_step = E.WEIGHT_VERSION[0]
+            E.TAPE.clear()
+            E.new_grad_epoch()
+            _launch_log()
+            y = E.conv(x, w, None, None, n_out, dense=(B, X, Y, Z, 3, st, 1), maps=lambda: grid.conv_map(3, st, 1)[:2])
+            y.g = gy.clone()
+            E.TAPE.backward()
+            log = _launch_log()
+            # dense on: forward + weight gradient (+ the stride-1 data gradient) on the dense engine, maps only for the strided dgrad
+            assert ('k_dconv<' in log) == dense_on and ('k_dconv_wgrad' in log) == dense_on, log
+            assert ('k_volume_map' in log) == (not dense_on or st != 1) or 'k_volume_map' not in log
+            res[dense_on] = (y.d.clone(), x.g.clone(), w.g.clone())
+        for a, b, name in zip(res[True], res[False], ('y', 'dx', 'dw')):
+            err = float((a - b).abs().max() / b.abs().max())
+            assert err < 2e-5, (name, st, err)
