@@ -99,6 +99,42 @@ def stage_times(step_fn, runs=3):
     return {k: round(statistics.median(p.get(k, 0.0) for p in per), 3) for k in per[0]}
 
 
+def self_launch(n):
+    """re-exec this command under torch.distributed.run with n local ranks (rendezvous on 127.0.0.1, a free port)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def dry_launch(rank, world):
+    """the launch / rendezvous / collective plumbing of the N > 1 path with no GPU: what tests/test_host_logic.py runs here"""
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get('ES_DIST_BACKEND', 'gloo')
+    if world > 1:
+        dist.init_process_group(backend)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+        ranks = dist.get_world_size()
+    else:
+        ranks = 1
+    ok = abs(float(t.item()) - world * (world + 1) / 2) < 1e-12
+    if rank == 0:
+        print(json.dumps(dict(dry_launch=True, n_gpus=world, rccl_ranks=ranks, dist_backend=backend if world > 1 else None,
+                              allreduce_ok=ok, master=f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}")))
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit('dry launch: all-reduce of the rank tokens is wrong')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -117,14 +153,27 @@ def main():
                     help='run ONLY that configuration and print its object as the JSON line (profiling passes)')
     ap.add_argument('--grounding-batch', type=int, default=12, help='scans per GPU per step of config 4 (reference: 8xb12)')
     ap.add_argument('--other-steps', type=int, default=10, help='timed steps of the other configs (capped by --steps)')
+    ap.add_argument('--dry-launch', action='store_true',
+                    help='N > 1 plumbing check without a GPU: every rank joins the process group (ES_DIST_BACKEND, default gloo here), '
+                         'all-reduces a token, rank 0 prints one JSON line')
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    # `python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): become the launcher -- one rank per GPU
+    # under torch.distributed.run on 127.0.0.1 (the container hostname may not resolve), same arguments, same stdout.  The
+    # documented form `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` arrives with WORLD_SIZE set.
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args.gpus)                                      # does not return
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus {args.gpus}` (self-launching) or '
+                         f'`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}`')
+    if args.dry_launch:
+        return dry_launch(rank, world)
+
+    import torch
+    import torch.distributed as dist
     n_dev = torch.cuda.device_count()
     torch.cuda.set_device(local_rank % n_dev)
     dev = torch.device('cuda', local_rank % n_dev)
@@ -369,7 +418,9 @@ def main():
     if scatter is not None:
         out['scatter_path'] = scatter
         out['stage_ms'] = stages
+    out['rccl_ranks'] = dist.get_world_size() if world > 1 else 1
     if world > 1:
+        out['dist_backend'] = dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')
         out['replicas_in_sync'] = in_sync
         out['rank_ms_per_step'] = rank_ms
         if red is not None and prof_red:

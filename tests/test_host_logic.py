@@ -530,3 +530,23 @@ def test_effective_cpus_honours_the_cgroup_quota(tmp_path):
     assert effective_cpus(str(v1)) == min(have, 3)
     (v2 / 'cpu.max').write_text('garbage\n')
     assert effective_cpus(str(v2)) == have
+
+
+def test_bench_self_launches_its_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset re-executes itself under torch.distributed.run (two local ranks, rendezvous on
+    127.0.0.1, a free port) instead of dying on a WORLD_SIZE assertion: the dry-launch mode runs that path end to end without a GPU
+    (process group on gloo, one all-reduce, ONE JSON line from rank 0); a mismatching launcher is refused with the command to use."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['ES_DIST_BACKEND'] = 'gloo'
+    bench = os.path.join(ROOT, 'bench.py')
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--dry-launch'], capture_output=True, text=True, timeout=300, env=env, cwd='/tmp')
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['allreduce_ok'] and out['master'].startswith('127.0.0.1:')
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--dry-launch'], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE='1', RANK='0'), cwd='/tmp')
+    assert r.returncode != 0 and 'torch.distributed.run' in r.stderr
