@@ -161,4 +161,32 @@ __device__ inline bool es_last_block_light(unsigned int* ticket, unsigned int nb
   __syncthreads();
   return es_s_last3 != 0u;
 }
+#ifdef ES_EMU
+#define ES_WAIT_VM0() ((void)0)                        // (tests/emu: x86 cannot assemble it; the emulated stores are performed at once)
+#else
+#define ES_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+// Selectable form (es_set_option key 18): 0 (default) = the light election above -- the exact sc1-store / vmcnt(0) / barrier /
+// relaxed-ticket / sc1-load recipe cdna_hip_programming.md section 5 lists as "equally valid" for a split-K seam; 1 = every
+// workgroup additionally issues an agent-scope RELEASE fence before the ticket and the winner an agent-scope ACQUIRE fence after
+// it (buffer_wbl2 / buffer_inv: what the LLVM AMDGPU memory model guarantees for ANY store / load flavour) -- slower (it writes
+// back / drops the XCD's L2 under the big kernels on the other streams), kept for the stress test and as the fall-back.
+__device__ inline bool es_last_block_sel(unsigned int* ticket, unsigned int nblocks, int conservative) {
+  if (!conservative) return es_last_block_light(ticket, nblocks);
+  __shared__ unsigned int es_s_last4;
+  ES_WAIT_VM0();
+  __syncthreads();
+  if ((threadIdx.x | threadIdx.y | threadIdx.z) == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    ES_WAIT_VM0();                                     // (the wait behind buffer_wbl2 restated where the compiler cannot drop it)
+    unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    es_s_last4 = (t == nblocks - 1u) ? 1u : 0u;
+    if (es_s_last4) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
+  __syncthreads();
+  return es_s_last4 != 0u;
+}
 #define ES_TICKET_FLOATS 4          // floats reserved at the head of a workspace for the ticket (keeps partials 16-byte aligned)

@@ -364,7 +364,7 @@ static int dc_geometry(const int* gh, int mode, DcGeom& g, int& M, int& n_src) {
 }
 
 static int ES_OPT_DC_ROWS = 0;          // es_set_option 20: row tile of k_dconv (0 = pick per launch, 256, 320)
-static int ES_OPT_DC_ORDER = 1;         // 21: 1 = channel chunk outer / tap inner (default), 0 = tap outer
+static int ES_OPT_DC_ORDER = 0;         // 21: 0 = tap outer / channel chunk inner (default: +5 .. 20 % on every neck shape, profiles/r5a_dconv_ab.txt), 1 = chunk outer / tap inner
 static int ES_OPT_DC_SPLIT = 0;         // 22: 0 = pick the slice count per launch, n = force
 extern "C" int es_dconv_set_option(int key, int value) {
   if (key == 20) { ES_OPT_DC_ROWS = value; return 0; }

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void k_norm_apply4(const float* __restrict__ x
 // Statistics: per-thread f32 sums about the first row (a shift that is itself a sample), combined over the 1024 threads in f64
 // in a fixed order (wave shuffles, then 8 wave partials) -- deterministic; var = Q/n - (S/n)^2 in f64 on shifted sums.
 // The apply arithmetic is the k_norm_apply4 / k_norm_bwd_apply4 expression, element for element.
+int ES_OPT_ELECT_SAFE = 0;            // es_set_option key 18: 1 = agent-scope release / acquire fences in the last-workgroup elections (common.h)
 int ES_OPT_NORM_CB_ROWS = 4096;       // es_set_option key 15: matrices with at most this many rows take the one-launch path (0: off).
                                       // Measured on the mv-3ddet step (profiles/r4j_sweep.txt): 4096 -> 26.6 ms, off -> 26.8, 16384 -> 27.3
                                       // (8 .. 16 k rows x 256 channels are only 16 workgroups: too few), 65536 -> 33.1
@@ -933,7 +934,7 @@ extern "C" int es_topk_mask(const float* values, const int* seg_off, int nseg, i
 #define TK_BASE (TK_CNT + TKP * ES_MAX_SEG)
 #define TK_INTS (TK_BASE + TKP * ES_MAX_SEG)
 __global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ v, Segs segs, int kkeep, int shift, uint32_t pmask,
-                                                   unsigned int* __restrict__ wsp) {
+                                                   unsigned int* __restrict__ wsp, int safe) {
   const int seg = blockIdx.y, r0 = segs.off[seg], r1 = segs.off[seg + 1], n = r1 - r0;
   if (kkeep >= n) return;                               // (segment-uniform: every workgroup of the segment leaves)
   unsigned int* tickets = wsp;
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ v, 
   }
   __syncthreads();
   if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
-  if (!es_last_block_light(tickets + seg, gridDim.x)) return;      // (everything the workgroups exchange goes through atomics)
+  if (!es_last_block_sel(tickets + seg, gridDim.x, safe)) return;      // (everything the workgroups exchange goes through atomics)
   // the segment's histogram is complete: walk the buckets from the largest digit (one thread; 256 coherent reads)
   if (threadIdx.x == 0) {
     unsigned int rem = shift == 24 ? (unsigned int)kkeep : state[1], b = 255;
@@ -976,7 +977,7 @@ __global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ v, 
   __syncthreads();
   es_coh_store_u(&hist[threadIdx.x], 0u);               // ready for the next pass / the next call
 }
-__global__ __launch_bounds__(256) void k_topk_eqcount(const float* __restrict__ v, Segs segs, int kkeep, unsigned int* __restrict__ wsp) {
+__global__ __launch_bounds__(256) void k_topk_eqcount(const float* __restrict__ v, Segs segs, int kkeep, unsigned int* __restrict__ wsp, int safe) {
   const int seg = blockIdx.y, r0 = segs.off[seg], r1 = segs.off[seg + 1], n = r1 - r0;
   if (kkeep >= n) return;
   unsigned int* tickets = wsp;
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(256) void k_topk_eqcount(const float* __restrict__ 
   if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) es_coh_store_u(&cnt[blockIdx.x], wc[0] + wc[1] + wc[2] + wc[3]);
-  if (!es_last_block_light(tickets + seg, gridDim.x)) return;
+  if (!es_last_block_sel(tickets + seg, gridDim.x, safe)) return;
   if (threadIdx.x == 0) {
     unsigned int run = 0;
     for (int b = 0; b < TKP; ++b) {
@@ -1050,10 +1051,10 @@ extern "C" int es_topk_mask_ws(const float* values, const int* seg_off, int nseg
   if (any) {
     uint32_t pmask = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
-      hipLaunchKernelGGL(k_topk_hist, dim3(TKP, nseg), dim3(256), 0, st, values, s, k, shift, pmask, w);
+      hipLaunchKernelGGL(k_topk_hist, dim3(TKP, nseg), dim3(256), 0, st, values, s, k, shift, pmask, w, ES_OPT_ELECT_SAFE);
       pmask |= (255u << shift);
     }
-    hipLaunchKernelGGL(k_topk_eqcount, dim3(TKP, nseg), dim3(256), 0, st, values, s, k, w);
+    hipLaunchKernelGGL(k_topk_eqcount, dim3(TKP, nseg), dim3(256), 0, st, values, s, k, w, ES_OPT_ELECT_SAFE);
   }
   hipLaunchKernelGGL(k_topk_write, dim3(TKP, nseg), dim3(256), 0, st, values, s, k, w, mask);
   ES_CHECK_LAUNCH();
@@ -1070,7 +1071,7 @@ extern "C" int es_topk_mask_ws(const float* values, const int* seg_off, int nseg
 static int colsum_rows(int n) { int r = es_cdiv(n > 0 ? n : 1, 256); r = (r + 3) / 4 * 4; return r < CS_ROWS ? CS_ROWS : r; }   // <= 256 chunks
 // (64 chunks were too few for the head's 4e5-row launches: 64 workgroups, 0.64 ms, profiles/r4_single_stream_kernel_stats.txt)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int ld, int n, int C, float* __restrict__ dst, int accumulate,
-                                                float* __restrict__ ws, int rows_per_block) {
+                                                float* __restrict__ ws, int rows_per_block, int safe) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
@@ -1091,7 +1092,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int
     if (ty == 0 && c < C) es_coh_store(part + c, (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
     __syncthreads();
   }
-  if (!es_last_block_light((unsigned int*)ws, gridDim.x)) return;
+  if (!es_last_block_sel((unsigned int*)ws, gridDim.x, safe)) return;
   for (int c = threadIdx.x; c < C; c += 256) {
     float t = es_coh_sum(ws + ES_TICKET_FLOATS + c, (int)gridDim.x, (size_t)C);
     dst[c] = accumulate ? dst[c] + t : t;
@@ -1104,7 +1105,7 @@ extern "C" int es_colsum(const float* g, int ld, int n, int C, float* dst, int a
   if (n <= 0) { if (!accumulate) ES_TRY(hipMemsetAsync(dst, 0, (size_t)C * 4, (hipStream_t)stream)); return 0; }
   if (!workspace || workspace_floats < es_colsum_workspace_floats(n, C)) return -5;
   const int rpb = colsum_rows(n);
-  hipLaunchKernelGGL(k_colsum, dim3(es_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, g, ld, n, C, dst, accumulate, workspace, rpb);
+  hipLaunchKernelGGL(k_colsum, dim3(es_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, g, ld, n, C, dst, accumulate, workspace, rpb, ES_OPT_ELECT_SAFE);
   ES_CHECK_LAUNCH();
   return 0;
 }

@@ -47,6 +47,7 @@ static int ES_OPT_SPLIT_FOLD = 0;           // tap-split launches: partial tiles
 static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
 extern int ES_OPT_NORM_CB_ROWS;          // rowops.hip: one-launch norm for matrices with at most this many rows (key 15)
 extern int ES_OPT_NORM_CB_BWD;           // ... for the backward pass too (key 17)
+extern int ES_OPT_ELECT_SAFE;            // rowops.hip: agent-scope fences in the last-workgroup elections (key 18)
 extern "C" int es_set_option(int key, int value) {
   if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
   if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }
@@ -64,6 +65,7 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 15) { ES_OPT_NORM_CB_ROWS = value; return 0; }
   if (key == 16) { ES_OPT_SPLIT_FOLD = value; return 0; }
   if (key == 17) { ES_OPT_NORM_CB_BWD = value; return 0; }
+  if (key == 18) { ES_OPT_ELECT_SAFE = value; return 0; }
   return -2;
 }
 

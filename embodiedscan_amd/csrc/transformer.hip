@@ -17,6 +17,7 @@
 // per-sample valid length (the reference's key_padding_mask is always a prefix mask: padded texts / padded point sets).
 #include "common.h"
 #include "../../include/es_hip.h"
+extern int ES_OPT_ELECT_SAFE;           // rowops.hip (es_set_option key 18): fenced last-workgroup elections
 
 typedef __bf16 tbf16x8_t __attribute__((ext_vector_type(8)));
 typedef float tf32x4_t __attribute__((ext_vector_type(4)));
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
                                                 const float* __restrict__ w, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, float* __restrict__ dz, int accumulate,
                                                 float* __restrict__ dw, float* __restrict__ db, int rows_per_block,
-                                                float* __restrict__ ws) {
+                                                float* __restrict__ ws, int safe) {
   __shared__ float sw[4][512], sb[4][512];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float aw[8], ab[8], wc[8];
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
     es_coh_store(part + ((size_t)blockIdx.x * 2) * C + c, sw[0][c] + sw[1][c] + sw[2][c] + sw[3][c]);
     es_coh_store(part + ((size_t)blockIdx.x * 2 + 1) * C + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
   }
-  if (!es_last_block_light((unsigned int*)ws, gridDim.x)) return;
+  if (!es_last_block_sel((unsigned int*)ws, gridDim.x, safe)) return;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float a = es_coh_sum(part + c, (int)gridDim.x, (size_t)2 * C);
     const float bsum = es_coh_sum(part + C + c, (int)gridDim.x, (size_t)2 * C);
@@ -477,7 +478,7 @@ extern "C" int es_layernorm_bwd(const float* dy, const float* z, int n, int C, c
   if ((dw || db) && (!workspace || workspace_floats < es_layernorm_bwd_workspace_floats(n, C))) return -5;
   int rpb = LN_ROWS_PER_BLOCK;
   hipLaunchKernelGGL(k_ln_bwd, dim3(es_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, dy, z, n, C, w, mean, rstd, dz, accumulate,
-                     dw, db, rpb, workspace);
+                     dw, db, rpb, workspace, ES_OPT_ELECT_SAFE);
   ES_CHECK_LAUNCH();
   return 0;
 }
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(256) void k_contrastive_bwd(const float* __restrict
                                                          const float* __restrict__ text, int T, int C,
                                                          const int* __restrict__ tlen, float* __restrict__ dv, int acc_v,
                                                          float* __restrict__ dtext, float* __restrict__ dbias, int nA,
-                                                         float* __restrict__ ws) {
+                                                         float* __restrict__ ws, int safe) {
   extern __shared__ float sh[];                         // dv workgroups: the sample's text block [tl * C]
   const int b = blockIdx.y;
   const int tl = min(tlen[b], T);
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(256) void k_contrastive_bwd(const float* __restrict
     if (threadIdx.x == 0) es_coh_store(ws + ES_TICKET_FLOATS + (size_t)b * T + t, bs);
   }
   if (!reduce) return;
-  if (!es_last_block_light((unsigned int*)ws, gridDim.x * gridDim.y)) return;
+  if (!es_last_block_sel((unsigned int*)ws, gridDim.x * gridDim.y, safe)) return;
   if (dbias && threadIdx.x == 0) {
     dbias[0] += es_coh_sum(ws + ES_TICKET_FLOATS, (int)(gridDim.y * T), 1);
   }
@@ -648,7 +649,7 @@ extern "C" int es_contrastive_bwd(const float* dlogits, int Tout, const float* v
   const int nx = nA + (reduce ? T : 0);
   if (nx <= 0) return 0;
   hipLaunchKernelGGL(k_contrastive_bwd, dim3(nx, B), dim3(256), sh, (hipStream_t)stream, dlogits, Tout, v, L, text, T, C, tlen_dev,
-                     dv, acc_v, dtext, dbias, nA, workspace);
+                     dv, acc_v, dtext, dbias, nA, workspace, ES_OPT_ELECT_SAFE);
   ES_CHECK_LAUNCH();
   return 0;
 }

@@ -387,6 +387,22 @@ def ticket_ws(floats, like, tag=''):
     return ws, ws.numel()
 
 
+def reset_tickets():
+    """re-zero the ticket heads of every cached election workspace (on the current stream).  A launch that faulted inside an
+    in-launch reduction leaves its ticket non-zero; the step that saw the fault has already raised HipError, a caller that
+    catches it and continues must call this (after synchronising) before the next step."""
+    for ws in _TICKET_WS.values():
+        ws[:min(ws.numel(), 2048)].zero_()
+
+
+def drop_caches():
+    """forget every per-stream workspace / kept temporary (tests that switch between devices or libraries in one process)"""
+    _TICKET_WS.clear()
+    _WGRAD_WS.clear()
+    _DC_WS.clear()
+    _KEEP.clear()
+
+
 MARKS = None            # bench.py sets a list: stage boundaries as (name, event) recorded on the current stream
 
 
@@ -603,7 +619,7 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         key = (sw, 'colsum')
         ws = _TICKET_WS.get(key)
         need = int(hip.raw('es_colsum_workspace_floats')(n_out, nb))
-        if ws is None or ws.numel() < need:
+        if ws is None or ws.numel() < need or ws.device != gy.device:      # (a cached buffer of another device is never handed out)
             if ws is not None:
                 _KEEP.append(ws)
             ws = _TICKET_WS[key] = torch.zeros(max(need, 1 << 16), dtype=torch.float32, device=gy.device)

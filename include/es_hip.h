@@ -93,10 +93,11 @@ int es_spconv_fwd(const float* X, int ldx, const float* W, const int* nbr, int n
 int es_spconv_fwd_bf16(const void* X, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in,
                        int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, void* stream);
 /* the same with a caller-provided workspace of es_spconv_split_workspace_floats() floats: launches with too few tiles to
- * fill the chip split their tap list over several workgroups, which write partial tiles to the workspace; the LAST workgroup
- * of every output tile adds them in slice order into Y inside the same launch (round 4; bit-reproducible, no f32 atomics, no
- * second launch).  The first 1024 floats of the workspace are the tiles' ticket counters: ZERO on entry, zero again on exit --
- * keep one zero-initialised workspace per stream and reuse it. */
+ * fill the chip split their tap list over several workgroups, which write partial tiles to the workspace; a SECOND launch
+ * (k_sum_splits) adds them in slice order into Y (the shipped default, es_set_option key 16 = 0: bit-reproducible, no f32
+ * atomics).  Key 16 = 1 folds that reduction into the launch (the last workgroup of a tile adds the slices; measured slower in
+ * round 4: an agent-scope fence per workgroup).  The first 1024 floats of the workspace are the tiles' ticket counters of the
+ * folded form (at most 1024 tiles): ZERO on entry, zero again on exit -- keep one zero-initialised workspace per stream. */
 size_t es_spconv_split_workspace_floats(int n_out, int K, int Cin, int Cout);
 int es_spconv_fwd_bf16_ws(const void* X, int x_is_bf16, int ldx, const void* W_bf16, const int* nbr, int n_out, int n_in,
                           int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, float* ws,
@@ -121,8 +122,12 @@ int es_gen_transpose_dgrad_bf16(const float* dY, const void* Wn_bf16, int n, int
  * 3 = EXPERIMENTAL three-buffer ring with two chunks in flight (32-channel chunks; not yet run on hardware);
  * key 11 = fewest input channels for which key 10 applies (default 768: the dense occupancy neck);
  * key 12 = fewest input channels for which the K = 1 row GEMM uses 128-column tiles (default 0);
- * key 13 = second-generation row GEMM (default 1); key 14 = EXPERIMENTAL weight-gradient tile with LDS-DMA staging and
- * transposed LDS reads (default 0, not yet run on hardware) */
+ * key 13 = second-generation row GEMM (default 1); key 14 = weight-gradient tile with LDS-DMA staging and transposed LDS
+ * reads (default 1 since round 4: bit-identical on the GPU); key 15 / 17 = one-launch norm forward / backward up to this many
+ * rows; key 16 = fold the tap-split reduction into the launch (default 0, see es_spconv_fwd_bf16_ws);
+ * key 18 = last-workgroup elections of the deterministic in-launch reductions (es_colsum, es_layernorm_bwd, es_contrastive_bwd,
+ * es_topk_mask_ws): 0 (default) coherent (sc1) stores + drained ticket, no cache maintenance; 1 adds an agent-scope release
+ * fence in every workgroup and an acquire fence in the winner (csrc/common.h es_last_block_sel; tests/test_gpu_elect.py) */
 int es_set_option(int key, int value);
 /* Y = act((X*W) * scale[c] + shift[c] (+ res)): conv2d + frozen BatchNorm2d (+ residual) (+ ReLU) of mmdet.ResNet in one
  * launch (any shape; the tap-split of under-filled launches is not applied to fused calls).  act: 0 none, 1 ReLU,

@@ -62,8 +62,10 @@ def emulated(monkeypatch):
     for flag in (E.TWO_STREAMS, E.WGRAD_ASYNC, E.GRAPHS):
         monkeypatch.setitem(_ListAsDict(flag), 0, False)
     # the engine allocates the weight-gradient slice workspace of a stream on 'cuda' when it has none: hand it a host buffer
+    E.drop_caches()                      # nothing cached by an earlier (GPU or emulated) test survives into this one ...
     monkeypatch.setitem(E._WGRAD_WS, 0, torch.empty(1 << 24, dtype=torch.float32))
-    return torch.device('cpu')
+    yield torch.device('cpu')
+    E.drop_caches()                      # ... and no host buffer of this one is handed to a later GPU test of the same process
 
 
 def test_voxelise_and_every_coordinate_map_bit_exact(emulated):
