@@ -527,11 +527,19 @@ def run_other_config(kind, args, dev):
     torch.cuda.synchronize()
     prof = {'names': ENGINE | ATTN | {'es_ground_match'}, 'records': [], 'event': lambda: torch.cuda.Event(enable_timing=True)}
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    diag = [] if os.environ.get('ES_BENCH_DIAG') else None      # per-step host / allocator / graph state (hunting step-time outliers)
     step_ev[0].record()
     t0 = time.perf_counter()
     for it in range(steps):
+        h0 = time.perf_counter()
         losses = step()
         step_ev[it + 1].record()
+        if diag is not None:
+            ms = torch.cuda.memory_stats()
+            diag.append(dict(host_ms=round((time.perf_counter() - h0) * 1e3, 2), reserved_MB=ms['reserved_bytes.all.current'] >> 20,
+                             allocated_MB=ms['allocated_bytes.all.current'] >> 20, mallocs=ms['num_device_alloc'], frees=ms['num_device_free'],
+                             retries=ms['num_alloc_retries'], graphs=dict(E.GRAPH_STATS),
+                             extra=dict(getattr(det, 'diag', None) or {})))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     hip.PROFILE = prof                          # one extra untimed step under the same schedule, every engine launch bracketed
@@ -605,6 +613,8 @@ def run_other_config(kind, args, dev):
                                single_stream=dict(kernel_ms_per_step=e1['ms'], tflops=e1['tflops'], frac_of_binding_roof=e1['frac_binding'])),
                classes=launch_classes(r1, peak), stage_ms=stages,
                step_ms=[round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(steps)], **extra)
+    if diag is not None:
+        res['step_diag'] = diag
     if parity is not None:
         res['parity'], res['cpu_baseline'] = parity, base
     del det, optim, feeder
@@ -733,7 +743,14 @@ def dense_info(name, a):
     ax = lambda d: sum(1 for q in range(o(d)) for k in range(ks) if 0 <= q * st - pad + k < d)
     pairs = float(B) * ax(X) * ax(Y) * ax(Z)
     n_in, n_out = B * X * Y * Z, B * o(X) * o(Y) * o(Z)
-    cin, cout = a[5], a[6]
+    cin, cout = (a[5], a[6]) if name == 'es_dconv_fwd_bf16' else (a[6], a[7])
+    if name == 'es_dconv_fwd_bf16' and a[4] in (3, 4) or (name == 'es_dconv_wgrad_bf16' and a[5]):
+        # nn.ConvTranspose3d(k = 2, s = 2): 8 taps, every (coarse voxel, tap) pair is valid; forward / weight gradient read Cin and
+        # write / pair with Cout on the fine grid, the data gradient the other way round
+        n_c, n_f, pairs = B * X * Y * Z, 8 * B * X * Y * Z, 8.0 * B * X * Y * Z
+        if name == 'es_dconv_fwd_bf16' and a[4] == 4:
+            return n_c, n_f, 8, cout, cin, pairs
+        return n_f, n_c, 8, cin, cout, pairs
     if name == 'es_dconv_fwd_bf16' and a[4] == 1:
         return n_in, n_out, ks ** 3, cout, cin, pairs
     return n_out, n_in, ks ** 3, cin, cout, pairs

@@ -43,6 +43,13 @@ struct DcGeom {
   unsigned mS, mYZ, mZ;                   // floor(2^32 / d) for d = rX*rY*rZ, rY*rZ, rZ (dc_div)
   int sX, sY, sZ, sm;                     // source grid per sample, row -> source coordinate multiplier (the stride)
   int nT;
+  // cls = 1 (the data gradient of a stride-2 convolution, the forward of a k = 2 / s = 2 transposed convolution): the rows are
+  // (parity class p = (px, py, pz), b, x, y, z) -- every row-grid voxel once per class -- row (p, b, x, y, z) is written to the
+  // voxel (2x + px, 2y + py, 2z + pz) of the output grid (2 rX, 2 rY, 2 rZ), and class p only has the taps
+  // taps[clsBeg[p] .. clsBeg[p + 1]) (a stride-2 3x3x3 kernel reaches an output voxel through 1, 2, 4 or 8 of its 27 taps,
+  // depending on the parity of its coordinates: no zero tap is ever multiplied).  A row tile never straddles two classes.
+  int cls;
+  short clsBeg[9];
   DcTap taps[DC_MAXT];
 };
 
@@ -93,8 +100,11 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
   const int L = dc_logical(per);
   if (L >= rowTiles * colTiles * nsplit) return;
   const int rt = L % rowTiles, ct = (L / rowTiles) % colTiles, bz = L / (rowTiles * colTiles);
-  const int row0 = rt * BMT, n0 = ct * 256;
-  if (t < g.nT) tapS[t] = g.taps[t];
+  const int tpc = g.cls ? rowTiles >> 3 : rowTiles;             // row tiles per parity class
+  const int pc = rt / tpc;                                      // this tile's class (0 without classes)
+  const int row0 = (rt - pc * tpc) * BMT, n0 = ct * 256;
+  const int tb = g.cls ? g.clsBeg[pc] : 0, nTl = g.cls ? g.clsBeg[pc + 1] - tb : g.nT;     // this tile's taps
+  if (t < nTl) tapS[t] = g.taps[tb + t];
   // this thread's A pieces: piece e = (j * 8 + wv) * 64 + lane lands at LDS byte e * 16 = tile row e >> 3, slot e & 7, and holds
   // the row's granule slot ^ key(row), key(row) = (row >> 1) & 7 (the same for all j: rows differ by multiples of 64)
   int a_pk[NA], a_base[NA];
@@ -102,10 +112,10 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
   for (int j = 0; j < NA; ++j) dc_row(g, row0 + (j * 8 + wv) * 8 + (lane >> 3), M, a_pk[j], a_base[j]);
   const int kslot = ((lane & 7) ^ (((wv & 1) * 4 + (lane >> 4)) & 7)) * 8;      // element offset of the source granule
   const int b_off0 = (n0 + wv * 8 + (lane >> 3)) * Kd + kslot;                  // piece j: + j * 64 * Kd
-  const int nC = Kd >> 6, nIt = nC * g.nT;
+  const int nC = Kd >> 6, nIt = nC * nTl;
   const int it0 = (int)(((long long)nIt * bz) / nsplit), it1 = (int)(((long long)nIt * (bz + 1)) / nsplit);
   int it_t, it_c0;                               // tap index and channel offset of the NEXT step to stage
-  if (TAP_INNER) { it_t = it0 % g.nT; it_c0 = (it0 / g.nT) * 64; }
+  if (TAP_INNER) { it_t = it0 % nTl; it_c0 = (it0 / nTl) * 64; }
   else { it_c0 = (it0 % nC) * 64; it_t = it0 / nC; }
   __syncthreads();                               // the tap table
 
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
 
   int a_off[NA], w_off = 0;
   auto set_tap = [&]() {
-    const DcTap tp = tapS[it_t < g.nT ? it_t : 0];
+    const DcTap tp = tapS[it_t < nTl ? it_t : 0];
     w_off = (int)tp.w * N * Kd;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
                                        (__attribute__((address_space(3))) void*)(smem + OFF_B + buf * B_BYTES + (j * 8 + wv) * 1024), 16, 0, 0);
     }
     if (TAP_INNER) {                             // next step of the sequence
-      if (++it_t == g.nT) { it_t = 0; it_c0 += 64; }
+      if (++it_t == nTl) { it_t = 0; it_c0 += 64; }
       set_tap();
     } else {
       it_c0 += 64;
@@ -181,6 +191,34 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
   float* const out = nsplit > 1 ? ws + (size_t)bz * M * N : Y;
   const int ldo = nsplit > 1 ? N : ldy;
   const bool add = nsplit > 1 ? false : (accumulate != 0);
+  if (g.cls) {                                   // rows of a parity class: scatter to the voxels (2x + px, 2y + py, 2z + pz)
+    const int px = pc >> 2, py = (pc >> 1) & 1, pz = pc & 1;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wr * (BMT / 4) + mf * 16 + kq * 4 + r;
+        if (row < M) {
+          unsigned b, rem, x, y, z;
+          dc_div((unsigned)row, (unsigned)(g.rX * g.rY * g.rZ), g.mS, b, rem);
+          dc_div(rem, (unsigned)(g.rY * g.rZ), g.mYZ, x, rem);
+          dc_div(rem, (unsigned)g.rZ, g.mZ, y, z);
+          const size_t orow = (((size_t)b * (2 * g.rX) + 2 * x + px) * (2 * g.rY) + 2 * y + py) * (2 * g.rZ) + 2 * z + pz;
+          float* p = Y + orow * ldy + n0 + wc * 128 + li;
+          if (add) {
+            float y0[NF];
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) y0[nf] = p[nf * 16];
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) p[nf * 16] = y0[nf] + acc[mf][nf][r];
+          } else {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) p[nf * 16] = acc[mf][nf][r];
+          }
+        }
+      }
+    return;
+  }
   if (add) {                                     // (hoisted: one uniform branch, not one per element)
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
@@ -232,7 +270,7 @@ __global__ void k_dconv_reduce(const float4* __restrict__ ws, int nsplit, size_t
 __global__ __launch_bounds__(512, 2) void k_dconv_wgrad(const unsigned short* __restrict__ Xh, int ldx,
                                                         const unsigned short* __restrict__ dYh, int ldy, int Cin, int Cout,
                                                         int M, DcGeom g, float* __restrict__ dW, int accumulate, int nCo,
-                                                        int nWG, int per) {
+                                                        int nWG, int per, int gatherB) {
   constexpr int TB = 64 * 512;                   // bytes of one operand tile: 64 voxels x 256 channels
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TB];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
@@ -259,8 +297,11 @@ __global__ __launch_bounds__(512, 2) void k_dconv_wgrad(const unsigned short* __
       int pk, base;
       dc_row(g, m, M, pk, base);
       const int s = dc_src(g, pk, base, tp.dx, tp.dy, tp.dz);
-      const unsigned short* px = s >= 0 ? (Xh + s * ldx + c0 + gk) : g_dc_zero;
-      const unsigned short* py = m < M ? (dYh + m * ldy + n0 + gk) : g_dc_zero;
+      // gatherB = 0 (convolution): X rows are gathered under the tap, dY rows are the rows themselves; 1 (transposed convolution:
+      // dW[p] = X^T dY[2 . + p]): the other way round
+      const int sx = gatherB ? (m < M ? m : -1) : s, sy = gatherB ? s : (m < M ? m : -1);
+      const unsigned short* px = sx >= 0 ? (Xh + sx * ldx + c0 + gk) : g_dc_zero;
+      const unsigned short* py = (sx >= 0 && sy >= 0) ? (dYh + sy * ldy + n0 + gk) : g_dc_zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)px,
                                        (__attribute__((address_space(3))) void*)(smem + (buf * 2 + 0) * TB + (j * 8 + wv) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
@@ -333,32 +374,79 @@ __global__ __launch_bounds__(512, 2) void k_dconv_wgrad(const unsigned short* __
 // ------------------------------------------------------------------ host side
 static unsigned dc_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)((1ull << 32) / d); }
 
-// geom_host: {B, X, Y, Z (input grid), ksize, stride, pad}; mode 0 forward (rows = output voxels, sources = input voxels),
-// 1 data gradient of a stride-1 convolution (rows = input voxels, sources = output voxels, mirrored taps),
-// 2 weight gradient (rows = output voxels, sources = input voxels)
+// geom_host: {B, X, Y, Z, ksize, stride, pad} of the operator's INPUT grid (nn.Conv3d: its input; nn.ConvTranspose3d: ITS input, the
+// coarse grid).  Modes:
+//   0  convolution forward            rows = output voxels, sources = input voxels * stride - pad + k
+//   1  convolution data gradient      stride 1: rows = input voxels, sources = output voxels + pad - k;
+//                                     stride 2 (k = 3, pad = 1, even input sizes): rows = (parity class, output-grid voxel), written to the
+//                                     input voxel 2 r + p, class p only through the taps with p + pad - k even (source r + (p + pad - k) / 2)
+//   2  convolution weight gradient    rows = output voxels; X gathered as in mode 0, dY direct
+//   3  transposed convolution (k = 2, s = 2, pad = 0) forward: rows = (class p, input voxel r), written to 2 r + p, one tap (p) per class
+//   4  ... its data gradient          rows = input voxels, sources = output voxels 2 r + p, 8 taps
+//   5  ... its weight gradient        rows = input voxels; X direct, dY gathered at 2 r + p
 static int dc_geometry(const int* gh, int mode, DcGeom& g, int& M, int& n_src) {
   const int B = gh[0], X = gh[1], Y = gh[2], Z = gh[3], ks = gh[4], st = gh[5], pad = gh[6];
-  if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || ks <= 0 || ks * ks * ks > DC_MAXT || st <= 0 || pad < 0) return -2;
-  const int Xo = (X + 2 * pad - ks) / st + 1, Yo = (Y + 2 * pad - ks) / st + 1, Zo = (Z + 2 * pad - ks) / st + 1;
+  if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || ks <= 0 || ks * ks * ks > DC_MAXT || st <= 0 || pad < 0 || mode < 0 || mode > 5) return -2;
+  const bool tr = mode >= 3;
+  if (tr && (ks != 2 || st != 2 || pad != 0)) return -4;
+  const int Xo = tr ? 2 * X : (X + 2 * pad - ks) / st + 1, Yo = tr ? 2 * Y : (Y + 2 * pad - ks) / st + 1,
+            Zo = tr ? 2 * Z : (Z + 2 * pad - ks) / st + 1;
   if (Xo <= 0 || Yo <= 0 || Zo <= 0) return -2;
-  if (mode == 1 && (st != 1 || ks != 2 * pad + 1)) return -4;          // (the strided data gradient stays on the map kernels)
-  if ((long long)(X > Xo ? X : Xo) * st >= 2048 || (long long)(Y > Yo ? Y : Yo) * st >= 2048 || (long long)(Z > Zo ? Z : Zo) * st >= 512)
+  const bool strided_dgrad = mode == 1 && st != 1;
+  if (mode == 1 && st == 1 && ks != 2 * pad + 1) return -4;
+  if (strided_dgrad && (st != 2 || ks != 3 || pad != 1 || X != 2 * Xo || Y != 2 * Yo || Z != 2 * Zo)) return -4;
+  const int bigX = X > Xo ? X : Xo, bigY = Y > Yo ? Y : Yo, bigZ = Z > Zo ? Z : Zo;
+  if ((long long)bigX * st >= 2048 || (long long)bigY * st >= 2048 || (long long)bigZ * st >= 512)
     return -4;                                                           // (11 / 11 / 9 bits of the packed row coordinates)
-  g.rX = mode == 1 ? X : Xo; g.rY = mode == 1 ? Y : Yo; g.rZ = mode == 1 ? Z : Zo;
-  g.sX = mode == 1 ? Xo : X; g.sY = mode == 1 ? Yo : Y; g.sZ = mode == 1 ? Zo : Z;
-  g.sm = mode == 1 ? 1 : st;
+  g.cls = (strided_dgrad || mode == 3) ? 1 : 0;
+  // row grid / source grid
+  const bool rows_out = mode == 0 || mode == 2 || strided_dgrad;          // rows over the convolution's OUTPUT grid
+  const bool rows_in = !rows_out;                                         // ... over the operator's input grid
+  g.rX = rows_out ? Xo : X; g.rY = rows_out ? Yo : Y; g.rZ = rows_out ? Zo : Z;
+  if (mode == 0 || mode == 2) { g.sX = X; g.sY = Y; g.sZ = Z; g.sm = st; }
+  else if (mode == 1) { g.sX = Xo; g.sY = Yo; g.sZ = Zo; g.sm = 1; }
+  else if (mode == 3) { g.sX = X; g.sY = Y; g.sZ = Z; g.sm = 1; }
+  else { g.sX = Xo; g.sY = Yo; g.sZ = Zo; g.sm = 2; }
+  (void)rows_in;
   g.mS = dc_magic((unsigned)(g.rX * g.rY * g.rZ)); g.mYZ = dc_magic((unsigned)(g.rY * g.rZ)); g.mZ = dc_magic((unsigned)g.rZ);
-  g.nT = ks * ks * ks;
-  for (int t = 0; t < g.nT; ++t) {
-    const int kx = t / (ks * ks), ky = (t / ks) % ks, kz = t % ks;
-    // forward: source = out * stride - pad + k.  data gradient (stride 1): dX[i] += dY[i + pad - k] . W[k]^T
-    g.taps[t].w = (short)t;
-    g.taps[t].dx = (short)(mode == 1 ? pad - kx : kx - pad);
-    g.taps[t].dy = (short)(mode == 1 ? pad - ky : ky - pad);
-    g.taps[t].dz = (short)(mode == 1 ? pad - kz : kz - pad);
+  g.nT = 0;
+  for (int p = 0; p < 9; ++p) g.clsBeg[p] = 0;
+  if (g.cls) {
+    for (int p = 0; p < 8; ++p) {
+      g.clsBeg[p] = (short)g.nT;
+      const int q[3] = {p >> 2, (p >> 1) & 1, p & 1};
+      if (mode == 3) {                                                     // transposed convolution: output 2 r + p comes from input r through tap p
+        g.taps[g.nT++] = DcTap{(short)p, 0, 0, 0};
+        continue;
+      }
+      for (int t = 0; t < ks * ks * ks; ++t) {
+        const int k[3] = {t / (ks * ks), (t / ks) % ks, t % ks};
+        int d[3];
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) {
+          const int e = q[a] + pad - k[a];
+          if (e & 1) ok = false;
+          d[a] = e / 2;                                                    // (exact when even)
+        }
+        if (ok) g.taps[g.nT++] = DcTap{(short)t, (short)d[0], (short)d[1], (short)d[2]};
+      }
+    }
+    g.clsBeg[8] = (short)g.nT;
+  } else {
+    g.nT = ks * ks * ks;
+    for (int t = 0; t < g.nT; ++t) {
+      const int kx = t / (ks * ks), ky = (t / ks) % ks, kz = t % ks;
+      // forward: source = out * stride - pad + k.  data gradient (stride 1): dX[i] += dY[i + pad - k] . W[k]^T.
+      // transposed convolution, data / weight gradient: source = 2 r + k
+      const bool back = mode == 1;
+      g.taps[t].w = (short)t;
+      g.taps[t].dx = (short)(back ? pad - kx : kx - pad);
+      g.taps[t].dy = (short)(back ? pad - ky : ky - pad);
+      g.taps[t].dz = (short)(back ? pad - kz : kz - pad);
+    }
   }
   const long long m = (long long)B * g.rX * g.rY * g.rZ, ns = (long long)B * g.sX * g.sY * g.sZ;
-  if (m >= (1ll << 31) || ns >= (1ll << 31)) return -4;
+  if (m * (g.cls ? 8 : 1) >= (1ll << 31) || ns >= (1ll << 31)) return -4;
   M = (int)m; n_src = (int)ns;
   return 0;
 }
@@ -374,7 +462,12 @@ extern "C" int es_dconv_set_option(int key, int value) {
 }
 
 struct DcPlan { int bm, rowTiles, colTiles, nsplit; };
-static DcPlan dc_plan(int M, int N, int nIt) {
+static DcPlan dc_plan(int M, int N, int nIt, int cls = 0) {
+  if (cls) {                                     // parity classes: 8 x tiles-per-class row tiles, no slices (the classes ARE the split)
+    int bm = (ES_OPT_DC_ROWS == 256 || ES_OPT_DC_ROWS == 320) ? ES_OPT_DC_ROWS
+             : (es_cdiv(M, 320) * 320 < es_cdiv(M, 256) * 256 || (es_cdiv(M, 320) * 320 == es_cdiv(M, 256) * 256 && M >= 320) ? 320 : 256);
+    return DcPlan{bm, 8 * es_cdiv(M, bm), N / 256, 1};
+  }
   DcPlan best{256, es_cdiv(M, 256), N / 256, 1};
   double best_cost = 1e30;
   for (int bm = 256; bm <= 320; bm += 64) {
@@ -393,36 +486,46 @@ static DcPlan dc_plan(int M, int N, int nIt) {
   return best;
 }
 
+// which (Kd, N) a mode runs with: the reduction runs over the channels of the SOURCE rows
+static void dc_roles(int mode, int Cin, int Cout, int& Kd, int& N) {
+  const bool back = mode == 1 || mode == 4;      // data gradients: source = the output gradient (Cout channels), result has Cin
+  Kd = back ? Cout : Cin; N = back ? Cin : Cout;
+}
+
 extern "C" int es_dconv_supported(const int* geom_host, int mode, int Cin, int Cout) {
   DcGeom g; int M, ns;
-  if (dc_geometry(geom_host, mode == 1 ? 1 : mode, g, M, ns) != 0) return 0;
-  const int Kd = mode == 1 ? Cout : Cin, N = mode == 1 ? Cin : Cout;
-  if (mode == 2) return (Cin % 256 == 0 && Cout % 256 == 0) ? 1 : 0;
+  if (dc_geometry(geom_host, mode, g, M, ns) != 0) return 0;
+  if (mode == 2 || mode == 5) return (Cin % 256 == 0 && Cout % 256 == 0) ? 1 : 0;
+  int Kd, N;
+  dc_roles(mode, Cin, Cout, Kd, N);
   return (Kd % 64 == 0 && N % 256 == 0) ? 1 : 0;
 }
 
 extern "C" size_t es_dconv_workspace_floats(const int* geom_host, int mode, int Cin, int Cout) {
   DcGeom g; int M, ns;
-  if (mode == 2 || dc_geometry(geom_host, mode, g, M, ns) != 0) return 0;
-  const int Kd = mode == 1 ? Cout : Cin, N = mode == 1 ? Cin : Cout;
+  if (mode == 2 || mode == 5 || dc_geometry(geom_host, mode, g, M, ns) != 0 || g.cls) return 0;
+  int Kd, N;
+  dc_roles(mode, Cin, Cout, Kd, N);
   if (Kd % 64 != 0 || N % 256 != 0) return 0;
   const DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT);
   return p.nsplit > 1 ? (size_t)p.nsplit * M * N : 0;
 }
 
-// mode 0: Y[M x Cout] = conv(X); W = the [K][Cout][Cin] bf16 copy.  mode 1: dX[M x Cin] = conv^T(dY) for stride 1; Xh = the
-// bf16 output gradient rows, W = the natural [K][Cin][Cout] bf16 copy, Y = dX.
+// modes 0 / 3 (forward): Xh = the operator's bf16 input rows, W_bf16 = the [K][Cout][Cin] copy, Y = its output rows (f32).
+// modes 1 / 4 (data gradient): Xh = bf16 rows of the output gradient, W_bf16 = the natural [K][Cin][Cout] copy, Y = the input gradient.
 extern "C" int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, const int* geom_host, int mode, int Cin, int Cout,
                                  float* Y, int ldy, int accumulate, float* ws, size_t ws_floats, void* stream) {
   DcGeom g; int M, ns;
-  if (mode != 0 && mode != 1) return -2;
+  if (mode != 0 && mode != 1 && mode != 3 && mode != 4) return -2;
   int rc = dc_geometry(geom_host, mode, g, M, ns);
   if (rc != 0) return rc;
-  const int Kd = mode == 1 ? Cout : Cin, N = mode == 1 ? Cin : Cout;
+  int Kd, N;
+  dc_roles(mode, Cin, Cout, Kd, N);
+  const int nTw = mode >= 3 ? 8 : g.nT;           // taps of the weight tensor
   if (Kd % 64 != 0 || N % 256 != 0 || (ldx & 7) != 0 || (ldy & 3) != 0 || ((uintptr_t)Xh & 15) != 0 || ((uintptr_t)W_bf16 & 15) != 0 ||
-      ((uintptr_t)Y & 15) != 0 || (long long)ns * ldx >= (1ll << 31) || (long long)g.nT * N * Kd >= (1ll << 31))
+      ((uintptr_t)Y & 15) != 0 || (long long)ns * ldx >= (1ll << 31) || (long long)(nTw > 27 ? nTw : 27) * N * Kd >= (1ll << 31))
     return -4;
-  DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT);
+  DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT, g.cls);
   if (p.nsplit > 1 && (ws == nullptr || ws_floats < (size_t)p.nsplit * M * N || ((uintptr_t)ws & 15) != 0)) return -5;
   hipStream_t st = (hipStream_t)stream;
   const int nwg = p.rowTiles * p.colTiles * p.nsplit, per = es_cdiv(nwg, 8);
@@ -445,18 +548,20 @@ extern "C" int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, co
   return 0;
 }
 
-// dW[K][Cin][Cout] (+)= X^T dY over the dense grid; Xh (B*X*Y*Z x ldx), dYh (B*Xo*Yo*Zo x ldy) bf16 rows
-extern "C" int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int Cin, int Cout,
-                                   float* dW, int accumulate, void* stream) {
+// dW[K][Cin][Cout] (+)= X^T dY over the dense grid; Xh = bf16 rows of the operator's input, dYh = bf16 rows of its output gradient;
+// transposed 0: nn.Conv3d (mode 2), 1: nn.ConvTranspose3d(k = 2, s = 2) (mode 5)
+extern "C" int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int transposed, int Cin,
+                                   int Cout, float* dW, int accumulate, void* stream) {
   DcGeom g; int M, ns;
-  int rc = dc_geometry(geom_host, 2, g, M, ns);
+  int rc = dc_geometry(geom_host, transposed ? 5 : 2, g, M, ns);
   if (rc != 0) return rc;
+  const long long nx = transposed ? M : ns, ny = transposed ? ns : M;     // rows of X / of dY
   if (Cin % 256 != 0 || Cout % 256 != 0 || (ldx & 7) != 0 || (ldy & 7) != 0 || ((uintptr_t)Xh & 15) != 0 || ((uintptr_t)dYh & 15) != 0 ||
-      (long long)ns * ldx >= (1ll << 31) || (long long)M * ldy >= (1ll << 31))
+      nx * ldx >= (1ll << 31) || ny * ldy >= (1ll << 31))
     return -4;
   const int nCo = Cout / 256, nwg = g.nT * (Cin / 256) * nCo, per = es_cdiv(nwg, 8);
   hipLaunchKernelGGL(k_dconv_wgrad, dim3(per * 8), dim3(512), 0, (hipStream_t)stream, (const unsigned short*)Xh, ldx,
-                     (const unsigned short*)dYh, ldy, Cin, Cout, M, g, dW, accumulate, nCo, nwg, per);
+                     (const unsigned short*)dYh, ldy, Cin, Cout, M, g, dW, accumulate, nCo, nwg, per, transposed ? 1 : 0);
   ES_CHECK_LAUNCH();
   return 0;
 }

@@ -605,7 +605,7 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     if w.g is not None or (bias is not None and bias.g is not None):
         sw = _wgrad_stream(gy, x.d, gh, x.dh)
     if dn_w is not None:
-        call('es_dconv_wgrad_bf16', P(x.dh), cin, P(gh), cout, _dense_geom(dn_w), cin, cout, P(w.g), _first_write(P(w.g)), sw)
+        call('es_dconv_wgrad_bf16', P(x.dh), cin, P(gh), cout, _dense_geom(dn_w), 0, cin, cout, P(w.g), _first_write(P(w.g)), sw)
     elif w.g is not None and bf and WGRAD_BF16[0] and SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None):
         xs, ys = x.dh if x.dh is not None else x.d, gh if gh is not None else gy
         _wgrad('es_spconv_wgrad_bf16_src', sw, P(w.g), P(xs), int(x.dh is not None), _ld(xs), P(ys), int(gh is not None), _ld(ys),
@@ -750,6 +750,40 @@ def gen_conv_transpose(x, w):
                      P(g), _ld(g), 1, 1 if (acc or k > 0) else 0, s)
         if recs is not None and x.rg:
             recs[-1]['after'] = x.g.clone()          # (after all eight taps)
+    TAPE.add(bwd)
+    return y
+
+
+def conv_transpose_dense(x, w, dense):
+    """nn.ConvTranspose3d(k=2, s=2) on a dense (B, X, Y, Z) grid (dense = (B, X, Y, Z, 2, 2, 0)): y (B*2X*2Y*2Z, Cout) in DENSE row order
+    by the parity-class launch of the dense engine (csrc/dconv.hip mode 3) -- no generative-layout intermediate, no row permutation;
+    backward: data gradient (mode 4: 8 taps gathered at 2 r + p) and weight gradient (mode 5).  Caller checks dense_ok(dense, 3 / 4 / 5)."""
+    K, cin, cout = w.d.shape
+    n = x.d.shape[0]
+    y = Var(empty((n * 8, cout), x.d))
+    _dense_launch(P(x.shadow()), cin, P(w.bf16()[1]), dense, 3, cin, cout, P(y.d), cout, 0, x.d)
+
+    def bwd():
+        if y.g is None:
+            return
+        gh = y.grad_shadow()
+        rec_before = x.g.clone() if (DEBUG_CONV is not None and x.rg and x.g is not None) else None
+        if w.g is not None:
+            x.shadow()
+            sw = _wgrad_stream(y.g, x.d, gh, x.dh)
+            call('es_dconv_wgrad_bf16', P(x.dh), cin, P(gh), cout, _dense_geom(dense), 1, cin, cout, P(w.g), _first_write(P(w.g)), sw)
+        if x.rg:
+            g, acc = _grad_target(x, x.d)
+            _dense_launch(P(gh), cout, P(w.bf16()[0]), dense, 4, cin, cout, P(g), _ld(g), acc, gh)
+        if DEBUG_CONV is not None:                     # the 8 taps as 8 identity-map K = 1 records sharing one data gradient (as gen_conv_transpose)
+            B, X, Y, Z = dense[:4]
+            gv = y.g.view(B, X, 2, Y, 2, Z, 2, cout)
+            recs = [dict(x=x.d, w=ParamSlice(w, k), nbr=None, n_out=n, gy=gv[:, :, k >> 2, :, (k >> 1) & 1, :, k & 1].reshape(n, cout).clone(),
+                         bf=True, gate=None, need_dx=bool(x.rg), before=rec_before, bias=None, bias_from=0, group=id(y), group_size=8)
+                    for k in range(8)]
+            if x.rg:
+                recs[-1]['after'] = x.g.clone()
+            DEBUG_CONV.extend(recs)
     TAPE.add(bwd)
     return y
 

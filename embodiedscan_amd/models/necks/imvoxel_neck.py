@@ -149,7 +149,12 @@ class IndoorImVoxelNeck:
             if i < self.n_scales - 1:
                 wt, bn1, wc, bn2 = self.up[i + 1]
                 gf = down[i][1]
-                up = E.gather_rows(E.gen_conv_transpose(x, wt), g.up_index())     # rows 8*i+tap -> dense order
+                geo = (g.B, g.X, g.Y, g.Z, 2, 2, 0)
+                ci_t, co_t = wt.d.shape[1], wt.d.shape[2]
+                if x.d.stride(0) == ci_t and all(E.dense_ok(geo, m, ci_t, co_t) for m in (3, 4, 5)):
+                    up = E.conv_transpose_dense(x, wt, geo)                       # dense engine: written straight into dense order
+                else:
+                    up = E.gather_rows(E.gen_conv_transpose(x, wt), g.up_index())     # rows 8*i+tap -> dense order
                 assert up.d.shape[0] == gf.n, 'odd volume sizes are not supported by ConvTranspose3d(k=2,s=2) + add'
                 up = bn1(up, act=1, training=tr)
                 up = bn2(self._conv3(up, wc, gf), act=1, training=tr)

@@ -435,21 +435,27 @@ int es_topk_sorted(const float* vals, int B, int L, const int* vlen_dev, int k, 
 /* ---- dense-volume convolution (occupancy neck; round 5, csrc/dconv.hip) ------------------------------------------------
  * nn.Conv3d(k, stride, pad) of IndoorImVoxelNeck on channels-last bf16 rows by ADDRESS ARITHMETIC (no neighbour map):
  * embodiedscan/models/necks/imvoxel_neck.py:78-143 (ResModule.conv1 / conv2, _make_block, _make_up_block).
- * geom_host: 7 host ints {B, X, Y, Z (input grid), ksize, stride, pad}; rows of a grid are ((b*X + x)*Y + y)*Z + z.
- * mode 0 forward: Xh (B*X*Y*Z x ldx) bf16 rows, W_bf16 = the [K][Cout][Cin] copy, Y (B*Xo*Yo*Zo x ldy) f32.
- * mode 1 data gradient of a stride-1 convolution: Xh = bf16 rows of the output gradient, W_bf16 = the natural
- * [K][Cin][Cout] copy, Y = the input gradient (B*X*Y*Z x ldy).  accumulate 1: Y += result.  Launches that would leave the
- * chip under-filled split their reduction over several workgroups per tile; the partial tiles go through `ws`
- * (es_dconv_workspace_floats; 0 = not needed) and are added in slice order (bit-reproducible).  -4: shape not taken
- * (es_dconv_supported: reduction channels % 64, output channels % 256; weight gradient: both % 256). */
+ * geom_host: 7 host ints {B, X, Y, Z, ksize, stride, pad} of the operator's INPUT grid; rows of a grid are ((b*X + x)*Y + y)*Z + z.
+ * mode 0 nn.Conv3d forward: Xh (B*X*Y*Z x ldx) bf16 rows, W_bf16 = the [K][Cout][Cin] copy, Y (B*Xo*Yo*Zo x ldy) f32.
+ * mode 1 its data gradient: Xh = bf16 rows of the output gradient, W_bf16 = the natural [K][Cin][Cout] copy, Y = the input
+ *   gradient (B*X*Y*Z x ldy); stride 1, or stride 2 with k = 3 / pad = 1 / even sizes (by parity classes of the input voxels:
+ *   no zero tap is multiplied).
+ * mode 3 nn.ConvTranspose3d(k = 2, s = 2) forward (imvoxel_neck.py:98-106 _make_up_block): Xh = input rows on the coarse grid,
+ *   W_bf16 = the [8][Cout][Cin] copy, Y = the (B*2X*2Y*2Z x ldy) output rows in dense order (no permutation pass);
+ * mode 4 its data gradient: Xh = bf16 rows of the output gradient on the fine grid, W_bf16 = the natural [8][Cin][Cout] copy.
+ * accumulate 1: Y += result.  Launches that would leave the chip under-filled split their reduction over several workgroups
+ * per tile; the partial tiles go through `ws` (es_dconv_workspace_floats; 0 = not needed) and are added in slice order
+ * (bit-reproducible).  -4: shape not taken (es_dconv_supported: reduction channels % 64, result channels % 256; weight
+ * gradients (modes 2 / 5 of es_dconv_supported): both % 256). */
 int es_dconv_supported(const int* geom_host, int mode, int Cin, int Cout);
 size_t es_dconv_workspace_floats(const int* geom_host, int mode, int Cin, int Cout);
 int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, const int* geom_host, int mode, int Cin, int Cout, float* Y,
                       int ldy, int accumulate, float* ws, size_t ws_floats, void* stream);
-/* dW[K][Cin][Cout] (f32) = (accumulate ? dW : 0) + sum over output voxels j of X[src(j, k)]^T . dY[j]; Xh / dYh bf16 rows of the
- * input / of the output gradient.  One workgroup per (tap, 256 x 256 tile): every element is written once, no atomics. */
-int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int Cin, int Cout, float* dW,
-                        int accumulate, void* stream);
+/* dW[K][Cin][Cout] (f32) = (accumulate ? dW : 0) + X^T . dY over the grid; Xh = bf16 rows of the operator's input, dYh = bf16 rows
+ * of its output gradient; transposed 0: nn.Conv3d (X gathered under the tap), 1: nn.ConvTranspose3d(k = 2, s = 2) (dY gathered at
+ * 2 r + p).  One workgroup per (tap, 256 x 256 tile): every element is written once, no atomics. */
+int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int transposed, int Cin, int Cout,
+                        float* dW, int accumulate, void* stream);
 /* tuning switches of the dense engine (A/B runs): 20 row tile (0 auto, 256, 320), 21 loop order (1 chunk outer / tap inner),
  * 22 slices per tile (0 auto) */
 int es_dconv_set_option(int key, int value);

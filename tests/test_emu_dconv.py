@@ -119,12 +119,12 @@ def test_dense_weight_gradient(emu, lazy):
             dw = np.full((27, cin, cout), np.nan, np.float32)
             xh, dyh = bf16_bits(x), bf16_bits(dy)                        # (kept alive: P() of a temporary would dangle)
             emu.launches()
-            emu('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, P(g), cin, cout, P(dw), 0, 0)
+            emu('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, P(g), 0, cin, cout, P(dw), 0, 0)
             assert any('k_dconv_wgrad' in k for k in emu.launches())
             scale = np.abs(want).max()
             assert np.abs(dw - want).max() / scale < 2e-6, (B, X, Y, Z, st)
             dw2 = np.ones((27, cin, cout), np.float32)
-            emu('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, P(g), cin, cout, P(dw2), 1, 0)
+            emu('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, P(g), 0, cin, cout, P(dw2), 1, 0)
             assert np.abs(dw2 - 1 - want).max() / scale < 2e-6
     finally:
         emu.lib.es_emu_set_dma_mode(0)
@@ -182,3 +182,120 @@ def test_engine_dense_path_equals_map_path_through_the_tape(emulated, monkeypatc
         for a, b, name in zip(res[True], res[False], ('y', 'dx', 'dw')):
             err = float((a - b).abs().max() / b.abs().max())
             assert err < 2e-5, (name, st, err)
+
+
+def _fine(t, B, X, Y, Z, C):
+    """(B*2X*2Y*2Z, C) rows -> (8, B*X*Y*Z, C): class p = (px, py, pz) holds the rows of the voxels (2x+px, 2y+py, 2z+pz)"""
+    v = t.reshape(B, X, 2, Y, 2, Z, 2, C)
+    return np.stack([v[:, :, px, :, py, :, pz].reshape(-1, C) for px in range(2) for py in range(2) for pz in range(2)])
+
+
+@pytest.mark.parametrize('lazy', [0, 1])
+def test_dense_strided_data_gradient_and_transposed_convolution(emu, lazy):
+    """the parity-class launches: data gradient of nn.Conv3d(k=3, s=2, p=1) (each input voxel through the 1 / 2 / 4 / 8 taps that
+    reach it) and nn.ConvTranspose3d(k=2, s=2) forward written straight into dense order, plus the transposed convolution's data
+    and weight gradients -- against f64 adjoints on the bf16-rounded operands"""
+    rng = np.random.default_rng(41 + lazy)
+    emu.lib.es_emu_set_dma_mode(lazy)
+    try:
+        for B, Xo, Yo, Zo, cin, cout in ((1, 5, 4, 3, 256, 64), (2, 4, 3, 3, 256, 128)) if not lazy else ((1, 4, 3, 2, 256, 64),):
+            # ---- strided data gradient: input grid (2Xo, 2Yo, 2Zo), cin channels; output grid (Xo, Yo, Zo), cout channels
+            X, Y, Z = 2 * Xo, 2 * Yo, 2 * Zo
+            g = _geom(B, X, Y, Z, 3, 2, 1)
+            assert emu.fns['es_dconv_supported'](P(g), 1, cin, cout) == 1
+            w = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cout)).astype(np.float32)
+            wt, wn = np.zeros((27, cout, cin), np.uint16), np.zeros((27, cin, cout), np.uint16)
+            emu('es_cast_weight_bf16', P(w), 27, cin, cout, P(wn), P(wt), 0)
+            M = B * Xo * Yo * Zo
+            dy = rng.standard_normal((M, cout)).astype(np.float32)
+            dyh = bf16_bits(dy)
+            dyb, wb = bf16_round(dy).astype(np.float64), bf16_round(w).astype(np.float64)
+            dxp = np.zeros((B, X + 2, Y + 2, Z + 2, cin))
+            for kx in range(3):
+                for ky in range(3):
+                    for kz in range(3):
+                        dxp[:, kx:kx + 2 * Xo:2, ky:ky + 2 * Yo:2, kz:kz + 2 * Zo:2] += (dyb @ wb[(kx * 3 + ky) * 3 + kz].T).reshape(B, Xo, Yo, Zo, cin)
+            want = dxp[:, 1:1 + X, 1:1 + Y, 1:1 + Z].reshape(-1, cin)
+            for rows in (0, 256, 320):
+                emu('es_dconv_set_option', 20, rows)
+                dx = np.full((B * X * Y * Z, cin), np.nan, np.float32)
+                emu.launches()
+                emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx), cin, 0, 0, 0, 0)
+                assert any('k_dconv<' in k for k in emu.launches())
+                assert np.abs(dx - want).max() / np.abs(want).max() < 2e-6, ('strided dgrad', rows)
+            emu('es_dconv_set_option', 20, 0)
+            dx2 = np.ones((B * X * Y * Z, cin), np.float32)
+            emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx2), cin, 1, 0, 0, 0)
+            assert np.abs(dx2 - 1 - want).max() / np.abs(want).max() < 2e-6
+            # ---- transposed convolution (k = 2, s = 2): coarse grid (Xo, Yo, Zo) with ci_t channels -> fine grid with co_t channels
+            ci_t, co_t = 256, 256
+            gt = _geom(B, Xo, Yo, Zo, 2, 2, 0)
+            assert emu.fns['es_dconv_supported'](P(gt), 3, ci_t, co_t) == 1
+            x = rng.standard_normal((M, ci_t)).astype(np.float32)
+            w8 = (rng.standard_normal((8, ci_t, co_t)) / np.sqrt(ci_t)).astype(np.float32)
+            w8t, w8n = np.zeros((8, co_t, ci_t), np.uint16), np.zeros((8, ci_t, co_t), np.uint16)
+            emu('es_cast_weight_bf16', P(w8), 8, ci_t, co_t, P(w8n), P(w8t), 0)
+            xh = bf16_bits(x)
+            xb, w8b = bf16_round(x).astype(np.float64), bf16_round(w8).astype(np.float64)
+            y = np.full((8 * M, co_t), np.nan, np.float32)
+            emu('es_dconv_fwd_bf16', P(xh), ci_t, P(w8t), P(gt), 3, ci_t, co_t, P(y), co_t, 0, 0, 0, 0)
+            got = _fine(y, B, Xo, Yo, Zo, co_t)
+            for p in range(8):
+                wantp = xb @ w8b[p]
+                assert np.abs(got[p] - wantp).max() / np.abs(wantp).max() < 2e-6, ('transposed fwd', p)
+            if ci_t % 256 == 0 or True:
+                # data gradient: dX[r] = sum_p dY[2r + p] W[p]^T  (N = ci_t must be a multiple of 256 for the dense engine)
+                dyf = rng.standard_normal((8 * M, co_t)).astype(np.float32)
+                dyfh = bf16_bits(dyf)
+                cls = _fine(bf16_round(dyf).astype(np.float64), B, Xo, Yo, Zo, co_t)
+                assert emu.fns['es_dconv_supported'](P(gt), 4, ci_t, co_t) == 1 and emu.fns['es_dconv_supported'](P(gt), 5, ci_t, co_t) == 1
+                if True:
+                    wantx = sum(cls[p] @ w8b[p].T for p in range(8))
+                    dxc = np.full((M, ci_t), np.nan, np.float32)
+                    nf = int(emu.fns['es_dconv_workspace_floats'](P(gt), 4, ci_t, co_t))
+                    wsb = np.zeros(max(nf, 4), np.float32)
+                    emu('es_dconv_fwd_bf16', P(dyfh), co_t, P(w8n), P(gt), 4, ci_t, co_t, P(dxc), ci_t, 0, P(wsb), nf, 0)
+                    assert np.abs(dxc - wantx).max() / np.abs(wantx).max() < 2e-6, 'transposed dgrad'
+                if emu.fns['es_dconv_supported'](P(gt), 5, ci_t, co_t) == 1:
+                    wantw = np.stack([xb.T @ cls[p] for p in range(8)])
+                    dw = np.full((8, ci_t, co_t), np.nan, np.float32)
+                    emu('es_dconv_wgrad_bf16', P(xh), ci_t, P(dyfh), co_t, P(gt), 1, ci_t, co_t, P(dw), 0, 0)
+                    assert np.abs(dw - wantw).max() / np.abs(wantw).max() < 2e-6, 'transposed wgrad'
+    finally:
+        emu.lib.es_emu_set_dma_mode(0)
+        emu('es_dconv_set_option', 20, 0)
+
+
+def test_engine_dense_transposed_convolution_equals_the_generative_path(emulated, monkeypatch):
+    """engine.conv_transpose_dense (parity-class launch, dense row order) against gather_rows(gen_conv_transpose(...), up_index) --
+    the path it replaces in IndoorImVoxelNeck -- forward, data gradient and the 8 weight-gradient taps, through the tape"""
+    import torch
+    from embodiedscan_amd import engine as E, hip
+    from embodiedscan_amd.models.necks.imvoxel_neck import VolumeGrid
+    dev = emulated
+    monkeypatch.setitem(_ListAsDict(E.PRECISION), 0, 'bf16')
+    gen = torch.Generator().manual_seed(6)
+    B, X, Y, Z, cin, cout = 1, 3, 4, 2, 256, 256
+    geo = (B, X, Y, Z, 2, 2, 0)
+    assert all(E.dense_ok(geo, m, cin, cout) for m in (3, 4, 5))
+    grid = VolumeGrid(B, X, Y, Z, dev)
+    n = B * X * Y * Z
+    xd = torch.randn(n, cin, generator=gen)
+    wd = torch.randn(8, cin, cout, generator=gen) / cin ** 0.5
+    gy = torch.randn(8 * n, cout, generator=gen)
+    res = {}
+    for dense_on in (True, False):
+        x = E.Var(xd.clone())
+        w = E.Param(wd.clone(), torch.zeros_like(wd))
+        w.bf_n, w.bf_t = torch.empty((8, cin, cout), dtype=torch.bfloat16), torch.empty((8, cout, cin), dtype=torch.bfloat16)
+        hip.call('es_cast_weight_bf16', hip.P(w.d), 8, cin, cout, hip.P(w.bf_n), hip.P(w.bf_t), 0)
+        w.bf_step = E.WEIGHT_VERSION[0]
+        E.TAPE.clear()
+        E.new_grad_epoch()
+        y = E.conv_transpose_dense(x, w, geo) if dense_on else E.gather_rows(E.gen_conv_transpose(x, w), grid.up_index())
+        y.g = gy.clone()
+        E.TAPE.backward()
+        res[dense_on] = (y.d.clone(), x.g.clone(), w.g.clone())
+    for a, b, name in zip(res[True], res[False], ('y', 'dx', 'dw')):
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err < 2e-5, (name, err)

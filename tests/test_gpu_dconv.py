@@ -82,10 +82,10 @@ def test_dense_engine_small_volumes_vs_f64():
                 wantw = torch.stack([xv[:, kx:kx + st * Xo:st, ky:ky + st * Yo:st, kz:kz + st * Zo:st].reshape(M, cin).T @ dyh.double()
                                      for kx in range(3) for ky in range(3) for kz in range(3)])
                 dw = torch.full((27, cin, cout), float('nan'), device=dev)
-                call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, cin, cout, P(dw), 0, st_)
+                call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, 0, cin, cout, P(dw), 0, st_)
                 assert float((dw.double() - wantw).abs().max() / wantw.abs().max()) < 2e-6, ('wgrad', B, X, Y, Z, st)
                 dw2 = torch.ones((27, cin, cout), device=dev)
-                call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, cin, cout, P(dw2), 1, st_)
+                call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, 0, cin, cout, P(dw2), 1, st_)
                 assert float((dw2.double() - 1 - wantw).abs().max() / wantw.abs().max()) < 2e-6
             if st == 1 and cin % 256 == 0:
                 # data gradient = the adjoint: conv of dY with the mirrored taps and W^T
@@ -136,7 +136,7 @@ def test_dense_engine_neck_shapes_vs_map_kernels(X, Y, Z, cin, cout, st):
     dy = torch.randn(n_out, cout, generator=gen).to(dev)
     dyh = dy.bfloat16().contiguous()
     dw = torch.empty(27, cin, cout, device=dev)
-    call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, cin, cout, P(dw), 0, st_)
+    call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, 0, cin, cout, P(dw), 0, st_)
     need = int(hip.raw('es_spconv_wgrad_workspace_floats')(1, P(xh), 1, cin, P(dyh), 1, cout, n_out, n_in, 27, cin, cout))
     wsw = torch.empty(max(need, 4), device=dev)
     dw0 = torch.empty(27, cin, cout, device=dev)
@@ -156,3 +156,104 @@ def test_dense_engine_neck_shapes_vs_map_kernels(X, Y, Z, cin, cout, st):
             call('es_spconv_fwd_bf16', P(dyh), 1, cout, P(wn), P(inv), n_in, n_out, 27, cout, cin, 0, P(dx0), cin, 0, st_)
         err = float((dx - dx0).abs().max() / dx0.abs().max())
         assert err < 2e-5, ('dgrad', err)
+
+
+def _classes(t, B, X, Y, Z, C):
+    """(B*2X*2Y*2Z, C) rows -> (8, B*X*Y*Z, C): class p = (px, py, pz) holds the rows of the voxels (2x+px, 2y+py, 2z+pz)"""
+    v = t.reshape(B, X, 2, Y, 2, Z, 2, C)
+    return torch.stack([v[:, :, px, :, py, :, pz].reshape(-1, C) for px in range(2) for py in range(2) for pz in range(2)])
+
+
+def test_parity_class_launches_small_volumes_vs_f64():
+    """data gradient of nn.Conv3d(k=3, s=2, p=1) and nn.ConvTranspose3d(k=2, s=2) forward / data gradient / weight gradient on the
+    dense engine against f64 adjoints on the bf16-rounded operands (2e-6)"""
+    from embodiedscan_amd import hip
+    from embodiedscan_amd.hip import call, P
+    dev = torch.device('cuda:0')
+    st_ = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(13)
+    opt = hip.raw('es_dconv_set_option')
+    try:
+        for B, Xo, Yo, Zo, cin, cout in ((1, 5, 4, 3, 256, 128), (2, 7, 6, 5, 512, 256), (1, 20, 20, 8, 256, 64)):
+            X, Y, Z = 2 * Xo, 2 * Yo, 2 * Zo
+            g = _geom(B, X, Y, Z, 3, 2, 1)
+            assert hip.raw('es_dconv_supported')(g, 1, cin, cout) == 1
+            w = (torch.randn(27, cin, cout, generator=gen) / (27 * cout) ** 0.5).to(dev)
+            wt = torch.empty((27, cout, cin), dtype=torch.bfloat16, device=dev)
+            wn = torch.empty((27, cin, cout), dtype=torch.bfloat16, device=dev)
+            call('es_cast_weight_bf16', P(w), 27, cin, cout, P(wn), P(wt), st_)
+            M = B * Xo * Yo * Zo
+            dyh = torch.randn(M, cout, generator=gen).to(dev).bfloat16().contiguous()
+            dyb, wb = dyh.double(), wn.double()
+            dxp = torch.zeros((B, X + 2, Y + 2, Z + 2, cin), dtype=torch.float64, device=dev)
+            for kx in range(3):
+                for ky in range(3):
+                    for kz in range(3):
+                        dxp[:, kx:kx + 2 * Xo:2, ky:ky + 2 * Yo:2, kz:kz + 2 * Zo:2] += (dyb @ wb[(kx * 3 + ky) * 3 + kz].T).reshape(B, Xo, Yo, Zo, cin)
+            want = dxp[:, 1:1 + X, 1:1 + Y, 1:1 + Z].reshape(-1, cin)
+            for rows in (0, 256, 320):
+                opt(20, rows)
+                dx = torch.full((B * X * Y * Z, cin), float('nan'), device=dev)
+                call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx), cin, 0, 0, 0, st_)
+                err = float((dx.double() - want).abs().max() / want.abs().max())
+                assert err < 2e-6, ('strided dgrad', B, Xo, Yo, Zo, rows, err)
+            opt(20, 0)
+            dx2 = torch.ones((B * X * Y * Z, cin), device=dev)
+            call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx2), cin, 1, 0, 0, st_)
+            assert float((dx2.double() - 1 - want).abs().max() / want.abs().max()) < 2e-6
+            # transposed convolution on the coarse grid (Xo, Yo, Zo)
+            ci_t, co_t = 256, 256
+            gt = _geom(B, Xo, Yo, Zo, 2, 2, 0)
+            assert all(hip.raw('es_dconv_supported')(gt, m, ci_t, co_t) == 1 for m in (3, 4, 5))
+            xh = torch.randn(M, ci_t, generator=gen).to(dev).bfloat16().contiguous()
+            w8 = (torch.randn(8, ci_t, co_t, generator=gen) / ci_t ** 0.5).to(dev)
+            w8t = torch.empty((8, co_t, ci_t), dtype=torch.bfloat16, device=dev)
+            w8n = torch.empty((8, ci_t, co_t), dtype=torch.bfloat16, device=dev)
+            call('es_cast_weight_bf16', P(w8), 8, ci_t, co_t, P(w8n), P(w8t), st_)
+            y = torch.full((8 * M, co_t), float('nan'), device=dev)
+            call('es_dconv_fwd_bf16', P(xh), ci_t, P(w8t), gt, 3, ci_t, co_t, P(y), co_t, 0, 0, 0, st_)
+            got = _classes(y.double(), B, Xo, Yo, Zo, co_t)
+            wantf = torch.stack([xh.double() @ w8n[p].double() for p in range(8)])
+            assert float((got - wantf).abs().max() / wantf.abs().max()) < 2e-6, 'transposed fwd'
+            dyf = torch.randn(8 * M, co_t, generator=gen).to(dev).bfloat16().contiguous()
+            cls = _classes(dyf.double(), B, Xo, Yo, Zo, co_t)
+            wantx = sum(cls[p] @ w8n[p].double().T for p in range(8))
+            ws, nf = _ws(hip, gt, 4, ci_t, co_t, dev)
+            dxc = torch.full((M, ci_t), float('nan'), device=dev)
+            call('es_dconv_fwd_bf16', P(dyf), co_t, P(w8n), gt, 4, ci_t, co_t, P(dxc), ci_t, 0, P(ws), nf, st_)
+            assert float((dxc.double() - wantx).abs().max() / wantx.abs().max()) < 2e-6, 'transposed dgrad'
+            wantw = torch.stack([xh.double().T @ cls[p] for p in range(8)])
+            dw = torch.full((8, ci_t, co_t), float('nan'), device=dev)
+            call('es_dconv_wgrad_bf16', P(xh), ci_t, P(dyf), co_t, gt, 1, ci_t, co_t, P(dw), 0, st_)
+            assert float((dw.double() - wantw).abs().max() / wantw.abs().max()) < 2e-6, 'transposed wgrad'
+    finally:
+        opt(20, 0)
+
+
+@pytest.mark.parametrize('X,Y,Z,cin,cout', [(40, 40, 16, 768, 1536), (20, 20, 8, 1536, 3072)])
+def test_strided_data_gradient_neck_shapes_vs_map_kernel(X, Y, Z, cin, cout):
+    from embodiedscan_amd import hip
+    from embodiedscan_amd.hip import call, P
+    from embodiedscan_amd.models.necks.imvoxel_neck import VolumeGrid
+    dev = torch.device('cuda:0')
+    st_ = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(17)
+    g = _geom(1, X, Y, Z, 3, 2, 1)
+    nbr, inv, n_out, _ = VolumeGrid(1, X, Y, Z, dev).conv_map(3, 2, 1)
+    n_in = X * Y * Z
+    w = (torch.randn(27, cin, cout, generator=gen) / (27 * cout) ** 0.5).to(dev)
+    wt = torch.empty((27, cout, cin), dtype=torch.bfloat16, device=dev)
+    wn = torch.empty((27, cin, cout), dtype=torch.bfloat16, device=dev)
+    call('es_cast_weight_bf16', P(w), 27, cin, cout, P(wn), P(wt), st_)
+    dyh = torch.randn(n_out, cout, generator=gen).to(dev).bfloat16().contiguous()
+    dx = torch.empty(n_in, cin, device=dev)
+    call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx), cin, 0, 0, 0, st_)
+    nfm = int(hip.raw('es_spconv_split_workspace_floats')(n_in, 27, cout, cin))
+    wsm = torch.zeros(max(nfm, 4), device=dev)
+    dx0 = torch.empty(n_in, cin, device=dev)
+    if nfm:
+        call('es_spconv_fwd_bf16_ws', P(dyh), 1, cout, P(wn), P(inv), n_in, n_out, 27, cout, cin, 0, P(dx0), cin, 0, P(wsm), nfm, st_)
+    else:
+        call('es_spconv_fwd_bf16', P(dyh), 1, cout, P(wn), P(inv), n_in, n_out, 27, cout, cin, 0, P(dx0), cin, 0, st_)
+    err = float((dx - dx0).abs().max() / dx0.abs().max())
+    assert err < 2e-5, err

@@ -92,7 +92,7 @@ def main():
                                                           P(dx), cin, 0, P(wsm), nfm, st_))
         else:
             line('dgrad map kernel', lambda: call('es_spconv_fwd_bf16', P(dyh), 1, cout, P(wn), P(inv), n_in, n_out, 27, cout, cin, 0, P(dx), cin, 0, st_))
-        if st == 1:
+        if hip.raw('es_dconv_supported')(g, 1, cin, cout) == 1:
             nf = int(hip.raw('es_dconv_workspace_floats')(g, 1, cin, cout))
             ws = torch.empty(max(nf, 4), device=dev)
             line('dgrad dense (auto)', lambda: call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx), cin, 0, P(ws), nf, st_))
@@ -101,7 +101,7 @@ def main():
         wsw = torch.empty(max(need, 4), device=dev)
         line('wgrad map kernel', lambda: call('es_spconv_wgrad_bf16_src', P(xh), 1, cin, P(dyh), 1, cout, P(nbr), n_out, n_in, 27, cin, cout,
                                               P(dw), 0, P(wsw), need, st_))
-        line('wgrad dense', lambda: call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, cin, cout, P(dw), 0, st_))
+        line('wgrad dense', lambda: call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, 0, cin, cout, P(dw), 0, st_))
         del grid, nbr, inv, x, w, xh, wt, wn, dy, dyh, y, dx, dw
         torch.cuda.empty_cache()
 
