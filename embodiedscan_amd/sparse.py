@@ -7,6 +7,8 @@ embodiedscan/models/detectors/sparse_featfusion_single_stage.py:215-218): every 
 derived from one input shares the maps cached here.
 """
 import ctypes
+import weakref
+
 import torch
 from . import hip
 from .hip import P, call
@@ -101,26 +103,38 @@ class CoordSet:
             self.cache[key] = unique_first(tmp, self.n, out_ts, self.n_batch)[0]
         return self.cache[key]
 
+    # Maps are cached per partner set, keyed by id(partner).  The entry holds the partner only through a WEAK reference, checked on
+    # every hit (a dead partner's id may be reused by a new set: then the entry is stale and is rebuilt).  A strong reference --
+    # rounds 1-4 -- closed reference cycles (a set's own 3x3x3 map refers to the set; parent -> strided child -> map keyed by the
+    # parent): every step's coordinate sets, their maps and ~0.8 GB of tensors hanging off them survived until Python's cyclic
+    # collector ran, ~every 20 steps, for 110-170 ms of host time (the 3.5x step-time outliers of profiles/r5b_bench_grounding_diag.json,
+    # tools/gc_hunt.py), and the allocator kept asking the driver for fresh memory in between.
+    def _cached(self, key, partner):
+        e = self.cache.get(key)
+        return e[0] if (e is not None and e[1]() is partner) else None
+
     def kernel_map(self, out, ksize):
         """nbr (out.n, ksize^3) int32: rows of self around each row of `out`."""
         key = ('kmap', id(out), ksize)
-        if key not in self.cache:
+        nbr = self._cached(key, out)
+        if nbr is None:
             tk, tv, cap = self.table()
             K = ksize ** 3
             nbr = torch.empty((out.n, K), dtype=torch.int32, device=self.device)
             call('es_kernel_map', P(out.keys), out.n, P(tk), P(tv), cap, ksize, self.ts, P(nbr), _stream())
-            self.cache[key] = (hip.register_map(nbr), out)
-        return self.cache[key][0]
+            self.cache[key] = (hip.register_map(nbr), weakref.ref(out))
+        return nbr
 
     def inverse_map(self, out, ksize):
         key = ('imap', id(out), ksize)
-        if key not in self.cache:
+        inv = self._cached(key, out)
+        if inv is None:
             nbr = self.kernel_map(out, ksize)
             K = ksize ** 3
             inv = torch.empty((self.n, K), dtype=torch.int32, device=self.device)
             call('es_inverse_map', P(nbr), out.n, K, self.n, P(inv), _stream())
-            self.cache[key] = (hip.register_map(inv), out)
-        return self.cache[key][0]
+            self.cache[key] = (hip.register_map(inv), weakref.ref(out))
+        return inv
 
     def children(self):
         """MinkowskiGenerativeConvolutionTranspose(k=2,s=2) output set: row 8*i+k."""
@@ -244,9 +258,10 @@ def union(a, b):
     """coordinate union for sparse a + b.  Returns (CoordSet, pos_a, pos_b) (int32 rows).  Cached on `a` per partner
     set (like the kernel maps), so a coordinate prefetch pass can pay the row-count read-back early."""
     key = ('union', id(b))
-    if key not in a.cache:
-        a.cache[key] = _union(a, b) + (b,)         # keep b alive: id() must stay unique
-    return a.cache[key][:3]
+    e = a.cache.get(key)
+    if e is None or e[3]() is not b:               # (weak reference to the partner, as for the maps: no reference cycles)
+        e = a.cache[key] = _union(a, b) + (weakref.ref(b),)
+    return e[:3]
 
 
 def _union(a, b):

@@ -38,3 +38,17 @@ print(f'\nmain stream {main}: kernel groups by busy + following gap')
 print(f'{"kernel":60s} {"calls":>6s} {"busy_ms":>9s} {"gap_ms":>8s} {"avg_us":>8s}')
 for n, (c, bsy, g) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:45]:
     print(f'{n:60s} {c:6d} {bsy / 1e6:9.3f} {g / 1e6:8.3f} {bsy / c / 1e3:8.1f}')
+
+# the longest idle gaps of the main stream with the kernels on either side and what the OTHER streams ran meanwhile (round 5)
+print('\nlongest main-stream gaps: start_ms gap_us | before -> after | busiest other-stream kernel inside the gap')
+gl = sorted(((rs[i + 1][0] - rs[i][1], i) for i in range(len(rs) - 1)), reverse=True)[:28]
+others = [r for s, v in by.items() if s != main for r in v]
+for g, i in sorted(gl, key=lambda t: t[1]):
+    b0, b1 = rs[i][1], rs[i + 1][0]
+    inside = defaultdict(float)
+    for b, e, n, s in others:
+        ov = min(e, b1) - max(b, b0)
+        if ov > 0:
+            inside[(s, n[:38])] += ov
+    top = max(inside.items(), key=lambda kv: kv[1]) if inside else (('-', '-'), 0.0)
+    print(f'{(b0 - t0) / 1e6:7.2f} {g / 1e3:8.1f} | {rs[i][2][:34]:34s} -> {rs[i + 1][2][:34]:34s} | s{top[0][0]} {top[0][1]} {top[1] / 1e3:.0f} us')
