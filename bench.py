@@ -99,6 +99,16 @@ def stage_times(step_fn, runs=3):
     return {k: round(statistics.median(p.get(k, 0.0) for p in per), 3) for k in per[0]}
 
 
+def release_frozen():
+    """between configurations: the detector that was just dropped froze the collector's generations after its warm-up
+    (BaseDetector._settle_gc); thaw them and collect once so that whatever it held in reference cycles goes back to the allocator"""
+    import gc
+    import torch
+    gc.unfreeze()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def self_launch(n):
     """re-exec this command under torch.distributed.run with n local ranks (rendezvous on 127.0.0.1, a free port)"""
     import socket
@@ -443,7 +453,7 @@ def main():
     if world == 1 and not args.no_other_configs:
         del det, optim, feeder, scans, losses
         E.TAPE.clear()
-        torch.cuda.empty_cache()
+        release_frozen()
         out['other_configs'] = {}
         for kind in ('grounding', 'occupancy', 'from_files'):
             try:
@@ -546,7 +556,7 @@ def run_from_files(args, dev, synthetic_scans_per_s=None):
             out['cores_for_8_gpus'] = f'{8 * workers} worker processes at this rate (one rank per GPU, {workers} each)'
         del det, optim
         E.TAPE.clear()
-        torch.cuda.empty_cache()
+        release_frozen()
         return out
     finally:
         shutil.rmtree(root, ignore_errors=True)
@@ -708,7 +718,7 @@ def run_other_config(kind, args, dev):
         res['parity'], res['cpu_baseline'] = parity, base
     del det, optim, feeder
     E.TAPE.clear()
-    torch.cuda.empty_cache()
+    release_frozen()
     return res
 
 
