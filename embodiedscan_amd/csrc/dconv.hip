@@ -377,10 +377,14 @@ __global__ __launch_bounds__(512, 2) void k_dconv_wgrad(const unsigned short* __
 // 16) on (n_img, H, W) grids of 10^5 .. 10^6 pixels: dW[t][ci][co] = sum_j X[src(j, t)][ci] dY[j][co].  The map kernel
 // (k_spconv_wgrad_bf16<1, 0>) gives every tap its own workgroups, so dY is read nine times and X is gathered through an index map:
 // 4 % matrix-core busy, 0.45 TB/s (profiles/r4_mfma_util.txt).  Here ONE workgroup owns a slice of the output pixels and ALL nine
-// taps: per 64-pixel chunk dY is read once (f32 rows are rounded to bf16 on the way into LDS, bf16 rows go by LDS-DMA), the nine
-// shifted X tiles are gathered by address arithmetic (LDS-DMA, absent neighbours read a zero granule; the re-reads of a 3-line
-// window hit L1 / L2), both are read transposed (ds_read_b64_tr_b16) and the 9 x (CI / 16) x (CO / 16) accumulator fragments stay
-// in registers across the whole slice.  Partial tiles [slice][9][CI][CO] are added in slice order by k_dconv_reduce.
+// taps of one kernel ROW (blockIdx.y = ky: dY is read three times instead of nine): per 64-pixel chunk the dY tile goes to LDS once
+// (f32 rows are rounded to bf16 on the way, bf16 rows go by LDS-DMA), the three shifted X tiles are gathered by address
+// arithmetic (LDS-DMA, absent neighbours read a zero granule; the re-reads of a line hit L1 / L2), both are read transposed
+// (ds_read_b64_tr_b16) and the 3 x (CI / 16) x (CO / 16) accumulator fragments stay in registers across the whole slice.  (First
+// version, profiles/r5f: all nine taps in one workgroup and ~250 slices = one 4-wave workgroup per CU walking 45 .. 160 dependent
+// DMA -> barrier -> 16-MFMA steps: 108 us per 64-channel launch, latency-bound.  Three workgroups per slice, more slices and 48
+// instead of 144 accumulator registers put 5+ workgroups on a CU.)  Partial tiles [slice][9][CI][CO] are added in slice order by
+// k_dconv_reduce.
 template <int CI, int CO, int YH>
 __global__ __launch_bounds__(256) void k_dconv_wgrad_taps9(const unsigned short* __restrict__ Xh, int ldx, const void* __restrict__ dYv,
                                                            int ldy, int M, DcGeom g, float* __restrict__ out, int accumulate,
@@ -393,11 +397,11 @@ __global__ __launch_bounds__(256) void k_dconv_wgrad_taps9(const unsigned short*
   static_assert(NP >= 1 && NPX >= 1, "32 or 64 channels on both sides");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TX + 2 * TY];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
-  const int slice = blockIdx.x;
+  const int slice = blockIdx.x, tg = blockIdx.y;      // tg: kernel row ky -- this workgroup's three taps are 3 tg .. 3 tg + 2
   const int c_beg = slice * chunks_per_slice, c_end = min((M + 63) >> 6, c_beg + chunks_per_slice);
-  f32x4 acc[9][NP];
+  f32x4 acc[3][NP];
 #pragma unroll
-  for (int a = 0; a < 9; ++a)
+  for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int b = 0; b < NP; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int pk[NPX], base[NPX];
@@ -455,23 +459,21 @@ __global__ __launch_bounds__(256) void k_dconv_wgrad_taps9(const unsigned short*
   if (c_beg < c_end) {
     rows_of(c_beg * 64);
     stage_y(0, c_beg * 64);
-    issue_x(0, 0);
+    issue_x(0, tg * 3);
     for (int c = c_beg; c < c_end; ++c) {
       const unsigned char* yt = smem + 2 * TX + ((c - c_beg) & 1) * TY;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int buf = tap & 1;                   // (9 taps per chunk: the first tile of the next chunk lands in buffer 1 ^ ... see below)
+      for (int tap = 0; tap < 3; ++tap) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // this step's X tile (and, at tap 0, the chunk's dY tile) is in LDS; the other X buffer is free
-        const int xb = ((c - c_beg) * 9 + tap) & 1;
-        if (tap < 8) {
-          issue_x(xb ^ 1, tap + 1);
+        const int xb = ((c - c_beg) * 3 + tap) & 1;
+        if (tap < 2) {
+          issue_x(xb ^ 1, tg * 3 + tap + 1);
         } else if (c + 1 < c_end) {
           rows_of((c + 1) * 64);
           stage_y(((c + 1 - c_beg) & 1), (c + 1) * 64);
-          issue_x(xb ^ 1, 0);
+          issue_x(xb ^ 1, tg * 3);
         }
-        (void)buf;
         const unsigned char* xt = smem + xb * TX;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -489,8 +491,8 @@ __global__ __launch_bounds__(256) void k_dconv_wgrad_taps9(const unsigned short*
   float* dst = out + (n_slices > 1 ? (size_t)slice * 9 * CI * CO : 0);
   const bool add = n_slices == 1 && accumulate;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int wt = g.taps[tap].w;
+  for (int tap = 0; tap < 3; ++tap) {
+    const int wt = g.taps[tg * 3 + tap].w;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const int pair = wv * NP + q, mf = pair / NFN, nf = pair % NFN;
@@ -717,10 +719,14 @@ static int dc_geometry2d(const int* gh, DcGeom& g, int& M, int& n_src) {
   M = (int)m; n_src = (int)ns;
   return 0;
 }
-static void dc_slices2d(int M, int& cps, int& slices) {
+static void dc_slices2d(int M, int Cin, int Cout, int& cps, int& slices) {
+  // slices: enough workgroups (x 3 kernel rows) to put several on every CU, capped so that the partial tiles (9 Cin Cout floats per
+  // slice, written and read once) stay below the operands' own traffic: ~1024 slices at 32 x 32, ~384 at 64 x 64
   const int chunks = es_cdiv(M, 64);
-  cps = es_cdiv(chunks, 256);
-  if (cps < 4) cps = 4;
+  int target = (int)(((long long)36 << 20) / ((long long)9 * Cin * Cout * 4));
+  target = target < 64 ? 64 : (target > 1024 ? 1024 : target);
+  cps = es_cdiv(chunks, target);
+  if (cps < 2) cps = 2;
   slices = es_cdiv(chunks, cps);
 }
 extern "C" int es_dconv_wgrad2d_supported(const int* geom_host, int Cin, int Cout) {
@@ -730,7 +736,7 @@ extern "C" int es_dconv_wgrad2d_supported(const int* geom_host, int Cin, int Cou
 extern "C" size_t es_dconv_wgrad2d_workspace_floats(const int* geom_host, int Cin, int Cout) {
   DcGeom g; int M, ns, cps, sl;
   if (dc_geometry2d(geom_host, g, M, ns) != 0) return 0;
-  dc_slices2d(M, cps, sl);
+  dc_slices2d(M, Cin, Cout, cps, sl);
   return sl > 1 ? (size_t)sl * 9 * Cin * Cout : 0;
 }
 extern "C" int es_dconv_wgrad2d_bf16(const void* Xh, int ldx, const void* dY, int dy_half, int ldy, const int* geom_host, int Cin, int Cout,
@@ -741,7 +747,7 @@ extern "C" int es_dconv_wgrad2d_bf16(const void* Xh, int ldx, const void* dY, in
   if (!((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) || (ldx & 7) != 0 || (ldy & (dy_half ? 7 : 3)) != 0 ||
       ((uintptr_t)Xh & 15) != 0 || ((uintptr_t)dY & 15) != 0 || ((uintptr_t)dW & 15) != 0 || (long long)ns * ldx >= (1ll << 31))
     return -4;
-  dc_slices2d(M, cps, sl);
+  dc_slices2d(M, Cin, Cout, cps, sl);
   const size_t nw = (size_t)9 * Cin * Cout;
   if (sl > 1 && (ws == nullptr || ws_floats < (size_t)sl * nw || ((uintptr_t)ws & 15) != 0)) return -5;
   hipStream_t st = (hipStream_t)stream;
@@ -749,8 +755,8 @@ extern "C" int es_dconv_wgrad2d_bf16(const void* Xh, int ldx, const void* dY, in
   const unsigned short* X = (const unsigned short*)Xh;
 #define T9_LAUNCH(CI_, CO_)                                                                                                    \
   do {                                                                                                                          \
-    if (dy_half) hipLaunchKernelGGL((k_dconv_wgrad_taps9<CI_, CO_, 1>), dim3(sl), dim3(256), 0, st, X, ldx, dY, ldy, M, g, out, accumulate, cps, sl); \
-    else hipLaunchKernelGGL((k_dconv_wgrad_taps9<CI_, CO_, 0>), dim3(sl), dim3(256), 0, st, X, ldx, dY, ldy, M, g, out, accumulate, cps, sl);         \
+    if (dy_half) hipLaunchKernelGGL((k_dconv_wgrad_taps9<CI_, CO_, 1>), dim3(sl, 3), dim3(256), 0, st, X, ldx, dY, ldy, M, g, out, accumulate, cps, sl); \
+    else hipLaunchKernelGGL((k_dconv_wgrad_taps9<CI_, CO_, 0>), dim3(sl, 3), dim3(256), 0, st, X, ldx, dY, ldy, M, g, out, accumulate, cps, sl);      \
   } while (0)
   if (Cin == 32 && Cout == 32) T9_LAUNCH(32, 32);
   else if (Cin == 64 && Cout == 64) T9_LAUNCH(64, 64);
