@@ -387,6 +387,26 @@ def ticket_ws(floats, like, tag=''):
     return ws, ws.numel()
 
 
+# Python's cyclic collector and the train loop (round 5, profiles/r5d / r5f_bench_grounding_diag.json: `gc_collections`): a generation-2
+# collection walks every live container of the process -- model, configs, the frozen text encoder's module tree, torch's own tables
+# -- and costs 110-170 ms of host time whenever the allocation counters trip it (every ~20-25 steps: the 3.5x step-time outliers of
+# rounds 3-4).  A step leaves no cyclic garbage (sparse.CoordSet caches are weak), so after a few steps everything alive is long-lived:
+# it is moved to the permanent generation once (gc.freeze) and later collections only look at what was allocated since (measured on
+# this image: a full collection of 10^6 tracked objects 180 ms -> 0.0 ms after the freeze).  ES_GC_FREEZE=0 turns this off; a process
+# that drops a detector and builds another should gc.unfreeze() + gc.collect() in between (bench.py release_frozen).
+GC_SETTLE_STEP = 6
+
+
+def settle_gc(det):
+    """called at the top of every train_step: freezes the collector's generations when `det` reaches its GC_SETTLE_STEP-th step"""
+    n = getattr(det, '_steps_done', 0) + 1
+    det._steps_done = n
+    if n == GC_SETTLE_STEP and os.environ.get('ES_GC_FREEZE', '1') != '0':
+        import gc
+        gc.collect()
+        gc.freeze()
+
+
 def reset_tickets():
     """re-zero the ticket heads of every cached election workspace (on the current stream).  A launch that faulted inside an
     in-launch reduction leaves its ticket non-zero; the step that saw the fault has already raised HipError, a caller that
@@ -549,12 +569,16 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0, dense=None
     bf = PRECISION[0] == 'bf16' and cin >= 16
     if maps is not None:
         maps = _Maps(maps) if not isinstance(maps, _Maps) else maps
+    x16 = x.d.dtype == torch.bfloat16                  # bf16 activation rows (the image backbone's outputs under ACT16): their own shadow
+    if x16:
+        assert bf and _ld(x.d) == cin, 'bf16 input rows need the bf16 kernels and contiguous rows'
+        x.dh = x.d
     dn = dense if (bf and bias is None and _ld(x.d) == cin and dense_ok(dense, 0, cin, cout)) else None
     if dn is None and maps is not None:
         nbr, inv = maps.get()
     if dn is not None:
         _dense_launch(P(x.shadow()), cin, P(w.bf16()[1]), dn, 0, cin, cout, P(y.d), cout, 0, x.d)
-    elif bf and SHADOW[0] and _ld(x.d) == cin and _use_shadow(n_in, cin, K, cin, cout):
+    elif bf and (x16 or (SHADOW[0] and _ld(x.d) == cin and _use_shadow(n_in, cin, K, cin, cout))):
         _fwd_bf16(P(x.shadow()), 1, cin, P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0, P(y.d),
                   cout, 0, x.d)
     elif bf:
@@ -625,6 +649,7 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         _wgrad('es_spconv_wgrad_bf16_src', sw, P(w.g), P(xs), int(x.dh is not None), _ld(xs), P(ys), int(gh is not None), _ld(ys),
                P(nbr), n_out, n_in, K, cin, cout)
     elif w.g is not None:
+        assert x.d.dtype == torch.float32, 'bf16 activation rows reach the weight gradient through their shadow (x.dh)'
         _wgrad('es_spconv_wgrad_bf16' if (bf and WGRAD_BF16[0]) else 'es_spconv_wgrad', sw, P(w.g), P(x.d), _ld(x.d), P(gy),
                _ld(gy), P(nbr), n_out, n_in, K, cin, cout)
     if bias is not None and bias.g is not None:

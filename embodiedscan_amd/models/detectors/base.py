@@ -126,24 +126,8 @@ class DetectorBase:
                     red.launch(part)
         E.TAPE.clear()
 
-    # Python's cyclic collector and the train loop (round 5, profiles/r5b / r5d_bench_grounding_diag.json): a generation-2 collection
-    # walks every live container of the process -- model, configs, the frozen text encoder's module tree, torch's own tables -- and
-    # costs 110-170 ms of host time whenever the allocation counters trip it (every ~20 steps: the 3.5x step-time outliers).  The
-    # step itself leaves no cyclic garbage (sparse.CoordSet caches are weak), so after a few steps everything alive is long-lived:
-    # it is moved to the permanent generation once (gc.freeze) and later collections only look at what was allocated since.
-    # ES_GC_FREEZE=0 turns this off.
-    _GC_SETTLE_STEP = 6
-
-    def _settle_gc(self):
-        n = getattr(self, '_steps_done', 0) + 1
-        self._steps_done = n
-        if n == self._GC_SETTLE_STEP and os.environ.get('ES_GC_FREEZE', '1') != '0':
-            import gc
-            gc.collect()
-            gc.freeze()
-
     def train_step(self, data, optim_wrapper):
-        self._settle_gc()
+        E.settle_gc(self)
         E.TAPE.clear()
         hip.refresh_stream()
         E.mark('data (caller)')

@@ -6,6 +6,8 @@ into every view (the A8 kernel with explicit float locations) -> image volume (2
 voxelisation at 2.5 mm -> MinkResNet34 -> last level (stride 64 = one voxel of the volume) scattered densely
 (25 600, 512); both written into ONE channels-last (25 600, 768) buffer (no cat) -> IndoorImVoxelNeck -> ImVoxelOccHead.
 """
+import os
+
 import torch
 from ... import engine as E
 from ... import hip
@@ -27,6 +29,8 @@ class DenseFusionOccPredictor(DetectorBase):
         assert use_xyz_feat, 'shipped config: use_xyz_feat=True (the other branch of the reference has a precedence bug, SURVEY Q15)'
         assert not use_valid_mask, 'use_valid_mask=True appends a 4th "level" the reference head cannot consume; shipped: False'
         self.backbone = MODELS.build(backbone)
+        self.backbone.act16 = os.environ.get('ES_OCC_ACT16', '1') != '0'   # round 5: its feature maps only feed the FPN laterals (K = 1 row GEMMs that
+                                                                              # read bf16 rows): bf16 activation storage as in the other two detectors
         self.backbone_3d = MODELS.build(backbone_3d)
         self.neck = MODELS.build(neck)
         self.neck_3d = MODELS.build(neck_3d)

@@ -293,7 +293,7 @@ class SparseFeatureFusionSingleStage3DDetector:
 
     def train_step(self, data, optim_wrapper):
         """mmengine BaseModel.train_step: preprocess, loss forward, sum of the 'loss' entries, backward, update."""
-        self._settle_gc()                        # (base.py: the collector's generations are frozen once the warm-up steps are through)
+        E.settle_gc(self)                        # (the collector's generations are frozen once the warm-up steps are through)
         E.TAPE.clear()
         hip.refresh_stream()
         E.mark('A1-A3 depth->points')            # whatever the caller queued before train_step (pipeline.make_batch)
