@@ -26,8 +26,8 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
 ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_fwd_bf16_io',
-          'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src', 'es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16', 'es_dconv_wgrad2d_bf16'}
-DENSE = ('es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16', 'es_dconv_wgrad2d_bf16')   # round 5: the dense-volume engine (csrc/dconv.hip), geometry instead of a map
+          'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src', 'es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16'}
+DENSE = ('es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16')   # round 5: the dense-volume engine (csrc/dconv.hip), geometry instead of a map
 FWD_X = ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_io')     # (X, x_half, ldx, W, nbr, n_out, n_in, K, Cin, Cout, ...)
 SCATTER = {'es_voxel_keys', 'es_unique_first', 'es_morton_sort', 'es_stride_keys', 'es_kernel_map', 'es_inverse_map',
            'es_union_plan', 'es_point_sample_fwd', 'es_point_sample_bwd', 'es_depth_to_points'}
@@ -770,7 +770,7 @@ def launch_classes(records, mfma_peak, top=6):
         if name not in ENGINE:
             continue
         nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
-        kind = 'wgrad' if (name.startswith('es_spconv_wgrad') or name in ('es_dconv_wgrad_bf16', 'es_dconv_wgrad2d_bf16')) else 'fwd/dgrad'
+        kind = 'wgrad' if (name.startswith('es_spconv_wgrad') or name == 'es_dconv_wgrad_bf16') else 'fwd/dgrad'
         if name in DENSE:
             kind += ' dense'
         key = f'{kind} K={K} {cin}->{cout}'
@@ -853,11 +853,6 @@ def other_parity(kind, cfg, det, scan, make, dev, args):
 def dense_info(name, a):
     """(n_out, n_in, K, cin, cout, valid (output, tap) pairs) of a dense-engine launch, in the convention of the map launches
     (the data gradient is a forward launch over the input voxels with the channel roles swapped)"""
-    if name == 'es_dconv_wgrad2d_bf16':            # 3x3 image convolution: (Xh, ldx, dY, dy_half, ldy, geom, Cin, Cout, ...)
-        B, H, W, _, ks, st, pad = list(a[5])
-        o = lambda d: (d + 2 * pad - ks) // st + 1
-        ax = lambda d: sum(1 for q in range(o(d)) for k in range(ks) if 0 <= q * st - pad + k < d)
-        return B * o(H) * o(W), B * H * W, 9, a[6], a[7], float(B) * ax(H) * ax(W)
     geom = list(a[3] if name == 'es_dconv_fwd_bf16' else a[4])
     B, X, Y, Z, ks, st, pad = geom
     o = lambda d: (d + 2 * pad - ks) // st + 1
@@ -919,7 +914,7 @@ def engine_totals(records, mfma_peak):
             pairs = pairs_dev
         else:
             pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
-        wgrad = name.startswith('es_spconv_wgrad') or name in ('es_dconv_wgrad_bf16', 'es_dconv_wgrad2d_bf16')
+        wgrad = name.startswith('es_spconv_wgrad') or name == 'es_dconv_wgrad_bf16'
         wb = 2 if ('bf16' in name and not wgrad) else 4
         f = 2.0 * pairs * cin * cout
         pb = pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wb
@@ -931,8 +926,6 @@ def engine_totals(records, mfma_peak):
             bx, by = (2.0 if a[1] else 4.0), (2.0 if a[4] else 4.0)
         elif name == 'es_dconv_wgrad_bf16':
             bx = by = 2.0
-        elif name == 'es_dconv_wgrad2d_bf16':
-            bx, by = 2.0, (2.0 if a[3] else 4.0)
         elif name in DENSE or (name in FWD_X and a[1]):
             bx = 2.0
         if name == 'es_spconv_fwd_bf16_io' and a[17]:           # bf16 activation rows written by the image backbone

@@ -372,139 +372,6 @@ __global__ __launch_bounds__(512, 2) void k_dconv_wgrad(const unsigned short* __
 }
 
 
-// ------------------------------------------------------------------ weight gradient of 3x3 image convolutions with few channels
-// The 2-D backbone's conv2 layers (mmdet.ResNet bottlenecks, configs/detection/mv-det3d_...py:24-34: 16 .. 64 channels at base width
-// 16) on (n_img, H, W) grids of 10^5 .. 10^6 pixels: dW[t][ci][co] = sum_j X[src(j, t)][ci] dY[j][co].  The map kernel
-// (k_spconv_wgrad_bf16<1, 0>) gives every tap its own workgroups, so dY is read nine times and X is gathered through an index map:
-// 4 % matrix-core busy, 0.45 TB/s (profiles/r4_mfma_util.txt).  Here ONE workgroup owns a slice of the output pixels and ALL nine
-// taps of one kernel ROW (blockIdx.y = ky: dY is read three times instead of nine): per 64-pixel chunk the dY tile goes to LDS once
-// (f32 rows are rounded to bf16 on the way, bf16 rows go by LDS-DMA), the three shifted X tiles are gathered by address
-// arithmetic (LDS-DMA, absent neighbours read a zero granule; the re-reads of a line hit L1 / L2), both are read transposed
-// (ds_read_b64_tr_b16) and the 3 x (CI / 16) x (CO / 16) accumulator fragments stay in registers across the whole slice.  (First
-// version, profiles/r5f: all nine taps in one workgroup and ~250 slices = one 4-wave workgroup per CU walking 45 .. 160 dependent
-// DMA -> barrier -> 16-MFMA steps: 108 us per 64-channel launch, latency-bound.  Three workgroups per slice, more slices and 48
-// instead of 144 accumulator registers put 5+ workgroups on a CU.)  Partial tiles [slice][9][CI][CO] are added in slice order by
-// k_dconv_reduce.
-template <int CI, int CO, int YH>
-__global__ __launch_bounds__(256) void k_dconv_wgrad_taps9(const unsigned short* __restrict__ Xh, int ldx, const void* __restrict__ dYv,
-                                                           int ldy, int M, DcGeom g, float* __restrict__ out, int accumulate,
-                                                           int chunks_per_slice, int n_slices) {
-  constexpr int RBX = CI * 2, RBY = CO * 2;      // bytes per LDS row
-  constexpr int TX = 64 * RBX, TY = 64 * RBY;    // one 64-pixel tile
-  constexpr int GX = CI / 8;                     // 16-byte granules per X row
-  constexpr int NPX = 64 * GX / 256;             // LDS-DMA pieces per thread and X tile (1 or 2)
-  constexpr int MFN = CI / 16, NFN = CO / 16, NP = MFN * NFN / 4;    // accumulator fragments (pairs) per wave
-  static_assert(NP >= 1 && NPX >= 1, "32 or 64 channels on both sides");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TX + 2 * TY];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
-  const int slice = blockIdx.x, tg = blockIdx.y;      // tg: kernel row ky -- this workgroup's three taps are 3 tg .. 3 tg + 2
-  const int c_beg = slice * chunks_per_slice, c_end = min((M + 63) >> 6, c_beg + chunks_per_slice);
-  f32x4 acc[3][NP];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < NP; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int pk[NPX], base[NPX];
-  auto rows_of = [&](int j0) {                   // packed coordinates of this thread's X-piece rows of the chunk at j0
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) dc_row(g, j0 + (q * 256 + t) / GX, M, pk[q], base[q]);
-  };
-  auto issue_x = [&](int buf, int tap) {
-    const DcTap tp = g.taps[tap];
-#pragma unroll
-    for (int q = 0; q < NPX; ++q) {
-      const int s = dc_src(g, pk[q], base[q], tp.dx, tp.dy, tp.dz);
-      const unsigned short* p = s >= 0 ? (Xh + s * ldx + ((q * 256 + t) % GX) * 8) : g_dc_zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                       (__attribute__((address_space(3))) void*)(smem + buf * TX + (q * 4 + wv) * 1024), 16, 0, 0);
-    }
-  };
-  auto stage_y = [&](int buf, int j0) {          // the chunk's dY rows -> LDS as bf16 [64][CO]
-    unsigned char* dst = smem + 2 * TX + buf * TY;
-    if (YH) {
-      constexpr int GY = CO / 8;
-#pragma unroll
-      for (int q = 0; q < 64 * GY / 256; ++q) {
-        const int e = q * 256 + t, m = j0 + e / GY;
-        const unsigned short* p = m < M ? ((const unsigned short*)dYv + (size_t)m * ldy + (e % GY) * 8) : g_dc_zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                         (__attribute__((address_space(3))) void*)(dst + (q * 4 + wv) * 1024), 16, 0, 0);
-      }
-    } else {
-      constexpr int F4 = CO / 4;                   // float4 pieces per row
-#pragma unroll
-      for (int q = 0; q < 64 * F4 / 256; ++q) {
-        const int e = q * 256 + t, r = e / F4, c4 = e % F4, m = j0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M) v = *(const float4*)((const float*)dYv + (size_t)m * ldy + c4 * 4);
-        uint2 h;
-        h.x = es_pack_bf16(v.x, v.y);
-        h.y = es_pack_bf16(v.z, v.w);
-        *(uint2*)(dst + r * RBY + c4 * 8) = h;
-      }
-    }
-  };
-  // transposed fragment: 16 channels from channel block cb of a [64][C] tile, pixels h * 32 + kq * 8 .. + 7, channel li
-  auto frag = [&](const unsigned char* tile, int rb, int cb, int h) -> bf16x8_t {
-    s16x4_t v[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int pr = h * 32 + kq * 8 + r * 4 + (li >> 2);
-      const unsigned char* a = tile + pr * rb + cb * 32 + (li & 3) * 8;
-      v[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
-    }
-    s16x8_t u = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8_t, u);
-  };
-  if (c_beg < c_end) {
-    rows_of(c_beg * 64);
-    stage_y(0, c_beg * 64);
-    issue_x(0, tg * 3);
-    for (int c = c_beg; c < c_end; ++c) {
-      const unsigned char* yt = smem + 2 * TX + ((c - c_beg) & 1) * TY;
-#pragma unroll
-      for (int tap = 0; tap < 3; ++tap) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                           // this step's X tile (and, at tap 0, the chunk's dY tile) is in LDS; the other X buffer is free
-        const int xb = ((c - c_beg) * 3 + tap) & 1;
-        if (tap < 2) {
-          issue_x(xb ^ 1, tg * 3 + tap + 1);
-        } else if (c + 1 < c_end) {
-          rows_of((c + 1) * 64);
-          stage_y(((c + 1 - c_beg) & 1), (c + 1) * 64);
-          issue_x(xb ^ 1, tg * 3);
-        }
-        const unsigned char* xt = smem + xb * TX;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-          for (int q = 0; q < NP; ++q) {
-            const int pair = wv * NP + q, mf = pair / NFN, nf = pair % NFN;
-            const bf16x8_t a = frag(xt, RBX, mf, h), b = frag(yt, RBY, nf, h);
-            acc[tap][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[tap][q], 0, 0, 0);
-          }
-        }
-      }
-    }
-  }
-  // partial tile of this slice (or, with one slice, the gradient itself)
-  float* dst = out + (n_slices > 1 ? (size_t)slice * 9 * CI * CO : 0);
-  const bool add = n_slices == 1 && accumulate;
-#pragma unroll
-  for (int tap = 0; tap < 3; ++tap) {
-    const int wt = g.taps[tg * 3 + tap].w;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const int pair = wv * NP + q, mf = pair / NFN, nf = pair % NFN;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float* p = dst + ((size_t)wt * CI + mf * 16 + kq * 4 + r) * CO + nf * 16 + li;
-        *p = add ? (*p + acc[tap][q][r]) : acc[tap][q][r];
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------ host side
 static unsigned dc_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)((1ull << 32) / d); }
 
@@ -697,78 +564,5 @@ extern "C" int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int
   hipLaunchKernelGGL(k_dconv_wgrad, dim3(per * 8), dim3(512), 0, (hipStream_t)stream, (const unsigned short*)Xh, ldx,
                      (const unsigned short*)dYh, ldy, Cin, Cout, M, g, dW, accumulate, nCo, nwg, per, transposed ? 1 : 0);
   ES_CHECK_LAUNCH();
-  return 0;
-}
-
-// ---- 3x3 image convolutions with 32 / 64 channels: all nine taps in one workgroup (k_dconv_wgrad_taps9)
-// geom_host: {n_img, H, W, 1, 3, stride, 1}; rows of the grids are (img * H + y) * W + x
-static int dc_geometry2d(const int* gh, DcGeom& g, int& M, int& n_src) {
-  const int B = gh[0], H = gh[1], W = gh[2], ks = gh[4], st = gh[5], pad = gh[6];
-  if (B <= 0 || H <= 0 || W <= 0 || gh[3] != 1 || ks != 3 || pad != 1 || (st != 1 && st != 2)) return -4;
-  const int Ho = (H + 2 * pad - ks) / st + 1, Wo = (W + 2 * pad - ks) / st + 1;
-  if (Ho <= 0 || Wo <= 0 || (long long)H * st >= 2048 || (long long)W * st >= 2048) return -4;
-  g.rX = Ho; g.rY = Wo; g.rZ = 1;
-  g.sX = H; g.sY = W; g.sZ = 1; g.sm = st;
-  g.mS = dc_magic((unsigned)(Ho * Wo)); g.mYZ = dc_magic((unsigned)Wo); g.mZ = dc_magic(1u);
-  g.cls = 0;
-  for (int p = 0; p < 9; ++p) g.clsBeg[p] = 0;
-  g.nT = 9;
-  for (int t = 0; t < 9; ++t) g.taps[t] = DcTap{(short)t, (short)(t / 3 - pad), (short)(t % 3 - pad), 0};
-  const long long m = (long long)B * Ho * Wo, ns = (long long)B * H * W;
-  if (m >= (1ll << 31) || ns >= (1ll << 31)) return -4;
-  M = (int)m; n_src = (int)ns;
-  return 0;
-}
-static void dc_slices2d(int M, int Cin, int Cout, int& cps, int& slices) {
-  // slices: enough workgroups (x 3 kernel rows) to put several on every CU, capped so that the partial tiles (9 Cin Cout floats per
-  // slice, written and read once) stay below the operands' own traffic: ~1024 slices at 32 x 32, ~384 at 64 x 64
-  const int chunks = es_cdiv(M, 64);
-  int target = (int)(((long long)36 << 20) / ((long long)9 * Cin * Cout * 4));
-  target = target < 64 ? 64 : (target > 1024 ? 1024 : target);
-  cps = es_cdiv(chunks, target);
-  if (cps < 2) cps = 2;
-  slices = es_cdiv(chunks, cps);
-}
-extern "C" int es_dconv_wgrad2d_supported(const int* geom_host, int Cin, int Cout) {
-  DcGeom g; int M, ns;
-  return (dc_geometry2d(geom_host, g, M, ns) == 0 && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) ? 1 : 0;
-}
-extern "C" size_t es_dconv_wgrad2d_workspace_floats(const int* geom_host, int Cin, int Cout) {
-  DcGeom g; int M, ns, cps, sl;
-  if (dc_geometry2d(geom_host, g, M, ns) != 0) return 0;
-  dc_slices2d(M, Cin, Cout, cps, sl);
-  return sl > 1 ? (size_t)sl * 9 * Cin * Cout : 0;
-}
-extern "C" int es_dconv_wgrad2d_bf16(const void* Xh, int ldx, const void* dY, int dy_half, int ldy, const int* geom_host, int Cin, int Cout,
-                                     float* dW, int accumulate, float* ws, size_t ws_floats, void* stream) {
-  DcGeom g; int M, ns, cps, sl;
-  int rc = dc_geometry2d(geom_host, g, M, ns);
-  if (rc != 0) return rc;
-  if (!((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) || (ldx & 7) != 0 || (ldy & (dy_half ? 7 : 3)) != 0 ||
-      ((uintptr_t)Xh & 15) != 0 || ((uintptr_t)dY & 15) != 0 || ((uintptr_t)dW & 15) != 0 || (long long)ns * ldx >= (1ll << 31))
-    return -4;
-  dc_slices2d(M, Cin, Cout, cps, sl);
-  const size_t nw = (size_t)9 * Cin * Cout;
-  if (sl > 1 && (ws == nullptr || ws_floats < (size_t)sl * nw || ((uintptr_t)ws & 15) != 0)) return -5;
-  hipStream_t st = (hipStream_t)stream;
-  float* out = sl > 1 ? ws : dW;
-  const unsigned short* X = (const unsigned short*)Xh;
-#define T9_LAUNCH(CI_, CO_)                                                                                                    \
-  do {                                                                                                                          \
-    if (dy_half) hipLaunchKernelGGL((k_dconv_wgrad_taps9<CI_, CO_, 1>), dim3(sl, 3), dim3(256), 0, st, X, ldx, dY, ldy, M, g, out, accumulate, cps, sl); \
-    else hipLaunchKernelGGL((k_dconv_wgrad_taps9<CI_, CO_, 0>), dim3(sl, 3), dim3(256), 0, st, X, ldx, dY, ldy, M, g, out, accumulate, cps, sl);      \
-  } while (0)
-  if (Cin == 32 && Cout == 32) T9_LAUNCH(32, 32);
-  else if (Cin == 64 && Cout == 64) T9_LAUNCH(64, 64);
-  else if (Cin == 32) T9_LAUNCH(32, 64);
-  else T9_LAUNCH(64, 32);
-#undef T9_LAUNCH
-  ES_CHECK_LAUNCH();
-  if (sl > 1) {
-    const size_t tot4 = nw / 4;
-    const int gr = es_cdiv((long long)tot4, 256);
-    hipLaunchKernelGGL(k_dconv_reduce, dim3(gr), dim3(256), 0, st, (const float4*)ws, sl, tot4, Cout / 4, dW, Cout, accumulate);
-    ES_CHECK_LAUNCH();
-  }
   return 0;
 }

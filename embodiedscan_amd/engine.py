@@ -518,7 +518,6 @@ def _grad_target(v, shape_like):
 # channels % 64, output channels % 256; the data gradient for stride 1) and falls back to the map kernels elsewhere -- `maps` is then
 # a callable returning (nbr, inv), so the maps of a layer the dense engine covers completely are never built.
 DENSE = [os.environ.get('ES_DENSE', '1') != '0']
-IMG_WGRAD = [os.environ.get('ES_IMG_WGRAD', '1') != '0']      # 3x3 image weight gradients: all nine taps in one workgroup
 _DC_WS = {}             # stream handle -> persistent workspace of the partial tiles of split dense launches
 
 
@@ -600,7 +599,7 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0, dense=None
     return y
 
 
-def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, gate=None, dense=None, maps=None, grid2d=None):
+def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, gate=None, dense=None, maps=None):
     """wgrad (+ bias grad) and dgrad of a convolution whose output gradient is the row matrix `gy`.
     gate: folded-BN scale of x's producer -- the dgrad launch then also applies that layer's ReLU mask and BN scale
     (x is its only consumer), leaving x.g as the gradient of the producer's raw conv output."""
@@ -631,19 +630,6 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         sw = _wgrad_stream(gy, x.d, gh, x.dh)
     if dn_w is not None:
         call('es_dconv_wgrad_bf16', P(x.dh), cin, P(gh), cout, _dense_geom(dn_w), 0, cin, cout, P(w.g), _first_write(P(w.g)), sw)
-    elif (w.g is not None and grid2d is not None and IMG_WGRAD[0] and bf and WGRAD_BF16[0] and x.dh is not None and _ld(x.dh) == cin
-          and gy.dtype == torch.float32 and hip.raw('es_dconv_wgrad2d_supported')(iarr(grid2d), cin, cout) == 1):
-        # 3x3 image convolution with 32 / 64 channels: all nine taps in one workgroup, dY read once (csrc/dconv.hip k_dconv_wgrad_taps9)
-        g2 = iarr(grid2d)
-        need = int(hip.raw('es_dconv_wgrad2d_workspace_floats')(g2, cin, cout))
-        ws = _WGRAD_WS.get(sw)
-        if need and (ws is None or ws.numel() < need):
-            if ws is not None:
-                _KEEP.append(ws)
-            ws = _WGRAD_WS[sw] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=gy.device)
-        ys, yh = (gh, 1) if gh is not None else (gy, 0)
-        call('es_dconv_wgrad2d_bf16', P(x.dh), cin, P(ys), yh, _ld(ys), g2, cin, cout, P(w.g), _first_write(P(w.g)), P(ws) if need else 0,
-             ws.numel() if need else 0, sw)
     elif w.g is not None and bf and WGRAD_BF16[0] and SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None):
         xs, ys = x.dh if x.dh is not None else x.d, gh if gh is not None else gy
         _wgrad('es_spconv_wgrad_bf16_src', sw, P(w.g), P(xs), int(x.dh is not None), _ld(xs), P(ys), int(gh is not None), _ld(ys),
@@ -690,7 +676,7 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         rec['after'] = x.g.clone()               # (gradient buffer after this launch; `before` = what it accumulated onto)
 
 
-def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True, sole_consumer=False, out_bf16=False, grid2d=None):
+def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True, sole_consumer=False, out_bf16=False):
     """conv -> frozen-BN affine (+ residual) (+ ReLU) of the 2-D backbone.  In bf16 mode this is ONE launch (affine
     fused into the conv epilogue); in f32 mode conv() followed by affine_act().
     sole_consumer: promise that x feeds nothing but this conv; if x itself came out of a fused conv+BN+ReLU, its
@@ -735,7 +721,7 @@ def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=Tr
             gconv = torch.empty((n_out, cout), dtype=torch.float32, device=y.d.device)   # gradient w.r.t. the conv output
             call('es_affine_act_bwd_yh' if y.d.dtype == h16 else 'es_affine_act_bwd', P(y.g), P(y.d), P(scale), n_out, cout, act,
                  P(gconv), 0, gr, accr, _stream())
-        _conv_backward(x, w, nbr, inv, n_out, y, gconv, None, 0, need_dx, True, gate, grid2d=grid2d)
+        _conv_backward(x, w, nbr, inv, n_out, y, gconv, None, 0, need_dx, True, gate)
     TAPE.add(bwd)
     return y
 

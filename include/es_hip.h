@@ -456,15 +456,6 @@ int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, const int* ge
  * 2 r + p).  One workgroup per (tap, 256 x 256 tile): every element is written once, no atomics. */
 int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int transposed, int Cin, int Cout,
                         float* dW, int accumulate, void* stream);
-/* Weight gradient of the 2-D backbone's 3x3 convolutions with 32 / 64 channels (mmdet.ResNet conv2 at base width 16,
- * configs/detection/mv-det3d_8xb4_embodiedscan-3d-284class-9dof.py:24-34) by address arithmetic, all nine taps in one workgroup:
- * geom_host = {n_img, H, W, 1, 3, stride (1 | 2), 1} of the INPUT image grid, rows (img*H + y)*W + x; Xh bf16 input rows, dY the
- * output gradient rows (f32, or bf16 with dy_half = 1; ldy in elements); dW[9][Cin][Cout] f32.  The output pixels are cut into
- * slices, the partial tiles go through `ws` (es_dconv_wgrad2d_workspace_floats) and are added in slice order: no atomics. */
-int es_dconv_wgrad2d_supported(const int* geom_host, int Cin, int Cout);
-size_t es_dconv_wgrad2d_workspace_floats(const int* geom_host, int Cin, int Cout);
-int es_dconv_wgrad2d_bf16(const void* Xh, int ldx, const void* dY, int dy_half, int ldy, const int* geom_host, int Cin, int Cout,
-                          float* dW, int accumulate, float* ws, size_t ws_floats, void* stream);
 /* tuning switches of the dense engine (A/B runs): 20 row tile (0 auto, 256, 320), 21 loop order (1 chunk outer / tap inner),
  * 22 slices per tile (0 auto) */
 int es_dconv_set_option(int key, int value);

@@ -299,39 +299,3 @@ def test_engine_dense_transposed_convolution_equals_the_generative_path(emulated
     for a, b, name in zip(res[True], res[False], ('y', 'dx', 'dw')):
         err = float((a - b).abs().max() / b.abs().max())
         assert err < 2e-5, (name, err)
-
-
-@pytest.mark.parametrize('lazy', [0, 1])
-def test_image_wgrad_all_taps(emu, lazy):
-    """k_dconv_wgrad_taps9: dW of a 3x3 image convolution (stride 1 and 2, several images, ragged last chunk, chunk straddling
-    two images), f32 and bf16 output-gradient rows, 32 / 64 channels, one slice and several slices -- against f64"""
-    rng = np.random.default_rng(51 + lazy)
-    emu.lib.es_emu_set_dma_mode(lazy)
-    try:
-        cases = ((3, 9, 7, 1, 32, 32), (2, 20, 23, 1, 64, 64), (2, 12, 10, 2, 32, 64), (5, 17, 15, 2, 64, 32)) if not lazy else ((2, 13, 11, 1, 32, 32),)
-        for B, H, W, st, cin, cout in cases:
-            g = np.array([B, H, W, 1, 3, st, 1], np.int32)
-            assert emu.fns['es_dconv_wgrad2d_supported'](P(g), cin, cout) == 1
-            Ho, Wo = (H + 2 - 3) // st + 1, (W + 2 - 3) // st + 1
-            M = B * Ho * Wo
-            x = rng.standard_normal((B * H * W, cin)).astype(np.float32)
-            dy = rng.standard_normal((M, cout)).astype(np.float32)
-            xh, dyh = bf16_bits(x), bf16_bits(dy)
-            xb, gb = bf16_round(x).astype(np.float64), bf16_round(dy).astype(np.float64)
-            xv = np.zeros((B, H + 2, W + 2, cin))
-            xv[:, 1:1 + H, 1:1 + W] = xb.reshape(B, H, W, cin)
-            want = np.stack([xv[:, ky:ky + st * Ho:st, kx:kx + st * Wo:st].reshape(M, cin).T @ gb for ky in range(3) for kx in range(3)])
-            nf = int(emu.fns['es_dconv_wgrad2d_workspace_floats'](P(g), cin, cout))
-            ws = np.full(max(nf, 4), np.nan, np.float32)
-            for half, src in ((0, dy), (1, dyh)):
-                dw = np.full((9, cin, cout), np.nan, np.float32)
-                emu.launches()
-                emu('es_dconv_wgrad2d_bf16', P(xh), cin, P(src), half, cout, P(g), cin, cout, P(dw), 0, P(ws), nf, 0)
-                assert any('k_dconv_wgrad_taps9' in k for k in emu.launches())
-                err = np.abs(dw - want).max() / np.abs(want).max()
-                assert err < 2e-6, (B, H, W, st, cin, cout, half, err)
-            dw2 = np.ones((9, cin, cout), np.float32)
-            emu('es_dconv_wgrad2d_bf16', P(xh), cin, P(dy), 0, cout, P(g), cin, cout, P(dw2), 1, P(ws), nf, 0)
-            assert np.abs(dw2 - 1 - want).max() / np.abs(want).max() < 2e-6
-    finally:
-        emu.lib.es_emu_set_dma_mode(0)

@@ -257,44 +257,3 @@ def test_strided_data_gradient_neck_shapes_vs_map_kernel(X, Y, Z, cin, cout):
         call('es_spconv_fwd_bf16', P(dyh), 1, cout, P(wn), P(inv), n_in, n_out, 27, cout, cin, 0, P(dx0), cin, 0, st_)
     err = float((dx - dx0).abs().max() / dx0.abs().max())
     assert err < 2e-5, err
-
-
-@pytest.mark.parametrize('n_img,H,W,st,cin,cout', [(80, 60, 60, 1, 32, 32), (40, 120, 120, 2, 32, 32), (80, 30, 30, 1, 64, 64), (7, 33, 29, 2, 64, 32)])
-def test_image_wgrad_all_taps_vs_map_kernel_and_f64(n_img, H, W, st, cin, cout):
-    """the 2-D backbone's conv2 weight gradients at base width 16 (mv-3ddet: 80 images): one workgroup over all nine taps
-    (k_dconv_wgrad_taps9) against the map kernel it replaces (2e-5) and, on the small case, against f64 (2e-6); bit-reproducible"""
-    from embodiedscan_amd import hip
-    from embodiedscan_amd.hip import call, P
-    dev = torch.device('cuda:0')
-    st_ = torch.cuda.current_stream().cuda_stream
-    gen = torch.Generator().manual_seed(23)
-    g = _geom(n_img, H, W, 1, 3, st, 1)
-    assert hip.raw('es_dconv_wgrad2d_supported')(g, cin, cout) == 1
-    Ho, Wo = (H + 2 - 3) // st + 1, (W + 2 - 3) // st + 1
-    M, n_in = n_img * Ho * Wo, n_img * H * W
-    xh = torch.randn(n_in, cin, generator=gen).to(dev).bfloat16().contiguous()
-    dy = torch.randn(M, cout, generator=gen).to(dev)
-    nf = int(hip.raw('es_dconv_wgrad2d_workspace_floats')(g, cin, cout))
-    ws = torch.empty(max(nf, 4), device=dev)
-    dw = torch.full((9, cin, cout), float('nan'), device=dev)
-    call('es_dconv_wgrad2d_bf16', P(xh), cin, P(dy), 0, cout, g, cin, cout, P(dw), 0, P(ws), nf, st_)
-    dwb = torch.full((9, cin, cout), float('nan'), device=dev)
-    call('es_dconv_wgrad2d_bf16', P(xh), cin, P(dy), 0, cout, g, cin, cout, P(dwb), 0, P(ws), nf, st_)
-    assert torch.equal(dw, dwb)
-    dyh = dy.bfloat16().contiguous()
-    dwh = torch.full((9, cin, cout), float('nan'), device=dev)
-    call('es_dconv_wgrad2d_bf16', P(xh), cin, P(dyh), 1, cout, g, cin, cout, P(dwh), 0, P(ws), nf, st_)
-    assert torch.equal(dw, dwh)                               # f32 rows are rounded exactly as the bf16 shadow is
-    nbr = torch.empty((M, 9), dtype=torch.int32, device=dev)
-    call('es_image_map', n_img, H, W, Ho, Wo, 3, 3, st, 1, P(nbr), st_)
-    need = int(hip.raw('es_spconv_wgrad_workspace_floats')(1, P(xh), 1, cin, P(dy), 0, cout, M, n_in, 9, cin, cout))
-    wsw = torch.empty(max(need, 4), device=dev)
-    dw0 = torch.empty(9, cin, cout, device=dev)
-    call('es_spconv_wgrad_bf16_src', P(xh), 1, cin, P(dy), 0, cout, P(nbr), M, n_in, 9, cin, cout, P(dw0), 0, P(wsw), need, st_)
-    err = float((dw - dw0).abs().max() / dw0.abs().max())
-    assert err < 2e-5, err
-    if n_img <= 8:
-        xv = torch.zeros((n_img, H + 2, W + 2, cin), dtype=torch.float64, device=dev)
-        xv[:, 1:1 + H, 1:1 + W] = xh.double().reshape(n_img, H, W, cin)
-        want = torch.stack([xv[:, ky:ky + st * Ho:st, kx:kx + st * Wo:st].reshape(M, cin).T @ dyh.double() for ky in range(3) for kx in range(3)])
-        assert float((dw.double() - want).abs().max() / want.abs().max()) < 2e-6

@@ -9,6 +9,8 @@ from collections import defaultdict
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info('kernels')")]
 key = 'stream_id' if 'stream_id' in cols else 'queue_id'
+if key == 'stream_id' and 'queue_id' in cols and len(db.execute('select distinct stream_id from kernels').fetchall()) <= 1:
+    key = 'queue_id'                      # (kernel-trace only: every stream_id is 0; the hardware queue tells the streams apart)
 rows = db.execute(f'select start, end, name, {key} from kernels order by start').fetchall()
 marks = [i for i, r in enumerate(rows) if r[2].startswith('k_adamw')]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3

@@ -6,6 +6,8 @@ db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info('kernels')")]
 print('columns:', cols)
 key = 'stream_id' if 'stream_id' in cols else ('queue_id' if 'queue_id' in cols else None)
+if key == 'stream_id' and 'queue_id' in cols and len(db.execute('select distinct stream_id from kernels').fetchall()) <= 1:
+    key = 'queue_id'
 rows = db.execute(f'select start, end, name, {key or 0} from kernels order by start').fetchall()
 marks = [i for i, r in enumerate(rows) if r[2].startswith('k_adamw')]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3     # which step, counted from the end (k_adamw marks)
