@@ -490,6 +490,11 @@ def run_from_files(args, dev, synthetic_scans_per_s=None):
     base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None
     root = tempfile.mkdtemp(prefix='es_files_', dir=base)
     steps, warmup = max(4, min(args.steps, args.other_steps)), 4
+    # the step loop's own host-side tensor ops are tiny: one intra-op thread.  (After the CPU-oracle legs of the default run torch
+    # holds a 16-thread OpenMP pool; with 12 decode workers on the 16 granted cores every small op then waits at an OpenMP barrier
+    # behind descheduled threads: 30.5 ms / step against 26.1 alone, profiles/r5i_bench_default.json.)
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     try:
         names = [f'class{i}' for i in range(284)]
         synth.write_dataset(root, n_scans=8, n_frames=22, height=480, width=640, n_boxes=25, class_names=names, seed=1,
@@ -536,9 +541,12 @@ def run_from_files(args, dev, synthetic_scans_per_s=None):
         for _ in range(4 + warmup):
             step()
         torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        ev[0].record()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             waits.append(step())
+            ev[i + 1].record()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         it.close()
@@ -551,6 +559,7 @@ def run_from_files(args, dev, synthetic_scans_per_s=None):
                                wait_ms_per_step=dict(mean=round(sum(waits) / len(waits) * 1e3, 3), max=round(max(waits) * 1e3, 3)),
                                dataset=dict(scans=len(ds), frames_per_scan=22, where=root.rsplit('/', 1)[0])),
                    losses={k: round(float(v), 6) for k, v in losses.items()},
+                   step_ms=[round(ev[i].elapsed_time(ev[i + 1]), 2) for i in range(steps)],
                    note='files in /dev/shm (page-cache speed: decode cost, not disk); JPEG decode = PIL on host cores (no rocJPEG in the image), 16-bit '
                         'PNG = csrc/host_codec.c; loader wait = host time next(loader) blocked per step')
         if synthetic_scans_per_s:
@@ -561,6 +570,7 @@ def run_from_files(args, dev, synthetic_scans_per_s=None):
         release_frozen()
         return out
     finally:
+        torch.set_num_threads(prev_threads)
         shutil.rmtree(root, ignore_errors=True)
 
 
