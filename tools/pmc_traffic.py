@@ -12,8 +12,8 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILY = {
     # the convolution engine: every kernel behind the es_spconv_* entry points (+ their split reductions)
-    'mv3ddet': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits'),
-    'occupancy': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits'),
+    'mv3ddet': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits', 'k_dconv'),
+    'occupancy': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits', 'k_dconv'),     # round 5: + the dense-volume engine
     'grounding': ('k_attn_',),
 }
 SCATTER = ('k_voxel_keys', 'k_insert_min', 'k_unique', 'k_morton', 'k_rs_', 'k_apply_sorted', 'k_stride_keys', 'k_kernel_map',
