@@ -33,6 +33,21 @@ SCATTER = {'es_voxel_keys', 'es_unique_first', 'es_morton_sort', 'es_stride_keys
            'es_union_plan', 'es_point_sample_fwd', 'es_point_sample_bwd', 'es_depth_to_points'}
 
 
+_COPY_STREAM = {}
+
+
+def copy_stream(dev):
+    """ONE copy stream per device for the whole process: every configuration of the default run feeds through it.  (A fresh
+    torch.cuda.Stream() per leg lands on another of the 4 hardware queues each time; whichever leg ran second then shared a queue
+    between two of its streams and measured ~10 % slower -- from_files behind grounding 131 vs 157-160 scans/s, grounding behind
+    from_files 62 vs 56.6 ms: profiles/r5k_*, r5_bench_default.json.)"""
+    import torch
+    key = str(dev)
+    if key not in _COPY_STREAM:
+        _COPY_STREAM[key] = torch.cuda.Stream()
+    return _COPY_STREAM[key]
+
+
 class Feeder:
     """Host->device feed of whole batches: every batch is ONE pinned slab (pipeline.pin_batch), the device side two byte
     slabs; the copy of step i+1 is queued on a copy stream under the kernels of step i (one hipMemcpyAsync per batch),
@@ -46,7 +61,7 @@ class Feeder:
         self.h2d_bytes = batches[0].nbytes
         cap = max(b.nbytes for b in batches)
         self.slots = [pipeline.alloc_batch_slot(cap, dev) for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream()
+        self.copy_stream = copy_stream(dev)
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]     # slot s holds its batch
         self.freed = [torch.cuda.Event(), torch.cuda.Event()]     # the step that read slot s has been queued completely
         self.i = 0
@@ -511,7 +526,7 @@ def run_from_files(args, dev, synthetic_scans_per_s=None):
         det = build_detector(cfg, device=dev, seed=0).to(dev)
         optim = build_optim_wrapper(cfg)
         it = iter(ld)
-        copy = torch.cuda.Stream()
+        copy = copy_stream(dev)
         slots = ready = done = None
         n, waits, losses = 0, [], None
 

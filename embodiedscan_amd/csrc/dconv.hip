@@ -83,15 +83,15 @@ __device__ __forceinline__ int dc_logical(int per) { return (int)(blockIdx.x & 7
 
 // ------------------------------------------------------------------ forward / data gradient
 // Xh (rows x ldx) bf16 source rows; W [tap][N][Kd] bf16 (Kd contiguous); Y (M x ldy) f32, or partial tiles ws[slice][M][N].
-template <int BMT, bool TAP_INNER>
+template <int BMT, bool TAP_INNER, int BNT = 256>
 __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restrict__ Xh, int ldx,
                                                   const unsigned short* __restrict__ W, int Kd, int N, int M, DcGeom g,
                                                   float* __restrict__ Y, int ldy, int accumulate, float* __restrict__ ws,
                                                   int nsplit, int rowTiles, int colTiles, int per) {
   constexpr int RB = 128;                        // bytes per tile row: 64 channels
-  constexpr int A_BYTES = BMT * RB, B_BYTES = 256 * RB;
-  constexpr int NA = BMT / 64, NB = 4;           // LDS-DMA pieces per thread and step (A, B): 8 granules per row / 512 threads
-  constexpr int MF = BMT / 64, NF = 8;           // 16 x 16 fragments per wave: (BMT / 4) rows x 128 columns
+  constexpr int A_BYTES = BMT * RB, B_BYTES = BNT * RB;
+  constexpr int NA = BMT / 64, NB = BNT / 64;    // LDS-DMA pieces per thread and step (A, B): 8 granules per row / 512 threads
+  constexpr int MF = BMT / 64, NF = BNT / 32;    // 16 x 16 fragments per wave: (BMT / 4) rows x BNT / 2 columns (BNT = 128: the neck's out blocks)
   constexpr int OFF_B = 2 * A_BYTES, OFF_TAP = OFF_B + 2 * B_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[OFF_TAP + 32 * 8];
   DcTap* const tapS = (DcTap*)(smem + OFF_TAP);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
   const int rt = L % rowTiles, ct = (L / rowTiles) % colTiles, bz = L / (rowTiles * colTiles);
   const int tpc = g.cls ? rowTiles >> 3 : rowTiles;             // row tiles per parity class
   const int pc = rt / tpc;                                      // this tile's class (0 without classes)
-  const int row0 = (rt - pc * tpc) * BMT, n0 = ct * 256;
+  const int row0 = (rt - pc * tpc) * BMT, n0 = ct * BNT;
   const int tb = g.cls ? g.clsBeg[pc] : 0, nTl = g.cls ? g.clsBeg[pc + 1] - tb : g.nT;     // this tile's taps
   if (t < nTl) tapS[t] = g.taps[tb + t];
   // this thread's A pieces: piece e = (j * 8 + wv) * 64 + lane lands at LDS byte e * 16 = tile row e >> 3, slot e & 7, and holds
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
   const int li = lane & 15, kq = lane >> 4;
   const int f_key = (li >> 1) & 7;               // tile rows of a fragment are 16 * x + li: the key depends on li only
   const unsigned char* a_frag = smem + (wr * (BMT / 4) + li) * RB;
-  const unsigned char* b_frag = smem + OFF_B + (wc * 128 + li) * RB;
+  const unsigned char* b_frag = smem + OFF_B + (wc * (BNT / 2) + li) * RB;
   auto compute = [&](int buf) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -188,10 +188,11 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
       compute(c & 1);
     }
   }
-  float* const out = nsplit > 1 ? ws + (size_t)bz * M * N : Y;
+  // partial tiles of a split launch: ws[slice][row][N]; with parity classes the rows are class-major (class p, row): 8 M per slice
+  float* const out = nsplit > 1 ? ws + ((size_t)bz * (g.cls ? 8 : 1) + (g.cls ? pc : 0)) * M * N : Y;
   const int ldo = nsplit > 1 ? N : ldy;
   const bool add = nsplit > 1 ? false : (accumulate != 0);
-  if (g.cls) {                                   // rows of a parity class: scatter to the voxels (2x + px, 2y + py, 2z + pz)
+  if (g.cls && nsplit == 1) {                    // rows of a parity class: scatter to the voxels (2x + px, 2y + py, 2z + pz)
     const int px = pc >> 2, py = (pc >> 1) & 1, pz = pc & 1;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf)
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
           dc_div(rem, (unsigned)(g.rY * g.rZ), g.mYZ, x, rem);
           dc_div(rem, (unsigned)g.rZ, g.mZ, y, z);
           const size_t orow = (((size_t)b * (2 * g.rX) + 2 * x + px) * (2 * g.rY) + 2 * y + py) * (2 * g.rZ) + 2 * z + pz;
-          float* p = Y + orow * ldy + n0 + wc * 128 + li;
+          float* p = Y + orow * ldy + n0 + wc * (BNT / 2) + li;
           if (add) {
             float y0[NF];
 #pragma unroll
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + wr * (BMT / 4) + mf * 16 + kq * 4 + r;
         if (row < M) {
-          float* p = out + (size_t)row * ldo + n0 + wc * 128 + li;
+          float* p = out + (size_t)row * ldo + n0 + wc * (BNT / 2) + li;
           float y0[NF];
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) y0[nf] = p[nf * 16];
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void k_dconv(const unsigned short* __restri
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + wr * (BMT / 4) + mf * 16 + kq * 4 + r;
         if (row < M) {
-          float* p = out + (size_t)row * ldo + n0 + wc * 128 + li;
+          float* p = out + (size_t)row * ldo + n0 + wc * (BNT / 2) + li;
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) p[nf * 16] = acc[mf][nf][r];
         }
@@ -260,6 +261,29 @@ __global__ void k_dconv_reduce(const float4* __restrict__ ws, int nsplit, size_t
     }
     const size_t row = e / N4;
     float4* p = (float4*)(Y + row * ldy + (e - row * N4) * 4);
+    if (accumulate) { const float4 y0 = *p; s.x = y0.x + s.x; s.y = y0.y + s.y; s.z = y0.z + s.z; s.w = y0.w + s.w; }
+    *p = s;
+  }
+}
+
+// the same for a split parity-class launch: partial row (class p, m) of every slice -> voxel 2 r(m) + p of the output grid
+__global__ void k_dconv_reduce_cls(const float4* __restrict__ ws, int nsplit, int M, int N4, DcGeom g, float* __restrict__ Y, int ldy,
+                                   int accumulate) {
+  const size_t tot4 = (size_t)8 * M * N4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot4; e += (size_t)gridDim.x * blockDim.x) {
+    float4 s = ws[e];
+    for (int z = 1; z < nsplit; ++z) {
+      const float4 v = ws[(size_t)z * tot4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const size_t rc = e / N4;
+    const int pc = (int)(rc / M), m = (int)(rc - (size_t)pc * M);
+    unsigned b, rem, x, y, z;
+    dc_div((unsigned)m, (unsigned)(g.rX * g.rY * g.rZ), g.mS, b, rem);
+    dc_div(rem, (unsigned)(g.rY * g.rZ), g.mYZ, x, rem);
+    dc_div(rem, (unsigned)g.rZ, g.mZ, y, z);
+    const size_t orow = (((size_t)b * (2 * g.rX) + 2 * x + (pc >> 2)) * (2 * g.rY) + 2 * y + ((pc >> 1) & 1)) * (2 * g.rZ) + 2 * z + (pc & 1);
+    float4* p = (float4*)(Y + orow * ldy + (e - rc * N4) * 4);
     if (accumulate) { const float4 y0 = *p; s.x = y0.x + s.x; s.y = y0.y + s.y; s.z = y0.z + s.z; s.w = y0.w + s.w; }
     *p = s;
   }
@@ -464,24 +488,30 @@ extern "C" int es_dconv_set_option(int key, int value) {
 
 struct DcPlan { int bm, rowTiles, colTiles, nsplit; };
 static DcPlan dc_plan(int M, int N, int nIt, int cls = 0) {
+  const int bn = (N % 256 == 0) ? 256 : 128;     // column tile
   if (cls) {                                     // parity classes: 8 x tiles-per-class row tiles, no slices (the classes ARE the split)
     int bm = (ES_OPT_DC_ROWS == 256 || ES_OPT_DC_ROWS == 320) ? ES_OPT_DC_ROWS
              : (es_cdiv(M, 320) * 320 < es_cdiv(M, 256) * 256 || (es_cdiv(M, 320) * 320 == es_cdiv(M, 256) * 256 && M >= 320) ? 320 : 256);
-    return DcPlan{bm, 8 * es_cdiv(M, bm), N / 256, 1};
+    // slices of every class's (tap, chunk) sequence when the launch would leave most CUs idle (the 400-voxel level: 96 workgroups,
+    // the 8-tap class walking 384 steps); partial rows class-major through the workspace, k_dconv_reduce_cls scatters them
+    const int wgs = 8 * es_cdiv(M, bm) * (N / bn);
+    int s = ES_OPT_DC_SPLIT ? ES_OPT_DC_SPLIT : (wgs < 200 ? (es_cdiv(384, wgs) < 8 ? es_cdiv(384, wgs) : 8) : 1);
+    if (s > nIt / 27) s = nIt / 27 > 0 ? nIt / 27 : 1;              // (a one-tap class keeps >= one chunk per slice)
+    return DcPlan{bm, 8 * es_cdiv(M, bm), N / bn, s};
   }
-  DcPlan best{256, es_cdiv(M, 256), N / 256, 1};
+  DcPlan best{256, es_cdiv(M, 256), N / bn, 1};
   double best_cost = 1e30;
   for (int bm = 256; bm <= 320; bm += 64) {
     if (ES_OPT_DC_ROWS && bm != ES_OPT_DC_ROWS) continue;
-    const int rtl = es_cdiv(M, bm), tiles = rtl * (N / 256);
+    const int rtl = es_cdiv(M, bm), tiles = rtl * (N / bn);
     for (int s = 1; s <= 16 && s <= nIt; ++s) {
       if (ES_OPT_DC_SPLIT && s != ES_OPT_DC_SPLIT) continue;
       // time in units of one 64-row x 256-column x 64-channel step on one CU: rounds x steps per workgroup x rows, plus the
       // partial-tile round trip (s slices written and read: ~ (s + 1) x 1 KB per row of a tile against ~ 0.45 us per step)
       const double rounds = (double)es_cdiv((long long)tiles * s, 256);
-      double cost = rounds * es_cdiv(nIt, s) * (bm / 64.0);
-      if (s > 1) cost += (double)tiles * (s + 1) * bm / 256.0 * 0.35;
-      if (cost < best_cost) { best_cost = cost; best = DcPlan{bm, rtl, N / 256, s}; }
+      double cost = rounds * es_cdiv(nIt, s) * (bm / 64.0) * (bn == 256 ? 1.0 : 0.6);
+      if (s > 1) cost += (double)tiles * (s + 1) * bm / 256.0 * 0.35 * (bn / 256.0);
+      if (cost < best_cost) { best_cost = cost; best = DcPlan{bm, rtl, N / bn, s}; }
     }
   }
   return best;
@@ -499,17 +529,17 @@ extern "C" int es_dconv_supported(const int* geom_host, int mode, int Cin, int C
   if (mode == 2 || mode == 5) return (Cin % 256 == 0 && Cout % 256 == 0) ? 1 : 0;
   int Kd, N;
   dc_roles(mode, Cin, Cout, Kd, N);
-  return (Kd % 64 == 0 && N % 256 == 0) ? 1 : 0;
+  return (Kd % 64 == 0 && N % 128 == 0) ? 1 : 0;
 }
 
 extern "C" size_t es_dconv_workspace_floats(const int* geom_host, int mode, int Cin, int Cout) {
   DcGeom g; int M, ns;
-  if (mode == 2 || mode == 5 || dc_geometry(geom_host, mode, g, M, ns) != 0 || g.cls) return 0;
+  if (mode == 2 || mode == 5 || dc_geometry(geom_host, mode, g, M, ns) != 0) return 0;
   int Kd, N;
   dc_roles(mode, Cin, Cout, Kd, N);
-  if (Kd % 64 != 0 || N % 256 != 0) return 0;
-  const DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT);
-  return p.nsplit > 1 ? (size_t)p.nsplit * M * N : 0;
+  if (Kd % 64 != 0 || N % 128 != 0) return 0;
+  const DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT, g.cls);
+  return p.nsplit > 1 ? (size_t)p.nsplit * (g.cls ? 8 : 1) * M * N : 0;
 }
 
 // modes 0 / 3 (forward): Xh = the operator's bf16 input rows, W_bf16 = the [K][Cout][Cin] copy, Y = its output rows (f32).
@@ -523,11 +553,11 @@ extern "C" int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, co
   int Kd, N;
   dc_roles(mode, Cin, Cout, Kd, N);
   const int nTw = mode >= 3 ? 8 : g.nT;           // taps of the weight tensor
-  if (Kd % 64 != 0 || N % 256 != 0 || (ldx & 7) != 0 || (ldy & 3) != 0 || ((uintptr_t)Xh & 15) != 0 || ((uintptr_t)W_bf16 & 15) != 0 ||
+  if (Kd % 64 != 0 || N % 128 != 0 || (ldx & 7) != 0 || (ldy & 3) != 0 || ((uintptr_t)Xh & 15) != 0 || ((uintptr_t)W_bf16 & 15) != 0 ||
       ((uintptr_t)Y & 15) != 0 || (long long)ns * ldx >= (1ll << 31) || (long long)(nTw > 27 ? nTw : 27) * N * Kd >= (1ll << 31))
     return -4;
   DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT, g.cls);
-  if (p.nsplit > 1 && (ws == nullptr || ws_floats < (size_t)p.nsplit * M * N || ((uintptr_t)ws & 15) != 0)) return -5;
+  if (p.nsplit > 1 && (ws == nullptr || ws_floats < (size_t)p.nsplit * (g.cls ? 8 : 1) * M * N || ((uintptr_t)ws & 15) != 0)) return -5;
   hipStream_t st = (hipStream_t)stream;
   const int nwg = p.rowTiles * p.colTiles * p.nsplit, per = es_cdiv(nwg, 8);
   const unsigned short* X = (const unsigned short*)Xh;
@@ -535,11 +565,21 @@ extern "C" int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, co
 #define DC_LAUNCH(BM_, TI_)                                                                                                   \
   hipLaunchKernelGGL((k_dconv<BM_, TI_>), dim3(per * 8), dim3(512), 0, st, X, ldx, Wh, Kd, N, M, g, Y, ldy, accumulate, ws, p.nsplit, \
                      p.rowTiles, p.colTiles, per)
-  if (p.bm == 320) { if (ES_OPT_DC_ORDER) DC_LAUNCH(320, true); else DC_LAUNCH(320, false); }
-  else             { if (ES_OPT_DC_ORDER) DC_LAUNCH(256, true); else DC_LAUNCH(256, false); }
+  if (N % 256 != 0) {                            // 128-column tiles (tap-outer order only)
+    if (p.bm == 320) hipLaunchKernelGGL((k_dconv<320, false, 128>), dim3(per * 8), dim3(512), 0, st, X, ldx, Wh, Kd, N, M, g, Y, ldy, accumulate, ws,
+                                        p.nsplit, p.rowTiles, p.colTiles, per);
+    else hipLaunchKernelGGL((k_dconv<256, false, 128>), dim3(per * 8), dim3(512), 0, st, X, ldx, Wh, Kd, N, M, g, Y, ldy, accumulate, ws, p.nsplit,
+                            p.rowTiles, p.colTiles, per);
+  } else if (p.bm == 320) { if (ES_OPT_DC_ORDER) DC_LAUNCH(320, true); else DC_LAUNCH(320, false); }
+  else                    { if (ES_OPT_DC_ORDER) DC_LAUNCH(256, true); else DC_LAUNCH(256, false); }
 #undef DC_LAUNCH
   ES_CHECK_LAUNCH();
-  if (p.nsplit > 1) {
+  if (p.nsplit > 1 && g.cls) {
+    const int gr = es_cdiv((long long)8 * M * (N / 4), 256);
+    hipLaunchKernelGGL(k_dconv_reduce_cls, dim3(gr > 8192 ? 8192 : gr), dim3(256), 0, st, (const float4*)ws, p.nsplit, M, N / 4, g, Y, ldy,
+                       accumulate);
+    ES_CHECK_LAUNCH();
+  } else if (p.nsplit > 1) {
     const size_t tot4 = (size_t)M * (N / 4);
     const int gr = es_cdiv((long long)tot4, 256);
     hipLaunchKernelGGL(k_dconv_reduce, dim3(gr > 8192 ? 8192 : gr), dim3(256), 0, st, (const float4*)ws, p.nsplit, tot4, N / 4, Y, ldy,

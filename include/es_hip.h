@@ -445,8 +445,8 @@ int es_topk_sorted(const float* vals, int B, int L, const int* vlen_dev, int k, 
  * mode 4 its data gradient: Xh = bf16 rows of the output gradient on the fine grid, W_bf16 = the natural [8][Cin][Cout] copy.
  * accumulate 1: Y += result.  Launches that would leave the chip under-filled split their reduction over several workgroups
  * per tile; the partial tiles go through `ws` (es_dconv_workspace_floats; 0 = not needed) and are added in slice order
- * (bit-reproducible).  -4: shape not taken (es_dconv_supported: reduction channels % 64, result channels % 256; weight
- * gradients (modes 2 / 5 of es_dconv_supported): both % 256). */
+ * (bit-reproducible).  -4: shape not taken (es_dconv_supported: reduction channels % 64, result channels % 128 -- 256-column tiles where they
+ * divide, 128-column tiles for the neck's 128-channel out blocks; weight gradients (modes 2 / 5): both % 256). */
 int es_dconv_supported(const int* geom_host, int mode, int Cin, int Cout);
 size_t es_dconv_workspace_floats(const int* geom_host, int mode, int Cin, int Cout);
 int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, const int* geom_host, int mode, int Cin, int Cout, float* Y,

@@ -34,6 +34,7 @@ CASES = [  # B, X, Y, Z, stride, Cin, Cout
     (1, 7, 6, 5, 1, 64, 256),        # 210 rows: one ragged tile, every border case
     (2, 9, 8, 5, 1, 128, 256),       # 720 rows: several tiles, batch boundary inside a tile
     (1, 10, 8, 6, 2, 64, 256),       # stride 2: 5 x 4 x 3 output voxels
+    (1, 9, 7, 5, 1, 64, 128),        # 128 output channels: the 128-column tile (the neck's out blocks)
 ]
 
 
@@ -42,7 +43,7 @@ def test_dense_forward_and_data_gradient(emu, lazy):
     rng = np.random.default_rng(21 + lazy)
     emu.lib.es_emu_set_dma_mode(lazy)
     try:
-        for ci, (B, X, Y, Z, st, cin, cout) in enumerate(CASES if not lazy else CASES[:2]):
+        for ci, (B, X, Y, Z, st, cin, cout) in enumerate(CASES if not lazy else CASES[:2] + CASES[3:]):
             g = _geom(B, X, Y, Z, 3, st, 1)
             assert emu.fns['es_dconv_supported'](P(g), 0, cin, cout) == 1
             x = rng.standard_normal((B * X * Y * Z, cin)).astype(np.float32)
@@ -79,7 +80,7 @@ def test_dense_forward_and_data_gradient(emu, lazy):
             dyb = bf16_round(dy)
             wf = bf16_round(w)[::-1].transpose(0, 2, 1)                  # (K, Cout, Cin), taps mirrored
             want_dx, _ = _conv3d_ref(dyb, wf, B, X, Y, Z, 3, 1, 1)
-            emu('es_dconv_set_option', 20, 0); emu('es_dconv_set_option', 21, 1); emu('es_dconv_set_option', 22, 0)
+            emu('es_dconv_set_option', 20, 0); emu('es_dconv_set_option', 21, 0); emu('es_dconv_set_option', 22, 0)
             nf = int(emu.fns['es_dconv_workspace_floats'](P(g), 1, cin, cout))
             ws = np.zeros(max(nf, 4), np.float32)
             dx = np.full((B * X * Y * Z, cin), np.nan, np.float32)
@@ -90,7 +91,7 @@ def test_dense_forward_and_data_gradient(emu, lazy):
         emu.lib.es_emu_set_dma_mode(0)
         for k in (20, 22):
             emu('es_dconv_set_option', k, 0)
-        emu('es_dconv_set_option', 21, 1)
+        emu('es_dconv_set_option', 21, 0)
 
 
 @pytest.mark.parametrize('lazy', [0, 1])
@@ -216,17 +217,22 @@ def test_dense_strided_data_gradient_and_transposed_convolution(emu, lazy):
                     for kz in range(3):
                         dxp[:, kx:kx + 2 * Xo:2, ky:ky + 2 * Yo:2, kz:kz + 2 * Zo:2] += (dyb @ wb[(kx * 3 + ky) * 3 + kz].T).reshape(B, Xo, Yo, Zo, cin)
             want = dxp[:, 1:1 + X, 1:1 + Y, 1:1 + Z].reshape(-1, cin)
-            for rows in (0, 256, 320):
+            for rows, split in ((0, 0), (256, 1), (320, 1), (0, 2), (256, 3)):      # split > 1: slices of every class, class-major partial rows
                 emu('es_dconv_set_option', 20, rows)
+                emu('es_dconv_set_option', 22, split)
+                nf = int(emu.fns['es_dconv_workspace_floats'](P(g), 1, cin, cout))
+                wsb = np.full(max(nf, 4), np.nan, np.float32)
                 dx = np.full((B * X * Y * Z, cin), np.nan, np.float32)
                 emu.launches()
-                emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx), cin, 0, 0, 0, 0)
-                assert any('k_dconv<' in k for k in emu.launches())
-                assert np.abs(dx - want).max() / np.abs(want).max() < 2e-6, ('strided dgrad', rows)
+                emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx), cin, 0, P(wsb), nf, 0)
+                ran = emu.launches()
+                assert any('k_dconv<' in k for k in ran) and (any('k_dconv_reduce_cls' in k for k in ran) == (nf > 0))
+                assert np.abs(dx - want).max() / np.abs(want).max() < 2e-6, ('strided dgrad', rows, split)
+                dx2 = np.ones((B * X * Y * Z, cin), np.float32)
+                emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx2), cin, 1, P(wsb), nf, 0)
+                assert np.abs(dx2 - 1 - want).max() / np.abs(want).max() < 2e-6, ('strided dgrad, accumulate', rows, split)
             emu('es_dconv_set_option', 20, 0)
-            dx2 = np.ones((B * X * Y * Z, cin), np.float32)
-            emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx2), cin, 1, 0, 0, 0)
-            assert np.abs(dx2 - 1 - want).max() / np.abs(want).max() < 2e-6
+            emu('es_dconv_set_option', 22, 0)
             # ---- transposed convolution (k = 2, s = 2): coarse grid (Xo, Yo, Zo) with ci_t channels -> fine grid with co_t channels
             ci_t, co_t = 256, 256
             gt = _geom(B, Xo, Yo, Zo, 2, 2, 0)
@@ -238,7 +244,9 @@ def test_dense_strided_data_gradient_and_transposed_convolution(emu, lazy):
             xh = bf16_bits(x)
             xb, w8b = bf16_round(x).astype(np.float64), bf16_round(w8).astype(np.float64)
             y = np.full((8 * M, co_t), np.nan, np.float32)
-            emu('es_dconv_fwd_bf16', P(xh), ci_t, P(w8t), P(gt), 3, ci_t, co_t, P(y), co_t, 0, 0, 0, 0)
+            nf3 = int(emu.fns['es_dconv_workspace_floats'](P(gt), 3, ci_t, co_t))
+            ws3 = np.full(max(nf3, 4), np.nan, np.float32)
+            emu('es_dconv_fwd_bf16', P(xh), ci_t, P(w8t), P(gt), 3, ci_t, co_t, P(y), co_t, 0, P(ws3), nf3, 0)
             got = _fine(y, B, Xo, Yo, Zo, co_t)
             for p in range(8):
                 wantp = xb @ w8b[p]
@@ -264,6 +272,7 @@ def test_dense_strided_data_gradient_and_transposed_convolution(emu, lazy):
     finally:
         emu.lib.es_emu_set_dma_mode(0)
         emu('es_dconv_set_option', 20, 0)
+        emu('es_dconv_set_option', 22, 0)
 
 
 def test_engine_dense_transposed_convolution_equals_the_generative_path(emulated, monkeypatch):

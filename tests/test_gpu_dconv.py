@@ -47,7 +47,7 @@ def test_dense_engine_small_volumes_vs_f64():
     opt = hip.raw('es_dconv_set_option')
     try:
         for B, X, Y, Z, st, cin, cout in ((1, 7, 6, 5, 1, 64, 256), (2, 9, 8, 5, 1, 256, 256), (1, 10, 8, 6, 2, 128, 512),
-                                          (1, 12, 11, 9, 1, 256, 512)):
+                                          (1, 12, 11, 9, 1, 256, 512), (2, 11, 9, 6, 1, 192, 128), (1, 40, 40, 16, 1, 768, 128)):
             g = _geom(B, X, Y, Z, 3, st, 1)
             x = torch.randn(B * X * Y * Z, cin, generator=gen).to(dev)
             w = (torch.randn(27, cin, cout, generator=gen) / (27 * cin) ** 0.5).to(dev)
@@ -72,10 +72,10 @@ def test_dense_engine_small_volumes_vs_f64():
             y3 = torch.ones((M, cout), device=dev)
             call('es_dconv_fwd_bf16', P(xh), cin, P(wt), g, 0, cin, cout, P(y3), cout, 1, P(ws), nf, st_)
             assert float((y3.double() - 1 - want).abs().max() / scale) < 2e-6
-            opt(20, 0); opt(21, 1); opt(22, 0)
+            opt(20, 0); opt(21, 0); opt(22, 0)
             dy = torch.randn(M, cout, generator=gen).to(dev)
             dyh = dy.bfloat16().contiguous()
-            if cin % 256 == 0:
+            if cin % 256 == 0 and cout % 256 == 0:
                 # weight gradient: dW[k] = X[src(., k)]^T dY
                 xv = torch.zeros((B, X + 2, Y + 2, Z + 2, cin), dtype=torch.float64, device=dev)
                 xv[:, 1:1 + X, 1:1 + Y, 1:1 + Z] = xb.reshape(B, X, Y, Z, cin)
@@ -96,7 +96,7 @@ def test_dense_engine_small_volumes_vs_f64():
                 call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx), cin, 0, P(ws), nf, st_)
                 assert float((dx.double() - wantx).abs().max() / wantx.abs().max()) < 2e-6, ('dgrad', B, X, Y, Z)
     finally:
-        opt(20, 0); opt(21, 1); opt(22, 0)
+        opt(20, 0); opt(21, 0); opt(22, 0)
 
 
 @pytest.mark.parametrize('X,Y,Z,cin,cout,st', [(40, 40, 16, 768, 768, 1), (40, 40, 16, 768, 1536, 2), (20, 20, 8, 1536, 1536, 1),

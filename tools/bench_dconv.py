@@ -83,7 +83,7 @@ def main():
             ws = torch.empty(max(nf, 4), device=dev)
             line(f'fwd   dense rows={rows} order={order} split={split}',
                  lambda: call('es_dconv_fwd_bf16', P(xh), cin, P(wt), g, 0, cin, cout, P(y), cout, 0, P(ws), nf, st_))
-        opt(20, 0); opt(21, 1); opt(22, 0)
+        opt(20, 0); opt(21, 0); opt(22, 0)
         # ---- data gradient
         nfm = int(hip.raw('es_spconv_split_workspace_floats')(n_in, 27, cout, cin))
         wsm = torch.zeros(max(nfm, 4), device=dev)
