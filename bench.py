@@ -401,28 +401,37 @@ def main():
                             f"of this command (profiles/{name}: {pmc['bytes_per_step'] / 1e9:.1f} GB per step over "
                             f"{pmc['launches'] // pmc['steps']} kernel launches = traffic x traffic_launches_per_step), not re-measured by this run")
             break
-    if eng['t_mfma'] >= eng['t_hbm']:
-        roof = dict(bound='mfma', achieved=eng['tflops'], peak=mfma_peak, unit='TFLOP/s',
-                    frac=round(eng['tflops'] / mfma_peak, 4))
+    # achieved / frac / kernel_ms_per_step come from the STAND-ALONE durations (the extra single-stream step, = what a rocprofv3 kernel
+    # trace of that schedule sums: profiles/r5_single_stream_kernel_stats.txt) when this is a one-GPU run: HIP-event brackets under the
+    # four-stream schedule overlap in time and over-count (round-4 finding: 29.3 ms of "kernel time" in a 25.6 ms step); the concurrent
+    # figures stay in `concurrent_schedule`
+    base = e1 if (world == 1 and single is not None) else eng
+    if base['t_mfma'] >= base['t_hbm']:
+        roof = dict(bound='mfma', achieved=base['tflops'], peak=mfma_peak, unit='TFLOP/s',
+                    frac=round(base['tflops'] / mfma_peak, 4))
     else:
-        roof = dict(bound='hbm', achieved=eng['comp_GBps'], peak=K_PEAK_HBM, unit='GB/s',
-                    frac=round(eng['comp_GBps'] / K_PEAK_HBM, 4))
+        roof = dict(bound='hbm', achieved=base['comp_GBps'], peak=K_PEAK_HBM, unit='GB/s',
+                    frac=round(base['comp_GBps'] / K_PEAK_HBM, 4))
     roofline = dict(roof, traffic=traffic, **traffic_extra,
                     kernel='convolution engine: k_spconv_bf16* / k_rowgemm_bf16 (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
                     else 'convolution engine: k_spconv / k_spconv_wgrad (exact-f32 MFMA)',
-                    launches_per_step=eng['launches'], kernel_ms_per_step=eng['ms'],
-                    frac_of_binding_roof=eng['frac_binding'],
-                    mfma=dict(achieved_tflops=eng['tflops'], peak_tflops=mfma_peak, frac=round(eng['tflops'] / mfma_peak, 4)),
-                    hbm_compulsory=dict(achieved_GBps=eng['comp_GBps'], frac=round(eng['comp_GBps'] / K_PEAK_HBM, 4),
-                                        bytes_per_step=eng['comp_bytes']),
-                    hbm_pair_bytes=dict(achieved_GBps=eng['pair_GBps'], frac=round(eng['pair_GBps'] / K_PEAK_HBM, 4),
-                                        bytes_per_step=eng['pair_bytes']),
+                    launches_per_step=base['launches'], kernel_ms_per_step=base['ms'],
+                    frac_of_binding_roof=base['frac_binding'],
+                    durations='stand-alone (single-stream extra step)' if base is not eng else 'concurrent four-stream schedule',
+                    concurrent_schedule=dict(kernel_ms_per_step=eng['ms'], achieved_GBps=eng['comp_GBps'], tflops=eng['tflops'],
+                                             frac_of_binding_roof=eng['frac_binding']),
+                    mfma=dict(achieved_tflops=base['tflops'], peak_tflops=mfma_peak, frac=round(base['tflops'] / mfma_peak, 4)),
+                    hbm_compulsory=dict(achieved_GBps=base['comp_GBps'], frac=round(base['comp_GBps'] / K_PEAK_HBM, 4),
+                                        bytes_per_step=base['comp_bytes']),
+                    hbm_pair_bytes=dict(achieved_GBps=base['pair_GBps'], frac=round(base['pair_GBps'] / K_PEAK_HBM, 4),
+                                        bytes_per_step=base['pair_bytes']),
                     single_stream=single, classes=classes,
                     note='per launch: algorithmic flops = 2*P*Cin*Cout (P = valid (output,tap) pairs), compulsory bytes = '
                          'every input row, output row and weight once, pair bytes = SURVEY 8(d) P*(Cin+Cout)*4 + weights; '
                          'binding roof per launch = max(flops/MFMA peak, compulsory bytes/HBM peak); frac_of_binding_roof = '
                          'sum of binding-roof times / sum of HIP-event launch durations; bound/achieved/peak/frac = the '
-                         'roof that binds the family in total; durations are HIP-event times on the launch stream under the '
+                         'roof that binds the family in total; durations (see `durations`) are HIP-event times on the launch stream: stand-alone = '
+                         'one extra single-stream step (round 5: the headline figures); under the '
                          'concurrent 4-stream schedule (kernels of different streams share the chip, so the sum exceeds wall '
                          'time), taken on ONE EXTRA untimed step right after the timed ones -- per-launch events cost ~3 ms of '
                          'host time and keep the image backbone off its hipGraph, so the timed steps carry no instrumentation; classes = the top engine launch classes of the single-stream step (stand-alone durations); '
