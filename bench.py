@@ -214,6 +214,9 @@ def main():
     from embodiedscan_amd import engine as E, hip, pipeline
     from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
     from embodiedscan_amd.synth import make_scan
+    # dev experiment (round 5, profiles/r5n_*): the step's streams land on the 4 hardware queues in creation order; ES_STREAM_SKEW=k
+    # creates k idle streams first and so rotates that assignment
+    _skew = [torch.cuda.Stream() for _ in range(int(os.environ.get('ES_STREAM_SKEW', '0')))]
 
     if args.only:
         assert world == 1

@@ -191,16 +191,17 @@ def test_parity_class_launches_small_volumes_vs_f64():
                     for kz in range(3):
                         dxp[:, kx:kx + 2 * Xo:2, ky:ky + 2 * Yo:2, kz:kz + 2 * Zo:2] += (dyb @ wb[(kx * 3 + ky) * 3 + kz].T).reshape(B, Xo, Yo, Zo, cin)
             want = dxp[:, 1:1 + X, 1:1 + Y, 1:1 + Z].reshape(-1, cin)
-            for rows in (0, 256, 320):
-                opt(20, rows)
+            for rows, split in ((0, 0), (256, 1), (320, 1), (0, 2), (320, 5)):      # split > 1: slices of every class through the workspace
+                opt(20, rows); opt(22, split)
+                ws, nf = _ws(hip, g, 1, cin, cout, dev)
                 dx = torch.full((B * X * Y * Z, cin), float('nan'), device=dev)
-                call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx), cin, 0, 0, 0, st_)
+                call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx), cin, 0, P(ws), nf, st_)
                 err = float((dx.double() - want).abs().max() / want.abs().max())
-                assert err < 2e-6, ('strided dgrad', B, Xo, Yo, Zo, rows, err)
-            opt(20, 0)
-            dx2 = torch.ones((B * X * Y * Z, cin), device=dev)
-            call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx2), cin, 1, 0, 0, st_)
-            assert float((dx2.double() - 1 - want).abs().max() / want.abs().max()) < 2e-6
+                assert err < 2e-6, ('strided dgrad', B, Xo, Yo, Zo, rows, split, err)
+                dx2 = torch.ones((B * X * Y * Z, cin), device=dev)
+                call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx2), cin, 1, P(ws), nf, st_)
+                assert float((dx2.double() - 1 - want).abs().max() / want.abs().max()) < 2e-6
+            opt(20, 0); opt(22, 0)
             # transposed convolution on the coarse grid (Xo, Yo, Zo)
             ci_t, co_t = 256, 256
             gt = _geom(B, Xo, Yo, Zo, 2, 2, 0)
@@ -211,7 +212,8 @@ def test_parity_class_launches_small_volumes_vs_f64():
             w8n = torch.empty((8, ci_t, co_t), dtype=torch.bfloat16, device=dev)
             call('es_cast_weight_bf16', P(w8), 8, ci_t, co_t, P(w8n), P(w8t), st_)
             y = torch.full((8 * M, co_t), float('nan'), device=dev)
-            call('es_dconv_fwd_bf16', P(xh), ci_t, P(w8t), gt, 3, ci_t, co_t, P(y), co_t, 0, 0, 0, st_)
+            ws, nf = _ws(hip, gt, 3, ci_t, co_t, dev)
+            call('es_dconv_fwd_bf16', P(xh), ci_t, P(w8t), gt, 3, ci_t, co_t, P(y), co_t, 0, P(ws), nf, st_)
             got = _classes(y.double(), B, Xo, Yo, Zo, co_t)
             wantf = torch.stack([xh.double() @ w8n[p].double() for p in range(8)])
             assert float((got - wantf).abs().max() / wantf.abs().max()) < 2e-6, 'transposed fwd'
@@ -227,7 +229,7 @@ def test_parity_class_launches_small_volumes_vs_f64():
             call('es_dconv_wgrad_bf16', P(xh), ci_t, P(dyf), co_t, gt, 1, ci_t, co_t, P(dw), 0, st_)
             assert float((dw.double() - wantw).abs().max() / wantw.abs().max()) < 2e-6, 'transposed wgrad'
     finally:
-        opt(20, 0)
+        opt(20, 0); opt(22, 0)
 
 
 @pytest.mark.parametrize('X,Y,Z,cin,cout', [(40, 40, 16, 768, 1536), (20, 20, 8, 1536, 3072)])
@@ -247,7 +249,8 @@ def test_strided_data_gradient_neck_shapes_vs_map_kernel(X, Y, Z, cin, cout):
     call('es_cast_weight_bf16', P(w), 27, cin, cout, P(wn), P(wt), st_)
     dyh = torch.randn(n_out, cout, generator=gen).to(dev).bfloat16().contiguous()
     dx = torch.empty(n_in, cin, device=dev)
-    call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx), cin, 0, 0, 0, st_)
+    ws, nf = _ws(hip, g, 1, cin, cout, dev)
+    call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx), cin, 0, P(ws), nf, st_)
     nfm = int(hip.raw('es_spconv_split_workspace_floats')(n_in, 27, cout, cin))
     wsm = torch.zeros(max(nfm, 4), device=dev)
     dx0 = torch.empty(n_in, cin, device=dev)
