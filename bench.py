@@ -214,9 +214,6 @@ def main():
     from embodiedscan_amd import engine as E, hip, pipeline
     from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
     from embodiedscan_amd.synth import make_scan
-    # dev experiment (round 5, profiles/r5n_*): the step's streams land on the 4 hardware queues in creation order; ES_STREAM_SKEW=k
-    # creates k idle streams first and so rotates that assignment
-    _skew = [torch.cuda.Stream() for _ in range(int(os.environ.get('ES_STREAM_SKEW', '0')))]
 
     if args.only:
         assert world == 1
@@ -716,8 +713,16 @@ def run_other_config(kind, args, dev):
     stages['_note'] = 'single-stream schedule (ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0): HIP-event time between stage boundaries, MEDIAN of 3 untimed ' \
                       'steps after one warm-up step on that schedule'
     e1 = engine_totals([r for r in r1 if r[0] in ENGINE], peak)
+    if os.environ.get('ES_BENCH_DUMP'):                         # dev: every engine launch of the single-stream step, in order
+        with open(os.environ['ES_BENCH_DUMP'], 'w') as f:
+            for name, ev0, ev1, a, _ in r1:
+                if name in ENGINE:
+                    nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
+                    f.write(json.dumps(dict(fn=name, K=K, cin=cin, cout=cout, n_out=n_out, n_in=n_in, map=bool(nbr),
+                                            us=round(ev0.elapsed_time(ev1) * 1e3, 1),
+                                            args=[x for x in a if isinstance(x, int) and abs(x) < (1 << 31)])) + '\n')
 
-    traffic, tnote = None, 'traffic: null (no PMC summary committed for this configuration)'
+    traffic, traffic_dense, tnote = None, None, 'traffic: null (no PMC summary committed for this configuration)'
     for tag in ('r5', 'r4', 'r3'):
         pmc_file = os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic_{kind}.json')
         if args.precision == 'bf16' and os.path.exists(pmc_file):
@@ -725,6 +730,11 @@ def run_other_config(kind, args, dev):
             traffic = pmc['bytes_per_launch']
             tnote = (f"traffic is STATIC: HBM bytes per launch of the named family from the committed PMC passes of `bench.py --only {kind}` "
                      f"(profiles/{tag}_pmc_traffic_{kind}.json: {pmc['launches'] // pmc['steps']} launches per step), not re-measured by this run")
+            if 'dense' in pmc:                  # occupancy: the dense-volume kernels alone (k_dconv*: the neck)
+                traffic_dense = pmc['dense']['bytes_per_launch']
+                tnote = (f"traffic is STATIC: HBM bytes per k_dconv* kernel launch (slice reductions are launches of their own) from the "
+                         f"committed PMC passes of `bench.py --only {kind}` (profiles/{tag}_pmc_traffic_{kind}.json: "
+                         f"{pmc['dense']['launches'] // pmc['steps']} such launches per step), not re-measured by this run")
             break
     if kind == 'grounding':
         klen = det.last_queries['klen'].cpu().tolist()
@@ -743,13 +753,26 @@ def run_other_config(kind, args, dev):
         extra = dict(point_tokens=klen, text_tokens=tl,
                      hungarian_ms=round(sum(e0.elapsed_time(e1_) for n, e0, e1_, a, _ in r1 if n == 'es_ground_match'), 3))
     else:
-        neck = [r for r in r1 if max(engine_args(r[0], r[3])[4:6]) >= 768]
-        nk = engine_totals(neck, peak)
-        neck_c = engine_totals([r for r in recs if r[0] in ENGINE and max(engine_args(r[0], r[3])[4:6]) >= 768], peak)
+        # the neck's launches: IndoorImVoxelNeck runs 768 / 1536 / 3072 channels (out blocks: -> 128), so one side is a multiple of 768.
+        # Rounds 4 and 5a..m filtered on ">= 768 channels on a side", which also caught the image backbone's 1024- / 2048-channel
+        # 1x1 launches (~2.7 ms of ~35 us row GEMMs per step, profiles/r5o_occ_launches.jsonl); that family is kept beside it.
+        is_neck = lambda r: any(c % 768 == 0 for c in engine_args(r[0], r[3])[4:6])
+        ge768 = lambda r: max(engine_args(r[0], r[3])[4:6]) >= 768
+        nk = engine_totals([r for r in r1 if r[0] in ENGINE and is_neck(r)], peak)
+        neck_c = engine_totals([r for r in recs if r[0] in ENGINE and is_neck(r)], peak)
+        old = engine_totals([r for r in r1 if r[0] in ENGINE and ge768(r)], peak)
+        if traffic_dense is not None:
+            traffic = traffic_dense
         roofline = dict(bound='mfma', achieved=nk['tflops'], peak=peak, unit='TFLOP/s', frac=round(nk['tflops'] / peak, 4),
-                        traffic=traffic, kernel='convolution engine on the dense 3-D neck (launches with >= 768 channels on a side)',
+                        traffic=traffic,
+                        kernel='convolution engine on the dense 3-D neck (IndoorImVoxelNeck: every engine launch with 768 / 1536 / 3072 '
+                               'channels on a side)',
                         launches_per_step=nk['launches'], kernel_ms_per_step=nk['ms'], frac_of_binding_roof=nk['frac_binding'],
                         concurrent_schedule=dict(kernel_ms_per_step=neck_c['ms'], tflops=neck_c['tflops']),
+                        family_ge768=dict(launches_per_step=old['launches'], kernel_ms_per_step=old['ms'], tflops=old['tflops'],
+                                          frac=round(old['tflops'] / peak, 4),
+                                          note='the filter of rounds 4 / 5a..m (>= 768 channels on a side): the neck PLUS the image '
+                                               "backbone's 1024- / 2048-channel 1x1 launches; comparable with VERDICT r4's 0.129"),
                         note='algorithmic flops = 2*P*Cin*Cout per launch (P = valid (output, tap) pairs of the dense 3x3x3 maps); '
                              'durations = HIP events on the launch stream, stand-alone (single-stream step); ' + tnote)
         extra = {}

@@ -403,8 +403,9 @@ static unsigned dc_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(
 // coarse grid).  Modes:
 //   0  convolution forward            rows = output voxels, sources = input voxels * stride - pad + k
 //   1  convolution data gradient      stride 1: rows = input voxels, sources = output voxels + pad - k;
-//                                     stride 2 (k = 3, pad = 1, even input sizes): rows = (parity class, output-grid voxel), written to the
-//                                     input voxel 2 r + p, class p only through the taps with p + pad - k even (source r + (p + pad - k) / 2)
+//                                     stride 2 (k = 3, pad = 1 or the 1x1x1 down-sample k = 1, pad = 0; even input sizes): rows = (parity
+//                                     class, output-grid voxel), written to the input voxel 2 r + p, class p only through the taps with
+//                                     p + pad - k even (source r + (p + pad - k) / 2); k = 1: class 0 alone has a tap, the others write zeros
 //   2  convolution weight gradient    rows = output voxels; X gathered as in mode 0, dY direct
 //   3  transposed convolution (k = 2, s = 2, pad = 0) forward: rows = (class p, input voxel r), written to 2 r + p, one tap (p) per class
 //   4  ... its data gradient          rows = input voxels, sources = output voxels 2 r + p, 8 taps
@@ -419,7 +420,7 @@ static int dc_geometry(const int* gh, int mode, DcGeom& g, int& M, int& n_src) {
   if (Xo <= 0 || Yo <= 0 || Zo <= 0) return -2;
   const bool strided_dgrad = mode == 1 && st != 1;
   if (mode == 1 && st == 1 && ks != 2 * pad + 1) return -4;
-  if (strided_dgrad && (st != 2 || ks != 3 || pad != 1 || X != 2 * Xo || Y != 2 * Yo || Z != 2 * Zo)) return -4;
+  if (strided_dgrad && (st != 2 || !((ks == 3 && pad == 1) || (ks == 1 && pad == 0)) || X != 2 * Xo || Y != 2 * Yo || Z != 2 * Zo)) return -4;
   const int bigX = X > Xo ? X : Xo, bigY = Y > Yo ? Y : Yo, bigZ = Z > Zo ? Z : Zo;
   if ((long long)bigX * st >= 2048 || (long long)bigY * st >= 2048 || (long long)bigZ * st >= 512)
     return -4;                                                           // (11 / 11 / 9 bits of the packed row coordinates)

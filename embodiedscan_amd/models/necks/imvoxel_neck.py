@@ -125,9 +125,11 @@ class IndoorImVoxelNeck:
             dims = tuple((d + 2 - 3) // st + 1 for d in (g.X, g.Y, g.Z))
             o = self._conv3(x, blk['conv1'], g, stride=st)
             g_out = self._grid(B, dims, x.d.device)
-            dn, di, n_d, ddims = g.conv_map(1, blk['stride'], 0)
-            assert ddims == dims
-            idt = blk['down'][1](E.conv(x, blk['down'][0], dn, di, n_d), act=0, training=tr)
+            # 1x1x1 stride-2 down-sample of the identity: dense engine (one tap; its data gradient touches class 0 of the parity
+            # classes only), the strided maps where a launch falls back
+            idt = E.conv(x, blk['down'][0], None, None, B * dims[0] * dims[1] * dims[2], dense=(g.B, g.X, g.Y, g.Z, 1, st, 0),
+                         maps=lambda g=g, st=st: g.conv_map(1, st, 0)[:2])
+            idt = blk['down'][1](idt, act=0, training=tr)
         o = blk['norm1'](o, act=1, training=tr)
         o = self._conv3(o, blk['conv2'], g_out)
         return blk['norm2'](o, act=1, res=idt, training=tr), g_out          # relu(bn(conv2) + identity)

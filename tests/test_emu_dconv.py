@@ -275,6 +275,52 @@ def test_dense_strided_data_gradient_and_transposed_convolution(emu, lazy):
         emu('es_dconv_set_option', 22, 0)
 
 
+def test_dense_pointwise_stride2_downsample(emu):
+    """the neck's identity down-sample nn.Conv3d(k=1, s=2, p=0): forward (one tap, source 2 r), data gradient (parity classes:
+    class 0 alone has a tap, the other seven write zeros -- or leave an accumulated gradient alone) and weight gradient"""
+    rng = np.random.default_rng(77)
+    for B, Xo, Yo, Zo, cin, cout in ((1, 5, 4, 3, 256, 256), (2, 3, 3, 2, 256, 512)):
+        X, Y, Z = 2 * Xo, 2 * Yo, 2 * Zo
+        g = _geom(B, X, Y, Z, 1, 2, 0)
+        for mode in (0, 1, 2):
+            assert emu.fns['es_dconv_supported'](P(g), mode, cin, cout) == 1, mode
+        n_in, M = B * X * Y * Z, B * Xo * Yo * Zo
+        x = rng.standard_normal((n_in, cin)).astype(np.float32)
+        w = (rng.standard_normal((1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        wt, wn = np.zeros((1, cout, cin), np.uint16), np.zeros((1, cin, cout), np.uint16)
+        emu('es_cast_weight_bf16', P(w), 1, cin, cout, P(wn), P(wt), 0)
+        xh = bf16_bits(x)
+        xb, wb = bf16_round(x).astype(np.float64), bf16_round(w).astype(np.float64)[0]
+        xs = xb.reshape(B, X, Y, Z, cin)[:, ::2, ::2, ::2].reshape(M, cin)              # the sampled voxels
+        # forward
+        nf = int(emu.fns['es_dconv_workspace_floats'](P(g), 0, cin, cout))
+        wsb = np.full(max(nf, 4), np.nan, np.float32)
+        y = np.full((M, cout), np.nan, np.float32)
+        emu('es_dconv_fwd_bf16', P(xh), cin, P(wt), P(g), 0, cin, cout, P(y), cout, 0, P(wsb), nf, 0)
+        want = xs @ wb
+        assert np.abs(y - want).max() / np.abs(want).max() < 2e-6
+        # data gradient: dX[2 r] = dY[r] W^T, every other voxel 0
+        dy = rng.standard_normal((M, cout)).astype(np.float32)
+        dyh = bf16_bits(dy)
+        dyb = bf16_round(dy).astype(np.float64)
+        wantx = np.zeros((B, X, Y, Z, cin))
+        wantx[:, ::2, ::2, ::2] = (dyb @ wb.T).reshape(B, Xo, Yo, Zo, cin)
+        wantx = wantx.reshape(n_in, cin)
+        nf = int(emu.fns['es_dconv_workspace_floats'](P(g), 1, cin, cout))
+        wsb = np.full(max(nf, 4), np.nan, np.float32)
+        dx = np.full((n_in, cin), np.nan, np.float32)
+        emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx), cin, 0, P(wsb), nf, 0)
+        assert np.abs(dx - wantx).max() / np.abs(wantx).max() < 2e-6
+        dx2 = np.ones((n_in, cin), np.float32)
+        emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx2), cin, 1, P(wsb), nf, 0)
+        assert np.abs(dx2 - 1 - wantx).max() / np.abs(wantx).max() < 2e-6
+        # weight gradient
+        dw = np.full((1, cin, cout), np.nan, np.float32)
+        emu('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, P(g), 0, cin, cout, P(dw), 0, 0)
+        wantw = xs.T @ dyb
+        assert np.abs(dw[0] - wantw).max() / np.abs(wantw).max() < 2e-6
+
+
 def test_engine_dense_transposed_convolution_equals_the_generative_path(emulated, monkeypatch):
     """engine.conv_transpose_dense (parity-class launch, dense row order) against gather_rows(gen_conv_transpose(...), up_index) --
     the path it replaces in IndoorImVoxelNeck -- forward, data gradient and the 8 weight-gradient taps, through the tape"""

@@ -260,3 +260,44 @@ def test_strided_data_gradient_neck_shapes_vs_map_kernel(X, Y, Z, cin, cout):
         call('es_spconv_fwd_bf16', P(dyh), 1, cout, P(wn), P(inv), n_in, n_out, 27, cout, cin, 0, P(dx0), cin, 0, st_)
     err = float((dx - dx0).abs().max() / dx0.abs().max())
     assert err < 2e-5, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('X,Y,Z,cin,cout', [(40, 40, 16, 768, 1536), (20, 20, 8, 1536, 3072)])
+def test_pointwise_stride2_downsample_neck_shapes_vs_f32(X, Y, Z, cin, cout):
+    """the neck's identity down-sample nn.Conv3d(k=1, s=2): forward, data gradient (parity classes, class 0 alone has a tap) and
+    weight gradient of the dense engine against f32 matrix products on the bf16-rounded operands.  Tolerance 2e-5 of the largest
+    magnitude (f32 accumulation order only)."""
+    from embodiedscan_amd import hip
+    from embodiedscan_amd.hip import call, P
+    dev = torch.device('cuda:0')
+    st_ = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(23)
+    g = _geom(1, X, Y, Z, 1, 2, 0)
+    for mode in (0, 1, 2):
+        assert hip.raw('es_dconv_supported')(g, mode, cin, cout) == 1
+    n_in, M = X * Y * Z, (X // 2) * (Y // 2) * (Z // 2)
+    x = torch.randn(n_in, cin, generator=gen).to(dev)
+    w = (torch.randn(1, cin, cout, generator=gen) / cin ** 0.5).to(dev)
+    wt = torch.empty((1, cout, cin), dtype=torch.bfloat16, device=dev)
+    wn = torch.empty((1, cin, cout), dtype=torch.bfloat16, device=dev)
+    call('es_cast_weight_bf16', P(w), 1, cin, cout, P(wn), P(wt), st_)
+    xh = x.bfloat16().contiguous()
+    xs = xh.float().view(X, Y, Z, cin)[::2, ::2, ::2].reshape(M, cin)
+    wb = wn.float()[0]
+    y = torch.empty(M, cout, device=dev)
+    ws, nf = _ws(hip, g, 0, cin, cout, dev)
+    call('es_dconv_fwd_bf16', P(xh), cin, P(wt), g, 0, cin, cout, P(y), cout, 0, P(ws), nf, st_)
+    want = xs @ wb
+    assert float((y - want).abs().max() / want.abs().max()) < 2e-5
+    dyh = torch.randn(M, cout, generator=gen).to(dev).bfloat16().contiguous()
+    dx = torch.full((n_in, cin), float('nan'), device=dev)
+    ws, nf = _ws(hip, g, 1, cin, cout, dev)
+    call('es_dconv_fwd_bf16', P(dyh), cout, P(wn), g, 1, cin, cout, P(dx), cin, 0, P(ws), nf, st_)
+    wantx = torch.zeros(X, Y, Z, cin, device=dev)
+    wantx[::2, ::2, ::2] = (dyh.float() @ wb.t()).view(X // 2, Y // 2, Z // 2, cin)
+    assert float((dx - wantx.view(n_in, cin)).abs().max() / wantx.abs().max()) < 2e-5
+    dw = torch.empty(1, cin, cout, device=dev)
+    call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, 0, cin, cout, P(dw), 0, st_)
+    wantw = xs.t() @ dyh.float()
+    assert float((dw[0] - wantw).abs().max() / wantw.abs().max()) < 2e-5

@@ -50,6 +50,11 @@ def main():
                       'the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE (KB) as reported',
                config=a.config, family=sorted(fam), steps=a.steps, launches=launches, fetch_bytes=fetch, write_bytes=write,
                bytes_per_step=int((fetch + write) / a.steps), bytes_per_launch=int((fetch + write) / max(launches, 1)))
+    if a.config == 'occupancy':                  # the dense-volume kernels alone: the neck (bench.py's roofline family)
+        dn = pick(('k_dconv',))
+        db = sum(f[k]['FETCH_SIZE'] for k in dn) * 1024 * 2 + sum(w[k]['WRITE_SIZE'] for k in dn if k in w) * 1024
+        dl = int(sum(f[k]['calls'] for k in dn))
+        out['dense'] = dict(kernels=sorted(dn), launches=dl, bytes_per_step=int(db / a.steps), bytes_per_launch=int(db / max(dl, 1)))
     if a.config == 'mv3ddet':
         sc = pick(SCATTER)
         sb = sum(f[k]['FETCH_SIZE'] for k in sc) * 1024 * 2 + sum(w[k]['WRITE_SIZE'] for k in sc if k in w) * 1024
