@@ -488,7 +488,7 @@ extern "C" int es_dconv_set_option(int key, int value) {
 }
 
 struct DcPlan { int bm, rowTiles, colTiles, nsplit; };
-static DcPlan dc_plan(int M, int N, int nIt, int cls = 0) {
+static DcPlan dc_plan(int M, int N, int nIt, int cls = 0, int nT = 27) {
   const int bn = (N % 256 == 0) ? 256 : 128;     // column tile
   if (cls) {                                     // parity classes: 8 x tiles-per-class row tiles, no slices (the classes ARE the split)
     int bm = (ES_OPT_DC_ROWS == 256 || ES_OPT_DC_ROWS == 320) ? ES_OPT_DC_ROWS
@@ -497,7 +497,7 @@ static DcPlan dc_plan(int M, int N, int nIt, int cls = 0) {
     // the 8-tap class walking 384 steps); partial rows class-major through the workspace, k_dconv_reduce_cls scatters them
     const int wgs = 8 * es_cdiv(M, bm) * (N / bn);
     int s = ES_OPT_DC_SPLIT ? ES_OPT_DC_SPLIT : (wgs < 200 ? (es_cdiv(384, wgs) < 8 ? es_cdiv(384, wgs) : 8) : 1);
-    if (s > nIt / 27) s = nIt / 27 > 0 ? nIt / 27 : 1;              // (a one-tap class keeps >= one chunk per slice)
+    if (s > nIt / nT) s = nIt / nT > 0 ? nIt / nT : 1;              // (a one-tap class keeps >= one channel chunk per slice)
     return DcPlan{bm, 8 * es_cdiv(M, bm), N / bn, s};
   }
   DcPlan best{256, es_cdiv(M, 256), N / bn, 1};
@@ -539,7 +539,7 @@ extern "C" size_t es_dconv_workspace_floats(const int* geom_host, int mode, int 
   int Kd, N;
   dc_roles(mode, Cin, Cout, Kd, N);
   if (Kd % 64 != 0 || N % 128 != 0) return 0;
-  const DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT, g.cls);
+  const DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT, g.cls, g.nT);
   return p.nsplit > 1 ? (size_t)p.nsplit * (g.cls ? 8 : 1) * M * N : 0;
 }
 
@@ -557,7 +557,7 @@ extern "C" int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, co
   if (Kd % 64 != 0 || N % 128 != 0 || (ldx & 7) != 0 || (ldy & 3) != 0 || ((uintptr_t)Xh & 15) != 0 || ((uintptr_t)W_bf16 & 15) != 0 ||
       ((uintptr_t)Y & 15) != 0 || (long long)ns * ldx >= (1ll << 31) || (long long)(nTw > 27 ? nTw : 27) * N * Kd >= (1ll << 31))
     return -4;
-  DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT, g.cls);
+  DcPlan p = dc_plan(M, N, (Kd / 64) * g.nT, g.cls, g.nT);
   if (p.nsplit > 1 && (ws == nullptr || ws_floats < (size_t)p.nsplit * (g.cls ? 8 : 1) * M * N || ((uintptr_t)ws & 15) != 0)) return -5;
   hipStream_t st = (hipStream_t)stream;
   const int nwg = p.rowTiles * p.colTiles * p.nsplit, per = es_cdiv(nwg, 8);

@@ -526,8 +526,13 @@ def _dense_geom(dense):
 
 
 def dense_ok(dense, mode, cin, cout):
-    return bool(DENSE[0] and dense is not None and PRECISION[0] == 'bf16' and
-                hip.raw('es_dconv_supported')(_dense_geom(dense), mode, cin, cout) == 1)
+    if not (DENSE[0] and dense is not None and PRECISION[0] == 'bf16'):
+        return False
+    if mode == 2 and dense[4] == 1 and (cin // 256) * (cout // 256) < 48:
+        # weight gradient of a 1x1x1 convolution: one workgroup per 256 x 256 channel tile walking every row -- the neck's 768 -> 1536
+        # down-sample would launch 18 of them (134 us against the map kernel's row-split 49 us, profiles/r5p_occ_launches.jsonl)
+        return False
+    return hip.raw('es_dconv_supported')(_dense_geom(dense), mode, cin, cout) == 1
 
 
 def _dense_launch(Xh, ldx, Wp, dense, mode, cin, cout, Y, ldy, acc, like):

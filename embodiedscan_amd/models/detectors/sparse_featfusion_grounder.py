@@ -3,7 +3,6 @@ kernels.  Same registry name, constructor arguments and forward(inputs, data_sam
 
 extract_feat is the mv-3ddet feature path (2-D / 3-D backbones + projection fusion, inherited) followed by MinkNeck;
 pre_decoder / forward_decoder / the head run on padded channels-last token matrices.  Text: see embodiedscan_amd/text.py."""
-import os
 import torch
 from ... import engine as E
 from ... import hip
@@ -13,8 +12,6 @@ from ...registry import MODELS
 from ...text import HashTokenizer, build_text_encoder, create_positive_map
 from ..layers.ground_transformer.decoder import SparseFeatureFusionTransformerDecoder, _Lin
 from .sparse_featfusion_single_stage import SparseFeatureFusionSingleStage3DDetector
-
-TEXT_EARLY = [os.environ.get('ES_TEXT_EARLY', '1') != '0']
 
 
 @MODELS.register_module()
@@ -115,9 +112,9 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         return self
 
     # ------------------------------------------------------------------ text
-    def _text_hidden(self, batch_data_samples):
-        """tokenise + positive maps + the frozen RoBERTa forward (:475-490): nothing here depends on the scans, so it can be queued
-        any time before the text map"""
+    def encode_text(self, batch_data_samples):
+        """:475-498: tokenise, positive maps, frozen RoBERTa, text_feat_map.  Returns (text Var (B*T, E), mask (B,T) bool
+        on the device, tlen (B,) int32 on the device, T) and attaches positive_maps / text_token_mask to the samples."""
         texts = [ds.text for ds in batch_data_samples]
         tok = self.tokenizer.batch_encode_plus(texts, padding='longest', return_tensors='pt')
         if all(getattr(ds, 'tokens_positive', None) is not None for ds in batch_data_samples):
@@ -128,24 +125,6 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         tok = tok.to(self.device)
         with torch.no_grad():
             hs = self.text_encoder(input_ids=tok.input_ids, attention_mask=tok.attention_mask).last_hidden_state
-        return tok, pmaps, hs
-
-    def _early_work(self, batch_data_samples):
-        """called by extract_feat once the image backbone is queued on the side stream: the text encoder's ~300 small launches
-        (4.5 ms alone, latency-bound) go onto the MAIN stream here, under the image backbone's kernels, instead of between the neck
-        and the decoder where nothing else runs (ES_TEXT_EARLY=0: the reference's order)"""
-        self._text_early = None
-        if TEXT_EARLY[0] and E.TWO_STREAMS[0] and batch_data_samples and all(hasattr(ds, 'text') for ds in batch_data_samples):
-            self._text_early = (batch_data_samples, self._text_hidden(batch_data_samples))
-
-    def encode_text(self, batch_data_samples):
-        """:475-498: tokenise, positive maps, frozen RoBERTa, text_feat_map.  Returns (text Var (B*T, E), mask (B,T) bool
-        on the device, tlen (B,) int32 on the device, T) and attaches positive_maps / text_token_mask to the samples."""
-        early, self._text_early = getattr(self, '_text_early', None), None
-        if early is not None and early[0] is batch_data_samples:
-            tok, pmaps, hs = early[1]
-        else:
-            tok, pmaps, hs = self._text_hidden(batch_data_samples)
         B, T = tok.input_ids.shape
         mask = tok.attention_mask.bool()
         for i, ds in enumerate(batch_data_samples):

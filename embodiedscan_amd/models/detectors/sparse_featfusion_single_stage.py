@@ -212,7 +212,6 @@ class SparseFeatureFusionSingleStage3DDetector:
         # behind the 3-D backbone, where the main stream had run dry: a 0.84 ms hole in every step (profiles/r5i_critical_chain.txt)
         metas = [ds.metainfo for ds in batch_data_samples]
         meta_dev = build_fusion_meta(metas, self.coord_type, (H, W), V).pin_memory().to(self.device, non_blocking=True)
-        self._early_work(batch_data_samples)
         pf = self._pf_cur
         if pf is not None and batch_inputs_dict is pf['pre']['inputs']:
             pts, cs, src = pf['pts'], pf['cs'], pf['src']      # voxelised (and mapped) under the previous step's backward
@@ -262,10 +261,6 @@ class SparseFeatureFusionSingleStage3DDetector:
             outs.append(SparseTensor(xl.cs, y))
         E.mark('A8+A9 projection fusion')
         return outs
-
-    def _early_work(self, batch_data_samples):
-        """hook: work of a derived detector that depends on the samples only (the grounder's frozen text encoder), queued on the
-        main stream while the image backbone occupies the side stream"""
 
     # ------------------------------------------------------------------ reference protocol
     def loss(self, batch_inputs_dict, batch_data_samples, **kwargs):

@@ -438,8 +438,9 @@ int es_topk_sorted(const float* vals, int B, int L, const int* vlen_dev, int k, 
  * geom_host: 7 host ints {B, X, Y, Z, ksize, stride, pad} of the operator's INPUT grid; rows of a grid are ((b*X + x)*Y + y)*Z + z.
  * mode 0 nn.Conv3d forward: Xh (B*X*Y*Z x ldx) bf16 rows, W_bf16 = the [K][Cout][Cin] copy, Y (B*Xo*Yo*Zo x ldy) f32.
  * mode 1 its data gradient: Xh = bf16 rows of the output gradient, W_bf16 = the natural [K][Cin][Cout] copy, Y = the input
- *   gradient (B*X*Y*Z x ldy); stride 1, or stride 2 with k = 3 / pad = 1 / even sizes (by parity classes of the input voxels:
- *   no zero tap is multiplied).
+ *   gradient (B*X*Y*Z x ldy); stride 1, or stride 2 with even sizes and k = 3 / pad = 1 or k = 1 / pad = 0 (the ResModule's 1x1x1
+ *   down-sample, imvoxel_neck.py:126-129) by parity classes of the input voxels: no zero tap is multiplied; with k = 1 only class
+ *   0 has a tap, the other seven classes write zeros (or leave an accumulated gradient alone).
  * mode 3 nn.ConvTranspose3d(k = 2, s = 2) forward (imvoxel_neck.py:98-106 _make_up_block): Xh = input rows on the coarse grid,
  *   W_bf16 = the [8][Cout][Cin] copy, Y = the (B*2X*2Y*2Z x ldy) output rows in dense order (no permutation pass);
  * mode 4 its data gradient: Xh = bf16 rows of the output gradient on the fine grid, W_bf16 = the natural [8][Cin][Cout] copy.
