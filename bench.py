@@ -468,6 +468,7 @@ def main():
                                                     'gradient part (0 = 2-D backbone, 1 = 3-D backbone, 2 = head; launched from tape markers '
                                                     'in backward-completion order 2, 1, 0; the clip norm is taken per bucket behind its all-reduce)')
     out['hipgraph'] = dict(E.GRAPH_STATS, what='image-backbone forward sequences (engine.graphed): captured / replayed / run eagerly')
+    out['optimizer_pass'] = OPT_PASS.get(optim.last_path, optim.last_path)
     # GPU-side duration of each timed step (events on the main stream)
     out['step_ms'] = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(args.steps)]
     if world == 1 and not args.no_cpu_baseline:
@@ -784,7 +785,7 @@ def run_other_config(kind, args, dev):
                engine_all=dict(launches_per_step=eng['launches'], kernel_ms_per_step=eng['ms'], tflops=eng['tflops'],
                                frac_of_binding_roof=eng['frac_binding'], compulsory_GBps=eng['comp_GBps'],
                                single_stream=dict(kernel_ms_per_step=e1['ms'], tflops=e1['tflops'], frac_of_binding_roof=e1['frac_binding'])),
-               classes=launch_classes(r1, peak, top=16), stage_ms=stages,
+               classes=launch_classes(r1, peak, top=16), stage_ms=stages, optimizer_pass=OPT_PASS.get(optim.last_path, optim.last_path),
                step_ms=[round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(steps)], **extra)
     if diag is not None:
         import gc
@@ -819,6 +820,10 @@ def attention_totals(records, klen, tl, Lmax):
     one = lambda d: dict(ms=round(d[0], 3), launches=d[2], tflops=round(d[1] / max(d[0], 1e-9) / 1e9, 3))
     return dict(ms=round(ms, 3), launches=att['fwd'][2] + att['bwd'][2], tflops=round(fl / max(ms, 1e-9) / 1e9, 3),
                 fwd=one(att['fwd']), bwd=one(att['bwd']))
+
+
+OPT_PASS = {'table': 'es_adamw_table: clip + AdamW + the bf16 copies of the kernels in one pass',
+            'flat': 'es_adamw_step (+ es_cast_weights_table at the next step)'}
 
 
 def launch_classes(records, mfma_peak, top=6):

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libes_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'es_hip.h')
 
-_CT = {'int': ctypes.c_int, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t}
+_CT = {'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double, 'size_t': ctypes.c_size_t}
 
 
 def parse_header(path=HEADER_PATH):

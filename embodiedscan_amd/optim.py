@@ -1,9 +1,17 @@
 """Optimiser wrapper over the flat parameter arena (mmengine OptimWrapper + torch AdamW + clip_grad as
 configured at configs/detection/mv-det3d_8xb4_embodiedscan-3d-284class-9dof.py:219-223), with the
 data-parallel gradient exchange folded in: ONE RCCL all-reduce of the flat gradient buffer per step."""
+import os
+import struct
+
 import torch
 from .hip import P, call
 from .parallel import allreduce_mean_
+
+# bf16 mode: AdamW writes the bf16 copies of the convolution kernels in the same pass (es_adamw_table) instead of leaving them to
+# the next step's es_cast_weights_table launch (8 B per parameter less; ES_ADAMW_CAST=0: the two-pass path)
+ADAMW_CAST = [os.environ.get('ES_ADAMW_CAST', '1') != '0']
+AW_CHUNK = 4096             # elements per work item of a plain range (csrc/optim.hip)
 
 
 class OptimWrapper:
@@ -17,6 +25,8 @@ class OptimWrapper:
         self.step = 0
         self.m = self.v = None
         self.last_norm = None
+        self._table = None          # (key, device table, rows, work items, covered Params, frozen Params) of es_adamw_table
+        self.last_path = None       # 'table' | 'flat': which AdamW pass the last step ran (bench.py reports it)
 
     def state_init(self, arena):
         n = arena.n_train
@@ -42,6 +52,77 @@ class OptimWrapper:
             else:
                 groups.append((o, e, lm, dm))
         self.groups = groups
+
+    def _adamw_table(self, arena):
+        """rows of es_adamw_table for this arena, or None when the one-pass update does not apply: every trainable convolution
+        kernel registered with the engine's cast table that lives in this arena becomes a tile row, the rest of the trainable
+        arena (norm parameters, biases, padding) plain ranges, each with the (lr_mult, decay_mult) of its paramwise group"""
+        from . import engine as E
+        dev = arena.data.device
+        tab = E._CAST_TABLE.get(dev) if (ADAMW_CAST[0] and E.PRECISION[0] == 'bf16' and arena.data.is_cuda) else None
+        if tab is None:
+            return None
+        key = (id(tab), arena.data.data_ptr(), arena.n_train, id(self.groups))
+        if self._table is not None and self._table[0] == key:
+            return self._table
+        n, base = arena.n_train, arena.data.data_ptr()
+        if self.paramwise and self.groups is None:
+            self._build_groups(arena)
+        groups = list(self.groups) if self.paramwise else [(0, n, 1.0, 1.0)]
+        if self.paramwise:                                      # (alignment padding between groups, if any, keeps multipliers 1)
+            full, pos = [], 0
+            for a, b, lm, dm in groups:
+                if a > pos:
+                    full.append((pos, a, 1.0, 1.0))
+                full.append((a, b, lm, dm))
+                pos = b
+            if pos < n:
+                full.append((pos, n, 1.0, 1.0))
+            groups = full
+        convs, frozen, seen = [], [], set()
+        for p in tab['params']:
+            off = (p.d.data_ptr() - base) // 4
+            inside = base <= p.d.data_ptr() < base + 4 * arena.data.numel()
+            if not inside:
+                continue
+            if off >= n:
+                frozen.append(p)
+                continue
+            if off in seen or not p.d.is_contiguous() or off + p.d.numel() > n:
+                return None                                     # aliased / strided kernels: leave them to the two-pass path
+            seen.add(off)
+            convs.append((off, p))
+        convs.sort(key=lambda t: t[0])
+        for (o0, p0), (o1, _) in zip(convs, convs[1:]):
+            if o0 + p0.d.numel() > o1:
+                return None
+        dbits = lambda x: struct.unpack('<q', struct.pack('<d', float(x)))[0]
+        rows, items, ci = [], 0, 0
+        for a, b, lm, dm in groups:
+            pos = a
+            while pos < b:
+                if ci < len(convs) and convs[ci][0] < b and convs[ci][0] >= pos:
+                    off, p = convs[ci]
+                    if off > pos:
+                        rows.append([pos, off - pos, 0, 0, 0, 0, items, dbits(lm), dbits(dm)])
+                        items += (off - pos + AW_CHUNK - 1) // AW_CHUNK
+                    K, A, B = p.d.shape
+                    if off + p.d.numel() > b:
+                        return None                             # a kernel straddling two groups cannot happen (groups are whole tensors)
+                    rows.append([off, K, A, B, p.bf_n.data_ptr(), p.bf_t.data_ptr(), items, dbits(lm), dbits(dm)])
+                    items += K * ((A + 63) // 64) * ((B + 63) // 64)
+                    pos = off + p.d.numel()
+                    ci += 1
+                else:
+                    rows.append([pos, b - pos, 0, 0, 0, 0, items, dbits(lm), dbits(dm)])
+                    items += (b - pos + AW_CHUNK - 1) // AW_CHUNK
+                    pos = b
+        if ci != len(convs) or items >= (1 << 31):
+            return None
+        as_i64 = lambda r: [v - (1 << 64) if v >= (1 << 63) else v for v in r]
+        t = torch.tensor([as_i64(r) for r in rows], dtype=torch.int64).to(dev)
+        self._table = (key, t, len(rows), items, [p for _, p in convs], frozen, tab)
+        return self._table
 
     def state_dict(self, arena):
         """Resume state: AdamW moments keyed by the reference's parameter names (reference shapes), the step count
@@ -89,6 +170,25 @@ class OptimWrapper:
             else:
                 allreduce_mean_(arena.grad)                   # ... else one flat all-reduce (RCCL over xGMI)
             call('es_grad_norm', P(arena.grad), n, P(self.partial), P(self.norm), s)
+        from . import engine
+        table = self._adamw_table(arena)
+        if table is not None:
+            # one pass: AdamW + the bf16 copies of every trainable kernel; copies that were up to date stay so (frozen kernels:
+            # weights untouched), so the next step's refresh_weight_copies() launches nothing
+            _, tdev, nrows, items, convs, frozen, tab = table
+            call('es_adamw_table', P(arena.data), P(arena.grad), P(self.m), P(self.v), P(tdev), nrows, items, float(self.lr),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step,
+                 float(self.max_norm if self.max_norm else 0.0), P(self.norm), gscale, s)
+            old = engine.WEIGHT_VERSION[0]
+            engine.WEIGHT_VERSION[0] += 1
+            for p in convs:
+                p.bf_step = engine.WEIGHT_VERSION[0]
+            for p in frozen:
+                if p.bf_step == old:
+                    p.bf_step = engine.WEIGHT_VERSION[0]
+            self.last_norm, self.last_gscale, self.last_path = self.norm, gscale, 'table'
+            return
+        self.last_path = 'flat'
         if not self.paramwise:
             call('es_adamw_step', P(arena.data), P(arena.grad), P(self.m), P(self.v), n, float(self.lr),
                  float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step,

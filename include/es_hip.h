@@ -309,6 +309,16 @@ int es_grad_norm(const float* grad, size_t n, double* partial /* 2048 */, float*
 int es_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float max_norm, const float* grad_norm_dev,
                   float grad_scale, void* stream);
+/* The same update over a TABLE of arena pieces, writing the bf16 copies of the convolution kernels in the same pass (replaces
+ * es_adamw_step + es_cast_weights_table after a step).  table_dev: n_entries rows of 9 int64 {offset into the arenas (elements),
+ * K | length, A, B, natural bf16 copy | 0, transposed bf16 copy, first work item, double bits of lr_mult, of decay_mult};
+ * a row with a natural-copy pointer is a kernel [K][A][B] (one work item per 64 x 64 tile of a tap), a row without a plain range
+ * (one work item per 4096 elements); total_items = the work items of all rows; lr / weight_decay (doubles) are multiplied by the
+ * row's lr_mult / decay_mult in double and rounded to float (mmengine paramwise_cfg; = the float(lr * lr_mult) es_adamw_step gets).  Element arithmetic identical to es_adamw_step, copies identical to
+ * es_cast_weights_table. */
+int es_adamw_table(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const void* table_dev, int n_entries,
+                   int total_items, double lr, float beta1, float beta2, float eps, double weight_decay, int step, float max_norm,
+                   const float* grad_norm_dev, float grad_scale, void* stream);
 /* data parallel (parallel.py): sum of squares of one reduced gradient bucket -> 2048 doubles; the clip norm of the mean
  * gradient from all buckets' partials (scale = 1 / world) */
 int es_sumsq_partial(const float* grad, size_t n, double* partial /* 2048 */, void* stream);

@@ -354,3 +354,64 @@ def test_engine_dense_transposed_convolution_equals_the_generative_path(emulated
     for a, b, name in zip(res[True], res[False], ('y', 'dx', 'dw')):
         err = float((a - b).abs().max() / b.abs().max())
         assert err < 2e-5, (name, err)
+
+
+def test_adamw_table_equals_flat_adamw_plus_weight_cast(emu):
+    """es_adamw_table (AdamW + the bf16 copies of the kernels in one pass) against es_adamw_step followed by es_cast_weights_table:
+    the same bits in the parameters, both moments and both copies -- ragged kernels (3 x 64 stem, 100 x 36), plain ranges between
+    them, paramwise multipliers, clipping active"""
+    import struct
+    rng = np.random.default_rng(5)
+    shapes = [(27, 3, 64), (1, 100, 36), (2, 128, 70), (8, 64, 64)]
+    gaps = [5, 4100, 0, 12, 33]                                   # plain elements before / between / after the kernels
+    n = sum(gaps) + sum(k * a * b for k, a, b in shapes)
+    p0 = rng.standard_normal(n).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    m0 = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    v0 = (0.01 * rng.random(n)).astype(np.float32)
+    norm = np.array([np.sqrt((g.astype(np.float64) ** 2).sum())], np.float32)
+    lr, wd, step, max_norm, gs = 1e-3, 1e-2, 7, 10.0, 0.5
+    dbits = lambda x: struct.unpack('<q', struct.pack('<d', float(x)))[0]
+    mult = [(1.0, 1.0), (0.1, 1.0), (1.0, 0.0)]
+    # ---- reference: flat AdamW per multiplier range, then the cast table
+    pr, mr, vr = p0.copy(), m0.copy(), v0.copy()
+    rows, cast_rows, items, tiles, off = [], [], 0, 0, 0
+    keep = []
+    for i in range(len(shapes) + 1):
+        lm, dm = mult[i % 3]
+        if gaps[i]:
+            rows.append([off, gaps[i], 0, 0, 0, 0, items, dbits(lm), dbits(dm)])
+            items += (gaps[i] + 4095) // 4096
+            sl = slice(off, off + gaps[i])
+            a, b_, c, d = pr[sl].copy(), g[sl].copy(), mr[sl].copy(), vr[sl].copy()
+            emu('es_adamw_step', P(a), P(b_), P(c), P(d), gaps[i], lr * lm, 0.9, 0.999, 1e-8, wd * dm, step, max_norm, P(norm), gs, 0)
+            pr[sl], mr[sl], vr[sl] = a, c, d
+            off += gaps[i]
+        if i < len(shapes):
+            K, A, B = shapes[i]
+            cnt = K * A * B
+            nat, tr = np.zeros(cnt, np.uint16), np.zeros(cnt, np.uint16)
+            nat2, tr2 = np.zeros(cnt, np.uint16), np.zeros(cnt, np.uint16)
+            keep.append((nat, tr, nat2, tr2, off, cnt))
+            rows.append([off, K, A, B, nat.ctypes.data, tr.ctypes.data, items, dbits(lm), dbits(dm)])
+            items += K * ((A + 63) // 64) * ((B + 63) // 64)
+            sl = slice(off, off + cnt)
+            a, b_, c, d = pr[sl].copy(), g[sl].copy(), mr[sl].copy(), vr[sl].copy()
+            emu('es_adamw_step', P(a), P(b_), P(c), P(d), cnt, lr * lm, 0.9, 0.999, 1e-8, wd * dm, step, max_norm, P(norm), gs, 0)
+            pr[sl], mr[sl], vr[sl] = a, c, d
+            off += cnt
+    assert off == n
+    for nat, tr, nat2, tr2, o, cnt in keep:                       # cast table over the REFERENCE parameters (pointers into pr)
+        K, A, B = shapes[len(cast_rows)]
+        cast_rows.append([pr.ctypes.data + 4 * o, nat2.ctypes.data, tr2.ctypes.data, K, A, B, tiles])
+        tiles += K * ((A + 63) // 64) * ((B + 63) // 64)
+    ct = np.array(cast_rows, np.int64)
+    emu('es_cast_weights_table', P(ct), len(cast_rows), tiles, 0)
+    # ---- one pass
+    p1, m1, v1 = p0.copy(), m0.copy(), v0.copy()
+    t = np.array([[x - (1 << 64) if x >= (1 << 63) else x for x in r] for r in rows], np.int64)
+    emu('es_adamw_table', P(p1), P(g), P(m1), P(v1), P(t), len(rows), items, lr, 0.9, 0.999, 1e-8, wd, step, max_norm, P(norm), gs, 0)
+    assert np.array_equal(p1, pr) and np.array_equal(m1, mr) and np.array_equal(v1, vr)
+    assert not np.array_equal(p1, p0)
+    for nat, tr, nat2, tr2, o, cnt in keep:
+        assert np.array_equal(nat, nat2) and np.array_equal(tr, tr2) and nat.any()

@@ -1,0 +1,105 @@
+"""AdamW with the bf16 copies of the convolution kernels written in the same pass (es_adamw_table, csrc/optim.hip): the same bits
+as es_adamw_step followed by es_cast_weights_table -- at kernel level on a synthetic arena, and through train steps of the mv-3ddet and
+grounding (paramwise lr multipliers) detectors against the two-pass path from the same seed."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_adamw_table_bits_equal_flat_adamw_plus_cast():
+    from embodiedscan_amd.hip import call, P
+    dev = torch.device('cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(27, 3, 64), (1, 100, 36), (27, 128, 128), (8, 256, 192), (1, 1024, 256)]
+    gaps = [5, 4100, 0, 12, 70001, 33]
+    n = sum(gaps) + sum(k * a * b for k, a, b in shapes)
+    p0 = torch.randn(n, generator=gen).to(dev)
+    g = torch.randn(n, generator=gen).to(dev)
+    m0 = (0.1 * torch.randn(n, generator=gen)).to(dev)
+    v0 = (0.01 * torch.rand(n, generator=gen)).to(dev)
+    norm = g.double().norm().float().reshape(1)
+    lr, wd, step, max_norm, gs = 1e-3, 1e-2, 7, 10.0, 0.5
+    dbits = lambda x: struct.unpack('<q', struct.pack('<d', float(x)))[0]
+    mult = [(1.0, 1.0), (0.1, 1.0), (1.0, 0.0)]
+    pr, mr, vr = p0.clone(), m0.clone(), v0.clone()
+    rows, cast_rows, copies, items, tiles, off = [], [], [], 0, 0, 0
+    for i in range(len(shapes) + 1):
+        lm, dm = mult[i % 3]
+        pieces = [('gap', gaps[i])] + ([('conv', shapes[i])] if i < len(shapes) else [])
+        for kind, what in pieces:
+            cnt = what if kind == 'gap' else what[0] * what[1] * what[2]
+            if cnt == 0:
+                continue
+            if kind == 'gap':
+                rows.append([off, cnt, 0, 0, 0, 0, items, dbits(lm), dbits(dm)])
+                items += (cnt + 4095) // 4096
+            else:
+                K, A, B = what
+                bufs = [torch.zeros(cnt, dtype=torch.int16, device=dev) for _ in range(4)]
+                copies.append(bufs)
+                rows.append([off, K, A, B, bufs[0].data_ptr(), bufs[1].data_ptr(), items, dbits(lm), dbits(dm)])
+                items += K * ((A + 63) // 64) * ((B + 63) // 64)
+                cast_rows.append([pr.data_ptr() + 4 * off, bufs[2].data_ptr(), bufs[3].data_ptr(), K, A, B, tiles])
+                tiles += K * ((A + 63) // 64) * ((B + 63) // 64)
+            call('es_adamw_step', pr.data_ptr() + 4 * off, g.data_ptr() + 4 * off, mr.data_ptr() + 4 * off, vr.data_ptr() + 4 * off, cnt,
+                 float(lr * lm), 0.9, 0.999, 1e-8, float(wd * dm), step, max_norm, P(norm), gs, st)
+            off += cnt
+    assert off == n
+    ct = torch.tensor(cast_rows, dtype=torch.int64).to(dev)
+    call('es_cast_weights_table', P(ct), len(cast_rows), tiles, st)
+    p1, m1, v1 = p0.clone(), m0.clone(), v0.clone()
+    t = torch.tensor(rows, dtype=torch.int64).to(dev)
+    call('es_adamw_table', P(p1), P(g), P(m1), P(v1), P(t), len(rows), items, lr, 0.9, 0.999, 1e-8, wd, step, max_norm, P(norm), gs, st)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, pr) and torch.equal(m1, mr) and torch.equal(v1, vr) and not torch.equal(p1, p0)
+    for nat, tr, nat2, tr2 in copies:
+        assert torch.equal(nat, nat2) and torch.equal(tr, tr2) and bool(nat.any())
+
+
+@pytest.mark.parametrize('name', ['mv_3ddet.py', 'mv_grounding.py'])
+def test_train_steps_one_pass_equals_two_pass(name):
+    from embodiedscan_amd import engine as E, optim as O, pipeline
+    from embodiedscan_amd.config import build_detector, build_optim_wrapper, load_config
+    from embodiedscan_amd.synth import make_grounding_sample, make_scan
+    dev = torch.device('cuda:0')
+    cfg = load_config(os.path.join(ROOT, 'configs', name))
+    scans = [make_scan(900 + i, n_views=4, height=240, width=320, img_size=(256, 256), n_points=30000) for i in range(2)]
+    anns = [make_grounding_sample(s, seed=i) for i, s in enumerate(scans)]
+
+    def run(one_pass):
+        O.ADAMW_CAST[0] = one_pass
+        det = build_detector(cfg, device=dev, seed=0).to(dev)
+        optim = build_optim_wrapper(cfg)
+        ds = [pipeline.upload_scan(s, dev) for s in scans]
+        make = (lambda: pipeline.make_grounding_batch(ds, anns)) if 'grounding' in name else (lambda: pipeline.make_batch(ds))
+        out = []
+        for _ in range(3):
+            out.append({k: float(v) for k, v in det.train_step(make(), optim).items()})
+        torch.cuda.synchronize()
+        n = det.arena.n_train
+        res = dict(losses=out, params=det.arena.data[:n].clone(), m=optim.m.clone(), v=optim.v.clone(), path=optim.last_path)
+        if one_pass:                         # the copies the NEXT step would read: equal to a cast of the updated weights
+            tab = E._CAST_TABLE[dev]
+            fresh = [p for p in tab['params'] if p.bf_step == E.WEIGHT_VERSION[0]]
+            assert len(fresh) == len(tab['params']) > 0
+            for p in fresh:
+                assert torch.equal(p.bf_n.view(torch.int16), p.d.bfloat16().view(torch.int16))
+                assert torch.equal(p.bf_t, p.bf_n.transpose(1, 2))
+        E.release(id(det))
+        return res
+    E.PRECISION[0] = 'bf16'
+    try:
+        a, b = run(True), run(False)
+    finally:
+        E.PRECISION[0] = 'f32'
+        O.ADAMW_CAST[0] = os.environ.get('ES_ADAMW_CAST', '1') != '0'
+    assert a['path'] == 'table' and b['path'] == 'flat'
+    assert a['losses'] == b['losses'], (a['losses'], b['losses'])
+    assert torch.equal(a['params'], b['params']) and torch.equal(a['m'], b['m']) and torch.equal(a['v'], b['v'])
