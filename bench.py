@@ -300,6 +300,7 @@ def main():
     prof = {'names': ENGINE, 'records': [], 'event': lambda: torch.cuda.Event(enable_timing=True)}
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     step_ev[0].record()
+    cfs0 = cfs_stat()
     t0 = time.perf_counter()
     for it in range(args.steps):
         losses = step()                                         # no instrumentation of any kind inside the timed region
@@ -309,6 +310,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    host = host_report(cfs0)
     # one extra UNTIMED step on the same (four-stream) schedule with every engine launch bracketed by HIP events (2 events per
     # launch and a pair counter per kernel map cost ~3 ms of host time, and instrumented launches cannot be replayed from the
     # image backbone's hipGraph -- so this step is kept out of the timed region since round 3)
@@ -469,6 +471,7 @@ def main():
                                                     'in backward-completion order 2, 1, 0; the clip norm is taken per bucket behind its all-reduce)')
     out['hipgraph'] = dict(E.GRAPH_STATS, what='image-backbone forward sequences (engine.graphed): captured / replayed / run eagerly')
     out['optimizer_pass'] = OPT_PASS.get(optim.last_path, optim.last_path)
+    out['host'] = host
     # GPU-side duration of each timed step (events on the main stream)
     out['step_ms'] = [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(args.steps)]
     if world == 1 and not args.no_cpu_baseline:
@@ -677,6 +680,7 @@ def run_other_config(kind, args, dev):
                 gc_log.append((len(diag), info['generation'], round((time.perf_counter() - _t[0]) * 1e3, 2), info['collected']))
         gc.callbacks.append(_gc_cb)
     step_ev[0].record()
+    cfs0 = cfs_stat()
     t0 = time.perf_counter()
     for it in range(steps):
         h0 = time.perf_counter()
@@ -690,6 +694,7 @@ def run_other_config(kind, args, dev):
                              extra=dict(getattr(det, 'diag', None) or {})))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    host = host_report(cfs0)
     hip.PROFILE = prof                          # one extra untimed step under the same schedule, every engine launch bracketed
     step()
     recs = resolve_pairs(hip, prof['records'])
@@ -785,7 +790,7 @@ def run_other_config(kind, args, dev):
                engine_all=dict(launches_per_step=eng['launches'], kernel_ms_per_step=eng['ms'], tflops=eng['tflops'],
                                frac_of_binding_roof=eng['frac_binding'], compulsory_GBps=eng['comp_GBps'],
                                single_stream=dict(kernel_ms_per_step=e1['ms'], tflops=e1['tflops'], frac_of_binding_roof=e1['frac_binding'])),
-               classes=launch_classes(r1, peak, top=16), stage_ms=stages, optimizer_pass=OPT_PASS.get(optim.last_path, optim.last_path),
+               classes=launch_classes(r1, peak, top=16), stage_ms=stages, optimizer_pass=OPT_PASS.get(optim.last_path, optim.last_path), host=host,
                step_ms=[round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(steps)], **extra)
     if diag is not None:
         import gc
@@ -822,6 +827,27 @@ def attention_totals(records, klen, tl, Lmax):
                 fwd=one(att['fwd']), bwd=one(att['bwd']))
 
 
+def cfs_stat(root='/sys/fs/cgroup'):
+    """(periods in which the kernel throttled this cgroup, microseconds throttled) so far, or None without a cgroup-v2 cpu.stat"""
+    try:
+        d = dict(l.split() for l in open(os.path.join(root, 'cpu.stat')).read().splitlines())
+        return int(d['nr_throttled']), int(d['throttled_usec'])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def host_report(before):
+    """host side of a timed region: torch's intra-op pool, the cores the cgroup grants, and how often the kernel's CPU-bandwidth
+    controller stopped the process inside the region (a throttled process cannot queue GPU work: profiles/r5w_*)"""
+    import torch
+    from embodiedscan_amd.datasets.loader import effective_cpus
+    after = cfs_stat()
+    out = dict(torch_threads=torch.get_num_threads(), granted_cores=effective_cpus(), visible_cpus=os.cpu_count())
+    if before is not None and after is not None:
+        out.update(cfs_throttled_periods=after[0] - before[0], cfs_throttled_ms=round((after[1] - before[1]) / 1e3, 1))
+    return out
+
+
 OPT_PASS = {'table': 'es_adamw_table: clip + AdamW + the bf16 copies of the kernels in one pass',
             'flat': 'es_adamw_step (+ es_cast_weights_table at the next step)'}
 
@@ -856,10 +882,16 @@ def _cap_cpu_threads():
     GPU boxes (256 shown, 16 granted) torch's default 128 threads time-slice 16 cores; `cores` in the line is this count"""
     import torch
     from embodiedscan_amd.datasets.loader import effective_cpus
-    n = min(torch.get_num_threads(), effective_cpus())
+    n = effective_cpus()                    # (set explicitly: the train steps run with the engine's smaller pool, settle_host_threads)
     if n != torch.get_num_threads():
         torch.set_num_threads(n)
     return n
+
+
+def _gpu_leg_threads():
+    """back to the train steps' host pool after a CPU leg"""
+    from embodiedscan_amd import engine as E
+    E.settle_host_threads(force=True)
 
 
 def other_parity(kind, cfg, det, scan, make, dev, args):
@@ -913,6 +945,7 @@ def other_parity(kind, cfg, det, scan, make, dev, args):
                 sample=f'1 scan x {scan["depth"].shape[0]} views 480x640, 100k points, ONE FORWARD (no backward, no optimiser) of the '
                        f'PyTorch-f32 CPU oracle, {dt:.1f} s')
     del d0, b0, data, l0
+    _gpu_leg_threads()
     return parity, base
 
 
@@ -1074,6 +1107,7 @@ def cpu_baseline(scan, sd0, det, parity_hip, args):
     base = dict(value=round(1.0 / dt, 5), unit='scans/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'1 scan x {scan["depth"].shape[0]} views 480x640, 100k points, one forward+backward of the '
                        f'PyTorch-f32 CPU oracle (no optimiser step), {dt:.1f} s; os.cpu_count()={os.cpu_count()}')
+    _gpu_leg_threads()
     return base, parity
 
 

@@ -397,8 +397,36 @@ def ticket_ws(floats, like, tag=''):
 GC_SETTLE_STEP = 6
 
 
+_HOST_SETTLED = [False]
+
+
+def settle_host_threads(force=False):
+    """Once per process (first train step): cap torch's intra-op (OpenMP) pool.  torch sizes it by the CPUs it SEES (128 threads on
+    the GPU boxes); the cgroup GRANTS 16 cores there, and after any CPU-side tensor operation of a step the idle workers spin before
+    they sleep -- together they exhaust the quota and the kernel throttles the whole process, the thread that queues the GPU's work
+    included: every ~9th occupancy step was 12 - 27 ms longer with the device idle (cpu.stat nr_throttled 28 -> 59 over two 60-step runs,
+    none with one thread: profiles/r5w_*).  A training step has no CPU tensor work worth a pool: a quarter of the granted cores per local
+    rank (ES_HOST_THREADS=n overrides, 0 leaves torch alone)."""
+    if _HOST_SETTLED[0] and not force:
+        return
+    _HOST_SETTLED[0] = True
+    want = os.environ.get('ES_HOST_THREADS', 'auto')
+    if want == '0':
+        return
+    if want == 'auto':
+        from .datasets.loader import effective_cpus
+        local = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1))
+        n = max(1, effective_cpus() // 4 // local)
+    else:
+        n = max(1, int(want))
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+
+
 def settle_gc(det):
-    """called at the top of every train_step: freezes the collector's generations when `det` reaches its GC_SETTLE_STEP-th step"""
+    """called at the top of every train_step: freezes the collector's generations when `det` reaches its GC_SETTLE_STEP-th step
+    (and, at the process's first step, caps the host thread pool: settle_host_threads)"""
+    settle_host_threads()
     n = getattr(det, '_steps_done', 0) + 1
     det._steps_done = n
     if n == GC_SETTLE_STEP and os.environ.get('ES_GC_FREEZE', '1') != '0':

@@ -550,3 +550,35 @@ def test_bench_self_launches_its_ranks_when_no_launcher_is_around():
     r = subprocess.run([sys.executable, bench, '--gpus', '2', '--dry-launch'], capture_output=True, text=True, timeout=120,
                        env=dict(env, WORLD_SIZE='1', RANK='0'), cwd='/tmp')
     assert r.returncode != 0 and 'torch.distributed.run' in r.stderr
+
+
+def test_host_thread_pool_is_capped_by_the_granted_cores(monkeypatch):
+    """engine.settle_host_threads (first train step of a process): torch's intra-op pool goes down to a quarter of the cores the
+    cgroup grants per local rank, never up; ES_HOST_THREADS overrides; 0 leaves torch alone (profiles/r5w_*: 128 OpenMP threads on a
+    16-core quota got the step loop throttled)"""
+    import torch
+    from embodiedscan_amd import engine as E
+    from embodiedscan_amd.datasets import loader
+    have = torch.get_num_threads()
+    calls = []
+    monkeypatch.setattr(torch, 'set_num_threads', lambda n: calls.append(n))
+    try:
+        for granted, local, env, seen, want in ((16, None, None, 128, [4]), (16, '8', None, 128, [1]), (16, None, '2', 128, [2]),
+                                                (16, None, '0', 128, []), (64, None, None, 8, []), (2, None, None, 128, [1])):
+            calls.clear()
+            monkeypatch.setattr(loader, 'effective_cpus', lambda g=granted: g)
+            monkeypatch.setattr(torch, 'get_num_threads', lambda s=seen: s)
+            for k, v in (('LOCAL_WORLD_SIZE', local), ('ES_HOST_THREADS', env)):
+                if v is None:
+                    monkeypatch.delenv(k, raising=False)
+                else:
+                    monkeypatch.setenv(k, v)
+            E.settle_host_threads(force=True)
+            assert calls == want, (granted, local, env, seen, calls)
+        calls.clear()
+        E.settle_host_threads()                       # once per process
+        assert calls == []
+    finally:
+        monkeypatch.undo()
+        assert torch.get_num_threads() == have
+        E._HOST_SETTLED[0] = False
