@@ -134,6 +134,12 @@ class SparseFeatureFusionSingleStage3DDetector:
         gate = getattr(self, '_ev_3d_done', None)
         if gate is not None and os.environ.get('ES_PF_GATE', '1') != '0':
             st.wait_event(gate)
+        else:
+            # no gate (first step, or ES_PF_GATE=0): the preprocessor's two image buffers are only safe to overwrite once the step
+            # queued last has read its own -- wait for everything it has queued, image branch included
+            st.wait_stream(hip.stream_obj())
+            if E._SIDE:
+                st.wait_event(E._SIDE['join'])
         self._bind()
         try:
             with torch.cuda.stream(st):

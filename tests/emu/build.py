@@ -32,6 +32,11 @@ def transform(text):
 
 def build(files=DEFAULT, force=False, lib_name='libes_emu_test.so'):
     """files: sources relative to embodiedscan_amd/csrc (sub-directories allowed: 'next/x.hip')"""
+    import shutil
+    if shutil.which(CLANG) is None and not os.path.exists(os.path.join(OUT, lib_name)):
+        # a host without the ROCm clang (ES_EMU_CXX names another C++17 compiler): the emulator tests skip instead of erroring
+        import pytest
+        pytest.skip(f'{CLANG} not found (set ES_EMU_CXX to a C++17 compiler to build the emulated kernel library)')
     os.makedirs(OUT, exist_ok=True)
     lib = os.path.join(OUT, lib_name)
     srcs = [os.path.join(CSRC, f) for f in files] + [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'es_hip.h'),
