@@ -26,8 +26,10 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
 ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_fwd_bf16_io',
-          'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src', 'es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16'}
-DENSE = ('es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16')   # round 5: the dense-volume engine (csrc/dconv.hip), geometry instead of a map
+          'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src', 'es_dconv_fwd_bf16',
+          'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16'}
+DENSE = ('es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16')   # round 5: the dense-volume engine (csrc/dconv.hip)
+DENSE_WGRAD = ('es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16')
 FWD_X = ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_io')     # (X, x_half, ldx, W, nbr, n_out, n_in, K, Cin, Cout, ...)
 SCATTER = {'es_voxel_keys', 'es_unique_first', 'es_morton_sort', 'es_stride_keys', 'es_kernel_map', 'es_inverse_map',
            'es_union_plan', 'es_point_sample_fwd', 'es_point_sample_bwd', 'es_depth_to_points'}
@@ -862,7 +864,7 @@ def launch_classes(records, mfma_peak, top=6):
         if name not in ENGINE:
             continue
         nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
-        kind = 'wgrad' if (name.startswith('es_spconv_wgrad') or name == 'es_dconv_wgrad_bf16') else 'fwd/dgrad'
+        kind = 'wgrad' if (name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD) else 'fwd/dgrad'
         if name in DENSE:
             kind += ' dense'
         key = f'{kind} K={K} {cin}->{cout}'
@@ -952,23 +954,27 @@ def other_parity(kind, cfg, det, scan, make, dev, args):
 def dense_info(name, a):
     """(n_out, n_in, K, cin, cout, valid (output, tap) pairs) of a dense-engine launch, in the convention of the map launches
     (the data gradient is a forward launch over the input voxels with the channel roles swapped)"""
-    geom = list(a[3] if name == 'es_dconv_fwd_bf16' else a[4])
+    fwd = name == 'es_dconv_fwd_bf16'
+    mode = a[4] if fwd else (5 if a[5] else 2)
+    geom = list(a[3] if fwd else a[4])
     B, X, Y, Z, ks, st, pad = geom
+    cin, cout = (a[5], a[6]) if fwd else (a[6], a[7])
     o = lambda d: (d + 2 * pad - ks) // st + 1
     ax = lambda d: sum(1 for q in range(o(d)) for k in range(ks) if 0 <= q * st - pad + k < d)
-    pairs = float(B) * ax(X) * ax(Y) * ax(Z)
-    n_in, n_out = B * X * Y * Z, B * o(X) * o(Y) * o(Z)
-    cin, cout = (a[5], a[6]) if name == 'es_dconv_fwd_bf16' else (a[6], a[7])
-    if name == 'es_dconv_fwd_bf16' and a[4] in (3, 4) or (name == 'es_dconv_wgrad_bf16' and a[5]):
+    if Z == 0:                                   # flat grid: nn.Conv2d on (B, X, Y) images, ks x ks taps
+        pairs, n_in, n_out, K = float(B) * ax(X) * ax(Y), B * X * Y, B * o(X) * o(Y), ks ** 2
+    else:
+        pairs, n_in, n_out, K = float(B) * ax(X) * ax(Y) * ax(Z), B * X * Y * Z, B * o(X) * o(Y) * o(Z), ks ** 3
+    if mode >= 3:
         # nn.ConvTranspose3d(k = 2, s = 2): 8 taps, every (coarse voxel, tap) pair is valid; forward / weight gradient read Cin and
         # write / pair with Cout on the fine grid, the data gradient the other way round
         n_c, n_f, pairs = B * X * Y * Z, 8 * B * X * Y * Z, 8.0 * B * X * Y * Z
-        if name == 'es_dconv_fwd_bf16' and a[4] == 4:
+        if mode == 4:
             return n_c, n_f, 8, cout, cin, pairs
         return n_f, n_c, 8, cin, cout, pairs
-    if name == 'es_dconv_fwd_bf16' and a[4] == 1:
-        return n_in, n_out, ks ** 3, cout, cin, pairs
-    return n_out, n_in, ks ** 3, cin, cout, pairs
+    if mode == 1:
+        return n_in, n_out, K, cout, cin, pairs
+    return n_out, n_in, K, cin, cout, pairs
 
 
 def resolve_pairs(hip, records):
@@ -1013,7 +1019,7 @@ def engine_totals(records, mfma_peak):
             pairs = pairs_dev
         else:
             pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
-        wgrad = name.startswith('es_spconv_wgrad') or name == 'es_dconv_wgrad_bf16'
+        wgrad = name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD
         wb = 2 if ('bf16' in name and not wgrad) else 4
         f = 2.0 * pairs * cin * cout
         pb = pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wb
@@ -1023,7 +1029,7 @@ def engine_totals(records, mfma_peak):
         bx = by = 4.0
         if name == 'es_spconv_wgrad_bf16_src':
             bx, by = (2.0 if a[1] else 4.0), (2.0 if a[4] else 4.0)
-        elif name == 'es_dconv_wgrad_bf16':
+        elif name in DENSE_WGRAD:
             bx = by = 2.0
         elif name in DENSE or (name in FWD_X and a[1]):
             bx = 2.0

@@ -13,8 +13,8 @@
 //     SOURCE address (conflict-free ds_read_b128 fragments: the layout of k_spconv_bf16_dma<*, 2>), one barrier per step.
 //     Per wave and step 24|26 KB of fragment reads for 64|80 MFMAs (1 024|1 280 matrix-pipe cycles): LDS traffic is 40 % of the
 //     matrix time, the 128 x 128 tile of spconv.hip sat at 100 %.
-//     Loop order: channel chunk OUTER, tap INNER -- the 27 taps of one 64-channel chunk re-read the same ~1 600 input rows
-//     (128 B each) from the XCD's L2 instead of streaming the whole (rows x C_in) slab 27 times through it; workgroups are
+//     Loop order: tap OUTER, channel chunk INNER (the other order -- the 27 taps of one chunk re-reading the same rows from L2 --
+//     measured 5 - 20 % slower: the per-step address recomputation costs more than the locality buys; option 21); workgroups are
 //     numbered so that one XCD holds consecutive row tiles of ONE column tile (shared weight tiles, overlapping halos).
 //     Under-filled launches (the 3 200- and 400-voxel levels) split the linear (chunk, tap) sequence over `nsplit` workgroups
 //     per tile; partial tiles go to a workspace and are added in slice order by k_dconv_reduce (bit-reproducible).
@@ -294,13 +294,16 @@ __global__ void k_dconv_reduce_cls(const float4* __restrict__ ws, int nsplit, in
 __global__ __launch_bounds__(512, 2) void k_dconv_wgrad(const unsigned short* __restrict__ Xh, int ldx,
                                                         const unsigned short* __restrict__ dYh, int ldy, int Cin, int Cout,
                                                         int M, DcGeom g, float* __restrict__ dW, int accumulate, int nCo,
-                                                        int nWG, int per, int gatherB) {
+                                                        int nWG, int per, int gatherB, int msplit, float* __restrict__ ws) {
   constexpr int TB = 64 * 512;                   // bytes of one operand tile: 64 voxels x 256 channels
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TB];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
   const int wr = wv >> 1, wc = wv & 1;
-  const int L = dc_logical(per);
-  if (L >= nWG) return;
+  const int L0 = dc_logical(per);
+  if (L0 >= nWG * msplit) return;
+  // msplit > 1 (a launch of few tiles over many rows: the 2-D 3x3 layers, 9 tiles over 192 000 pixels): slice z of the 64-row steps,
+  // partial dW tiles through the workspace ws[z][K][Cin][Cout], added in slice order by k_dconv_reduce
+  const int L = L0 % nWG, zs = L0 / nWG;
   const int ti = L % g.nT, pair = L / g.nT;
   const int c0 = (pair / nCo) * 256, n0 = (pair % nCo) * 256;
   const DcTap tp = g.taps[ti];
@@ -346,12 +349,13 @@ __global__ __launch_bounds__(512, 2) void k_dconv_wgrad(const unsigned short* __
     s16x8_t u = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, u);
   };
-  const int n = (M + 63) >> 6;
-  issue(0, 0);
+  const int nst = (M + 63) >> 6;
+  const int s0 = (int)(((long long)nst * zs) / msplit), n = (int)(((long long)nst * (zs + 1)) / msplit) - s0;
+  if (n > 0) issue(0, s0 * 64);
   for (int c = 0; c < n; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (c + 1 < n) issue((c + 1) & 1, (c + 1) * 64);
+    if (c + 1 < n) issue((c + 1) & 1, (s0 + c + 1) * 64);
     const unsigned char* xt = smem + ((c & 1) * 2 + 0) * TB;
     const unsigned char* yt = smem + ((c & 1) * 2 + 1) * TB;
 #pragma unroll
@@ -368,8 +372,8 @@ __global__ __launch_bounds__(512, 2) void k_dconv_wgrad(const unsigned short* __
           acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
     }
   }
-  float* const dst = dW + (size_t)tp.w * Cin * Cout;
-  if (accumulate) {
+  float* const dst = (msplit > 1 ? ws + (size_t)zs * g.nT * Cin * Cout : dW) + (size_t)tp.w * Cin * Cout;
+  if (accumulate && msplit == 1) {
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
@@ -411,14 +415,18 @@ static unsigned dc_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(
 //   4  ... its data gradient          rows = input voxels, sources = output voxels 2 r + p, 8 taps
 //   5  ... its weight gradient        rows = input voxels; X direct, dY gathered at 2 r + p
 static int dc_geometry(const int* gh, int mode, DcGeom& g, int& M, int& n_src) {
-  const int B = gh[0], X = gh[1], Y = gh[2], Z = gh[3], ks = gh[4], st = gh[5], pad = gh[6];
-  if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || ks <= 0 || ks * ks * ks > DC_MAXT || st <= 0 || pad < 0 || mode < 0 || mode > 5) return -2;
+  // Z = 0: a FLAT grid (nn.Conv2d on (B, X, Y) images, rows (b * X + x) * Y + y): one z slab, ks x ks taps, weights [ks*ks][..][..]
+  const bool flat = gh[3] == 0;
+  const int B = gh[0], X = gh[1], Y = gh[2], Z = flat ? 1 : gh[3], ks = gh[4], st = gh[5], pad = gh[6];
+  const int ksz = flat ? 1 : ks, padz = flat ? 0 : pad;           // kernel extent / padding along z
+  if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || ks <= 0 || ks * ks * ksz > DC_MAXT || st <= 0 || pad < 0 || mode < 0 || mode > 5) return -2;
   const bool tr = mode >= 3;
-  if (tr && (ks != 2 || st != 2 || pad != 0)) return -4;
+  if (tr && (flat || ks != 2 || st != 2 || pad != 0)) return -4;
   const int Xo = tr ? 2 * X : (X + 2 * pad - ks) / st + 1, Yo = tr ? 2 * Y : (Y + 2 * pad - ks) / st + 1,
-            Zo = tr ? 2 * Z : (Z + 2 * pad - ks) / st + 1;
+            Zo = tr ? 2 * Z : (flat ? 1 : (Z + 2 * pad - ks) / st + 1);
   if (Xo <= 0 || Yo <= 0 || Zo <= 0) return -2;
   const bool strided_dgrad = mode == 1 && st != 1;
+  if (flat && strided_dgrad) return -4;                           // (the parity classes are written for three axes)
   if (mode == 1 && st == 1 && ks != 2 * pad + 1) return -4;
   if (strided_dgrad && (st != 2 || !((ks == 3 && pad == 1) || (ks == 1 && pad == 0)) || X != 2 * Xo || Y != 2 * Yo || Z != 2 * Zo)) return -4;
   const int bigX = X > Xo ? X : Xo, bigY = Y > Yo ? Y : Yo, bigZ = Z > Zo ? Z : Zo;
@@ -459,16 +467,16 @@ static int dc_geometry(const int* gh, int mode, DcGeom& g, int& M, int& n_src) {
     }
     g.clsBeg[8] = (short)g.nT;
   } else {
-    g.nT = ks * ks * ks;
+    g.nT = ks * ks * ksz;
     for (int t = 0; t < g.nT; ++t) {
-      const int kx = t / (ks * ks), ky = (t / ks) % ks, kz = t % ks;
+      const int kx = t / (ks * ksz), ky = (t / ksz) % ks, kz = t % ksz;
       // forward: source = out * stride - pad + k.  data gradient (stride 1): dX[i] += dY[i + pad - k] . W[k]^T.
       // transposed convolution, data / weight gradient: source = 2 r + k
       const bool back = mode == 1;
       g.taps[t].w = (short)t;
       g.taps[t].dx = (short)(back ? pad - kx : kx - pad);
       g.taps[t].dy = (short)(back ? pad - ky : ky - pad);
-      g.taps[t].dz = (short)(back ? pad - kz : kz - pad);
+      g.taps[t].dz = (short)(back ? padz - kz : kz - padz);
     }
   }
   const long long m = (long long)B * g.rX * g.rY * g.rZ, ns = (long long)B * g.sX * g.sY * g.sZ;
@@ -480,10 +488,12 @@ static int dc_geometry(const int* gh, int mode, DcGeom& g, int& M, int& n_src) {
 static int ES_OPT_DC_ROWS = 0;          // es_set_option 20: row tile of k_dconv (0 = pick per launch, 256, 320)
 static int ES_OPT_DC_ORDER = 0;         // 21: 0 = tap outer / channel chunk inner (default: +5 .. 20 % on every neck shape, profiles/r5a_dconv_ab.txt), 1 = chunk outer / tap inner
 static int ES_OPT_DC_SPLIT = 0;         // 22: 0 = pick the slice count per launch, n = force
+static int ES_OPT_DC_WSPLIT = 0;        // 23: row slices of the weight gradient with a workspace (0 = pick, n = force)
 extern "C" int es_dconv_set_option(int key, int value) {
   if (key == 20) { ES_OPT_DC_ROWS = value; return 0; }
   if (key == 21) { ES_OPT_DC_ORDER = value; return 0; }
   if (key == 22) { ES_OPT_DC_SPLIT = value; return 0; }
+  if (key == 23) { ES_OPT_DC_WSPLIT = value; return 0; }
   return -2;
 }
 
@@ -592,8 +602,24 @@ extern "C" int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, co
 
 // dW[K][Cin][Cout] (+)= X^T dY over the dense grid; Xh = bf16 rows of the operator's input, dYh = bf16 rows of its output gradient;
 // transposed 0: nn.Conv3d (mode 2), 1: nn.ConvTranspose3d(k = 2, s = 2) (mode 5)
-extern "C" int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int transposed, int Cin,
-                                   int Cout, float* dW, int accumulate, void* stream) {
+// row slices of a weight-gradient launch: only for launches of few tiles (< 64 workgroups; every shape of the neck keeps one pass)
+static int dc_wgrad_split(int nwg, int M) {
+  if (ES_OPT_DC_WSPLIT > 0) return ES_OPT_DC_WSPLIT;
+  if (nwg >= 64) return 1;
+  const int nst = (M + 63) >> 6;
+  int s = es_cdiv(240, nwg);
+  if (s > nst / 16) s = nst / 16;                // (>= 16 steps of 64 rows per slice)
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : s;
+}
+extern "C" size_t es_dconv_wgrad_workspace_floats(const int* geom_host, int transposed, int Cin, int Cout) {
+  DcGeom g; int M, ns;
+  if (dc_geometry(geom_host, transposed ? 5 : 2, g, M, ns) != 0 || Cin % 256 != 0 || Cout % 256 != 0) return 0;
+  const int nwg = g.nT * (Cin / 256) * (Cout / 256), ms = dc_wgrad_split(nwg, M);
+  return ms > 1 ? (size_t)ms * g.nT * Cin * Cout : 0;
+}
+static int dconv_wgrad_impl(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int transposed, int Cin, int Cout,
+                            float* dW, int accumulate, float* ws, size_t ws_floats, int allow_split, void* stream) {
   DcGeom g; int M, ns;
   int rc = dc_geometry(geom_host, transposed ? 5 : 2, g, M, ns);
   if (rc != 0) return rc;
@@ -601,9 +627,32 @@ extern "C" int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int
   if (Cin % 256 != 0 || Cout % 256 != 0 || (ldx & 7) != 0 || (ldy & 7) != 0 || ((uintptr_t)Xh & 15) != 0 || ((uintptr_t)dYh & 15) != 0 ||
       nx * ldx >= (1ll << 31) || ny * ldy >= (1ll << 31))
     return -4;
-  const int nCo = Cout / 256, nwg = g.nT * (Cin / 256) * nCo, per = es_cdiv(nwg, 8);
-  hipLaunchKernelGGL(k_dconv_wgrad, dim3(per * 8), dim3(512), 0, (hipStream_t)stream, (const unsigned short*)Xh, ldx,
-                     (const unsigned short*)dYh, ldy, Cin, Cout, M, g, dW, accumulate, nCo, nwg, per, transposed ? 1 : 0);
+  const int nCo = Cout / 256, nwg = g.nT * (Cin / 256) * nCo;
+  const int ms = allow_split ? dc_wgrad_split(nwg, M) : 1;
+  const size_t tot = (size_t)g.nT * Cin * Cout;
+  if (ms > 1 && (ws == nullptr || ws_floats < (size_t)ms * tot || ((uintptr_t)ws & 15) != 0)) return -5;
+  const int per = es_cdiv(nwg * ms, 8);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_dconv_wgrad, dim3(per * 8), dim3(512), 0, st, (const unsigned short*)Xh, ldx,
+                     (const unsigned short*)dYh, ldy, Cin, Cout, M, g, dW, accumulate, nCo, nwg, per, transposed ? 1 : 0, ms, ws);
   ES_CHECK_LAUNCH();
+  if (ms > 1) {
+    const size_t tot4 = tot / 4;
+    const int gr = es_cdiv((long long)tot4, 256);
+    hipLaunchKernelGGL(k_dconv_reduce, dim3(gr > 8192 ? 8192 : gr), dim3(256), 0, st, (const float4*)ws, ms, tot4, Cout / 4, dW, Cout,
+                       accumulate);
+    ES_CHECK_LAUNCH();
+  }
   return 0;
+}
+// dW[K][Cin][Cout] (+)= X^T dY over the dense grid; Xh = bf16 rows of the operator's input, dYh = bf16 rows of its output gradient;
+// transposed 0: nn.Conv3d (mode 2), 1: nn.ConvTranspose3d(k = 2, s = 2) (mode 5)
+extern "C" int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int transposed, int Cin,
+                                   int Cout, float* dW, int accumulate, void* stream) {
+  return dconv_wgrad_impl(Xh, ldx, dYh, ldy, geom_host, transposed, Cin, Cout, dW, accumulate, nullptr, 0, 0, stream);
+}
+// ... with a workspace (es_dconv_wgrad_workspace_floats; 0 = not needed): launches of few tiles over many rows slice the rows
+extern "C" int es_dconv_wgrad_ws_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int transposed, int Cin,
+                                      int Cout, float* dW, int accumulate, float* ws, size_t ws_floats, void* stream) {
+  return dconv_wgrad_impl(Xh, ldx, dYh, ldy, geom_host, transposed, Cin, Cout, dW, accumulate, ws, ws_floats, 1, stream);
 }

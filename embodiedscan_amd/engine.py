@@ -545,6 +545,7 @@ def _grad_target(v, shape_like):
 # INPUT grid; a convolution that passes it runs on the dense engine wherever the library takes the shape (bf16 mode, reduction
 # channels % 64, output channels % 256; the data gradient for stride 1) and falls back to the map kernels elsewhere -- `maps` is then
 # a callable returning (nbr, inv), so the maps of a layer the dense engine covers completely are never built.
+# Z = 0 names a FLAT grid: nn.Conv2d on (B, X, Y) images (the FPN's 3x3 output convolutions); a bias is pre-filled, the launch accumulates.
 DENSE = [os.environ.get('ES_DENSE', '1') != '0']
 _DC_WS = {}             # stream handle -> persistent workspace of the partial tiles of split dense launches
 
@@ -563,18 +564,31 @@ def dense_ok(dense, mode, cin, cout):
     return hip.raw('es_dconv_supported')(_dense_geom(dense), mode, cin, cout) == 1
 
 
+def _dense_ws(s, need, like):
+    """the partial-tile workspace of split dense launches on stream `s` (None when the launch needs none)"""
+    if not need:
+        return None
+    ws = _DC_WS.get(s)
+    if ws is None or ws.numel() < need or ws.device != like.device:
+        if ws is not None:
+            _KEEP.append(ws)                     # launches already queued on this stream may still use the old buffer
+        ws = _DC_WS[s] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=like.device)
+    return ws
+
+
 def _dense_launch(Xh, ldx, Wp, dense, mode, cin, cout, Y, ldy, acc, like):
     g = _dense_geom(dense)
-    need = int(hip.raw('es_dconv_workspace_floats')(g, mode, cin, cout))
     s = _stream()
-    ws = None
-    if need:
-        ws = _DC_WS.get(s)
-        if ws is None or ws.numel() < need or ws.device != like.device:
-            if ws is not None:
-                _KEEP.append(ws)                 # launches already queued on this stream may still use the old buffer
-            ws = _DC_WS[s] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=like.device)
+    ws = _dense_ws(s, int(hip.raw('es_dconv_workspace_floats')(g, mode, cin, cout)), like)
     call('es_dconv_fwd_bf16', Xh, ldx, Wp, g, mode, cin, cout, Y, ldy, acc, P(ws), ws.numel() if ws is not None else 0, s)
+
+
+def _dense_wgrad(xh, ldx, gh, ldy, dense, transposed, cin, cout, dW, acc, sw, like):
+    """weight gradient on the dense engine, on the weight-gradient stream `sw`; launches of few tiles over many rows (the 2-D 3x3
+    layers) slice the rows through that stream's workspace"""
+    g = _dense_geom(dense)
+    ws = _dense_ws(sw, int(hip.raw('es_dconv_wgrad_workspace_floats')(g, transposed, cin, cout)), like)
+    call('es_dconv_wgrad_ws_bf16', xh, ldx, gh, ldy, g, transposed, cin, cout, dW, acc, P(ws), ws.numel() if ws is not None else 0, sw)
 
 
 class _Maps:
@@ -605,11 +619,13 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0, dense=None
     if x16:
         assert bf and _ld(x.d) == cin, 'bf16 input rows need the bf16 kernels and contiguous rows'
         x.dh = x.d
-    dn = dense if (bf and bias is None and _ld(x.d) == cin and dense_ok(dense, 0, cin, cout)) else None
+    dn = dense if (bf and _ld(x.d) == cin and dense_ok(dense, 0, cin, cout)) else None
     if dn is None and maps is not None:
         nbr, inv = maps.get()
     if dn is not None:
-        _dense_launch(P(x.shadow()), cin, P(w.bf16()[1]), dn, 0, cin, cout, P(y.d), cout, 0, x.d)
+        if bias:                                  # rows pre-filled with the bias, the launch accumulates (the tile's accumulators fill the
+            y.d.copy_(bias.d.expand_as(y.d))      # register file: an epilogue that also held the bias spilled)
+        _dense_launch(P(x.shadow()), cin, P(w.bf16()[1]), dn, 0, cin, cout, P(y.d), cout, 1 if bias else 0, x.d)
     elif bf and (x16 or (SHADOW[0] and _ld(x.d) == cin and _use_shadow(n_in, cin, K, cin, cout))):
         _fwd_bf16(P(x.shadow()), 1, cin, P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0, P(y.d),
                   cout, 0, x.d)
@@ -662,7 +678,7 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     if w.g is not None or (bias is not None and bias.g is not None):
         sw = _wgrad_stream(gy, x.d, gh, x.dh)
     if dn_w is not None:
-        call('es_dconv_wgrad_bf16', P(x.dh), cin, P(gh), cout, _dense_geom(dn_w), 0, cin, cout, P(w.g), _first_write(P(w.g)), sw)
+        _dense_wgrad(P(x.dh), cin, P(gh), cout, dn_w, 0, cin, cout, P(w.g), _first_write(P(w.g)), sw, gh)
     elif w.g is not None and bf and WGRAD_BF16[0] and SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None):
         xs, ys = x.dh if x.dh is not None else x.d, gh if gh is not None else gy
         _wgrad('es_spconv_wgrad_bf16_src', sw, P(w.g), P(xs), int(x.dh is not None), _ld(xs), P(ys), int(gh is not None), _ld(ys),
@@ -829,7 +845,7 @@ def conv_transpose_dense(x, w, dense):
         if w.g is not None:
             x.shadow()
             sw = _wgrad_stream(y.g, x.d, gh, x.dh)
-            call('es_dconv_wgrad_bf16', P(x.dh), cin, P(gh), cout, _dense_geom(dense), 1, cin, cout, P(w.g), _first_write(P(w.g)), sw)
+            _dense_wgrad(P(x.dh), cin, P(gh), cout, dense, 1, cin, cout, P(w.g), _first_write(P(w.g)), sw, gh)
         if x.rg:
             g, acc = _grad_target(x, x.d)
             _dense_launch(P(gh), cout, P(w.bf16()[0]), dense, 4, cin, cout, P(g), _ld(g), acc, gh)

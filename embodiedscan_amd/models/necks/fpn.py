@@ -4,9 +4,14 @@ embodiedscan/models/detectors/dense_fusion_occ.py:147-154).  Channels-last row m
 with bias, the top-down pathway is one in-place nearest-upsample-add kernel per level, the output 3x3 convs run through
 the static image-grid maps of the 2-D backbone.  mmdet is an un-vendored dependency: semantics restated (laterals ->
 top-down F.interpolate(size=..., mode='nearest') adds -> 3x3 output convs, no norm / activation, num_outs == num_ins)."""
+import os
+
 from ... import engine as E
 from ...registry import MODELS
 from ..backbones.resnet2d import _Grid
+
+
+FPN_DENSE = [os.environ.get('ES_FPN_DENSE', '1') != '0']      # A/B switch: the 3x3 output convolutions on the dense engine (flat grid)
 
 
 @MODELS.register_module(name='mmdet.FPN')
@@ -46,9 +51,12 @@ class FPN:
             key = (n_img, h, w)
             if key not in self.grids:
                 self.grids[key] = _Grid(n_img, h, w, lats[i].d.device)
-            nbr, inv, n_out, _, _ = self.grids[key].conv_map(3, 1, 1)
             wt, b = self.out[i]
-            outs.append((E.conv(lats[i], wt, nbr, inv, n_out, bias=b), h, w))
+            # 3x3 / pad 1 on a dense image grid: the dense engine by address arithmetic (flat grid: Z = 0) where it takes the shape
+            # (bf16 mode, 256 channels), the 9-wide image map elsewhere -- built only if a launch needs it
+            dense = (n_img, h, w, 0, 3, 1, 1) if FPN_DENSE[0] else None
+            outs.append((E.conv(lats[i], wt, None, None, n_img * h * w, bias=b, dense=dense,
+                                maps=lambda g=self.grids[key]: g.conv_map(3, 1, 1)[:2]), h, w))
         return outs
 
     __call__ = forward

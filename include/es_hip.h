@@ -462,13 +462,23 @@ int es_dconv_supported(const int* geom_host, int mode, int Cin, int Cout);
 size_t es_dconv_workspace_floats(const int* geom_host, int mode, int Cin, int Cout);
 int es_dconv_fwd_bf16(const void* Xh, int ldx, const void* W_bf16, const int* geom_host, int mode, int Cin, int Cout, float* Y,
                       int ldy, int accumulate, float* ws, size_t ws_floats, void* stream);
+/* FLAT grids: geom_host[3] = 0 is a 2-D operator (nn.Conv2d on (B, X, Y) images, rows (b*X + x)*Y + y, ksize x ksize taps, weights
+ * [ksize*ksize][..][..]; the FPN's 3x3 output convolutions, mmdet/models/necks/fpn.py via
+ * configs/occupancy/mv-occ_8xb1_embodiedscan-occ-80class.py:32-35); modes 0, 1 (stride 1) and 2 take them.  A bias is the caller's:
+ * rows pre-filled with it and accumulate = 1 (the tile's accumulators fill the register file; an epilogue that also held the bias spilled). */
 /* dW[K][Cin][Cout] (f32) = (accumulate ? dW : 0) + X^T . dY over the grid; Xh = bf16 rows of the operator's input, dYh = bf16 rows
  * of its output gradient; transposed 0: nn.Conv3d (X gathered under the tap), 1: nn.ConvTranspose3d(k = 2, s = 2) (dY gathered at
  * 2 r + p).  One workgroup per (tap, 256 x 256 tile): every element is written once, no atomics. */
 int es_dconv_wgrad_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int transposed, int Cin, int Cout,
                         float* dW, int accumulate, void* stream);
+/* ... with a workspace: a launch of fewer than 64 tiles (the 2-D 3x3 layers: 9 tiles over 192 000 pixel rows) slices the ROWS over
+ * several workgroups per tile; partial dW tensors ws[slice][K][Cin][Cout], added in slice order (bit-reproducible).
+ * es_dconv_wgrad_workspace_floats: floats needed (0: one pass, ws may be NULL).  -5: workspace too small. */
+size_t es_dconv_wgrad_workspace_floats(const int* geom_host, int transposed, int Cin, int Cout);
+int es_dconv_wgrad_ws_bf16(const void* Xh, int ldx, const void* dYh, int ldy, const int* geom_host, int transposed, int Cin, int Cout,
+                           float* dW, int accumulate, float* ws, size_t ws_floats, void* stream);
 /* tuning switches of the dense engine (A/B runs): 20 row tile (0 auto, 256, 320), 21 loop order (1 chunk outer / tap inner),
- * 22 slices per tile (0 auto) */
+ * 22 slices per tile (0 auto), 23 row slices of a weight gradient launched with a workspace (0 auto) */
 int es_dconv_set_option(int key, int value);
 
 #ifdef __cplusplus

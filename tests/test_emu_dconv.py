@@ -415,3 +415,122 @@ def test_adamw_table_equals_flat_adamw_plus_weight_cast(emu):
     assert not np.array_equal(p1, p0)
     for nat, tr, nat2, tr2, o, cnt in keep:
         assert np.array_equal(nat, nat2) and np.array_equal(tr, tr2) and nat.any()
+
+
+def _conv2d_ref(xb, wb, B, X, Y, st):
+    """f64 nn.Conv2d(k=3, stride, pad=1) on channels-last rows: xb (B*X*Y, Cin), wb (9, Cin, Cout), taps ordered (kx, ky)"""
+    Xo, Yo = (X + 2 - 3) // st + 1, (Y + 2 - 3) // st + 1
+    cin, cout = wb.shape[1], wb.shape[2]
+    xv = np.zeros((B, X + 2, Y + 2, cin))
+    xv[:, 1:1 + X, 1:1 + Y] = xb.reshape(B, X, Y, cin)
+    y = np.zeros((B, Xo, Yo, cout))
+    for kx in range(3):
+        for ky in range(3):
+            y += xv[:, kx:kx + st * Xo:st, ky:ky + st * Yo:st] @ wb[kx * 3 + ky].astype(np.float64)
+    return y.reshape(-1, cout), (Xo, Yo)
+
+
+def test_dense_flat_grid_2d_convolution_with_bias_and_row_sliced_weight_gradient(emu):
+    """geom[3] = 0: nn.Conv2d(k=3, p=1) on (B, X, Y) images by the same kernels -- forward onto rows pre-filled with the bias (also through the slice
+    reduction of a forced split), stride-1 data gradient, stride-2 forward, and the weight gradient with its rows sliced over several
+    workgroups per tile (partial tensors through the workspace) -- against f64 on the bf16-rounded operands"""
+    rng = np.random.default_rng(99)
+    for B, X, Y, st, cin, cout in ((2, 13, 11, 1, 256, 256), (1, 12, 10, 2, 256, 256)):
+        g = _geom(B, X, Y, 0, 3, st, 1)
+        assert emu.fns['es_dconv_supported'](P(g), 0, cin, cout) == 1 and emu.fns['es_dconv_supported'](P(g), 2, cin, cout) == 1
+        assert emu.fns['es_dconv_supported'](P(g), 1, cin, cout) == (1 if st == 1 else 0)
+        assert emu.fns['es_dconv_supported'](P(g), 3, cin, cout) == 0
+        x = rng.standard_normal((B * X * Y, cin)).astype(np.float32)
+        w = (rng.standard_normal((9, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+        bias = rng.standard_normal(cout).astype(np.float32)
+        wt, wn = np.zeros((9, cout, cin), np.uint16), np.zeros((9, cin, cout), np.uint16)
+        emu('es_cast_weight_bf16', P(w), 9, cin, cout, P(wn), P(wt), 0)
+        xh = bf16_bits(x)
+        xb, wb = bf16_round(x).astype(np.float64), bf16_round(w).astype(np.float64)
+        want, (Xo, Yo) = _conv2d_ref(xb, wb, B, X, Y, st)
+        M = B * Xo * Yo
+        for split in (0, 3):
+            emu('es_dconv_set_option', 22, split)
+            nf = int(emu.fns['es_dconv_workspace_floats'](P(g), 0, cin, cout))
+            wsb = np.full(max(nf, 4), np.nan, np.float32)
+            y = np.ascontiguousarray(np.broadcast_to(bias, (M, cout))).copy()      # the caller's bias: rows pre-filled, accumulate = 1
+            emu('es_dconv_fwd_bf16', P(xh), cin, P(wt), P(g), 0, cin, cout, P(y), cout, 1, P(wsb), nf, 0)
+            assert np.abs(y - (want + bias)).max() / np.abs(want).max() < 2e-6, ('flat fwd + bias', st, split)
+            y3 = np.full((M, cout), np.nan, np.float32)
+            emu('es_dconv_fwd_bf16', P(xh), cin, P(wt), P(g), 0, cin, cout, P(y3), cout, 0, P(wsb), nf, 0)
+            assert np.abs(y3 - want).max() / np.abs(want).max() < 2e-6, ('flat fwd', st, split)
+        emu('es_dconv_set_option', 22, 0)
+        dy = rng.standard_normal((M, cout)).astype(np.float32)
+        dyh = bf16_bits(dy)
+        dyb = bf16_round(dy).astype(np.float64)
+        if st == 1:                               # data gradient: the adjoint, tap by tap
+            dxp = np.zeros((B, X + 2, Y + 2, cin))
+            for kx in range(3):
+                for ky in range(3):
+                    dxp[:, kx:kx + X, ky:ky + Y] += (dyb @ wb[kx * 3 + ky].T).reshape(B, X, Y, cin)
+            wantx = dxp[:, 1:1 + X, 1:1 + Y].reshape(-1, cin)
+            nf = int(emu.fns['es_dconv_workspace_floats'](P(g), 1, cin, cout))
+            wsb = np.full(max(nf, 4), np.nan, np.float32)
+            dx = np.full((B * X * Y, cin), np.nan, np.float32)
+            emu('es_dconv_fwd_bf16', P(dyh), cout, P(wn), P(g), 1, cin, cout, P(dx), cin, 0, P(wsb), nf, 0)
+            assert np.abs(dx - wantx).max() / np.abs(wantx).max() < 2e-6, 'flat dgrad'
+        # weight gradient: X gathered under the tap
+        xv = np.zeros((B, X + 2, Y + 2, cin))
+        xv[:, 1:1 + X, 1:1 + Y] = xb.reshape(B, X, Y, cin)
+        wantw = np.stack([xv[:, kx:kx + st * Xo:st, ky:ky + st * Yo:st].reshape(M, cin).T @ dyb for kx in range(3) for ky in range(3)])
+        for ws_split in (1, 2, 5):
+            emu('es_dconv_set_option', 23, ws_split)
+            nfw = int(emu.fns['es_dconv_wgrad_workspace_floats'](P(g), 0, cin, cout))
+            assert (nfw > 0) == (ws_split > 1)
+            wsw = np.full(max(nfw, 4), np.nan, np.float32)
+            dw = np.full((9, cin, cout), np.nan, np.float32)
+            emu.launches()
+            emu('es_dconv_wgrad_ws_bf16', P(xh), cin, P(dyh), cout, P(g), 0, cin, cout, P(dw), 0, P(wsw), nfw, 0)
+            ran = emu.launches()
+            assert any('k_dconv_reduce' in k for k in ran) == (ws_split > 1)
+            assert np.abs(dw - wantw).max() / np.abs(wantw).max() < 2e-6, ('flat wgrad', st, ws_split)
+            dw2 = np.ones((9, cin, cout), np.float32)
+            emu('es_dconv_wgrad_ws_bf16', P(xh), cin, P(dyh), cout, P(g), 0, cin, cout, P(dw2), 1, P(wsw), nfw, 0)
+            assert np.abs(dw2 - 1 - wantw).max() / np.abs(wantw).max() < 2e-6, ('flat wgrad, accumulate', st, ws_split)
+        emu('es_dconv_set_option', 23, 0)
+
+
+def test_engine_fpn_output_convolution_dense_equals_image_map_path(emulated, monkeypatch):
+    """engine.conv(bias=..., dense=(n_img, h, w, 0, 3, 1, 1), maps=...) -- the FPN's 3x3 output convolution (models/necks/fpn.py) -- on the
+    dense engine (flat grid, bias pre-filled, row-sliced weight gradient) against the same call on the 9-wide image map: forward,
+    data gradient, weight and bias gradients through the tape, on the emulated library (this also pins the tap order of the two paths)"""
+    import torch
+    from embodiedscan_amd import engine as E, hip
+    from embodiedscan_amd.models.backbones.resnet2d import _Grid
+    dev = emulated
+    monkeypatch.setitem(_ListAsDict(E.PRECISION), 0, 'bf16')
+    gen = torch.Generator().manual_seed(8)
+    n_img, h, w_, cin, cout = 2, 9, 7, 256, 256
+    grid = _Grid(n_img, h, w_, dev)
+    n = n_img * h * w_
+    xd = torch.randn(n, cin, generator=gen)
+    wd = torch.randn(9, cin, cout, generator=gen) / (9 * cin) ** 0.5
+    bd = torch.randn(cout, generator=gen)
+    gy = torch.randn(n, cout, generator=gen)
+    res = {}
+    for dense_on in (True, False):
+        monkeypatch.setitem(_ListAsDict(E.DENSE), 0, dense_on)
+        x = E.Var(xd.clone())
+        x.g = torch.ones_like(xd)
+        w = E.Param(wd.clone(), torch.zeros_like(wd))
+        b = E.Param(bd.clone(), torch.zeros_like(bd))
+        w.bf_n, w.bf_t = torch.empty((9, cin, cout), dtype=torch.bfloat16), torch.empty((9, cout, cin), dtype=torch.bfloat16)
+        hip.call('es_cast_weight_bf16', hip.P(w.d), 9, cin, cout, hip.P(w.bf_n), hip.P(w.bf_t), 0)
+        w.bf_step = E.WEIGHT_VERSION[0]
+        E.TAPE.clear()
+        E.new_grad_epoch()
+        _launch_log()
+        y = E.conv(x, w, None, None, n, bias=b, dense=(n_img, h, w_, 0, 3, 1, 1), maps=lambda: grid.conv_map(3, 1, 1)[:2])
+        y.g = gy.clone()
+        E.TAPE.backward()
+        log = _launch_log()
+        assert ('k_dconv<' in log) == dense_on and ('k_dconv_wgrad' in log) == dense_on and ('k_image_map' in log) == (not dense_on), log
+        res[dense_on] = (y.d.clone(), x.g.clone(), w.g.clone(), b.g.clone())
+    for a, b_, name in zip(res[True], res[False], ('y', 'dx', 'dw', 'db')):
+        err = float((a - b_).abs().max() / b_.abs().max())
+        assert err < 2e-5, (name, err)

@@ -301,3 +301,51 @@ def test_pointwise_stride2_downsample_neck_shapes_vs_f32(X, Y, Z, cin, cout):
     call('es_dconv_wgrad_bf16', P(xh), cin, P(dyh), cout, g, 0, cin, cout, P(dw), 0, st_)
     wantw = xs.t() @ dyh.float()
     assert float((dw[0] - wantw).abs().max() / wantw.abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_fpn_output_convolution_dense_engine_vs_image_map_kernels():
+    """The FPN's 3x3 output convolution at the occupancy configuration's size (10 views x 120 x 160 pixels, 256 -> 256, bias) through
+    engine.conv: the dense engine on a flat grid (address arithmetic, bias pre-filled, weight gradient with its rows sliced over
+    ~27 workgroups per tile) against the 9-wide image-map kernels -- forward, data gradient, weight and bias gradients through the tape.
+    Tolerance 2e-5 of the largest magnitude (same bf16 operands, f32 accumulation order only)."""
+    from embodiedscan_amd import engine as E, hip
+    from embodiedscan_amd.models.backbones.resnet2d import _Grid
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(31)
+    n_img, h, w_, cin, cout = 10, 120, 160, 256, 256
+    grid = _Grid(n_img, h, w_, dev)
+    n = n_img * h * w_
+    xd = torch.randn(n, cin, generator=gen).to(dev)
+    wd = (torch.randn(9, cin, cout, generator=gen) / (9 * cin) ** 0.5).to(dev)
+    bd = torch.randn(cout, generator=gen).to(dev)
+    gy = torch.randn(n, cout, generator=gen).to(dev)
+    assert int(hip.raw('es_dconv_wgrad_workspace_floats')(_geom(n_img, h, w_, 0, 3, 1, 1), 0, cin, cout)) > 0      # row slices
+    res, prev_p, prev_d = {}, E.PRECISION[0], E.DENSE[0]
+    E.PRECISION[0] = 'bf16'
+    try:
+        for dense_on in (True, False):
+            E.DENSE[0] = dense_on
+            E.begin_bind(('test_fpn', dense_on))
+            try:
+                w = E.Param(wd.clone(), torch.zeros_like(wd))
+            finally:
+                E.end_bind()
+            b = E.Param(bd.clone(), torch.zeros_like(bd))
+            x = E.Var(xd.clone())
+            x.g = torch.ones_like(xd)
+            E.TAPE.clear()
+            E.new_grad_epoch()
+            y = E.conv(x, w, None, None, n, bias=b, dense=(n_img, h, w_, 0, 3, 1, 1), maps=lambda: grid.conv_map(3, 1, 1)[:2])
+            y.g = gy.clone()
+            E.TAPE.backward()
+            E.join_wgrad_streams()
+            torch.cuda.synchronize()
+            res[dense_on] = (y.d.clone(), x.g.clone(), w.g.clone(), b.g.clone())
+            E.release(('test_fpn', dense_on))
+    finally:
+        E.PRECISION[0], E.DENSE[0] = prev_p, prev_d
+        E.TAPE.clear()
+    for a, b_, name in zip(res[True], res[False], ('y', 'dx', 'dw', 'db')):
+        err = float((a - b_).abs().max() / b_.abs().max())
+        assert err < 2e-5, (name, err)
