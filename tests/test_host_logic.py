@@ -546,7 +546,7 @@ def test_bench_self_launches_its_ranks_when_no_launcher_is_around():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['allreduce_ok'] and out['master'].startswith('127.0.0.1:')
+    assert out['n_gpus'] == 2 and out['ranks'] == 2 and out['allreduce_ok'] and out['master'].startswith('127.0.0.1:')
     r = subprocess.run([sys.executable, bench, '--gpus', '2', '--dry-launch'], capture_output=True, text=True, timeout=120,
                        env=dict(env, WORLD_SIZE='1', RANK='0'), cwd='/tmp')
     assert r.returncode != 0 and 'torch.distributed.run' in r.stderr
