@@ -120,10 +120,14 @@ def test_config5_train_step_vs_oracle():
         if mode == 'f32':
             assert all(v < tol for v in rel.values()), {k: v for k, v in rel.items() if v >= tol}
         else:
-            # bf16: DIAGNOSTIC ONLY (printed above).  End-to-end bf16 gradients of 100+ layers with train-mode BatchNorm are chaotic in
+            # bf16: no tight gate (values printed above).  End-to-end bf16 gradients of 100+ layers with train-mode BatchNorm are chaotic in
             # the summation order; their arithmetic is gated per launch on the operands each launch saw (2e-4, spec in f64 on rocBLAS)
             # by tests/test_gpu_insitu.py::test_config5_scale_occupancy_step_in_situ.  Held here: finite and not identically zero.
             assert all(np.isfinite(v) for v in rel.values()) and all(bool(torch.isfinite(res[mode]['grads'][k]).all()) for k in rel)
+            # ... and a LOOSE numeric bound all the same: a zeroed tensor scores 1.0, an uncorrelated one (wrong tap mirror,
+            # wrong parity class) ~1.41, a flipped sign 2.0; the chaos described above measures 0.26 median / 0.33 worst (profiles/r5_*)
+            med = float(np.median(list(rel.values())))
+            assert rel[worst] < 0.9 and med < 0.6, (worst, rel[worst], med)
         big = [k for k in neck_keys if sd[k].shape[0] == 3072 and sd[k].shape[1] == 3072]
         assert big, 'the 3072 x 3072 level is missing from the watched tensors'
 

@@ -255,10 +255,13 @@ def test_occ_detector_train_step_vs_oracle(dev):
     worst = max(rel, key=rel.get)
     med, p90 = float(np.median(v)), float(v[int(0.9 * (len(v) - 1))])
     print(f'bf16 parameter gradients vs bf16-operand oracle: {len(v)} tensors, median {med:.2e}, 90th percentile {p90:.2e}, worst '
-          f'{rel[worst]:.2e} at {worst} -- DIAGNOSTIC ONLY, not a gate: two bf16 summation orders drift apart by the quantisation noise '
+          f'{rel[worst]:.2e} at {worst} -- loosely bounded (worst < 0.9, median < 0.6), not a tight gate: two bf16 summation orders drift apart by the quantisation noise '
           f'within a few layers and the train-mode BatchNorm backwards over 4 .. 256 rows amplify it; the arithmetic gate of every bf16 '
           f'backward launch (2e-4 on the operands it saw) is tests/test_gpu_insitu.py::test_every_conv_backward_of_a_bf16_occupancy_step_matches_its_specification')
     assert np.isfinite(v).all() and all(bool(torch.isfinite(g).all()) for g in res['bf16']['grads'].values())
+    # a LOOSE bound stays: a zeroed tensor scores 1.0, an uncorrelated one (wrong tap mirror / parity class) ~1.41, a
+    # flipped sign 2.0; summation-order chaos measures 0.28 - 0.38 median, 0.43 - 0.54 worst (profiles/r5_*)
+    assert rel[worst] < 0.9 and med < 0.6, (worst, rel[worst], med)
 
 
 def test_occ_full_width_forward_and_predict(dev):
