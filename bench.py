@@ -27,7 +27,8 @@ K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
 ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_fwd_bf16_io',
           'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src', 'es_dconv_fwd_bf16',
-          'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16'}
+          'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16', 'es_spconv_halo_bf16'}
+HALO = ('es_spconv_halo_bf16',)      # round 6: (Xh, ldx, W, loc, hrows, hcnt, n_out, n_in, K, Cin, Cout, bias, Y, ldy, acc, stream)
 DENSE = ('es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16')   # round 5: the dense-volume engine (csrc/dconv.hip)
 DENSE_WGRAD = ('es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16')
 FWD_X = ('es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_io')     # (X, x_half, ldx, W, nbr, n_out, n_in, K, Cin, Cout, ...)
@@ -1108,6 +1109,8 @@ def resolve_pairs(hip, records):
             continue
         if name == 'es_spconv_wgrad_bf16_src':
             key = a[6]
+        elif name in HALO:
+            key = a[3]                                   # (the plan's position table stands for the map)
         elif name in ENGINE:
             key = a[4] if (name.startswith('es_spconv_wgrad') or name in FWD_X) else a[3]
         out.append((name, e0, e1, a, hip.PAIRS.get(key)))
@@ -1120,6 +1123,8 @@ def engine_args(name, a):
         return 1, n_out, n_in, K, cin, cout
     if name == 'es_spconv_wgrad_bf16_src':      # (X, x_half, ldx, dY, dy_half, ldy, nbr, n_out, n_in, K, Cin, Cout, dW, stream)
         return a[6], a[7], a[8], a[9], a[10], a[11]
+    if name in HALO:
+        return a[3], a[6], a[7], a[8], a[9], a[10]
     if name in FWD_X:
         return a[4], a[5], a[6], a[7], a[8], a[9]
     if not name.startswith('es_spconv_wgrad'):
@@ -1152,7 +1157,7 @@ def engine_totals(records, mfma_peak):
             bx, by = (2.0 if a[1] else 4.0), (2.0 if a[4] else 4.0)
         elif name in DENSE_WGRAD:
             bx = by = 2.0
-        elif name in DENSE or (name in FWD_X and a[1]):
+        elif name in DENSE or name in HALO or (name in FWD_X and a[1]):
             bx = 2.0
         if name == 'es_spconv_fwd_bf16_io' and a[17]:           # bf16 activation rows written by the image backbone
             by = 2.0

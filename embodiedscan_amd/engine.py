@@ -517,6 +517,44 @@ def _use_shadow(n_rows, C, K, cin, cout):
     return K > 1 and hip.raw('es_spconv_bf16_is_fast')(n_rows, C, K, cin, cout) == 1
 
 
+# ------------------------------------------------------------------ halo-tile K = 27 convolutions (round 6, csrc/halo.hip)
+HALO = [os.environ.get('ES_HALO', '1') != '0']
+if os.environ.get('ES_HALO_MIN_WGS') is not None:
+    hip.raw('es_halo_set_option')(30, int(os.environ['ES_HALO_MIN_WGS']))
+
+
+def _halo_ok(nbr, n_out, n_in, ldx, K, cin, cout):
+    return (HALO[0] and K == 27 and nbr is not None
+            and hip.raw('es_spconv_halo_supported')(n_out, n_in, ldx, K, cin, cout) == 1)
+
+
+def halo_plan(nbr):
+    """(loc, hrows, hcnt) of a kernel map: per 256-row tile the sorted distinct source rows and the 16-bit positions of every
+    (row, tap) neighbour in that list (es_halo_plan).  Built on the current stream at first use and kept ON the map tensor, so it
+    lives and dies with the map's cache entry (sparse.CoordSet.kernel_map / inverse_map)."""
+    plan = getattr(nbr, '_halo', None)
+    if plan is None:
+        n_out, K = nbr.shape
+        rows = int(hip.raw('es_halo_plan_rows')(n_out))
+        loc = torch.empty((rows, K), dtype=torch.int16, device=nbr.device)
+        hrows = torch.empty((rows // 256, 256 * K), dtype=torch.int32, device=nbr.device)
+        hcnt = torch.empty((rows // 256,), dtype=torch.int32, device=nbr.device)
+        call('es_halo_plan', P(nbr), n_out, K, P(loc), P(hrows), P(hcnt), _stream())
+        plan = nbr._halo = (loc, hrows, hcnt)
+        if hip.PROFILE is not None:
+            hip.PAIRS[loc.data_ptr()] = (nbr >= 0).sum()
+    return plan
+
+
+def _halo_launch(Xh, ldx, Wp, nbr, n_out, n_in, K, cin, cout, bias_p, Y, ldy, acc):
+    """nbr: the launch's gather map.  The INVERSE map of a stride-1 convolution on one coordinate set is its forward map with the
+    taps mirrored (sparse.CoordSet.inverse_map marks it `_mirror_of`): such a data gradient runs on the forward map's plan."""
+    fwd = getattr(nbr, '_mirror_of', None)
+    loc, hrows, hcnt = halo_plan(fwd if fwd is not None else nbr)
+    call('es_spconv_halo_bf16', Xh, ldx, Wp, P(loc), P(hrows), P(hcnt), n_out, n_in, K, cin, cout, bias_p, Y, ldy, acc,
+         int(fwd is not None), _stream())
+
+
 def empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -627,8 +665,11 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0, dense=None
             y.d.copy_(bias.d.expand_as(y.d))      # register file: an epilogue that also held the bias spilled)
         _dense_launch(P(x.shadow()), cin, P(w.bf16()[1]), dn, 0, cin, cout, P(y.d), cout, 1 if bias else 0, x.d)
     elif bf and (x16 or (SHADOW[0] and _ld(x.d) == cin and _use_shadow(n_in, cin, K, cin, cout))):
-        _fwd_bf16(P(x.shadow()), 1, cin, P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0, P(y.d),
-                  cout, 0, x.d)
+        if _halo_ok(nbr, n_out, n_in, cin, K, cin, cout):
+            _halo_launch(P(x.shadow()), cin, P(w.bf16()[1]), nbr, n_out, n_in, K, cin, cout, P(bias.d) if bias else 0, P(y.d), cout, 0)
+        else:
+            _fwd_bf16(P(x.shadow()), 1, cin, P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0, P(y.d),
+                      cout, 0, x.d)
     elif bf:
         _fwd_bf16(P(x.d), 0, _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(bias.d) if bias else 0, P(y.d),
                   cout, 0, x.d)
@@ -715,6 +756,8 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         g, acc = _grad_target(x, x.d)
         if dn_d is not None:
             _dense_launch(P(gh), cout, P(w.bf16()[0]), dn_d, 1, cin, cout, P(g), _ld(g), acc, gh)
+        elif gh is not None and _halo_ok(inv, n_in, n_out, cout, K, cout, cin):
+            _halo_launch(P(gh), cout, P(w.bf16()[0]), inv, n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc)
         elif gh is not None:
             _fwd_bf16(P(gh), 1, cout, P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, 0, P(g), _ld(g), acc, gh)
         elif bf and cout >= 16:

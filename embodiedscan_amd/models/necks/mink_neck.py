@@ -63,7 +63,7 @@ class MinkNeck:
             c = x.children()
             if maps:
                 c.kernel_map(c, 3), c.inverse_map(c, 3)
-            u, _, _ = sparse.union(level_sets[i], c)
+            u, _, _ = sparse.union(c, level_sets[i])          # (generated children first: see _levels)
             off = u.offsets()
             if any(off[b + 1] - off[b] > thr for b in range(u.n_batch)):
                 break
@@ -84,8 +84,13 @@ class MinkNeck:
                 y = SparseTensor(x.cs.children(), bn1(E.gen_conv_transpose(x.F, wt), act=2, training=tr))
                 y = conv3(y, wc)
                 y = SparseTensor(y.cs, bn2(y.F, act=2, training=tr))
-                u, pa, pb = sparse.union(inputs[i].cs, y.cs)
-                x = SparseTensor(u, E.union_add(inputs[i].F, y.F, pa, pb, u.n))
+                # union rows = the generated children (Z order, inherited from the parents) followed by the few backbone voxels
+                # they do not cover -- NOT backbone first (rounds 1-5): a + b is the same sum, but with the children appended behind
+                # the backbone rows a 256-row tile's 3x3x3 neighbourhood straddled two row ranges and its halo (csrc/halo.hip) grew
+                # from ~470 to ~600-700 source rows (profiles/r6d_halo_stats_*.txt); ME's own row order is hash order, ours is a spec
+                # the oracle shares (oracle/model.py, oracle/grounding.py)
+                u, pa, pb = sparse.union(y.cs, inputs[i].cs)
+                x = SparseTensor(u, E.union_add(y.F, inputs[i].F, pa, pb, u.n))
                 x = self._prune(x, score_set, score)
             wo, bno = self.out[i]
             out = conv3(x, wo)

@@ -133,6 +133,11 @@ class CoordSet:
             K = ksize ** 3
             inv = torch.empty((self.n, K), dtype=torch.int32, device=self.device)
             call('es_inverse_map', P(nbr), out.n, K, self.n, P(inv), _stream())
+            if out is self and ksize % 2 == 1:
+                # a set's own odd-kernel map: row j is the neighbour of row i under offset d iff i is the neighbour of j under -d, and the
+                # taps are ordered so that offset(K - 1 - k) = -offset(k): inv[i][k] == nbr[i][K - 1 - k] (tests/test_gpu_halo.py checks it).
+                # The halo kernel runs such a data gradient on the forward map's plan with mirrored taps (engine._halo_launch).
+                inv._mirror_of = nbr
             self.cache[key] = (hip.register_map(inv), weakref.ref(out))
         return inv
 

@@ -481,6 +481,29 @@ int es_dconv_wgrad_ws_bf16(const void* Xh, int ldx, const void* dYh, int ldy, co
  * 22 slices per tile (0 auto), 23 row slices of a weight gradient launched with a workspace (0 auto) */
 int es_dconv_set_option(int key, int value);
 
+/* ---- halo-tile sparse convolution (round 6, csrc/halo.hip) ---------------------------------------------------------------
+ * K = 27 MinkowskiConvolution(kernel_size=3) forward / data gradient on the big sparse levels
+ * (embodiedscan/models/backbones/mink_resnet.py:88-140, dense_heads/fcaf3d_head.py:907-1020): the distinct source rows of a
+ * 256-row output tile (its halo: ~1.3 - 2.2 x the tile on Z-ordered sets) are staged in LDS once per 64-channel chunk and all 27
+ * taps run out of LDS; only the weight tiles stream.
+ * es_halo_plan: from a kernel map nbr[n_out][27] (es_kernel_map / es_inverse_map) -> loc[rows][27] uint16 (position of the
+ *   neighbour in its tile's halo list, 0xFFFF absent), hrows[tiles][256*27] int32 (the tile's sorted distinct source rows),
+ *   hcnt[tiles]; rows = es_halo_plan_rows(n_out) (whole tiles), tiles = rows / 256.  Cached with the map by the caller.
+ * es_spconv_halo_bf16: Y (n_out x ldy, f32) (+)= conv of the bf16 rows Xh (n_in x ldx) with W_bf16 = the [27][Cout][Cin] copy
+ *   (forward) or the natural [27][Cin][Cout] copy with the roles of Cin / Cout swapped and the plan of the inverse map (data
+ *   gradient).  Cin % 64, Cout % 128, ldx % 8; -4 otherwise.  A tile whose halo exceeds the 640 resident rows runs in pages
+ *   (slower, same result).  Fixed summation order: bit-reproducible.  mirror 1: tap k reads the plan's column 26 - k -- the data
+ *   gradient of a stride-1 convolution on ONE coordinate set (its inverse map is the forward map with the taps mirrored:
+ *   inv[i][k] == nbr[i][26 - k]) runs on the FORWARD map's plan, no second plan is built.
+ * es_spconv_halo_supported: 1 when the shape is taken AND the launch fills the chip (>= `min workgroups`, es_halo_set_option 30;
+ *   smaller launches belong to the tap-split gather kernels). */
+size_t es_halo_plan_rows(int n_out);
+int es_halo_plan(const int* nbr, int n_out, int K, void* loc, int* hrows, int* hcnt, void* stream);
+int es_halo_set_option(int key, int value);
+int es_spconv_halo_supported(int n_out, int n_in, int ldx, int K, int Cin, int Cout);
+int es_spconv_halo_bf16(const void* Xh, int ldx, const void* W_bf16, const void* loc, const int* hrows, const int* hcnt, int n_out,
+                        int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, int mirror, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -232,7 +232,7 @@ def mink_neck(xs, sd, batch_size, prefix='neck_3d.', voxel_size=0.01, thr=1000, 
     for i in range(n_lvl - 1, -1, -1):
         if i < n_lvl - 1:
             x = M._up_block(x, sd, f'{prefix}up_block_{i + 1}', training)
-            x = S.union_add(xs[i], x)
+            x = S.union_add(x, xs[i])          # rows: generated children first, then the backbone voxels they miss (our row-order spec, round 6)
             x = S.prune(x, M.prune_mask(x, score, thr))
         out = _block(x, sd, f'{prefix}out_block_{i}', training)
         cls = R.op(lambda a, b: a @ b, out.feats.detach(), sd[prefix + 'conv_cls.kernel'], out.feats.shape[1]) + sd[prefix + 'conv_cls.bias']

@@ -258,7 +258,7 @@ def head_forward(xs, sd, prefix='bbox_head.', voxel_size=0.01, thr=100000, train
     for i in range(n_lvl - 1, -1, -1):
         if i < n_lvl - 1:
             x = _up_block(x, sd, f'{prefix}up_block_{i + 1}', training)
-            x = S.union_add(xs[i], x)
+            x = S.union_add(x, xs[i])          # rows: generated children first, then the backbone voxels they miss (our row-order spec, round 6)
             x = S.prune(x, prune_mask(x, score, thr))
         out = _block(x, sd, f'{prefix}out_block_{i}', training)
         mm = lambda w: R.op(lambda a, b: a @ b, out.feats, w, out.feats.shape[1], 16)    # one padded 320-column GEMM on the device

@@ -80,7 +80,7 @@ def _oracle_levels(points_np, n_batch, voxel_size=0.01):
     heads[3] = x
     for i in (2, 1, 0):
         ch = C.gen_transpose_coords(x, 8 * 2 ** (i + 1))
-        x, _, _ = C.union_coords(lv[i], ch, n_batch)
+        x, _, _ = C.union_coords(ch, lv[i], n_batch)            # (round 6 row-order spec: generated children first)
         heads[i] = x
     return c, lv, heads
 
