@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64) void k_box_cd_pairs(const float* __restrict__ p
                                                      int n_rows, const float* __restrict__ gt_boxes,
                                                      const int* __restrict__ gt_off, float inv_mean, float grad_scale,
                                                      float w0, float w1, float w2, float w3, float* __restrict__ dpred,
-                                                     float* __restrict__ loss_acc) {
+                                                     double* __restrict__ loss_acc) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = tid >> 2, grp = tid & 3;
   float lb = 0.f;
@@ -537,10 +537,14 @@ __global__ __launch_bounds__(64) void k_box_cd_pairs(const float* __restrict__ p
     }
   }
   lb = es_wave_sum(lb);
-  if ((threadIdx.x & 63) == 0 && lb != 0.f) unsafeAtomicAdd(loss_acc, lb);    // loss VALUE only (gradients are per row)
+  // loss VALUE only (gradients are per row).  Round 6: accumulated in f64 like k_pos_losses / k_ground_focal -- the f32 atomic made the
+  // reported loss_bbox depend on the arrival order of ~190 workgroups (1 ulp from run to run: tools/bisect_determinism.py found every
+  // Var and gradient of two grounder builds bit-identical and only these scalars apart); a wave's f32 sum is taken in a fixed order, the
+  // f64 sum of those exact f32 terms does not depend on the order after rounding back to f32
+  if ((threadIdx.x & 63) == 0 && lb != 0.f) unsafeAtomicAdd(loss_acc, (double)lb);
 }
 extern "C" int es_box_cd_pairs(const float* pred, const int* q2g, int B, int Q, const float* gt_boxes, const int* gt_off_dev,
-                               int n_pairs, float grad_scale, const float* group_w, float* dpred, float* loss_acc,
+                               int n_pairs, float grad_scale, const float* group_w, float* dpred, double* loss_acc,
                                void* stream) {
   int n = B * Q;
   if (n <= 0 || n_pairs <= 0) return 0;

@@ -178,14 +178,14 @@ class GroundingHead:
             logits.g = torch.empty_like(logits.d)
             call('es_ground_focal', P(logits.d), T, B, Q, P(q2g), P(pos_map), P(gt_off), P(tlen), T, self.focal_alpha,
                  self.focal_gamma, P(avg), self.loss_cls_weight, P(logits.g), P(lsum), s)
-            lbox = torch.zeros(1, dtype=torch.float32, device=dev)
+            lbox = torch.zeros(1, dtype=torch.float64, device=dev)         # (f64 accumulator: order-independent, see csrc/losses.hip)
             boxes.g = torch.zeros_like(boxes.d)
             if n_pos:
                 call('es_box_cd_pairs', P(boxes.d), P(q2g), B, Q, P(gt_boxes), P(gt_off), n_pos, 1.0, gwa, P(boxes.g), P(lbox), s)
             loss_cls = (lsum.float() / (avg + eps) * self.loss_cls_weight)[0]
             name = '' if l == L - 1 else f'd{l}.'
             losses[name + 'loss_cls'] = loss_cls
-            losses[name + 'loss_bbox'] = lbox[0]
+            losses[name + 'loss_bbox'] = lbox.float()[0]
             self.last.append(dict(logits=logits, boxes=boxes, q2g=q2g))
             if getattr(self, 'force_assign', None) is not None:
                 self.last[-1]['q2g_free'] = free

@@ -435,10 +435,10 @@ int es_ground_match(const float* logits, int Tout, const float* boxes, int B, in
 int es_ground_focal(const float* logits, int Tout, int B, int Q, const int* q2g, const unsigned char* pos_map,
                     const int* gt_off_dev, const int* tlen_dev, int T, float alpha, float gamma, const float* avg_factor_dev,
                     float grad_scale, float* dlogits, double* loss_sum, void* stream);
-/* 4-group decoupled corner-Chamfer loss on the matched (prediction, target) pairs of a batch: loss_acc[0] += weighted mean
+/* 4-group decoupled corner-Chamfer loss on the matched (prediction, target) pairs of a batch: loss_acc[0] (f64: the sum must not depend on the arrival order of the workgroups) += weighted mean
  * over n_pairs*8 corners; dpred (B*Q,9) written at matched rows.  grounding_head.py:750-822, losses/chamfer_distance.py */
 int es_box_cd_pairs(const float* pred, const int* q2g, int B, int Q, const float* gt_boxes, const int* gt_off_dev, int n_pairs,
-                    float grad_scale, const float* group_w_host, float* dpred, float* loss_acc, void* stream);
+                    float grad_scale, const float* group_w_host, float* dpred, double* loss_acc, void* stream);
 /* per-sample indices of the k largest values, descending, ties by lower row; segment length <= 8192 */
 int es_topk_sorted(const float* vals, int B, int L, const int* vlen_dev, int k, int* idx, void* stream);
 

@@ -239,7 +239,7 @@ def test_matching_and_losses_vs_reference(dev):
     lsum = torch.zeros(1, dtype=torch.float64, device=dev)
     call('es_ground_focal', P(logits), T, B, Q, P(q2g), P(pos_map), P(gt_off), P(tlen), T, 0.25, 2.0, P(avg), 1.0, P(dlog), P(lsum), st)
     dbox = torch.zeros_like(boxes)
-    lbox = torch.zeros(1, device=dev)
+    lbox = torch.zeros(1, dtype=torch.float64, device=dev)
     call('es_box_cd_pairs', P(boxes), P(q2g), B, Q, P(gt_boxes), P(gt_off), n_pos, 1.0, farr([0.2, 0.2, 0.2, 0.4]), P(dbox), P(lbox), st)
     torch.cuda.synchronize()
     lc = float(lsum) / (float(avg) + float(torch.finfo(torch.float32).eps))

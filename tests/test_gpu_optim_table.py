@@ -103,12 +103,8 @@ def test_train_steps_one_pass_equals_two_pass(name):
         E.PRECISION[0] = 'f32'
         O.ADAMW_CAST[0] = os.environ.get('ES_ADAMW_CAST', '1') != '0'
     assert a['path'] == 'table' and b['path'] == 'flat'
-    if 'grounding' in name:
-        # the grounding step is not bit-reproducible from build to build (its FIRST losses already differ in the last digits, before any
-        # optimiser step); its paramwise multipliers are covered bit for bit by the kernel-level test above.  Here: same path taken, the
-        # copies checked inside run(), and the two runs agree to bf16 accuracy after three steps
-        for la, lb in zip(a['losses'], b['losses']):
-            assert all(abs(la[k] - lb[k]) <= 5e-2 * max(1.0, abs(lb[k])) for k in lb), (la, lb)
-        return
+    # (Round 6: the grounding step is bit-reproducible from build to build as well.  Until round 5 its FIRST losses differed in the last
+    # digit: tools/bisect_determinism.py found every Var and every gradient of two builds identical and only the reported loss_bbox
+    # scalars apart -- an f32 atomic over ~190 workgroups in k_box_cd_pairs, now an f64 accumulator like the other loss values.)
     assert a['losses'] == b['losses'], (a['losses'], b['losses'])
     assert torch.equal(a['params'], b['params']) and torch.equal(a['m'], b['m']) and torch.equal(a['v'], b['v'])
