@@ -504,7 +504,7 @@ def main():
 
     # static PMC figures of the same command (separate rocprofv3 --pmc passes, see profiles/): bytes per engine launch
     traffic, traffic_extra, traffic_note = None, {}, 'traffic: null (no PMC summary for this precision under profiles/)'
-    for name in ('r5_pmc_traffic.json', 'r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_final_pmc_traffic.json'):
+    for name in ('r6_pmc_traffic.json', 'r5_pmc_traffic.json', 'r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json', 'r1_final_pmc_traffic.json'):
         pmc_file = os.path.join(ROOT, 'profiles', name)
         if args.precision == 'bf16' and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
@@ -853,7 +853,7 @@ def run_other_config(kind, args, dev):
                                             args=[x for x in a if isinstance(x, int) and abs(x) < (1 << 31)])) + '\n')
 
     traffic, traffic_dense, tnote = None, None, 'traffic: null (no PMC summary committed for this configuration)'
-    for tag in ('r5', 'r4', 'r3'):
+    for tag in ('r6', 'r5', 'r4', 'r3'):
         pmc_file = os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic_{kind}.json')
         if args.precision == 'bf16' and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))

@@ -12,7 +12,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILY = {
     # the convolution engine: every kernel behind the es_spconv_* entry points (+ their split reductions)
-    'mv3ddet': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits', 'k_dconv'),
+    'mv3ddet': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits', 'k_dconv', 'k_halo_plan'),     # round 6: + the halo kernel (k_spconv_halo) and its plan
     'occupancy': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits', 'k_dconv'),     # round 5: + the dense-volume engine
     'grounding': ('k_attn_',),
 }
