@@ -15,8 +15,8 @@
 //     barrier per step).  Tile 256 rows x 128 columns, 8 waves as 4 x 2 (64 x 64 each: 16 accumulator fragments), one
 //     workgroup per CU (126 KB of LDS).  L2 -> LDS traffic per tile and chunk: 59 KB of halo + 27 x 16 KB of weights, where the
 //     gather kernels move 27 x (32 + 16) KB for the same 256 rows.
-//   * a tile whose halo exceeds the 640 resident rows (never seen on Z-ordered sets; possible on adversarial row orders) is
-//     processed in PAGES of 640 halo rows: every page runs all taps, positions outside the page read the zero row -- slower,
+//   * a tile whose halo exceeds the 704 resident rows (never seen on Z-ordered sets; possible on adversarial row orders) is
+//     processed in PAGES of 704 halo rows: every page runs all taps, positions outside the page read the zero row -- slower,
 //     never wrong, no second kernel.
 // Arithmetic: bf16 operands, f32 accumulation on v_mfma_f32_16x16x32_bf16, additions in (chunk, page, tap) order -- a fixed
 // order: run-to-run bit-identical; differs from the gather kernels' (tap, chunk) order in f32 rounding only.
@@ -38,7 +38,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 #define HL_BM 256                 // output rows per tile
 #define HL_K 27
-#define HL_UMAX 640               // halo rows resident per page
+#define HL_UMAX 704               // halo rows resident per page (in situ: mean 470 - 520, max 711 on the pruned finest level)
 #define HL_HT 8192                // plan: LDS hash slots per tile (>= 256 * 27 = 6 912 distinct rows at worst)
 
 __device__ __attribute__((aligned(16))) unsigned short g_hl_zero[8];

@@ -89,6 +89,7 @@ def refresh_weight_copies():
 # tagged with the owner that was binding when they were made (a detector passes id(self) to begin_bind()); re-binding or
 # releasing an owner drops its old entries, so a process that builds several detectors neither leaks their arenas nor
 # keeps re-casting stale weights, and the tables of different devices never mix pointers.
+_GC_FROZEN = [False]
 CONV_PARAMS = {}          # torch.device -> [Param]
 _CAST_TABLE = {}          # torch.device -> dict(dev=table tensor, n, tiles, params, set)
 _OWNER = [None]
@@ -105,6 +106,12 @@ def end_bind():
 
 
 def release(owner):
+    """forget what detector `owner` registered here; objects frozen out of the collector's sight by settle_gc (gc.freeze at the
+    detector's 6th step: everything alive then, the dropped detector's graph included) are handed back to it"""
+    if _GC_FROZEN[0]:
+        import gc
+        gc.unfreeze()
+        _GC_FROZEN[0] = False
     for dev in list(CONV_PARAMS):
         keep = [p for p in CONV_PARAMS[dev] if p.owner != owner]
         if len(keep) != len(CONV_PARAMS[dev]):
@@ -433,6 +440,7 @@ def settle_gc(det):
         import gc
         gc.collect()
         gc.freeze()
+        _GC_FROZEN[0] = True                     # (release() unfreezes)
 
 
 def reset_tickets():
@@ -599,6 +607,13 @@ def dense_ok(dense, mode, cin, cout):
         # weight gradient of a 1x1x1 convolution: one workgroup per 256 x 256 channel tile walking every row -- the neck's 768 -> 1536
         # down-sample would launch 18 of them (134 us against the map kernel's row-split 49 us, profiles/r5p_occ_launches.jsonl)
         return False
+    # the library's own 32-bit index limits (rows x leading dimension, taps x channels^2: es_dconv_* return -4 beyond them) are part of
+    # the answer, so that such a shape falls back to the map kernels instead of raising; callers check contiguity
+    B, X, Y, Z, ks = dense[:5]
+    rows = B * X * Y * max(Z, 1) * (8 if mode >= 3 else 1)
+    taps = ks ** (2 if Z == 0 else 3)
+    if rows * max(cin, cout) >= (1 << 31) or taps * cin * cout >= (1 << 31):
+        return False
     return hip.raw('es_dconv_supported')(_dense_geom(dense), mode, cin, cout) == 1
 
 
@@ -720,7 +735,8 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         sw = _wgrad_stream(gy, x.d, gh, x.dh)
     if dn_w is not None:
         _dense_wgrad(P(x.dh), cin, P(gh), cout, dn_w, 0, cin, cout, P(w.g), _first_write(P(w.g)), sw, gh)
-    elif w.g is not None and bf and WGRAD_BF16[0] and SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None):
+    elif w.g is not None and bf and WGRAD_BF16[0] and ((SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None))
+                                                  or x.d.dtype == torch.bfloat16):      # (bf16 activation rows ARE their shadow: ES_SHADOW=0 must not strand them)
         xs, ys = x.dh if x.dh is not None else x.d, gh if gh is not None else gy
         _wgrad('es_spconv_wgrad_bf16_src', sw, P(w.g), P(xs), int(x.dh is not None), _ld(xs), P(ys), int(gh is not None), _ld(ys),
                P(nbr), n_out, n_in, K, cin, cout)

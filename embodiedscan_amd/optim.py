@@ -54,6 +54,21 @@ class OptimWrapper:
         self.groups = groups
 
     def _adamw_table(self, arena):
+        """_adamw_table_build with BOTH outcomes cached per (cast table, arena, groups): a negative answer (aliased / strided
+        kernels: the two-pass path) used to rebuild the whole table on every step"""
+        from . import engine as E
+        tab = E._CAST_TABLE.get(arena.data.device) if (ADAMW_CAST[0] and E.PRECISION[0] == 'bf16' and arena.data.is_cuda) else None
+        if tab is None:
+            return None
+        key = (id(tab), arena.data.data_ptr(), arena.n_train, id(self.groups))
+        if getattr(self, '_table_none', None) == key:
+            return None
+        res = self._adamw_table_build(arena)
+        if res is None:
+            self._table_none = (id(tab), arena.data.data_ptr(), arena.n_train, id(self.groups))     # (groups may have been built inside)
+        return res
+
+    def _adamw_table_build(self, arena):
         """rows of es_adamw_table for this arena, or None when the one-pass update does not apply: every trainable convolution
         kernel registered with the engine's cast table that lives in this arena becomes a tile row, the rest of the trainable
         arena (norm parameters, biases, padding) plain ranges, each with the (lr_mult, decay_mult) of its paramwise group"""

@@ -491,7 +491,7 @@ int es_dconv_set_option(int key, int value);
  *   hcnt[tiles]; rows = es_halo_plan_rows(n_out) (whole tiles), tiles = rows / 256.  Cached with the map by the caller.
  * es_spconv_halo_bf16: Y (n_out x ldy, f32) (+)= conv of the bf16 rows Xh (n_in x ldx) with W_bf16 = the [27][Cout][Cin] copy
  *   (forward) or the natural [27][Cin][Cout] copy with the roles of Cin / Cout swapped and the plan of the inverse map (data
- *   gradient).  Cin % 64, Cout % 128, ldx % 8; -4 otherwise.  A tile whose halo exceeds the 640 resident rows runs in pages
+ *   gradient).  Cin % 64, Cout % 128, ldx % 8; -4 otherwise.  A tile whose halo exceeds the 704 resident rows runs in pages
  *   (slower, same result).  Fixed summation order: bit-reproducible.  mirror 1: tap k reads the plan's column 26 - k -- the data
  *   gradient of a stride-1 convolution on ONE coordinate set (its inverse map is the forward map with the taps mirrored:
  *   inv[i][k] == nbr[i][26 - k]) runs on the FORWARD map's plan, no second plan is built.

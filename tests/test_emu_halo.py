@@ -1,7 +1,7 @@
 """The halo-tile sparse convolution (embodiedscan_amd/csrc/halo.hip: es_halo_plan + es_spconv_halo_bf16) under the CDNA emulator of
 tests/emu: the plan against a numpy restatement (sorted distinct source rows per 256-row tile, 16-bit positions), the convolution
 against an f64 evaluation on the bf16-rounded operands -- local maps (the halo fits), ragged last tiles, two column tiles,
-bias / accumulate, absent neighbours, inactive taps, and SCATTERED maps whose halo exceeds the 640 resident rows (paged path) --
+bias / accumulate, absent neighbours, inactive taps, and SCATTERED maps whose halo exceeds the 704 resident rows (paged path) --
 under two thread schedules and with late LDS-DMA delivery; and against the gather kernel (es_spconv_fwd_bf16) on the same
 operands.  TEST INFRASTRUCTURE: the product binds libes_hip.so only."""
 import ctypes
@@ -89,7 +89,7 @@ def test_halo_convolution_matches_f64_and_the_gather_kernel(emu, lazy):
         for n_out, n_in, cin, cout, fill, dead, bias, acc, ext in cases:
             nbr = _local_map(rng, n_out, n_in, fill, dead_taps=dead)
             xh, wt, b, y, umax = _run(emu, rng, n_out, n_in, cin, cout, nbr, bias, acc, ext)
-            assert umax <= 640
+            assert umax <= 704
             if not acc and not ext:                               # the gather kernel on the same operands: same products, another order
                 y2 = np.zeros((n_out, cout), np.float32)
                 emu('es_spconv_fwd_bf16', P(xh), 1, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(b), P(y2), cout, 0, 0)
@@ -99,14 +99,14 @@ def test_halo_convolution_matches_f64_and_the_gather_kernel(emu, lazy):
 
 
 def test_halo_pages_when_the_halo_exceeds_the_resident_rows(emu):
-    """a scattered map (rows in hash order, not Z order): ~1 500 distinct source rows per tile -> three pages of 640"""
+    """a scattered map (rows in hash order, not Z order): ~1 500 distinct source rows per tile -> three pages of 704"""
     rng = np.random.default_rng(77)
     n_out, n_in, cin, cout = 300, 3000, 64, 128
     nbr = np.full((n_out, K), -1, np.int32)
     m = rng.random((n_out, K)) < 0.3
     nbr[m] = rng.integers(0, n_in, int(m.sum()))
     *_, umax = _run(emu, rng, n_out, n_in, cin, cout, nbr, bias=True)
-    assert umax > 2 * 640                                          # really paged
+    assert umax > 2 * 704                                          # really paged
 
 
 @pytest.mark.parametrize('lazy', [0, 1])
@@ -124,9 +124,9 @@ def test_halo_one_tap_groups(emu, lazy):
         nbr = np.full((n_out, K), -1, np.int32)
         nbr[:, 4] = rng.permutation(n_in)[:n_out]                # 256 distinct rows per tile... one page
         nbr[:, 9] = rng.permutation(n_in)[:n_out]
-        nbr[:, 20] = rng.permutation(n_in)[:n_out]               # 3 x 256 > 640: two pages, three taps
+        nbr[:, 20] = rng.permutation(n_in)[:n_out]               # 3 x 256 > 704: two pages, three taps
         *_, umax = _run(emu, rng, n_out, n_in, cin, cout, nbr, bias=True)
-        assert umax > 640
+        assert umax > 704
         nbr2 = np.full((n_out, K), -1, np.int32)
         nbr2[:, 7] = nbr[:, 4]
         _run(emu, rng, n_out, n_in, 192, cout, nbr2)             # three chunks, one tap

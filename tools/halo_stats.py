@@ -1,5 +1,5 @@
 """in-situ halo statistics (dev tool): one mv-3ddet train step at the bench's batch; for every halo plan built: rows, halo rows per
-256-row tile (mean / p95 / max), tiles beyond the 640 resident rows"""
+256-row tile (mean / p95 / max), tiles beyond the 704 resident rows"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,4 +35,4 @@ for n, hc in plans:
     h = hc.float()
     q = torch.quantile(h, torch.tensor([0.5, 0.95], device=dev))
     print(f'rows {n:7d} tiles {hc.numel():5d} halo mean {float(h.mean()):7.1f} median {float(q[0]):6.0f} p95 {float(q[1]):6.0f} max {int(h.max()):5d} '
-          f'tiles > 640: {int((hc > 640).sum()):5d} ({float((hc > 640).float().mean()) * 100:.1f} %) pages total {int(((hc + 639) // 640).clamp(min=1).sum())}')
+          f'tiles > 704: {int((hc > 704).sum()):5d} ({float((hc > 704).float().mean()) * 100:.1f} %) pages total {int(((hc + 703) // 704).clamp(min=1).sum())}')
