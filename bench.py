@@ -27,7 +27,8 @@ K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
 ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_fwd_bf16_io',
           'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src', 'es_dconv_fwd_bf16',
-          'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16', 'es_spconv_halo_bf16'}
+          'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16', 'es_spconv_halo_bf16', 'es_img_wgrad9_bf16'}
+IMGW = ('es_img_wgrad9_bf16',)       # round 6: (Xh, ldx, dY, ldy, n_img, H, W, C, dW, acc, ws, ws_floats, stream)
 HALO = ('es_spconv_halo_bf16',)      # round 6: (Xh, ldx, W, loc, hrows, hcnt, n_out, n_in, K, Cin, Cout, bias, Y, ldy, acc, stream)
 DENSE = ('es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16')   # round 5: the dense-volume engine (csrc/dconv.hip)
 DENSE_WGRAD = ('es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16')
@@ -986,7 +987,7 @@ def launch_classes(records, mfma_peak, top=6):
         if name not in ENGINE:
             continue
         nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
-        kind = 'wgrad' if (name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD) else 'fwd/dgrad'
+        kind = 'wgrad' if (name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD or name in IMGW) else 'fwd/dgrad'
         if name in DENSE:
             kind += ' dense'
         key = f'{kind} K={K} {cin}->{cout}'
@@ -1107,6 +1108,9 @@ def resolve_pairs(hip, records):
         if name in DENSE:
             out.append((name, e0, e1, a, dense_info(name, a)[5]))
             continue
+        if name in IMGW:                                 # valid (pixel, tap) pairs of a 3x3 / pad 1 / stride 1 image convolution
+            out.append((name, e0, e1, a, float(a[4]) * (3 * a[5] - 2) * (3 * a[6] - 2)))
+            continue
         if name == 'es_spconv_wgrad_bf16_src':
             key = a[6]
         elif name in HALO:
@@ -1125,6 +1129,8 @@ def engine_args(name, a):
         return a[6], a[7], a[8], a[9], a[10], a[11]
     if name in HALO:
         return a[3], a[6], a[7], a[8], a[9], a[10]
+    if name in IMGW:
+        return 1, a[4] * a[5] * a[6], a[4] * a[5] * a[6], 9, a[7], a[7]
     if name in FWD_X:
         return a[4], a[5], a[6], a[7], a[8], a[9]
     if not name.startswith('es_spconv_wgrad'):
@@ -1145,7 +1151,7 @@ def engine_totals(records, mfma_peak):
             pairs = pairs_dev
         else:
             pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
-        wgrad = name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD
+        wgrad = name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD or name in IMGW
         wb = 2 if ('bf16' in name and not wgrad) else 4
         f = 2.0 * pairs * cin * cout
         pb = pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wb
@@ -1155,6 +1161,8 @@ def engine_totals(records, mfma_peak):
         bx = by = 4.0
         if name == 'es_spconv_wgrad_bf16_src':
             bx, by = (2.0 if a[1] else 4.0), (2.0 if a[4] else 4.0)
+        elif name in IMGW:
+            bx = 2.0                                     # bf16 activation rows, f32 gradient rows
         elif name in DENSE_WGRAD:
             bx = by = 2.0
         elif name in DENSE or name in HALO or (name in FWD_X and a[1]):

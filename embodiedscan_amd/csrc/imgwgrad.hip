@@ -1,0 +1,232 @@
+// Weight gradient of the image backbone's 3x3 convolutions on small channel counts (round 6; SURVEY 8a row A7: mmdet.ResNet
+// depth 50, base_channels 16 -- configs/detection/mv-det3d_8xb4_embodiedscan-3d-284class-9dof.py:24-34 -- Bottleneck.conv2 of
+// layer2 / layer3: 32 -> 32 on 120 x 120 and 64 -> 64 on 60 x 60 feature maps, 80 images per mv-3ddet step).
+//
+// dW[t][ci][co] = sum over (image, y, x) of X[y + ty - 1][x + tx - 1][ci] * dY[y][x][co],  t = ty * 3 + tx, zero padding.
+//
+// The map kernel (k_spconv_wgrad_bf16<1, 0>, spconv.hip) runs one workgroup per (tap, row slice): it compacts (row, neighbour)
+// pairs through a ring, gathers 2 x 4 channels per thread and chunk, stores them transposed to LDS and issues FOUR MFMAs behind
+// two barriers -- 4 % MFMA busy, 83 % of the wave cycles waiting (profiles/r6m_mfma_util.txt), 150 us for a 55 MB problem.  On an
+// image grid nothing has to be gathered or compacted: the neighbour of pixel x under tap tx is pixel x + tx - 1 of an image row
+// that is already in LDS.  Here
+//   * a workgroup owns a band of output rows of ONE image and ALL nine taps: wave w holds dW[.][16 w .. 16 w + 16][.] for the nine
+//     taps in registers (9 x C / 16 accumulator fragments), so X and dY are each read from memory ONCE (the map kernel: once per tap);
+//   * the image rows live in a four-slot LDS ring ((W + 2) pixels, the two pad pixels stay zero: no border test in the loop),
+//     filled by LDS-DMA one output row ahead; the dY row (f32 in memory) is prefetched into registers one row ahead, rounded to
+//     bf16 and stored to one of two LDS tiles: one barrier per output ROW (72 / 144 MFMAs per wave behind it);
+//   * both MFMA operands are read TRANSPOSED from their natural [pixel][channel] layout by ds_read_b64_tr_b16 (as k_dconv_wgrad):
+//     A = X^T (16 ci x 32 pixels, shifted by the tap), B = dY (32 pixels x 16 co);
+//   * partial dW tensors per workgroup go to a workspace and are added in workgroup order by k_img_wgrad_reduce: bit-reproducible.
+// Arithmetic: bf16 operands (dY rounded to nearest even like every gradient shadow), f32 accumulation; the summation order
+// differs from the map kernel's, the products do not.
+#include "common.h"
+#include "../../include/es_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __attribute__((aligned(16))) unsigned short g_iw_zero[8];
+
+// C channels (= Cin = Cout), WP = padded output width (multiple of 32, >= W)
+template <int C, int WP>
+__global__ __launch_bounds__(C * 4) void k_img_wgrad9(const unsigned short* __restrict__ Xh, int ldx,
+                                                      const float* __restrict__ dY, int ldy, int H, int W, int rows_per_wg,
+                                                      int bands, float* __restrict__ out /* dW or ws[wg][9][C][C] */,
+                                                      int to_ws, int accumulate) {
+  constexpr int NW = C / 16, NT = NW * 64;                 // waves / threads per workgroup
+  constexpr int RB = C * 2;                                 // bytes per pixel row of an LDS tile
+  constexpr int XP = WP + 2;                                // pixels per ring slot: x = -1 .. WP (pads and the tail stay zero)
+  constexpr int X_BYTES = XP * RB, Y_BYTES = WP * RB;
+  constexpr int NF = C / 16;
+  constexpr int GX = RB / 16;                               // 16-byte granules per pixel row
+  constexpr int NPX = WP * GX / NT;                         // LDS-DMA pieces per thread and image row
+  static_assert(WP * GX % NT == 0 && (WP * C / 4) % NT == 0, "whole pieces per row");
+  constexpr int NLY = (WP * C / 4 + NT - 1) / NT;           // float4 loads per thread and dY row
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * X_BYTES + 2 * Y_BYTES];
+  unsigned char* const ytile = smem + 4 * X_BYTES;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int im = blockIdx.x / bands, band = blockIdx.x - im * bands;
+  const int oy0 = band * rows_per_wg, oy1 = min(H, oy0 + rows_per_wg);
+  if (oy0 >= oy1) return;
+
+  for (int i = t; i < (4 * X_BYTES + 2 * Y_BYTES) / 16; i += NT) ((uint4*)smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+
+  f32x4 acc[9][NF];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // image row iy -> ring slot iy & 3, pixels 0 .. W - 1 at LDS pixels 1 .. W (granules past W read a zero granule: the tail stays zero)
+  auto issue_x = [&](int iy) {
+    if (iy < 0 || iy >= H) return;                          // (uniform)
+    const unsigned short* src = Xh + ((size_t)im * H + iy) * W * ldx;
+    unsigned char* dst = smem + (iy & 3) * X_BYTES + RB;
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      const int e = (j * NW + wv) * 64 + lane;              // granule of the row: pixel e / GX, granule e % GX
+      const int px = e / GX, g = e - px * GX;
+      const unsigned short* p = px < W ? (src + (size_t)px * ldx + g * 8) : g_iw_zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)(dst + (j * NW + wv) * 1024), 16, 0, 0);
+    }
+  };
+  float4 yreg[NLY];
+  auto load_y = [&](int oy) {                                // dY row oy -> registers (f32)
+    const float* src = dY + ((size_t)im * H + oy) * W * ldy;
+#pragma unroll
+    for (int j = 0; j < NLY; ++j) {
+      const int e = j * NT + t;                             // float4 index: pixel e / (C / 4), channel quad e % (C / 4)
+      const int px = e / (C / 4), c4 = e - px * (C / 4);
+      yreg[j] = (oy < oy1 && px < W) ? *(const float4*)(src + (size_t)px * ldy + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_y = [&](int buf) {                              // registers -> bf16 tile (pixels >= W: zeros)
+#pragma unroll
+    for (int j = 0; j < NLY; ++j) {
+      const int e = j * NT + t;
+      const int px = e / (C / 4), c4 = e - px * (C / 4);
+      if (px < WP) {
+        uint2 v;
+        v.x = es_pack_bf16(yreg[j].x, yreg[j].y);
+        v.y = es_pack_bf16(yreg[j].z, yreg[j].w);
+        *(uint2*)(ytile + buf * Y_BYTES + px * RB + c4 * 8) = v;
+      }
+    }
+  };
+  // transposed fragment: 8 consecutive pixels (p0 + kq * 8 ..) of channel cb * 16 + li from a [pixel][channel] tile
+  auto frag = [&](const unsigned char* tile, int p0, int cb) -> bf16x8_t {
+    s16x4_t h[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int px = p0 + kq * 8 + r * 4 + (li >> 2);
+      const unsigned char* a = tile + px * RB + cb * 32 + (li & 3) * 8;
+      h[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
+    }
+    s16x8_t v = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  // prologue: image rows oy0 - 1, oy0, oy0 + 1 and the first dY row
+  issue_x(oy0 - 1);
+  issue_x(oy0);
+  issue_x(oy0 + 1);
+  load_y(oy0);
+  for (int oy = oy0; oy < oy1; ++oy) {
+    const int buf = (oy - oy0) & 1;
+    store_y(buf);                                            // (the tile was last read two rows ago: a barrier has passed since)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of image row oy + 1 have landed ...
+    __syncthreads();                                          // ... everybody's; the dY tile is complete; row oy - 1 has been consumed
+    issue_x(oy + 2);                                         // slot (oy + 2) & 3 = (oy - 2) & 3: free
+    load_y(oy + 1);
+    const unsigned char* yt = ytile + buf * Y_BYTES;
+#pragma unroll 1
+    for (int p0 = 0; p0 < WP; p0 += 32) {
+      if (p0 >= W) break;
+      bf16x8_t b[NF];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) b[nf] = frag(yt, p0, nf);
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const int iy = oy + ty - 1;
+        if (iy < 0 || iy >= H) continue;                    // (uniform: a row outside the image contributes nothing)
+        const unsigned char* xt = smem + (iy & 3) * X_BYTES;
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const bf16x8_t a = frag(xt, p0 + tx, wv);          // LDS pixel of x + tx - 1 is x + tx
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf)
+            acc[ty * 3 + tx][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nf], acc[ty * 3 + tx][nf], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* const dst = to_ws ? out + (size_t)blockIdx.x * 9 * C * C : out;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* p = dst + ((size_t)tp * C + wv * 16 + kq * 4 + r) * C + nf * 16 + li;
+        *p = (!to_ws && accumulate) ? (*p + acc[tp][nf][r]) : acc[tp][nf][r];
+      }
+}
+
+// dW (+)= sum over the workgroups' partial tensors, in workgroup order
+__global__ void k_img_wgrad_reduce(const float* __restrict__ ws, int parts, int n, float* __restrict__ dW, int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  int p = 0;
+  for (; p + 8 <= parts; p += 8) {                            // eight loads in flight, added in order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(p + u) * n + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; p < parts; ++p) s += ws[(size_t)p * n + e];
+  dW[e] = accumulate ? dW[e] + s : s;
+}
+
+static int ES_OPT_IMG_WGRAD = 1;
+static int ES_OPT_IMG_WGRAD_WGS32 = 400, ES_OPT_IMG_WGRAD_WGS64 = 160;      // workgroups a launch aims for (partial tensors: 36 / 147 KB each)
+extern "C" int es_img_wgrad_set_option(int key, int value) {
+  if (key == 40) { ES_OPT_IMG_WGRAD = value; return 0; }
+  if (key == 41) { ES_OPT_IMG_WGRAD_WGS32 = value; return 0; }
+  if (key == 42) { ES_OPT_IMG_WGRAD_WGS64 = value; return 0; }
+  return -1;
+}
+
+static bool img_wgrad_plan(int n_img, int H, int W, int C, int& wp, int& rows, int& bands) {
+  if (!ES_OPT_IMG_WGRAD || n_img <= 0 || H <= 0 || W <= 0) return false;
+  if (C == 32 && W <= 128) wp = W <= 64 ? 64 : 128;
+  else if (C == 64 && W <= 64) wp = W <= 32 ? 32 : 64;
+  else return false;
+  const int target = C == 32 ? ES_OPT_IMG_WGRAD_WGS32 : ES_OPT_IMG_WGRAD_WGS64;
+  bands = target / n_img;
+  if (bands < 1) bands = 1;
+  if (bands > H) bands = H;
+  rows = es_cdiv(H, bands);
+  bands = es_cdiv(H, rows);
+  return true;
+}
+
+extern "C" size_t es_img_wgrad9_workspace_floats(int n_img, int H, int W, int C) {
+  int wp, rows, bands;
+  if (!img_wgrad_plan(n_img, H, W, C, wp, rows, bands)) return 0;
+  return (size_t)n_img * bands * 9 * C * C;
+}
+
+extern "C" int es_img_wgrad9_bf16(const void* Xh, int ldx, const float* dY, int ldy, int n_img, int H, int W, int C, float* dW,
+                                  int accumulate, float* ws, size_t ws_floats, void* stream) {
+  int wp, rows, bands;
+  if (!img_wgrad_plan(n_img, H, W, C, wp, rows, bands)) return -4;
+  if ((ldx % 8) || (ldy % 4) || ((((uintptr_t)Xh) | ((uintptr_t)dY)) & 15)) return -4;
+  if ((long long)n_img * H * W * (ldx > ldy ? ldx : ldy) >= (1ll << 31)) return -4;
+  const int parts = n_img * bands;
+  if (parts > 1 && (ws == nullptr || ws_floats < (size_t)parts * 9 * C * C)) return -5;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short* X = (const unsigned short*)Xh;
+  float* out = parts > 1 ? ws : dW;
+  const int to_ws = parts > 1;
+#define IW_LAUNCH(C_, WP_)                                                                                              \
+  hipLaunchKernelGGL((k_img_wgrad9<C_, WP_>), dim3(parts), dim3(C_ * 4), 0, st, X, ldx, dY, ldy, H, W, rows, bands, out, \
+                     to_ws, accumulate)
+  if (C == 32 && wp == 128) IW_LAUNCH(32, 128);
+  else if (C == 32) IW_LAUNCH(32, 64);
+  else if (wp == 64) IW_LAUNCH(64, 64);
+  else IW_LAUNCH(64, 32);
+#undef IW_LAUNCH
+  ES_CHECK_LAUNCH();
+  if (parts > 1) {
+    const int n = 9 * C * C;
+    hipLaunchKernelGGL(k_img_wgrad_reduce, dim3(es_cdiv(n, 256)), dim3(256), 0, st, ws, parts, n, dW, accumulate);
+    ES_CHECK_LAUNCH();
+  }
+  return 0;
+}

@@ -364,6 +364,26 @@ def _wgrad(name, sw, dW, *args):
     call(name, *args, dW, _first_write(dW), P(ws), ws.numel() if ws is not None else 0, sw)
 
 
+IMG_WGRAD = [os.environ.get('ES_IMG_WGRAD', '1') != '0']     # round 6: 3x3 image weight gradients on csrc/imgwgrad.hip (A/B switch)
+
+
+def _img_wgrad_floats(img, K, cin, cout, x, gy):
+    """workspace floats of the image weight-gradient kernel for this launch, 0 when it does not take it: `img` = (n_img, H, W, stride)
+    of a 3x3 / pad 1 convolution on image rows; bf16 activation rows, f32 gradient rows, C -> C channels (32 / 64), stride 1"""
+    if not (IMG_WGRAD[0] and img is not None and K == 9 and img[3] == 1 and cin == cout and x.dh is not None and gy.dtype == torch.float32):
+        return 0
+    return int(hip.raw('es_img_wgrad9_workspace_floats')(img[0], img[1], img[2], cin))
+
+
+def _img_wgrad(sw, dW, xh, ldx, gy, ldy, img, C, need):
+    ws = _WGRAD_WS.get(sw)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _KEEP.append(ws)                     # launches already queued on `sw` may still use the old buffer
+        ws = _WGRAD_WS[sw] = torch.empty(max(int(need), 1 << 22), dtype=torch.float32, device=gy.device)
+    call('es_img_wgrad9_bf16', P(xh), ldx, P(gy), ldy, img[0], img[1], img[2], C, dW, _first_write(dW), P(ws), ws.numel(), sw)
+
+
 def join_wgrad_streams(final=True):
     """make the current stream wait for every queued weight-gradient launch (before the gradients are reduced or
     consumed by the optimiser)"""
@@ -704,7 +724,7 @@ def conv(x, w, nbr, inv, n_out, bias=None, need_dx=True, bias_from=0, dense=None
     return y
 
 
-def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, gate=None, dense=None, maps=None):
+def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, gate=None, dense=None, maps=None, img=None):
     """wgrad (+ bias grad) and dgrad of a convolution whose output gradient is the row matrix `gy`.
     gate: folded-BN scale of x's producer -- the dgrad launch then also applies that layer's ReLU mask and BN scale
     (x is its only consumer), leaving x.g as the gradient of the producer's raw conv output."""
@@ -733,8 +753,11 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         x.shadow()                               # (made by the forward launch; never on the weight-gradient stream)
     if w.g is not None or (bias is not None and bias.g is not None):
         sw = _wgrad_stream(gy, x.d, gh, x.dh)
+    iw = _img_wgrad_floats(img, K, cin, cout, x, gy) if (w.g is not None and bf and dn_w is None) else 0
     if dn_w is not None:
         _dense_wgrad(P(x.dh), cin, P(gh), cout, dn_w, 0, cin, cout, P(w.g), _first_write(P(w.g)), sw, gh)
+    elif iw:
+        _img_wgrad(sw, P(w.g), x.dh, _ld(x.dh), gy, _ld(gy), img, cin, iw)
     elif w.g is not None and bf and WGRAD_BF16[0] and ((SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None))
                                                   or x.d.dtype == torch.bfloat16):      # (bf16 activation rows ARE their shadow: ES_SHADOW=0 must not strand them)
         xs, ys = x.dh if x.dh is not None else x.d, gh if gh is not None else gy
@@ -784,12 +807,14 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
         rec['after'] = x.g.clone()               # (gradient buffer after this launch; `before` = what it accumulated onto)
 
 
-def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True, sole_consumer=False, out_bf16=False):
+def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=True, sole_consumer=False, out_bf16=False, img=None):
     """conv -> frozen-BN affine (+ residual) (+ ReLU) of the 2-D backbone.  In bf16 mode this is ONE launch (affine
     fused into the conv epilogue); in f32 mode conv() followed by affine_act().
     sole_consumer: promise that x feeds nothing but this conv; if x itself came out of a fused conv+BN+ReLU, its
     ReLU/BN backward is then folded into this conv's data-gradient launch.
-    out_bf16: store the output rows in bf16 (ACT16); x / res may themselves be bf16 row matrices."""
+    out_bf16: store the output rows in bf16 (ACT16); x / res may themselves be bf16 row matrices.
+    img: (n_img, H, W, stride) when the map is a 3x3 / pad 1 image-grid map: the weight gradient may then run by address arithmetic
+    (csrc/imgwgrad.hip) instead of through the map."""
     K, cin, cout = w.d.shape
     n_in = x.d.shape[0]
     if PRECISION[0] != 'bf16':
@@ -829,7 +854,7 @@ def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=Tr
             gconv = torch.empty((n_out, cout), dtype=torch.float32, device=y.d.device)   # gradient w.r.t. the conv output
             call('es_affine_act_bwd_yh' if y.d.dtype == h16 else 'es_affine_act_bwd', P(y.g), P(y.d), P(scale), n_out, cout, act,
                  P(gconv), 0, gr, accr, _stream())
-        _conv_backward(x, w, nbr, inv, n_out, y, gconv, None, 0, need_dx, True, gate)
+        _conv_backward(x, w, nbr, inv, n_out, y, gconv, None, 0, need_dx, True, gate, img=img)
     TAPE.add(bwd)
     return y
 

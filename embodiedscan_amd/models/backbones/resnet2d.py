@@ -149,7 +149,7 @@ class ResNet:
                                   act=1, out_bf16=a16)
                 nbr, inv, n_out, _, _ = g_in.conv_map(3, stride, 1)
                 o = E.conv_affine(o, self._par(p + 'conv2.weight'), nbr, inv, n_out, *self.fold[p + 'bn2'], act=1,
-                                  sole_consumer=True, out_bf16=a16)
+                                  sole_consumer=True, out_bf16=a16, img=(n_img, g_in.H, g_in.W, stride))
                 if bi == 0:
                     if stride == 1:
                         idt = E.conv_affine(cur, self._par(p + 'downsample.0.weight'), None, None, n_out,
