@@ -28,7 +28,7 @@ K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-co
 ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_fwd_bf16_io',
           'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src', 'es_dconv_fwd_bf16',
           'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16', 'es_spconv_halo_bf16', 'es_img_wgrad9_bf16'}
-IMGW = ('es_img_wgrad9_bf16',)       # round 6: (Xh, ldx, dY, ldy, n_img, H, W, C, dW, acc, ws, ws_floats, stream)
+IMGW = ('es_img_wgrad9_bf16',)       # round 6: (Xh, ldx, dY, ldy, n_img, H, W, C, stride, dW, acc, ws, ws_floats, stream)
 HALO = ('es_spconv_halo_bf16',)      # round 6: (Xh, ldx, W, loc, hrows, hcnt, n_out, n_in, K, Cin, Cout, bias, Y, ldy, acc, stream)
 DENSE = ('es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16')   # round 5: the dense-volume engine (csrc/dconv.hip)
 DENSE_WGRAD = ('es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16')
@@ -1109,7 +1109,8 @@ def resolve_pairs(hip, records):
             out.append((name, e0, e1, a, dense_info(name, a)[5]))
             continue
         if name in IMGW:                                 # valid (pixel, tap) pairs of a 3x3 / pad 1 / stride 1 image convolution
-            out.append((name, e0, e1, a, float(a[4]) * (3 * a[5] - 2) * (3 * a[6] - 2)))
+            ax = lambda d: sum(1 for q in range(d // a[8]) for k in range(3) if 0 <= q * a[8] - 1 + k < d)
+            out.append((name, e0, e1, a, float(a[4]) * ax(a[5]) * ax(a[6])))
             continue
         if name == 'es_spconv_wgrad_bf16_src':
             key = a[6]
@@ -1130,7 +1131,7 @@ def engine_args(name, a):
     if name in HALO:
         return a[3], a[6], a[7], a[8], a[9], a[10]
     if name in IMGW:
-        return 1, a[4] * a[5] * a[6], a[4] * a[5] * a[6], 9, a[7], a[7]
+        return 1, a[4] * (a[5] // a[8]) * (a[6] // a[8]), a[4] * a[5] * a[6], 9, a[7], a[7]
     if name in FWD_X:
         return a[4], a[5], a[6], a[7], a[8], a[9]
     if not name.startswith('es_spconv_wgrad'):

@@ -29,29 +29,32 @@ typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __attribute__((aligned(16))) unsigned short g_iw_zero[8];
 
-// C channels (= Cin = Cout), WP = padded output width (multiple of 32, >= W)
-template <int C, int WP>
+// C channels (= Cin = Cout), WP = padded OUTPUT width (multiple of 32, >= Wo), S = stride (1, 2): the input grid is (H, W), the
+// output grid (H / S, W / S) (3x3, pad 1: output (oy, ox) under tap (ty, tx) reads input (S oy + ty - 1, S ox + tx - 1))
+template <int C, int WP, int S>
 __global__ __launch_bounds__(C * 4) void k_img_wgrad9(const unsigned short* __restrict__ Xh, int ldx,
                                                       const float* __restrict__ dY, int ldy, int H, int W, int rows_per_wg,
                                                       int bands, float* __restrict__ out /* dW or ws[wg][9][C][C] */,
                                                       int to_ws, int accumulate) {
   constexpr int NW = C / 16, NT = NW * 64;                 // waves / threads per workgroup
   constexpr int RB = C * 2;                                 // bytes per pixel row of an LDS tile
-  constexpr int XP = WP + 2;                                // pixels per ring slot: x = -1 .. WP (pads and the tail stay zero)
+  constexpr int XP = S * WP + 2;                            // pixels per ring slot: x = -1 .. S * WP (pads and the tail stay zero)
+  constexpr int NS = S == 1 ? 4 : 8;                        // ring slots (rows S oy - 1 .. S oy + 1 in use, S more in flight)
   constexpr int X_BYTES = XP * RB, Y_BYTES = WP * RB;
   constexpr int NF = C / 16;
   constexpr int GX = RB / 16;                               // 16-byte granules per pixel row
-  constexpr int NPX = WP * GX / NT;                         // LDS-DMA pieces per thread and image row
-  static_assert(WP * GX % NT == 0 && (WP * C / 4) % NT == 0, "whole pieces per row");
+  constexpr int NPX = S * WP * GX / NT;                     // LDS-DMA pieces per thread and image row
+  static_assert(S * WP * GX % NT == 0 && (WP * C / 4) % NT == 0, "whole pieces per row");
   constexpr int NLY = (WP * C / 4 + NT - 1) / NT;           // float4 loads per thread and dY row
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * X_BYTES + 2 * Y_BYTES];
-  unsigned char* const ytile = smem + 4 * X_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * X_BYTES + 2 * Y_BYTES];
+  unsigned char* const ytile = smem + NS * X_BYTES;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
   const int im = blockIdx.x / bands, band = blockIdx.x - im * bands;
-  const int oy0 = band * rows_per_wg, oy1 = min(H, oy0 + rows_per_wg);
+  const int Ho = H / S, Wo = W / S;
+  const int oy0 = band * rows_per_wg, oy1 = min(Ho, oy0 + rows_per_wg);
   if (oy0 >= oy1) return;
 
-  for (int i = t; i < (4 * X_BYTES + 2 * Y_BYTES) / 16; i += NT) ((uint4*)smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = t; i < (NS * X_BYTES + 2 * Y_BYTES) / 16; i += NT) ((uint4*)smem)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
 
   f32x4 acc[9][NF];
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(C * 4) void k_img_wgrad9(const unsigned short* __re
   auto issue_x = [&](int iy) {
     if (iy < 0 || iy >= H) return;                          // (uniform)
     const unsigned short* src = Xh + ((size_t)im * H + iy) * W * ldx;
-    unsigned char* dst = smem + (iy & 3) * X_BYTES + RB;
+    unsigned char* dst = smem + (iy & (NS - 1)) * X_BYTES + RB;
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
       const int e = (j * NW + wv) * 64 + lane;              // granule of the row: pixel e / GX, granule e % GX
@@ -76,12 +79,12 @@ __global__ __launch_bounds__(C * 4) void k_img_wgrad9(const unsigned short* __re
   };
   float4 yreg[NLY];
   auto load_y = [&](int oy) {                                // dY row oy -> registers (f32)
-    const float* src = dY + ((size_t)im * H + oy) * W * ldy;
+    const float* src = dY + ((size_t)im * Ho + oy) * Wo * ldy;
 #pragma unroll
     for (int j = 0; j < NLY; ++j) {
       const int e = j * NT + t;                             // float4 index: pixel e / (C / 4), channel quad e % (C / 4)
       const int px = e / (C / 4), c4 = e - px * (C / 4);
-      yreg[j] = (oy < oy1 && px < W) ? *(const float4*)(src + (size_t)px * ldy + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      yreg[j] = (oy < oy1 && px < Wo) ? *(const float4*)(src + (size_t)px * ldy + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_y = [&](int buf) {                              // registers -> bf16 tile (pixels >= W: zeros)
@@ -98,11 +101,11 @@ __global__ __launch_bounds__(C * 4) void k_img_wgrad9(const unsigned short* __re
     }
   };
   // transposed fragment: 8 consecutive pixels (p0 + kq * 8 ..) of channel cb * 16 + li from a [pixel][channel] tile
-  auto frag = [&](const unsigned char* tile, int p0, int cb) -> bf16x8_t {
+  auto frag = [&](const unsigned char* tile, int p0, int cb, int step, int off) -> bf16x8_t {      // LDS pixel = step * pixel + off
     s16x4_t h[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const int px = p0 + kq * 8 + r * 4 + (li >> 2);
+      const int px = (p0 + kq * 8 + r * 4 + (li >> 2)) * step + off;
       const unsigned char* a = tile + px * RB + cb * 32 + (li & 3) * 8;
       h[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
     }
@@ -110,33 +113,34 @@ __global__ __launch_bounds__(C * 4) void k_img_wgrad9(const unsigned short* __re
     return __builtin_bit_cast(bf16x8_t, v);
   };
 
-  // prologue: image rows oy0 - 1, oy0, oy0 + 1 and the first dY row
-  issue_x(oy0 - 1);
-  issue_x(oy0);
-  issue_x(oy0 + 1);
+  // prologue: the image rows of the first output row (S oy0 - 1 .. S oy0 + 1), the rows the second one adds, and the first dY row
+  for (int r = -1; r <= 1 + (S - 1); ++r) issue_x(S * oy0 + r);
   load_y(oy0);
   for (int oy = oy0; oy < oy1; ++oy) {
     const int buf = (oy - oy0) & 1;
     store_y(buf);                                            // (the tile was last read two rows ago: a barrier has passed since)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of image row oy + 1 have landed ...
-    __syncthreads();                                          // ... everybody's; the dY tile is complete; row oy - 1 has been consumed
-    issue_x(oy + 2);                                         // slot (oy + 2) & 3 = (oy - 2) & 3: free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the image rows of output row oy have landed ...
+    __syncthreads();                                          // ... everybody's; the dY tile is complete; output row oy - 1 has been consumed
+    // the rows output row oy + 1 adds (S = 1: oy + 2; S = 2: 2 oy + 3 and -- a row further ahead -- 2 oy + 4): their ring slots held
+    // rows S oy - 2 .. that nobody reads any more
+    if (S == 1) issue_x(oy + 2);
+    else { issue_x(2 * oy + 3); issue_x(2 * oy + 4); }
     load_y(oy + 1);
     const unsigned char* yt = ytile + buf * Y_BYTES;
 #pragma unroll 1
     for (int p0 = 0; p0 < WP; p0 += 32) {
-      if (p0 >= W) break;
+      if (p0 >= Wo) break;
       bf16x8_t b[NF];
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) b[nf] = frag(yt, p0, nf);
+      for (int nf = 0; nf < NF; ++nf) b[nf] = frag(yt, p0, nf, 1, 0);
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty) {
-        const int iy = oy + ty - 1;
+        const int iy = S * oy + ty - 1;
         if (iy < 0 || iy >= H) continue;                    // (uniform: a row outside the image contributes nothing)
-        const unsigned char* xt = smem + (iy & 3) * X_BYTES;
+        const unsigned char* xt = smem + (iy & (NS - 1)) * X_BYTES;
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
-          const bf16x8_t a = frag(xt, p0 + tx, wv);          // LDS pixel of x + tx - 1 is x + tx
+          const bf16x8_t a = frag(xt, p0, wv, S, tx);        // LDS pixel of input x = S ox + tx - 1 is S ox + tx
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf)
             acc[ty * 3 + tx][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nf], acc[ty * 3 + tx][nf], 0, 0, 0);
@@ -182,30 +186,36 @@ extern "C" int es_img_wgrad_set_option(int key, int value) {
   return -1;
 }
 
-static bool img_wgrad_plan(int n_img, int H, int W, int C, int& wp, int& rows, int& bands) {
+static bool img_wgrad_plan(int n_img, int H, int W, int C, int stride, int& wp, int& rows, int& bands) {
   if (!ES_OPT_IMG_WGRAD || n_img <= 0 || H <= 0 || W <= 0) return false;
-  if (C == 32 && W <= 128) wp = W <= 64 ? 64 : 128;
-  else if (C == 64 && W <= 64) wp = W <= 32 ? 32 : 64;
+  if (stride != 1 && !(stride == 2 && H % 2 == 0 && W % 2 == 0)) return false;
+  const int Ho = H / stride, Wo = W / stride;
+  if (C == 32 && Wo <= 128) wp = Wo <= 64 ? 64 : 128;
+  else if (C == 64 && Wo <= 64) wp = Wo <= 32 ? 32 : 64;
   else return false;
-  const int target = C == 32 ? ES_OPT_IMG_WGRAD_WGS32 : ES_OPT_IMG_WGRAD_WGS64;
+  if (stride == 2 && wp == 128) return false;               // (8 ring slots of 258 pixels: 132 KB)
+  // workgroups aimed for: enough to fill the chip, few enough that the partial tensors (36 / 147 KB each) stay small next to the
+  // operands; with many images (the grounder: 240) three bands per image at C = 32 (A/B: profiles/r6g_imgwgrad_ab.txt)
+  int target = C == 32 ? ES_OPT_IMG_WGRAD_WGS32 : ES_OPT_IMG_WGRAD_WGS64;
+  if (C == 32 && target < 3 * n_img) target = 3 * n_img;
   bands = target / n_img;
   if (bands < 1) bands = 1;
-  if (bands > H) bands = H;
-  rows = es_cdiv(H, bands);
-  bands = es_cdiv(H, rows);
+  if (bands > Ho) bands = Ho;
+  rows = es_cdiv(Ho, bands);
+  bands = es_cdiv(Ho, rows);
   return true;
 }
 
-extern "C" size_t es_img_wgrad9_workspace_floats(int n_img, int H, int W, int C) {
+extern "C" size_t es_img_wgrad9_workspace_floats(int n_img, int H, int W, int C, int stride) {
   int wp, rows, bands;
-  if (!img_wgrad_plan(n_img, H, W, C, wp, rows, bands)) return 0;
+  if (!img_wgrad_plan(n_img, H, W, C, stride, wp, rows, bands)) return 0;
   return (size_t)n_img * bands * 9 * C * C;
 }
 
-extern "C" int es_img_wgrad9_bf16(const void* Xh, int ldx, const float* dY, int ldy, int n_img, int H, int W, int C, float* dW,
-                                  int accumulate, float* ws, size_t ws_floats, void* stream) {
+extern "C" int es_img_wgrad9_bf16(const void* Xh, int ldx, const float* dY, int ldy, int n_img, int H, int W, int C, int stride,
+                                  float* dW, int accumulate, float* ws, size_t ws_floats, void* stream) {
   int wp, rows, bands;
-  if (!img_wgrad_plan(n_img, H, W, C, wp, rows, bands)) return -4;
+  if (!img_wgrad_plan(n_img, H, W, C, stride, wp, rows, bands)) return -4;
   if ((ldx % 8) || (ldy % 4) || ((((uintptr_t)Xh) | ((uintptr_t)dY)) & 15)) return -4;
   if ((long long)n_img * H * W * (ldx > ldy ? ldx : ldy) >= (1ll << 31)) return -4;
   const int parts = n_img * bands;
@@ -214,13 +224,19 @@ extern "C" int es_img_wgrad9_bf16(const void* Xh, int ldx, const float* dY, int 
   const unsigned short* X = (const unsigned short*)Xh;
   float* out = parts > 1 ? ws : dW;
   const int to_ws = parts > 1;
-#define IW_LAUNCH(C_, WP_)                                                                                              \
-  hipLaunchKernelGGL((k_img_wgrad9<C_, WP_>), dim3(parts), dim3(C_ * 4), 0, st, X, ldx, dY, ldy, H, W, rows, bands, out, \
+#define IW_LAUNCH(C_, WP_, S_)                                                                                              \
+  hipLaunchKernelGGL((k_img_wgrad9<C_, WP_, S_>), dim3(parts), dim3(C_ * 4), 0, st, X, ldx, dY, ldy, H, W, rows, bands, out, \
                      to_ws, accumulate)
-  if (C == 32 && wp == 128) IW_LAUNCH(32, 128);
-  else if (C == 32) IW_LAUNCH(32, 64);
-  else if (wp == 64) IW_LAUNCH(64, 64);
-  else IW_LAUNCH(64, 32);
+  if (stride == 1) {
+    if (C == 32 && wp == 128) IW_LAUNCH(32, 128, 1);
+    else if (C == 32) IW_LAUNCH(32, 64, 1);
+    else if (wp == 64) IW_LAUNCH(64, 64, 1);
+    else IW_LAUNCH(64, 32, 1);
+  } else {
+    if (C == 32) IW_LAUNCH(32, 64, 2);
+    else if (wp == 64) IW_LAUNCH(64, 64, 2);
+    else IW_LAUNCH(64, 32, 2);
+  }
 #undef IW_LAUNCH
   ES_CHECK_LAUNCH();
   if (parts > 1) {

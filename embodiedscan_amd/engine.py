@@ -369,10 +369,11 @@ IMG_WGRAD = [os.environ.get('ES_IMG_WGRAD', '1') != '0']     # round 6: 3x3 imag
 
 def _img_wgrad_floats(img, K, cin, cout, x, gy):
     """workspace floats of the image weight-gradient kernel for this launch, 0 when it does not take it: `img` = (n_img, H, W, stride)
-    of a 3x3 / pad 1 convolution on image rows; bf16 activation rows, f32 gradient rows, C -> C channels (32 / 64), stride 1"""
-    if not (IMG_WGRAD[0] and img is not None and K == 9 and img[3] == 1 and cin == cout and x.dh is not None and gy.dtype == torch.float32):
+    of a 3x3 / pad 1 convolution on image rows ((H, W) = its INPUT grid); bf16 activation rows, f32 gradient rows, C -> C channels
+    (32 / 64), stride 1 or 2"""
+    if not (IMG_WGRAD[0] and img is not None and K == 9 and cin == cout and x.dh is not None and gy.dtype == torch.float32):
         return 0
-    return int(hip.raw('es_img_wgrad9_workspace_floats')(img[0], img[1], img[2], cin))
+    return int(hip.raw('es_img_wgrad9_workspace_floats')(img[0], img[1], img[2], cin, img[3]))
 
 
 def _img_wgrad(sw, dW, xh, ldx, gy, ldy, img, C, need):
@@ -381,7 +382,7 @@ def _img_wgrad(sw, dW, xh, ldx, gy, ldy, img, C, need):
         if ws is not None:
             _KEEP.append(ws)                     # launches already queued on `sw` may still use the old buffer
         ws = _WGRAD_WS[sw] = torch.empty(max(int(need), 1 << 22), dtype=torch.float32, device=gy.device)
-    call('es_img_wgrad9_bf16', P(xh), ldx, P(gy), ldy, img[0], img[1], img[2], C, dW, _first_write(dW), P(ws), ws.numel(), sw)
+    call('es_img_wgrad9_bf16', P(xh), ldx, P(gy), ldy, img[0], img[1], img[2], C, img[3], dW, _first_write(dW), P(ws), ws.numel(), sw)
 
 
 def join_wgrad_streams(final=True):

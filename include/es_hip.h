@@ -505,15 +505,16 @@ int es_spconv_halo_bf16(const void* Xh, int ldx, const void* W_bf16, const void*
                         int n_in, int K, int Cin, int Cout, const float* bias, float* Y, int ldy, int accumulate, int mirror, void* stream);
 
 /* ---- 3x3 image weight gradient on small channel counts (round 6, csrc/imgwgrad.hip) ---------------------------------------
- * dW[9][C][C] (f32) (+)= X^T . dY of Bottleneck.conv2 (mmdet.ResNet, stride 1, pad 1) of the image backbone
+ * dW[9][C][C] (f32) (+)= X^T . dY of Bottleneck.conv2 (mmdet.ResNet, stride 1 or 2, pad 1; (H, W) = the INPUT grid, even for stride 2,
+ * dY on the (H / stride, W / stride) output grid) of the image backbone
  * (configs/detection/mv-det3d_8xb4_embodiedscan-3d-284class-9dof.py:24-34): Xh (n_img*H*W x ldx) bf16 activation rows, dY
  * (n_img*H*W x ldy) f32 rows of the output gradient (rounded to bf16 in the kernel), taps t = ty*3 + tx with the neighbour
- * (y + ty - 1, x + tx - 1) -- es_image_map's order.  Takes C = 32 with W <= 128 and C = 64 with W <= 64 (the w16 backbone's
+ * (stride*y + ty - 1, stride*x + tx - 1) -- es_image_map's order.  Takes C = 32 with output width <= 128 (64 for stride 2) and C = 64 with <= 64 (the w16 backbone's
  * layer2 / layer3); es_img_wgrad9_workspace_floats returns 0 for any other shape (the caller keeps the map kernel) and -4 / -5
  * are returned for an unsupported shape / a workspace that is too small.  Partial tensors per workgroup are added in workgroup
  * order: bit-reproducible.  es_img_wgrad_set_option: 40 on / off, 41 / 42 workgroups aimed for at C = 32 / 64. */
-size_t es_img_wgrad9_workspace_floats(int n_img, int H, int W, int C);
-int es_img_wgrad9_bf16(const void* Xh, int ldx, const float* dY, int ldy, int n_img, int H, int W, int C, float* dW,
+size_t es_img_wgrad9_workspace_floats(int n_img, int H, int W, int C, int stride);
+int es_img_wgrad9_bf16(const void* Xh, int ldx, const float* dY, int ldy, int n_img, int H, int W, int C, int stride, float* dW,
                        int accumulate, float* ws, size_t ws_floats, void* stream);
 int es_img_wgrad_set_option(int key, int value);
 

@@ -9,24 +9,27 @@ import pytest
 from test_emu_kernels import P, bf16_bits, bf16_round, emu  # noqa: F401  (the fixture)
 
 
-def _ref(xb, gyb, n_img, H, W, C):
-    """dW[t][ci][co] in f64: xb (n_img*H*W, C), gyb (n_img*H*W, C) already bf16-rounded"""
+def _ref(xb, gyb, n_img, H, W, C, S=1):
+    """dW[t][ci][co] in f64: xb (n_img*H*W, C) on the input grid, gyb (n_img*(H/S)*(W/S), C) on the output grid, already bf16-rounded"""
+    Ho, Wo = H // S, W // S
     x = np.zeros((n_img, H + 2, W + 2, C))
     x[:, 1:H + 1, 1:W + 1] = xb.reshape(n_img, H, W, C)
-    g = gyb.reshape(n_img, H, W, C).astype(np.float64)
+    g = gyb.reshape(n_img, Ho, Wo, C).astype(np.float64)
     dw = np.zeros((9, C, C))
     for ty in range(3):
         for tx in range(3):
-            xs = x[:, ty:ty + H, tx:tx + W]
+            xs = x[:, ty:ty + S * Ho:S, tx:tx + S * Wo:S]
             dw[ty * 3 + tx] = np.einsum('nhwi,nhwo->io', xs, g)
     return dw
 
 
-CASES = [  # n_img, H, W, C, workgroups aimed for (option 41 / 42), ld extra, accumulate
-    (2, 5, 7, 32, 2, 0, 0),        # one band per image, WP = 64
-    (1, 9, 70, 32, 4, 8, 1),       # four bands (3 + 3 + 3 rows), WP = 128, strided rows, accumulate
-    (2, 6, 33, 64, 6, 0, 0),       # C = 64, three bands per image, WP = 64
-    (1, 4, 20, 64, 1, 16, 1),      # C = 64, WP = 32, one workgroup: writes dW directly (accumulating)
+CASES = [  # n_img, H, W (input grid), C, workgroups aimed for (option 41 / 42), ld extra, accumulate, stride
+    (2, 5, 7, 32, 2, 0, 0, 1),        # one band per image, WP = 64
+    (1, 9, 70, 32, 4, 8, 1, 1),       # four bands (3 + 3 + 3 rows), WP = 128, strided rows, accumulate
+    (2, 6, 33, 64, 6, 0, 0, 1),       # C = 64, three bands per image, WP = 64
+    (1, 4, 20, 64, 1, 16, 1, 1),      # C = 64, WP = 32, one workgroup: writes dW directly (accumulating)
+    (2, 10, 14, 32, 4, 0, 0, 2),      # stride 2: 5 x 7 outputs per image, two bands
+    (1, 12, 72, 64, 3, 8, 1, 2),      # stride 2, C = 64, 36 outputs per row (WP = 64), three bands, strided rows, accumulate
 ]
 
 
@@ -35,26 +38,26 @@ def test_image_weight_gradient_matches_f64_and_the_map_kernel(emu, lazy):
     rng = np.random.default_rng(17 + lazy)
     emu.lib.es_emu_set_dma_mode(lazy)
     try:
-        for n_img, H, W, C, wgs, ext, acc in (CASES if not lazy else CASES[1:3]):
-            n = n_img * H * W
+        for n_img, H, W, C, wgs, ext, acc, S in (CASES if not lazy else CASES[1:3] + CASES[4:]):
+            n, n_o = n_img * H * W, n_img * (H // S) * (W // S)
             x = rng.standard_normal((n, C + ext)).astype(np.float32)
-            gy = rng.standard_normal((n, C + ext)).astype(np.float32)
+            gy = rng.standard_normal((n_o, C + ext)).astype(np.float32)
             xh = bf16_bits(x)
             emu('es_img_wgrad_set_option', 41 if C == 32 else 42, wgs)
-            nf = emu.fns['es_img_wgrad9_workspace_floats'](n_img, H, W, C)
+            nf = emu.fns['es_img_wgrad9_workspace_floats'](n_img, H, W, C, S)
             assert nf > 0 and nf % (9 * C * C) == 0
             ws = np.full(nf, np.nan, np.float32)
             dw0 = rng.standard_normal((9, C, C)).astype(np.float32)
             dw = dw0.copy()
-            emu('es_img_wgrad9_bf16', P(xh), C + ext, P(gy), C + ext, n_img, H, W, C, P(dw), acc, P(ws), nf, 0)
-            want = _ref(bf16_round(x)[:, :C], bf16_round(gy)[:, :C], n_img, H, W, C) + (dw0 if acc else 0)
+            emu('es_img_wgrad9_bf16', P(xh), C + ext, P(gy), C + ext, n_img, H, W, C, S, P(dw), acc, P(ws), nf, 0)
+            want = _ref(bf16_round(x)[:, :C], bf16_round(gy)[:, :C], n_img, H, W, C, S) + (dw0 if acc else 0)
             err = np.abs(dw - want).max() / np.abs(want).max()
             assert err < 2e-6, (n_img, H, W, C, err)
             if not ext and not acc:                   # the map kernel on the same operands (it rounds dY the same way)
-                nbr = np.zeros((n, 9), np.int32)
-                emu('es_image_map', n_img, H, W, H, W, 3, 3, 1, 1, P(nbr), 0)
+                nbr = np.zeros((n_o, 9), np.int32)
+                emu('es_image_map', n_img, H, W, H // S, W // S, 3, 3, S, 1, P(nbr), 0)
                 dw2 = np.zeros((9, C, C), np.float32)
-                emu('es_spconv_wgrad_bf16_src', P(xh), 1, C, P(gy), 0, C, P(nbr), n, n, 9, C, C, P(dw2), 0, 0, 0, 0)
+                emu('es_spconv_wgrad_bf16_src', P(xh), 1, C, P(gy), 0, C, P(nbr), n_o, n, 9, C, C, P(dw2), 0, 0, 0, 0)
                 assert np.abs(dw - dw2).max() <= 3e-6 * np.abs(dw2).max()
     finally:
         emu.lib.es_emu_set_dma_mode(0)
@@ -64,10 +67,11 @@ def test_image_weight_gradient_matches_f64_and_the_map_kernel(emu, lazy):
 
 def test_image_weight_gradient_support_rule(emu):
     wsf = emu.fns['es_img_wgrad9_workspace_floats']
-    assert wsf(80, 120, 120, 32) > 0 and wsf(80, 60, 60, 64) > 0
-    assert wsf(80, 120, 160, 32) == 0          # wider than the LDS ring takes
-    assert wsf(80, 30, 30, 128) == 0           # 128 channels: the 128 x 128 tile's case
-    assert wsf(80, 240, 240, 16) == 0
+    assert wsf(80, 120, 120, 32, 1) > 0 and wsf(80, 60, 60, 64, 1) > 0 and wsf(80, 120, 120, 32, 2) > 0 and wsf(80, 60, 60, 64, 2) > 0
+    assert wsf(80, 120, 160, 32, 1) == 0       # wider than the LDS ring takes
+    assert wsf(80, 30, 30, 128, 1) == 0        # 128 channels: the 128 x 128 tile's case
+    assert wsf(80, 240, 240, 16, 1) == 0
+    assert wsf(80, 15, 15, 32, 2) == 0         # odd grid under stride 2
     x = np.zeros((64, 64), np.float32)
-    assert emu.fns['es_img_wgrad9_bf16'](P(x), 32, P(x), 32, 1, 4, 200, 32, P(x), 0, P(x), 1 << 20, 0) == -4
-    assert emu.fns['es_img_wgrad9_bf16'](P(x), 32, P(x), 32, 4, 8, 8, 32, P(x), 0, 0, 0, 0) == -5       # several workgroups, no workspace
+    assert emu.fns['es_img_wgrad9_bf16'](P(x), 32, P(x), 32, 1, 4, 200, 32, 1, P(x), 0, P(x), 1 << 20, 0) == -4
+    assert emu.fns['es_img_wgrad9_bf16'](P(x), 32, P(x), 32, 4, 8, 8, 32, 1, P(x), 0, 0, 0, 0) == -5       # several workgroups, no workspace

@@ -9,29 +9,31 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('case', [(8, 120, 120, 32), (8, 60, 60, 64), (3, 17, 45, 32), (2, 9, 21, 64)])
+@pytest.mark.parametrize('case', [(8, 120, 120, 32, 1), (8, 60, 60, 64, 1), (3, 17, 45, 32, 1), (2, 9, 21, 64, 1), (8, 120, 120, 32, 2), (8, 60, 60, 64, 2),
+                                  (2, 10, 22, 32, 2)])
 def test_image_wgrad_vs_map_kernel(case):
     from embodiedscan_amd.engine import _wgrad as WG
     from embodiedscan_amd.hip import P, call, raw
-    n_img, H, W, C = case
+    n_img, H, W, C, S = case
+    Ho, Wo = H // S, W // S
     dev = torch.device('cuda:0')
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(5)
-    n = n_img * H * W
+    n, n_o = n_img * H * W, n_img * Ho * Wo
     x = torch.randn(n, C, generator=g).to(dev)
     xh = x.to(torch.bfloat16)
-    gy = torch.randn(n, C, generator=g).to(dev)
-    nbr = torch.empty((n, 9), dtype=torch.int32, device=dev)
-    call('es_image_map', n_img, H, W, H, W, 3, 3, 1, 1, P(nbr), st)
+    gy = torch.randn(n_o, C, generator=g).to(dev)
+    nbr = torch.empty((n_o, 9), dtype=torch.int32, device=dev)
+    call('es_image_map', n_img, H, W, Ho, Wo, 3, 3, S, 1, P(nbr), st)
     d1 = torch.zeros(9, C, C, device=dev)
-    WG('es_spconv_wgrad_bf16_src', st, P(d1), P(xh), 1, C, P(gy), 0, C, P(nbr), n, n, 9, C, C)
-    nf = int(raw('es_img_wgrad9_workspace_floats')(n_img, H, W, C))
+    WG('es_spconv_wgrad_bf16_src', st, P(d1), P(xh), 1, C, P(gy), 0, C, P(nbr), n_o, n, 9, C, C)
+    nf = int(raw('es_img_wgrad9_workspace_floats')(n_img, H, W, C, S))
     assert nf > 0
     ws = torch.full((nf,), float('nan'), device=dev)
     d2 = torch.full((9, C, C), float('nan'), device=dev)
-    call('es_img_wgrad9_bf16', P(xh), C, P(gy), C, n_img, H, W, C, P(d2), 0, P(ws), nf, st)
+    call('es_img_wgrad9_bf16', P(xh), C, P(gy), C, n_img, H, W, C, S, P(d2), 0, P(ws), nf, st)
     d3 = torch.full((9, C, C), float('nan'), device=dev)
-    call('es_img_wgrad9_bf16', P(xh), C, P(gy), C, n_img, H, W, C, P(d3), 0, P(ws), nf, st)
+    call('es_img_wgrad9_bf16', P(xh), C, P(gy), C, n_img, H, W, C, S, P(d3), 0, P(ws), nf, st)
     torch.cuda.synchronize()
     assert torch.equal(d2, d3), 'two runs differ'
     err = float((d1 - d2).abs().max() / d1.abs().max())
@@ -39,15 +41,15 @@ def test_image_wgrad_vs_map_kernel(case):
     assert err < 3e-6
     if n <= 4000:                                             # f64 on the bf16-rounded operands
         xr = xh.double().reshape(n_img, H, W, C)
-        gr = gy.to(torch.bfloat16).double().reshape(n_img, H, W, C)
+        gr = gy.to(torch.bfloat16).double().reshape(n_img, Ho, Wo, C)
         xp = torch.zeros(n_img, H + 2, W + 2, C, dtype=torch.float64, device=dev)
         xp[:, 1:H + 1, 1:W + 1] = xr
-        want = torch.stack([torch.einsum('nhwi,nhwo->io', xp[:, ty:ty + H, tx:tx + W], gr) for ty in range(3) for tx in range(3)])
+        want = torch.stack([torch.einsum('nhwi,nhwo->io', xp[:, ty:ty + S * Ho:S, tx:tx + S * Wo:S], gr) for ty in range(3) for tx in range(3)])
         e64 = float((d2.double() - want).abs().max() / want.abs().max())
         print(f'   vs f64: {e64:.2e} (tol 2e-6)')
         assert e64 < 2e-6
     d4 = d1.clone()                                           # accumulate
-    call('es_img_wgrad9_bf16', P(xh), C, P(gy), C, n_img, H, W, C, P(d4), 1, P(ws), nf, st)
+    call('es_img_wgrad9_bf16', P(xh), C, P(gy), C, n_img, H, W, C, S, P(d4), 1, P(ws), nf, st)
     torch.cuda.synchronize()
     assert float((d4 - (d1 + d2)).abs().max() / d1.abs().max()) < 1e-6
 
@@ -67,7 +69,7 @@ def test_engine_takes_the_image_kernel_for_the_backbone_conv2():
     orig = hip._fn['es_img_wgrad9_bf16']
 
     def spy(*a):
-        seen.append((a[4], a[5], a[6], a[7]))
+        seen.append((a[4], a[5], a[6], a[7], a[8]))
         return orig(*a)
     saved = (E.PRECISION[0], E.IMG_WGRAD[0])
     grads = {}
@@ -96,7 +98,7 @@ def test_engine_takes_the_image_kernel_for_the_backbone_conv2():
         E.PRECISION[0], E.IMG_WGRAD[0] = saved
         E.TAPE.clear()
     assert grads[True][1] > 0 and grads[False][1] == 0, (grads[True][1], grads[False][1])
-    assert {c for *_, c in seen_on} <= {32, 64}
+    assert {c for *_, c, _s in seen_on} <= {32, 64} and {s_ for *_, s_ in seen_on} == {1, 2}
     a, b = grads[True][0], grads[False][0]
     err = float((a - b).norm() / b.norm())
     print(f'image kernel taken {grads[True][1]} times {sorted(set(seen_on))}; arena gradient vs map kernels: rel-L2 {err:.2e}')

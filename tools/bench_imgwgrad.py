@@ -21,25 +21,26 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for n_img, H, W, C in ((80, 60, 60, 32), (80, 30, 30, 64), (240, 60, 60, 32), (240, 30, 30, 64), (80, 120, 120, 32)):      # mv-3ddet (4 scans x 20 views), grounding (12 x 20), a larger map
-    n = n_img * H * W
+for n_img, H, W, C, S in ((80, 60, 60, 32, 1), (80, 30, 30, 64, 1), (240, 60, 60, 32, 1), (240, 30, 30, 64, 1), (80, 120, 120, 32, 1),
+                          (80, 120, 120, 32, 2), (80, 60, 60, 64, 2)):      # mv-3ddet (4 scans x 20 views), grounding (12 x 20), a larger map, the stride-2 layers
+    n, n_o = n_img * H * W, n_img * (H // S) * (W // S)
     xh = torch.randn(n, C, device=dev).to(torch.bfloat16)
-    gy = torch.randn(n, C, device=dev)
-    nbr = torch.empty((n, 9), dtype=torch.int32, device=dev)
-    call('es_image_map', n_img, H, W, H, W, 3, 3, 1, 1, P(nbr), st)
+    gy = torch.randn(n_o, C, device=dev)
+    nbr = torch.empty((n_o, 9), dtype=torch.int32, device=dev)
+    call('es_image_map', n_img, H, W, H // S, W // S, 3, 3, S, 1, P(nbr), st)
     d1, d2 = torch.zeros(9, C, C, device=dev), torch.zeros(9, C, C, device=dev)
-    t_map = timeit(lambda: WG('es_spconv_wgrad_bf16_src', st, P(d1), P(xh), 1, C, P(gy), 0, C, P(nbr), n, n, 9, C, C))
+    t_map = timeit(lambda: WG('es_spconv_wgrad_bf16_src', st, P(d1), P(xh), 1, C, P(gy), 0, C, P(nbr), n_o, n, 9, C, C))
     d1.zero_()
-    WG('es_spconv_wgrad_bf16_src', st, P(d1), P(xh), 1, C, P(gy), 0, C, P(nbr), n, n, 9, C, C)      # (accumulates after its first call of an epoch)
+    WG('es_spconv_wgrad_bf16_src', st, P(d1), P(xh), 1, C, P(gy), 0, C, P(nbr), n_o, n, 9, C, C)      # (accumulates after its first call of an epoch)
     res = []
     for wgs in ((100, 200, 400, 800) if C == 32 else (40, 80, 160, 320)):
         raw('es_img_wgrad_set_option')(41 if C == 32 else 42, wgs)
-        nf = int(raw('es_img_wgrad9_workspace_floats')(n_img, H, W, C))
+        nf = int(raw('es_img_wgrad9_workspace_floats')(n_img, H, W, C, S))
         ws = torch.empty(nf, device=dev)
-        t = timeit(lambda: call('es_img_wgrad9_bf16', P(xh), C, P(gy), C, n_img, H, W, C, P(d2), 0, P(ws), nf, st))
+        t = timeit(lambda: call('es_img_wgrad9_bf16', P(xh), C, P(gy), C, n_img, H, W, C, S, P(d2), 0, P(ws), nf, st))
         res.append(f'{wgs} wgs {t:6.1f} us')
-    mb = n * C * (2 + 4) / 1e6
-    print(f'{n_img} x {H} x {W} x {C}: {mb:.0f} MB of operands | map kernel {t_map:6.1f} us | image kernel ' + ', '.join(res) +
+    mb = (n * 2 + n_o * 4) * C / 1e6
+    print(f'{n_img} x {H} x {W} x {C} stride {S}: {mb:.0f} MB of operands | map kernel {t_map:6.1f} us | image kernel ' + ', '.join(res) +
           f' | max rel diff {float((d1 - d2).abs().max() / d1.abs().max()):.1e}')
 raw('es_img_wgrad_set_option')(41, 400)
 raw('es_img_wgrad_set_option')(42, 160)
