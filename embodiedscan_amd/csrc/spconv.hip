@@ -1879,8 +1879,9 @@ __device__ __forceinline__ void ring_refill(PairRing& q, const int* __restrict__
   q.nextb += 256;
   __syncthreads();
 }
-__device__ __forceinline__ void ring_fill(PairRing& q, const int* __restrict__ nbr, long long sj, long long koff, int rend, int n_in) {
-  while (q.tail - q.head < 2 * GR && q.nextb < rend) ring_refill(q, nbr, sj, koff, rend, n_in);
+__device__ __forceinline__ void ring_fill(PairRing& q, const int* __restrict__ nbr, long long sj, long long koff, int rend, int n_in,
+                                          int need = 2 * GR) {
+  while (q.tail - q.head < need && q.nextb < rend) ring_refill(q, nbr, sj, koff, rend, n_in);
 }
 
 // 4 consecutive channels of one row as floats; HALF: the row matrix is a bf16 shadow (exact widening)
@@ -2139,12 +2140,13 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_big(const void* __res
 // (p & 3) | ((p >> 3) & 1) << 2: the 8 pair rows a 32-lane read group touches land on 8 distinct 32-byte bank positions.
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
+template <int GT>      // pairs per chunk: 32 (one MFMA k step behind every barrier) or 64 (two; 64 KB of LDS: round 6 A/B)
 __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_tr(const unsigned short* __restrict__ Xh, int ldx,
                                                               const unsigned short* __restrict__ dYh, int ldy,
                                                               const int* __restrict__ nbr, int n_out, int n_in, int K,
                                                               int Cin, int Cout, int rows_per_split, int n_slices,
                                                               float* __restrict__ dW, float* __restrict__ ws, int accumulate) {
-  constexpr int TB = GR * 256;                              // bytes of one operand tile: 32 pairs x 128 channels
+  constexpr int TB = GT * 256;                              // bytes of one operand tile: GT pairs x 128 channels
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TB + 2 * QCAP * 4 + 16];
   int* const s_qj = (int*)(smem + 4 * TB);
   int* const s_qi = s_qj + QCAP;
@@ -2167,7 +2169,7 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_tr(const unsigned sho
   // DMA piece e = (j * 4 + wv) * 64 + lane of a tile: pair e >> 4, slot e & 15 (16 granules per 256-byte row)
   auto issue = [&](int buf, int head) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < GT / 16; ++j) {
       const int e = (j * 4 + wv) * 64 + lane, pr = e >> 4, g = (e & 15) ^ key(pr);
       const int qq = head + pr;
       const bool v = qq < q.tail;
@@ -2183,11 +2185,11 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_tr(const unsigned sho
     }
   };
   // transposed fragment of channel block cb (16 channels) of a tile: the 8 pairs kq * 8 .. of channel li
-  auto frag = [&](const unsigned char* tile, int cb) -> bf16x8_t {
+  auto frag = [&](const unsigned char* tile, int cb, int ks) -> bf16x8_t {
     s16x4_t h[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const int pr = kq * 8 + r * 4 + (li >> 2);
+      const int pr = ks * 32 + kq * 8 + r * 4 + (li >> 2);
       const int g = cb * 2 + ((li & 3) >> 1);
       const unsigned char* a = tile + pr * 256 + ((g ^ key(pr)) * 16) + (li & 1) * 8;
       h[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
@@ -2195,27 +2197,30 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad_bf16_tr(const unsigned sho
     s16x8_t v = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, v);
   };
-  ring_fill(q, nbr, sj, koff, rend, n_in);
+  ring_fill(q, nbr, sj, koff, rend, n_in, 2 * GT);
   int buf = 0;
   if (q.head < q.tail) issue(0, q.head);
   while (q.head < q.tail) {
-    q.head += GR;
-    ring_fill(q, nbr, sj, koff, rend, n_in);               // the NEXT chunk's pairs are in the ring before its DMA is issued
+    q.head += GT;
+    ring_fill(q, nbr, sj, koff, rend, n_in, 2 * GT);       // the NEXT chunk's pairs are in the ring before its DMA is issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // the current chunk has landed; the other buffer has been consumed
     if (q.head < q.tail) issue(buf ^ 1, q.head);
     const unsigned char* xt = smem + (buf * 2 + 0) * TB;
     const unsigned char* yt = smem + (buf * 2 + 1) * TB;
-    bf16x8_t a[4], b[4];
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) a[mf] = frag(xt, wr * 4 + mf);
+    for (int ks = 0; ks < GT / 32; ++ks) {
+      bf16x8_t a[4], b[4];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) b[nf] = frag(yt, wc * 4 + nf);
+      for (int mf = 0; mf < 4; ++mf) a[mf] = frag(xt, wr * 4 + mf, ks);
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf)
+      for (int nf = 0; nf < 4; ++nf) b[nf] = frag(yt, wc * 4 + nf, ks);
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
-        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+      for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+    }
     buf ^= 1;
   }
   if (q.tail == 0 && !ws && accumulate) return;
@@ -2409,8 +2414,12 @@ static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, co
                        (const unsigned short*)dY, ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);
   } else if (p.kind == 2 && XH && YH && ES_OPT_WGRAD_TR && (ldx % 8 == 0) && (ldy % 8 == 0)) {
     dim3 grid(K * (Cin / 128), Cout / 128, gz);                // experimental: LDS-DMA staging + transposed LDS reads
-    hipLaunchKernelGGL(k_spconv_wgrad_bf16_tr, grid, dim3(256), 0, st, (const unsigned short*)X, ldx, (const unsigned short*)dY,
-                       ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);
+    if (ES_OPT_WGRAD_TR == 2)
+      hipLaunchKernelGGL(k_spconv_wgrad_bf16_tr<64>, grid, dim3(256), 0, st, (const unsigned short*)X, ldx, (const unsigned short*)dY,
+                         ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);
+    else
+      hipLaunchKernelGGL(k_spconv_wgrad_bf16_tr<32>, grid, dim3(256), 0, st, (const unsigned short*)X, ldx, (const unsigned short*)dY,
+                         ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);
   } else if (p.kind == 2) {
     dim3 grid(K * (Cin / 128), Cout / 128, gz);
     hipLaunchKernelGGL((k_spconv_wgrad_bf16_big<XH, YH>), grid, dim3(256), 0, st, X, ldx, dY, ldy, nbr, n_out, n_in, K, Cin,

@@ -189,9 +189,9 @@ def test_weight_gradient_tiles(emu):
     transposed-read tile whose lane mapping was probed on the GPU) -- row slices through the workspace included"""
     rng = np.random.default_rng(11)
     for n_out, n_in, K, cin, cout, tr in ((700, 650, 27, 64, 64, 0), (900, 900, 8, 128, 128, 0), (900, 900, 8, 128, 128, 1),
-                                          (900, 900, 8, 128, 128, 2)):
-        emu.lib.es_emu_set_dma_mode(1 if tr == 2 else 0)            # the transposed-read tile stages by LDS-DMA: also with late delivery
-        tr = min(tr, 1)
+                                          (900, 900, 8, 128, 128, 2), (900, 900, 8, 128, 128, 3), (900, 900, 8, 128, 128, 4)):
+        emu.lib.es_emu_set_dma_mode(1 if tr in (2, 4) else 0)       # the transposed-read tile stages by LDS-DMA: also with late delivery
+        tr = {0: 0, 1: 1, 2: 1, 3: 2, 4: 2}[tr]                    # option 14: 1 = 32 pairs per chunk, 2 = 64 (round 6)
         emu('es_set_option', 14, tr)
         nbr = _map(rng, n_out, n_in, K, 0.4)
         x = rng.standard_normal((n_in, cin)).astype(np.float32)
