@@ -365,6 +365,7 @@ def _wgrad(name, sw, dW, *args):
 
 
 IMG_WGRAD = [os.environ.get('ES_IMG_WGRAD', '1') != '0']     # round 6: 3x3 image weight gradients on csrc/imgwgrad.hip (A/B switch)
+IMG_CONV = [os.environ.get('ES_IMG_CONV', '1') != '0']       # round 6: 3x3 image forward / gated data gradient on csrc/imgconv.hip
 
 
 def _img_wgrad_floats(img, K, cin, cout, x, gy):
@@ -786,7 +787,13 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     if need_dx and x.rg and gate is not None:
         assert x.g is None and bf, 'gated dgrad: x must have exactly one consumer'
         x.g, x.gated = torch.empty(x.d.shape, dtype=torch.float32, device=x.d.device), True
-        if x.d.dtype == torch.bfloat16:          # the gate operand is the bf16 activation (only its sign is read)
+        if (IMG_CONV[0] and img is not None and K == 9 and img[3] == 1 and cin == cout and x.d.dtype == torch.bfloat16
+                and gy.dtype == torch.float32 and _ld(x.d) == cin
+                and hip.raw('es_img_conv3_supported')(img[0], img[1], img[2], cin, 1, 1) == 1):
+            # gated data gradient of a 3x3 image layer by address arithmetic (csrc/imgconv.hip, mode 1)
+            call('es_img_conv3_bf16', P(gy), _ld(gy), P(w.bf16()[0]), img[0], img[1], img[2], cin, 1, 1, P(gate), 0, P(x.d), _ld(x.d), 3,
+                 P(x.g), 0, _ld(x.g), s)
+        elif x.d.dtype == torch.bfloat16:        # the gate operand is the bf16 activation (only its sign is read)
             call('es_spconv_fwd_bf16_io', P(gy), 0, _ld(gy), P(w.bf16()[0]), P(inv), n_in, n_out, K, cout, cin, P(gate), 0,
                  P(x.d), 1, _ld(x.d), 3, P(x.g), 0, _ld(x.g), s)
         else:
@@ -824,7 +831,13 @@ def conv_affine(x, w, nbr, inv, n_out, scale, shift, act=1, res=None, need_dx=Tr
     y16 = bool(out_bf16 and ACT16[0] and cout % 4 == 0)
     x16, r16 = x.d.dtype == h16, (res is not None and res.d.dtype == h16)
     y = Var(empty((n_out, cout), x.d, dtype=h16 if y16 else torch.float32))
-    if x16 or r16 or y16:
+    # round 6: 3x3 layers on an image grid by address arithmetic (csrc/imgconv.hip) where the library takes the shape
+    ic = (IMG_CONV[0] and img is not None and K == 9 and x16 and res is None and act in (0, 1) and cin == cout and _ld(x.d) == cin
+          and hip.raw('es_img_conv3_supported')(img[0], img[1], img[2], cin, img[3], 0) == 1)
+    if ic:
+        call('es_img_conv3_bf16', P(x.d), cin, P(w.bf16()[1]), img[0], img[1], img[2], cin, img[3], 0, P(scale), P(shift), 0, 0, act,
+             P(y.d), int(y16), cout, _stream())
+    elif x16 or r16 or y16:
         call('es_spconv_fwd_bf16_io', P(x.d), int(x16), _ld(x.d), P(w.bf16()[1]), P(nbr), n_out, n_in, K, cin, cout, P(scale),
              P(shift), P(res.d) if res is not None else 0, int(r16), _ld(res.d) if res is not None else 0, act, P(y.d),
              int(y16), cout, _stream())

@@ -175,5 +175,5 @@ class ResNet:
         # cast without executing the launch, and every replay would redo it): bring the copies up to date first
         E.refresh_weight_copies()
         key = (x.data_ptr(), tuple(x.shape), E.PRECISION[0], bool(self.act16 and E.ACT16[0]), E.TAPE.enabled, self._fold_version,
-               self.arena.data.data_ptr(), E.SHADOW[0], E.WGRAD_SHADOW[0])
+               self.arena.data.data_ptr(), E.SHADOW[0], E.WGRAD_SHADOW[0], E.IMG_CONV[0])
         return E.graphed(self._graphs, key, lambda: self.forward(x))

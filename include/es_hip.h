@@ -518,6 +518,21 @@ int es_img_wgrad9_bf16(const void* Xh, int ldx, const float* dY, int ldy, int n_
                        int accumulate, float* ws, size_t ws_floats, void* stream);
 int es_img_wgrad_set_option(int key, int value);
 
+/* ---- 3x3 image convolutions by address arithmetic (round 6, csrc/imgconv.hip) -------------------------------------------
+ * Bottleneck.conv2 (3x3, pad 1) of the w16 image backbone (mmdet.ResNet, mv-det3d_...py:24-34) fused with its frozen BatchNorm2d
+ * (+ ReLU) -- what es_spconv_fwd_bf16_io does through es_image_map's 9-wide map -- on C -> C channels (C = 16 / 32 / 64):
+ * mode 0 forward: X (n_img*H*W x ldx) bf16 rows on the INPUT grid, W_bf16 = the [9][Cout][Cin] copy, Y = act((X*W)*scale[c] +
+ *   shift[c]) on the (H/stride, W/stride) output grid, bf16 rows (y_half 1) or f32; stride 1 or 2 (even H, W); act 0 / 1 (ReLU);
+ * mode 1 gated data gradient of a stride-1 layer: X = f32 rows of the output gradient, W_bf16 = the natural [9][Cin][Cout] copy,
+ *   gate (n_img*H*W x ldg) = the layer input's bf16 activation rows, Y (f32) = (gate > 0) ? (X * W^T, taps mirrored) * scale[c] : 0.
+ * es_img_conv3_supported: 1 when the shape is taken (C = 16: output width <= 128, stride 1; 32: <= 64; 64: <= 32); -4 otherwise.
+ * es_img_conv_set_option: 50 on / off, 51 workgroups aimed for. */
+int es_img_conv3_supported(int n_img, int H, int W, int C, int stride, int mode);
+int es_img_conv3_bf16(const void* X, int ldx, const void* W_bf16, int n_img, int H, int W, int C, int stride, int mode,
+                      const float* scale, const float* shift, const void* gate, int ldg, int act, void* Y, int y_half, int ldy,
+                      void* stream);
+int es_img_conv_set_option(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ CSRC = os.path.join(ROOT, 'embodiedscan_amd', 'csrc')
 OUT = os.path.join(HERE, '_build')
 CLANG = os.environ.get('ES_EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
 DEFAULT = ('coords.hip', 'sort.hip', 'spconv.hip', 'rowops.hip', 'fusion.hip', 'targets.hip', 'losses.hip', 'optim.hip', 'data.hip',
-           'predict.hip', 'dense.hip', 'occ.hip', 'transformer.hip', 'ground.hip', 'dconv.hip', 'halo.hip', 'imgwgrad.hip')
+           'predict.hip', 'dense.hip', 'occ.hip', 'transformer.hip', 'ground.hip', 'dconv.hip', 'halo.hip', 'imgwgrad.hip', 'imgconv.hip')
 
 
 def transform(text):
