@@ -45,6 +45,7 @@ static int ES_OPT_SPLIT_FOLD = 0;           // tap-split launches: partial tiles
                                            // L2 write-backs inside a streaming kernel cost far more than the 70 reduce launches they replace:
                                            // mv-3ddet step 30.9 ms against 25.9 (with a seq_cst fence, i.e. + buffer_inv: 32.6).  Kept as a tested option.
 static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
+static int ES_OPT_RG128_MIN_WGS = 0;       // ... and only for launches with at least this many 128-column workgroups (key 19; round 6 A/B: no measurable change, off)
 extern int ES_OPT_NORM_CB_ROWS;          // rowops.hip: one-launch norm for matrices with at most this many rows (key 15)
 extern int ES_OPT_NORM_CB_BWD;           // ... for the backward pass too (key 17)
 extern int ES_OPT_ELECT_SAFE;            // rowops.hip: agent-scope fences in the last-workgroup elections (key 18)
@@ -66,6 +67,7 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 16) { ES_OPT_SPLIT_FOLD = value; return 0; }
   if (key == 17) { ES_OPT_NORM_CB_BWD = value; return 0; }
   if (key == 18) { ES_OPT_ELECT_SAFE = value; return 0; }
+  if (key == 19) { ES_OPT_RG128_MIN_WGS = value; return 0; }
   return -2;
 }
 
@@ -1617,7 +1619,12 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
       (Cout % 16 == 0) && (ldx % (x_is_bf16 ? 8 : 4) == 0) && (ldy % 4 == 0) &&
       (((((uintptr_t)Xv) | ((uintptr_t)Wh)) & 15) == 0) && ((((uintptr_t)Y) & (y_half ? 7 : 15)) == 0) &&
       (!ep_res || ((ep_ldr % 4 == 0) && ((((uintptr_t)ep_res) & ((io & ES_IO_R16) ? 7 : 15)) == 0)))) {
-    const int nt = (Cout % 128 == 0 && Cin >= ES_OPT_RG128_MIN_CIN) ? 128 : (Cout % 64 == 0) ? 64 : (Cout % 32 == 0) ? 32 : 16;
+    // 128-column tiles only when they still fill the chip: a launch of fewer than ES_OPT_RG128_MIN_WGS such workgroups (the grounder's
+    // 256 -> 256 linears on 3 072 query rows: 48) runs 64-column tiles -- twice the workgroups, half the serial k loop per output
+    // column (round 6 A/B with the threshold at 256: grounding 53.35 vs 53.03, mv-3ddet 23.62 vs 23.56, occupancy 34.69 vs 34.76: noise; default 0 = off)
+    const bool wide = Cout % 128 == 0 && Cin >= ES_OPT_RG128_MIN_CIN &&
+                      (long long)es_cdiv(n_out, BM) * (Cout / 128) >= ES_OPT_RG128_MIN_WGS;
+    const int nt = wide ? 128 : (Cout % 64 == 0) ? 64 : (Cout % 32 == 0) ? 32 : 16;
     dim3 g(es_cdiv(n_out, BM), Cout / nt);
 #define RG_LAUNCH(NT_)                                                                                              \
     do {                                                                                                            \
