@@ -27,8 +27,9 @@ K_PEAK_HBM = 8000.0               # GB/s      (MI355X_MICROARCH.md)
 K_PEAK_MFMA = {'bf16': 2500.0, 'f32': 157.3}    # dense TFLOP/s of the matrix-core type the engine computes in
 ENGINE = {'es_spconv_fwd', 'es_spconv_fwd_bf16', 'es_spconv_fwd_bf16_ws', 'es_spconv_fwd_bf16_affine', 'es_spconv_fwd_bf16_io',
           'es_spconv_wgrad', 'es_spconv_wgrad_bf16', 'es_spconv_wgrad_bf16_src', 'es_dconv_fwd_bf16',
-          'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16', 'es_spconv_halo_bf16', 'es_img_wgrad9_bf16', 'es_img_conv3_bf16'}
+          'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16', 'es_spconv_halo_bf16', 'es_img_wgrad9_bf16', 'es_img_conv3_bf16', 'es_rows_wgrad1_bf16'}
 IMGC = ('es_img_conv3_bf16',)        # round 6: (X, ldx, W, n_img, H, W, C, stride, mode, scale, shift, gate, ldg, act, Y, y_half, ldy, stream)
+ROWW = ('es_rows_wgrad1_bf16',)      # round 6: (Xh, ldx, dY, ldy, n, Cin, Cout, dW, acc, ws, ws_floats, stream)
 IMGW = ('es_img_wgrad9_bf16',)       # round 6: (Xh, ldx, dY, ldy, n_img, H, W, C, stride, dW, acc, ws, ws_floats, stream)
 HALO = ('es_spconv_halo_bf16',)      # round 6: (Xh, ldx, W, loc, hrows, hcnt, n_out, n_in, K, Cin, Cout, bias, Y, ldy, acc, stream)
 DENSE = ('es_dconv_fwd_bf16', 'es_dconv_wgrad_bf16', 'es_dconv_wgrad_ws_bf16')   # round 5: the dense-volume engine (csrc/dconv.hip)
@@ -988,7 +989,7 @@ def launch_classes(records, mfma_peak, top=6):
         if name not in ENGINE:
             continue
         nbr, n_out, n_in, K, cin, cout = engine_args(name, a)
-        kind = 'wgrad' if (name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD or name in IMGW) else 'fwd/dgrad'
+        kind = 'wgrad' if (name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD or name in IMGW or name in ROWW) else 'fwd/dgrad'
         if name in DENSE:
             kind += ' dense'
         key = f'{kind} K={K} {cin}->{cout}'
@@ -1109,6 +1110,9 @@ def resolve_pairs(hip, records):
         if name in DENSE:
             out.append((name, e0, e1, a, dense_info(name, a)[5]))
             continue
+        if name in ROWW:
+            out.append((name, e0, e1, a, float(a[4])))
+            continue
         if name in IMGC:
             axc = lambda d: sum(1 for q in range(d // a[7]) for k in range(3) if 0 <= q * a[7] - 1 + k < d)
             out.append((name, e0, e1, a, float(a[3]) * axc(a[4]) * axc(a[5])))
@@ -1137,6 +1141,8 @@ def engine_args(name, a):
         return a[3], a[6], a[7], a[8], a[9], a[10]
     if name in IMGW:
         return 1, a[4] * (a[5] // a[8]) * (a[6] // a[8]), a[4] * a[5] * a[6], 9, a[7], a[7]
+    if name in ROWW:
+        return 0, a[4], a[4], 1, a[5], a[6]
     if name in IMGC:
         return 1, a[3] * (a[4] // a[7]) * (a[5] // a[7]), a[3] * a[4] * a[5], 9, a[6], a[6]
     if name in FWD_X:
@@ -1159,7 +1165,7 @@ def engine_totals(records, mfma_peak):
             pairs = pairs_dev
         else:
             pairs = float(pairs_dev.item()) if pairs_dev is not None else (float(min(n_out, n_in)) if not nbr else float(n_out) * K)
-        wgrad = name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD or name in IMGW
+        wgrad = name.startswith('es_spconv_wgrad') or name in DENSE_WGRAD or name in IMGW or name in ROWW
         wb = 2 if ('bf16' in name and not wgrad) else 4
         f = 2.0 * pairs * cin * cout
         pb = pairs * (cin + cout) * 4.0 + float(K) * cin * cout * wb
@@ -1171,7 +1177,7 @@ def engine_totals(records, mfma_peak):
             bx, by = (2.0 if a[1] else 4.0), (2.0 if a[4] else 4.0)
         elif name in IMGC:
             bx, by = (2.0, 2.0 if a[15] else 4.0) if a[8] == 0 else (4.0, 4.0)     # forward: bf16 in, bf16 / f32 out; data gradient: f32 in / out
-        elif name in IMGW:
+        elif name in IMGW or name in ROWW:
             bx = 2.0                                     # bf16 activation rows, f32 gradient rows
         elif name in DENSE_WGRAD:
             bx = by = 2.0

@@ -178,12 +178,175 @@ __global__ void k_img_wgrad_reduce(const float* __restrict__ ws, int parts, int 
 }
 
 static int ES_OPT_IMG_WGRAD = 1;
+static int ES_OPT_ROWS_WGRAD_MIN_ROWS = 500000;              // 1x1 streaming kernel: rows from which it is taken whatever the width (key 43)
 static int ES_OPT_IMG_WGRAD_WGS32 = 400, ES_OPT_IMG_WGRAD_WGS64 = 160;      // workgroups a launch aims for (partial tensors: 36 / 147 KB each)
 extern "C" int es_img_wgrad_set_option(int key, int value) {
   if (key == 40) { ES_OPT_IMG_WGRAD = value; return 0; }
   if (key == 41) { ES_OPT_IMG_WGRAD_WGS32 = value; return 0; }
   if (key == 42) { ES_OPT_IMG_WGRAD_WGS64 = value; return 0; }
+  if (key == 43) { ES_OPT_ROWS_WGRAD_MIN_ROWS = value; return 0; }
   return -1;
+}
+
+// ------------------------------------------------------------------ 1x1 layers: dW[Cin][Cout] = X^T . dY over contiguous rows
+// The image backbone's 1x1 convolutions (Bottleneck.conv1 / conv3: 64 -> 32, 128 -> 32, 32 -> 128, ... on 10^5 .. 10^6 pixel rows) ran on
+// the same ring / gather kernel as the 3x3 ones (k_spconv_wgrad_bf16<1, 0>: 1.0 - 2.8 TB/s of operand bytes).  With the identity map there
+// is nothing to gather: a workgroup streams a slice of rows in 64-row steps -- X tile [64][CI] by LDS-DMA, dY tile [64][CO] f32 through
+// registers (prefetched one step ahead, rounded to bf16) -- into two LDS buffers and reads both operands transposed; a (CI x CO) tile of dW
+// per workgroup (128 x 128 at most: 16 accumulator fragments per wave), partial tensors per slice added in slice order.
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void k_rows_wgrad1(const unsigned short* __restrict__ Xh, int ldx, const float* __restrict__ dY, int ldy,
+                                                     int n, int Cin, int Cout, int rows_per_slice, float* __restrict__ out, int to_ws,
+                                                     int accumulate) {
+  constexpr int FA = CI / 16, FB = CO / 16;
+  constexpr bool CI_SPLIT = FA >= 4;                         // waves split the ci blocks (else the co blocks)
+  constexpr int WA = CI_SPLIT ? FA / 4 : FA, WB = CI_SPLIT ? FB : FB / 4;
+  static_assert(CI_SPLIT || FB >= 4, "a 32-channel side needs at least 64 on the other");
+  constexpr int RA = CI * 2, RBY = CO * 2;                   // bytes per row of the X / dY tile
+  constexpr int XT = 64 * RA, YT = 64 * RBY;
+  constexpr int NPX = 64 * (RA / 16) / 256;                  // LDS-DMA pieces per thread and step (CI = 32: 1, 64: 2, 128: 4)
+  constexpr int NLY = 64 * CO / 4 / 256;                     // float4 loads per thread and step
+  static_assert(NPX >= 1 && NLY >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * XT + 2 * YT];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int c0 = blockIdx.y * CI, n0 = blockIdx.z * CO;
+  const int r0 = blockIdx.x * rows_per_slice, r1 = min(n, r0 + rows_per_slice);
+  f32x4 acc[WA][WB];
+#pragma unroll
+  for (int a = 0; a < WA; ++a)
+#pragma unroll
+    for (int b = 0; b < WB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto issue_x = [&](int buf, int row) {                     // rows row .. row + 63 (past r1: zero granules)
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      const int e = (j * 4 + wv) * 64 + lane, rr = e / (RA / 16), g = e - rr * (RA / 16);
+      const unsigned short* p = row + rr < r1 ? (Xh + (size_t)(row + rr) * ldx + c0 + g * 8) : g_iw_zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)(smem + buf * XT + (j * 4 + wv) * 1024), 16, 0, 0);
+    }
+  };
+  float4 yreg[NLY];
+  auto load_y = [&](int row) {
+#pragma unroll
+    for (int j = 0; j < NLY; ++j) {
+      const int e = j * 256 + t, rr = e / (CO / 4), c4 = e - rr * (CO / 4);
+      yreg[j] = row + rr < r1 ? *(const float4*)(dY + (size_t)(row + rr) * ldy + n0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_y = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NLY; ++j) {
+      const int e = j * 256 + t, rr = e / (CO / 4), c4 = e - rr * (CO / 4);
+      uint2 v;
+      v.x = es_pack_bf16(yreg[j].x, yreg[j].y);
+      v.y = es_pack_bf16(yreg[j].z, yreg[j].w);
+      *(uint2*)(smem + 2 * XT + buf * YT + rr * RBY + c4 * 8) = v;
+    }
+  };
+  auto frag = [&](const unsigned char* tile, int rb, int p0, int cb) -> bf16x8_t {      // rows p0 + kq * 8 .. of channel cb * 16 + li
+    s16x4_t h[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int pr = p0 + kq * 8 + r * 4 + (li >> 2);
+      h[r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + pr * rb + cb * 32 + (li & 3) * 8));
+    }
+    s16x8_t v = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  if (r0 < r1) {
+    issue_x(0, r0);
+    load_y(r0);
+    int buf = 0;
+    for (int row = r0; row < r1; row += 64, buf ^= 1) {
+      store_y(buf);                                          // (this buffer was last read two steps ago: a barrier has passed since)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the X tile have landed ...
+      __syncthreads();                                        // ... everybody's; the dY tile is complete; the other buffer has been consumed
+      if (row + 64 < r1) { issue_x(buf ^ 1, row + 64); load_y(row + 64); }
+      const unsigned char* xt = smem + buf * XT;
+      const unsigned char* yt = smem + 2 * XT + buf * YT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t a[WA], b[WB];
+#pragma unroll
+        for (int i = 0; i < WA; ++i) a[i] = frag(xt, RA, ks * 32, CI_SPLIT ? wv * WA + i : i);
+#pragma unroll
+        for (int i = 0; i < WB; ++i) b[i] = frag(yt, RBY, ks * 32, CI_SPLIT ? i : wv * WB + i);
+#pragma unroll
+        for (int i = 0; i < WA; ++i)
+#pragma unroll
+          for (int k = 0; k < WB; ++k) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[k], acc[i][k], 0, 0, 0);
+      }
+    }
+  }
+  // partial tensor of this slice: the full [Cin][Cout] layout (tiles of other workgroups interleave)
+  float* const dst = to_ws ? out + (size_t)blockIdx.x * Cin * Cout : out;
+#pragma unroll
+  for (int i = 0; i < WA; ++i)
+#pragma unroll
+    for (int k = 0; k < WB; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = c0 + (CI_SPLIT ? wv * WA + i : i) * 16 + kq * 4 + r, co = n0 + (CI_SPLIT ? k : wv * WB + k) * 16 + li;
+        float* p = dst + (size_t)ci * Cout + co;
+        *p = (!to_ws && accumulate) ? (*p + acc[i][k][r]) : acc[i][k][r];
+      }
+}
+
+static bool rows_wgrad_plan(int n, int Cin, int Cout, int& ci, int& co, int& slices, int& rows) {
+  if (!ES_OPT_IMG_WGRAD || n < 4096) return false;
+  // A/B against the ring kernel (profiles/r6h_imgwgrad_ab.txt): that one already streams these launches at 2 - 3 TB/s; this kernel wins from
+  // 256 input channels (38 -> 27 us) or half a million rows (144 -> 98 us, 160 -> 129 us) and loses a few us below
+  if (!(Cin >= 256 || n >= ES_OPT_ROWS_WGRAD_MIN_ROWS)) return false;
+  ci = Cin % 128 == 0 ? 128 : Cin % 64 == 0 ? 64 : Cin == 32 ? 32 : 0;
+  co = Cout % 128 == 0 ? 128 : Cout % 64 == 0 ? 64 : Cout == 32 ? 32 : 0;
+  if (!ci || !co || (ci == 32 && co == 32) || Cin > 512 || Cout > 512) return false;
+  const long long tiles = (long long)(Cin / ci) * (Cout / co);
+  // slices: enough workgroups to stream at full bandwidth, few enough that the partial tensors stay a fraction of the operand bytes
+  const long long in_bytes = (long long)n * (Cin * 2 + Cout * 4), dw_bytes = (long long)Cin * Cout * 4;
+  long long s = in_bytes / (4 * dw_bytes);
+  const long long cap = 1024 / tiles > 1 ? 1024 / tiles : 1;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  rows = es_cdiv(es_cdiv(n, (int)s), 64) * 64;
+  slices = es_cdiv(n, rows);
+  return true;
+}
+
+extern "C" size_t es_rows_wgrad1_workspace_floats(int n, int Cin, int Cout) {
+  int ci, co, slices, rows;
+  if (!rows_wgrad_plan(n, Cin, Cout, ci, co, slices, rows)) return 0;
+  return (size_t)slices * Cin * Cout;
+}
+
+extern "C" int es_rows_wgrad1_bf16(const void* Xh, int ldx, const float* dY, int ldy, int n, int Cin, int Cout, float* dW, int accumulate,
+                                   float* ws, size_t ws_floats, void* stream) {
+  int ci, co, slices, rows;
+  if (!rows_wgrad_plan(n, Cin, Cout, ci, co, slices, rows)) return -4;
+  if ((ldx % 8) || (ldy % 4) || ((((uintptr_t)Xh) | ((uintptr_t)dY)) & 15)) return -4;
+  if ((long long)n * (ldx > ldy ? ldx : ldy) >= (1ll << 31)) return -4;
+  if (slices > 1 && (ws == nullptr || ws_floats < (size_t)slices * Cin * Cout)) return -5;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short* X = (const unsigned short*)Xh;
+  float* out = slices > 1 ? ws : dW;
+  const int to_ws = slices > 1;
+  dim3 grid(slices, Cin / ci, Cout / co);
+#define RW_LAUNCH(CI_, CO_) hipLaunchKernelGGL((k_rows_wgrad1<CI_, CO_>), grid, dim3(256), 0, st, X, ldx, dY, ldy, n, Cin, Cout, rows, out, to_ws, accumulate)
+  if (ci == 128 && co == 128) RW_LAUNCH(128, 128);
+  else if (ci == 128 && co == 64) RW_LAUNCH(128, 64);
+  else if (ci == 128 && co == 32) RW_LAUNCH(128, 32);
+  else if (ci == 64 && co == 128) RW_LAUNCH(64, 128);
+  else if (ci == 64 && co == 64) RW_LAUNCH(64, 64);
+  else if (ci == 64 && co == 32) RW_LAUNCH(64, 32);
+  else if (ci == 32 && co == 128) RW_LAUNCH(32, 128);
+  else RW_LAUNCH(32, 64);
+#undef RW_LAUNCH
+  ES_CHECK_LAUNCH();
+  if (slices > 1) {
+    const int nn = Cin * Cout;
+    hipLaunchKernelGGL(k_img_wgrad_reduce, dim3(es_cdiv(nn, 256)), dim3(256), 0, st, ws, slices, nn, dW, accumulate);
+    ES_CHECK_LAUNCH();
+  }
+  return 0;
 }
 
 static bool img_wgrad_plan(int n_img, int H, int W, int C, int stride, int& wp, int& rows, int& bands) {

@@ -365,6 +365,7 @@ def _wgrad(name, sw, dW, *args):
 
 
 IMG_WGRAD = [os.environ.get('ES_IMG_WGRAD', '1') != '0']     # round 6: 3x3 image weight gradients on csrc/imgwgrad.hip (A/B switch)
+ROWS_WGRAD = [os.environ.get('ES_ROWS_WGRAD', '1') != '0']   # round 6: 1x1 weight gradients on contiguous rows (streaming kernel of csrc/imgwgrad.hip)
 IMG_CONV = [os.environ.get('ES_IMG_CONV', '1') != '0']       # round 6: 3x3 image forward / gated data gradient on csrc/imgconv.hip
 
 
@@ -756,10 +757,22 @@ def _conv_backward(x, w, nbr, inv, n_out, y, gy, bias, bias_from, need_dx, bf, g
     if w.g is not None or (bias is not None and bias.g is not None):
         sw = _wgrad_stream(gy, x.d, gh, x.dh)
     iw = _img_wgrad_floats(img, K, cin, cout, x, gy) if (w.g is not None and bf and dn_w is None) else 0
+    # 1x1 layers on contiguous rows (identity map), bf16 activation rows, f32 gradient rows: streaming kernel (csrc/imgwgrad.hip)
+    rw = 0
+    if (w.g is not None and bf and dn_w is None and not iw and ROWS_WGRAD[0] and K == 1 and nbr is None and n_in == n_out
+            and x.dh is not None and gy.dtype == torch.float32):
+        rw = int(hip.raw('es_rows_wgrad1_workspace_floats')(n_out, cin, cout))
     if dn_w is not None:
         _dense_wgrad(P(x.dh), cin, P(gh), cout, dn_w, 0, cin, cout, P(w.g), _first_write(P(w.g)), sw, gh)
     elif iw:
         _img_wgrad(sw, P(w.g), x.dh, _ld(x.dh), gy, _ld(gy), img, cin, iw)
+    elif rw:
+        ws = _WGRAD_WS.get(sw)
+        if ws is None or ws.numel() < rw:
+            if ws is not None:
+                _KEEP.append(ws)
+            ws = _WGRAD_WS[sw] = torch.empty(max(rw, 1 << 22), dtype=torch.float32, device=gy.device)
+        call('es_rows_wgrad1_bf16', P(x.dh), _ld(x.dh), P(gy), _ld(gy), n_out, cin, cout, P(w.g), _first_write(P(w.g)), P(ws), ws.numel(), sw)
     elif w.g is not None and bf and WGRAD_BF16[0] and ((SHADOW[0] and WGRAD_SHADOW[0] and (gh is not None or x.dh is not None))
                                                   or x.d.dtype == torch.bfloat16):      # (bf16 activation rows ARE their shadow: ES_SHADOW=0 must not strand them)
         xs, ys = x.dh if x.dh is not None else x.d, gh if gh is not None else gy

@@ -517,6 +517,14 @@ size_t es_img_wgrad9_workspace_floats(int n_img, int H, int W, int C, int stride
 int es_img_wgrad9_bf16(const void* Xh, int ldx, const float* dY, int ldy, int n_img, int H, int W, int C, int stride, float* dW,
                        int accumulate, float* ws, size_t ws_floats, void* stream);
 int es_img_wgrad_set_option(int key, int value);
+/* dW[Cin][Cout] (f32) (+)= X^T . dY of a 1x1 convolution / Linear on CONTIGUOUS rows (identity map): Xh (n x ldx) bf16 activation rows, dY
+ * (n x ldy) f32 gradient rows (rounded to bf16 in the kernel) -- Bottleneck.conv1 / conv3 of the image backbone.  Channel counts: multiples
+ * of 64 up to 512, or 32 against >= 64; taken from 256 input channels or from 500 000 rows (es_img_wgrad_set_option 43), where it beats
+ * the ring kernel.  es_rows_wgrad1_workspace_floats returns 0 for a shape it does not take (the caller keeps
+ * es_spconv_wgrad_bf16_src); -4 / -5 as above.  Partial tensors per row slice, added in slice order: bit-reproducible. */
+size_t es_rows_wgrad1_workspace_floats(int n, int Cin, int Cout);
+int es_rows_wgrad1_bf16(const void* Xh, int ldx, const float* dY, int ldy, int n, int Cin, int Cout, float* dW, int accumulate, float* ws,
+                        size_t ws_floats, void* stream);
 
 /* ---- 3x3 image convolutions by address arithmetic (round 6, csrc/imgconv.hip) -------------------------------------------
  * Bottleneck.conv2 (3x3, pad 1) of the w16 image backbone (mmdet.ResNet, mv-det3d_...py:24-34) fused with its frozen BatchNorm2d

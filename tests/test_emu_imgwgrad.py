@@ -75,3 +75,36 @@ def test_image_weight_gradient_support_rule(emu):
     x = np.zeros((64, 64), np.float32)
     assert emu.fns['es_img_wgrad9_bf16'](P(x), 32, P(x), 32, 1, 4, 200, 32, 1, P(x), 0, P(x), 1 << 20, 0) == -4
     assert emu.fns['es_img_wgrad9_bf16'](P(x), 32, P(x), 32, 4, 8, 8, 32, 1, P(x), 0, 0, 0, 0) == -5       # several workgroups, no workspace
+
+
+@pytest.mark.parametrize('lazy', [0, 1])
+def test_rows_weight_gradient_of_1x1_layers(emu, lazy):
+    """dW[Cin][Cout] = X^T dY on contiguous rows (es_rows_wgrad1_bf16): every (Cin tile, Cout tile) combination the plan picks, ragged last
+    step, several slices, strided rows, accumulation -- against f64 on the bf16-rounded operands"""
+    rng = np.random.default_rng(41 + lazy)
+    emu.lib.es_emu_set_dma_mode(lazy)
+    emu('es_img_wgrad_set_option', 43, 0)                 # (every width from 4 096 rows: the shipped rule takes < 256 channels only from 500 000)
+    try:
+        cases = [(4500, 32, 128, 0, 0), (4200, 128, 32, 8, 1), (4100, 64, 256, 0, 0), (4300, 256, 64, 0, 1), (4096, 64, 64, 16, 0),
+                 (4400, 32, 64, 0, 0), (4200, 128, 128, 0, 0), (4150, 192, 32, 0, 0)]
+        for n, cin, cout, ext, acc in (cases if not lazy else cases[:3]):
+            nf = emu.fns['es_rows_wgrad1_workspace_floats'](n, cin, cout)
+            assert nf > 0 and nf % (cin * cout) == 0, (n, cin, cout, nf)
+            x = rng.standard_normal((n, cin + ext)).astype(np.float32)
+            gy = rng.standard_normal((n, cout + ext)).astype(np.float32)
+            xh = bf16_bits(x)
+            ws = np.full(nf, np.nan, np.float32)
+            dw0 = rng.standard_normal((cin, cout)).astype(np.float32)
+            dw = dw0.copy()
+            emu('es_rows_wgrad1_bf16', P(xh), cin + ext, P(gy), cout + ext, n, cin, cout, P(dw), acc, P(ws), nf, 0)
+            want = bf16_round(x)[:, :cin].astype(np.float64).T @ bf16_round(gy)[:, :cout].astype(np.float64) + (dw0 if acc else 0)
+            err = np.abs(dw - want).max() / np.abs(want).max()
+            assert err < 2e-6, (n, cin, cout, err)
+        wsf = emu.fns['es_rows_wgrad1_workspace_floats']
+        assert wsf(1000, 64, 64) == 0 and wsf(100000, 16, 64) == 0 and wsf(100000, 32, 32) == 0 and wsf(100000, 1024, 256) == 0
+        assert wsf(288000, 32, 128) > 0 and wsf(18000, 128, 512) > 0
+        emu('es_img_wgrad_set_option', 43, 500000)
+        assert wsf(288000, 32, 128) == 0 and wsf(864000, 32, 128) > 0 and wsf(72000, 256, 64) > 0
+    finally:
+        emu.lib.es_emu_set_dma_mode(0)
+        emu('es_img_wgrad_set_option', 43, 500000)

@@ -103,3 +103,33 @@ def test_engine_takes_the_image_kernel_for_the_backbone_conv2():
     err = float((a - b).norm() / b.norm())
     print(f'image kernel taken {grads[True][1]} times {sorted(set(seen_on))}; arena gradient vs map kernels: rel-L2 {err:.2e}')
     assert err < 1e-5
+
+
+@pytest.mark.parametrize('case', [(288000, 32, 128), (288000, 128, 32), (72000, 64, 256), (72000, 256, 64), (18000, 128, 512), (18000, 512, 128),
+                                  (1152000, 64, 32), (5000, 64, 64)])
+def test_rows_wgrad_of_1x1_layers_vs_map_kernel(case):
+    """es_rows_wgrad1_bf16 against the ring / gather kernel on the same operands (identity map), run-to-run bit-identical"""
+    from embodiedscan_amd.engine import _wgrad as WG
+    from embodiedscan_amd.hip import P, call, raw
+    n, cin, cout = case
+    dev = torch.device('cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    raw('es_img_wgrad_set_option')(43, 0)                  # every width (the shipped rule: < 256 input channels only from 500 000 rows)
+    g = torch.Generator().manual_seed(6)
+    xh = torch.randn(n, cin, generator=g).to(dev).to(torch.bfloat16)
+    gy = torch.randn(n, cout, generator=g).to(dev)
+    d1 = torch.zeros(1, cin, cout, device=dev)
+    WG('es_spconv_wgrad_bf16_src', st, P(d1), P(xh), 1, cin, P(gy), 0, cout, 0, n, n, 1, cin, cout)
+    nf = int(raw('es_rows_wgrad1_workspace_floats')(n, cin, cout))
+    assert nf > 0
+    ws = torch.full((nf,), float('nan'), device=dev)
+    d2 = torch.full((cin, cout), float('nan'), device=dev)
+    call('es_rows_wgrad1_bf16', P(xh), cin, P(gy), cout, n, cin, cout, P(d2), 0, P(ws), nf, st)
+    d3 = torch.full((cin, cout), float('nan'), device=dev)
+    call('es_rows_wgrad1_bf16', P(xh), cin, P(gy), cout, n, cin, cout, P(d3), 0, P(ws), nf, st)
+    torch.cuda.synchronize()
+    assert torch.equal(d2, d3)
+    err = float((d1[0] - d2).abs().max() / d1.abs().max())
+    raw('es_img_wgrad_set_option')(43, 500000)
+    print(f'{case}: rows kernel vs map kernel {err:.2e} (tol 5e-6), {nf // (cin * cout)} slices')
+    assert err < 5e-6

@@ -44,3 +44,16 @@ for n_img, H, W, C, S in ((80, 60, 60, 32, 1), (80, 30, 30, 64, 1), (240, 60, 60
           f' | max rel diff {float((d1 - d2).abs().max() / d1.abs().max()):.1e}')
 raw('es_img_wgrad_set_option')(41, 400)
 raw('es_img_wgrad_set_option')(42, 160)
+print('--- 1x1 layers on contiguous rows: map kernel vs streaming kernel')
+raw('es_img_wgrad_set_option')(43, 0)
+for n, cin, cout in ((288000, 32, 128), (288000, 128, 32), (72000, 64, 256), (72000, 256, 64), (18000, 128, 512), (18000, 512, 128), (1152000, 64, 32),
+                     (864000, 32, 128), (864000, 128, 32), (216000, 64, 256), (216000, 256, 64)):
+    xh = torch.randn(n, cin, device=dev).to(torch.bfloat16)
+    gy = torch.randn(n, cout, device=dev)
+    d1, d2 = torch.zeros(1, cin, cout, device=dev), torch.zeros(cin, cout, device=dev)
+    t1 = timeit(lambda: WG('es_spconv_wgrad_bf16_src', st, P(d1), P(xh), 1, cin, P(gy), 0, cout, 0, n, n, 1, cin, cout))
+    nf = int(raw('es_rows_wgrad1_workspace_floats')(n, cin, cout))
+    ws = torch.empty(nf, device=dev)
+    t2 = timeit(lambda: call('es_rows_wgrad1_bf16', P(xh), cin, P(gy), cout, n, cin, cout, P(d2), 0, P(ws), nf, st))
+    mb = n * (cin * 2 + cout * 4) / 1e6
+    print(f'{n} x {cin}->{cout}: {mb:.0f} MB | map kernel {t1:6.1f} us ({mb / t1 / 1e3 * 1e3:.2f} TB/s) | rows kernel {t2:6.1f} us ({mb / t2:.2f} TB/s), {nf // (cin * cout)} slices')
