@@ -12,7 +12,11 @@
 // Rows per statistics chunk: 128 for small levels (enough chunks to fill the chip), up to 512 for the 1e5..1e6-row levels so
 // that the finalize kernels do not walk thousands of partials (round 2: 2969 partials per channel on the finest level,
 // finalize kernels at 15-18 us for a few-hundred-float reduction).
-static int norm_chunk_rows(int max_rows) { return max_rows <= (1 << 17) ? 128 : (max_rows <= (1 << 18) ? 256 : 512); }
+int ES_OPT_NORM_CHUNK = 0;               // es_set_option key 9: rows per statistics chunk (0: the rule below)
+static int norm_chunk_rows(int max_rows) {
+  if (ES_OPT_NORM_CHUNK > 0) return ES_OPT_NORM_CHUNK;
+  return max_rows <= (1 << 17) ? 128 : (max_rows <= (1 << 18) ? 256 : 512);
+}
 // finalize kernels: a block owns FCH channels x FST chunk stripes (round 2: 64 x 16 -> ONE block for a 64-channel level)
 #define FCH 16
 #define FST 64

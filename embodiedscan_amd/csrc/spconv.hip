@@ -49,6 +49,7 @@ static int ES_OPT_RG128_MIN_WGS = 0;       // ... and only for launches with at 
 extern int ES_OPT_NORM_CB_ROWS;          // rowops.hip: one-launch norm for matrices with at most this many rows (key 15)
 extern int ES_OPT_NORM_CB_BWD;           // ... for the backward pass too (key 17)
 extern int ES_OPT_ELECT_SAFE;            // rowops.hip: agent-scope fences in the last-workgroup elections (key 18)
+extern int ES_OPT_NORM_CHUNK;            // rowops.hip: rows per norm-statistics chunk (key 9)
 extern "C" int es_set_option(int key, int value) {
   if (key == 1) { ES_OPT_PINGPONG = value; return 0; }
   if (key == 2) { ES_OPT_WGRAD_HUGE = value; return 0; }
@@ -58,6 +59,7 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 6) { ES_OPT_WG_SMALL_TARGET = value; return 0; }
   if (key == 7) { ES_OPT_WG_CAP_MB = value; return 0; }
   if (key == 8) { ES_OPT_FWD_SPLIT_WGS = value; return 0; }
+  if (key == 9) { ES_OPT_NORM_CHUNK = value; return 0; }
   if (key == 10) { ES_OPT_DMA = value; return 0; }
   if (key == 11) { ES_OPT_DMA_MIN_CIN = value; return 0; }
   if (key == 12) { ES_OPT_RG128_MIN_CIN = value; return 0; }

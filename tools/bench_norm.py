@@ -27,6 +27,11 @@ def timeit(fn, n=20):
 # (rows, channels, residual) of the 3-D backbone / head levels of 4 synthetic scans
 CASES = [(132358, 64, False), (23307, 64, True), (7493, 128, True), (2308, 256, True), (740, 512, True), (5920, 512, False),
          (47360, 256, False), (378880, 128, False), (358208, 128, False)]
+CHUNK = int(os.environ.get('NORM_CHUNK', '0'))
+if CHUNK:
+    from embodiedscan_amd import hip
+    hip.raw('es_set_option')(9, CHUNK)
+    CASES = CASES[-3:]
 for n, C, with_res in CASES:
     x = E.Var(torch.randn(n, C, device=dev))
     w = E.Param(torch.rand(C, device=dev) + 0.5, torch.zeros(C, device=dev))
