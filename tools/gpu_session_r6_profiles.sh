@@ -32,4 +32,7 @@ for kind in occupancy grounding; do
   (cd /tmp && ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0 timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks_$kind -o p -- $C2 > /tmp/prof_ks_$kind.log 2>&1); echo "rc $?"
   python tools/rocpd_stats.py "$(db ks_$kind)" $OUT/${T}_single_stream_kernel_stats_$kind.txt > /dev/null
 done
-ls -la $OUT | grep "${T}_" | tail -20
+timeout 300 python tools/bench_halo.py > $OUT/${T}_halo_ab.txt 2>&1
+timeout 300 python tools/bench_imgwgrad.py > $OUT/${T}_imgwgrad_ab.txt 2>&1
+timeout 300 python tools/bench_imgconv.py > $OUT/${T}_imgconv_ab.txt 2>&1
+ls -la $OUT | grep "${T}_" | tail -24
