@@ -45,6 +45,8 @@ static int ES_OPT_SPLIT_FOLD = 0;           // tap-split launches: partial tiles
                                            // L2 write-backs inside a streaming kernel cost far more than the 70 reduce launches they replace:
                                            // mv-3ddet step 30.9 ms against 25.9 (with a seq_cst fence, i.e. + buffer_inv: 32.6).  Kept as a tested option.
 static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
+static int ES_OPT_NARROW = 1;              // 3-channel K = 27 convolutions (MinkResNet.conv1) on the lane-per-output-channel kernels (key 21)
+static int ES_OPT_WSHARE = 0;              // tap-split launches in the weight-sharing workgroup order (key 20)
 static int ES_OPT_RG128_MIN_WGS = 0;       // ... and only for launches with at least this many 128-column workgroups (key 19; round 6 A/B: no measurable change, off)
 extern int ES_OPT_NORM_CB_ROWS;          // rowops.hip: one-launch norm for matrices with at most this many rows (key 15)
 extern int ES_OPT_NORM_CB_BWD;           // ... for the backward pass too (key 17)
@@ -70,6 +72,8 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 17) { ES_OPT_NORM_CB_BWD = value; return 0; }
   if (key == 18) { ES_OPT_ELECT_SAFE = value; return 0; }
   if (key == 19) { ES_OPT_RG128_MIN_WGS = value; return 0; }
+  if (key == 20) { ES_OPT_WSHARE = value; return 0; }
+  if (key == 21) { ES_OPT_NARROW = value; return 0; }
   return -2;
 }
 
@@ -243,11 +247,102 @@ __global__ __launch_bounds__(256) void k_spconv(const float* __restrict__ X, int
     }
 }
 
+// ------------------------------------------------------------------ narrow-input convolution (round 6)
+// MinkResNet.conv1 (mink_resnet.py:131: 3 point-colour channels -> 64, k3 s2) on the exact-f32 path: K * Cin = 81 products per
+// output element.  The tiled kernels above pad Cin = 3 to a 16-channel MFMA chunk and walk 27 mostly empty taps per tile (99 us
+// forward, 350 us weight gradient on 132 k rows); here a lane owns one output channel with its K * Cin weights (forward) /
+// partial sums (weight gradient) in REGISTERS, a wave walks the rows of a 64-row tile, the gathered inputs sit in LDS as
+// [row][tap][4] floats read as one broadcast ds_read_b128 per PRESENT tap (a stride-2 map fills ~ 5 of 27), absent taps are
+// skipped by a wave-uniform test of the row's tap mask.  Plain f32 FMAs in (tap, channel) order.
+#define NW_ROWS 64
+#if defined(ES_EMU)
+#define NW_UNIFORM(x) (x)
+#else
+#define NW_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+template <int CIN>
+__device__ __forceinline__ void narrow_stage(const float* __restrict__ X, int ldx, const int* __restrict__ nbr, int row0,
+                                             int n_out, int n_in, float* xg, int* idxS, int* maskS) {
+  const int t = threadIdx.x;
+  for (int e = t; e < NW_ROWS * 27; e += 256) {
+    const int r = e / 27, j = row0 + r;
+    int v = -1;
+    if (j < n_out) v = nbr[(size_t)row0 * 27 + e];
+    if (v >= n_in) v = -1;
+    idxS[e] = v;
+    float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v >= 0) {
+      const float* p = X + (size_t)v * ldx;
+      x4.x = p[0];
+      if (CIN > 1) x4.y = p[1];
+      if (CIN > 2) x4.z = p[2];
+      if (CIN > 3) x4.w = p[3];
+    }
+    *(float4*)&xg[e * 4] = x4;
+  }
+  __syncthreads();
+  if (t < NW_ROWS) {
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) m |= (idxS[t * 27 + k] >= 0) ? (1 << k) : 0;
+    maskS[t] = m;
+  }
+  __syncthreads();
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void k_spconv_narrow_fwd(const float* __restrict__ X, int ldx, const float* __restrict__ W,
+                                                           const int* __restrict__ nbr, int n_out, int n_in,
+                                                           const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                           int accumulate) {
+  __shared__ __attribute__((aligned(16))) float xg[NW_ROWS * 27 * 4];
+  __shared__ int idxS[NW_ROWS * 27];
+  __shared__ int maskS[NW_ROWS];
+  const int t = threadIdx.x, co = t & 63, wv = t >> 6;
+  float w[27][CIN];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) w[k][c] = W[(k * CIN + c) * 64 + co];
+  const float bv = bias ? bias[co] : 0.f;
+  const int tiles = (n_out + NW_ROWS - 1) / NW_ROWS;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int row0 = tile * NW_ROWS;
+    narrow_stage<CIN>(X, ldx, nbr, row0, n_out, n_in, xg, idxS, maskS);
+    for (int rr = 0; rr < NW_ROWS / 4; ++rr) {
+      const int r = wv * (NW_ROWS / 4) + rr;
+      if (row0 + r >= n_out) break;
+      const int m = NW_UNIFORM(maskS[r]);
+      float acc = bv;
+#pragma unroll
+      for (int k = 0; k < 27; ++k)
+        if (m & (1 << k)) {
+          const float4 x4 = *(const float4*)&xg[(r * 27 + k) * 4];
+          acc = fmaf(x4.x, w[k][0], acc);
+          if (CIN > 1) acc = fmaf(x4.y, w[k][1], acc);
+          if (CIN > 2) acc = fmaf(x4.z, w[k][2], acc);
+          if (CIN > 3) acc = fmaf(x4.w, w[k][3], acc);
+        }
+      float* p = Y + (size_t)(row0 + r) * ldy + co;
+      *p = accumulate ? (*p + acc) : acc;
+    }
+    __syncthreads();
+  }
+}
+static bool narrow_ok(const int* nbr, int K, int Cin, int Cout) { return ES_OPT_NARROW && nbr != nullptr && K == 27 && Cin == 3 && Cout == 64; }
+
 extern "C" int es_spconv_fwd(const float* X, int ldx, const float* W, const int* nbr, int n_out, int n_in, int K,
                              int Cin, int Cout, const float* bias, float* Y, int ldy, int trans_w, int accumulate,
                              void* stream) {
   if (n_out <= 0 || Cout <= 0) return 0;
   if (K > MAXK) return -2;
+  if (!trans_w && narrow_ok(nbr, K, Cin, Cout)) {
+    const int tiles = es_cdiv(n_out, NW_ROWS);
+    hipLaunchKernelGGL(k_spconv_narrow_fwd<3>, dim3(tiles > 2048 ? 2048 : tiles), dim3(256), 0, (hipStream_t)stream, X, ldx, W, nbr,
+                       n_out, n_in, bias, Y, ldy, accumulate);
+    ES_CHECK_LAUNCH();
+    return 0;
+  }
   dim3 grid(es_cdiv(n_out, BM), es_cdiv(Cout, BN));
   if (trans_w)
     hipLaunchKernelGGL(k_spconv<true>, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, W, nbr, n_out, n_in, K, Cin,
@@ -373,7 +468,70 @@ static int cap_splits(int splits, long long dw_floats, bool have_ws) {
   if (splits > cap) splits = (int)cap;
   return splits < 1 ? 1 : splits;
 }
+// narrow-input weight gradient (see k_spconv_narrow_fwd): lane = output channel, wave g owns taps g, g + 4, ...; a workgroup walks
+// its row slice in 64-row tiles (gathered inputs + the dY tile in LDS) and leaves its [27][CIN][64] partial sums in the slice's
+// workspace block (or, as the only slice, in dW).
+template <int CIN>
+__global__ __launch_bounds__(256) void k_spconv_narrow_wgrad(const float* __restrict__ X, int ldx, const float* __restrict__ dY,
+                                                             int ldy, const int* __restrict__ nbr, int n_out, int n_in,
+                                                             int rows_per_split, float* __restrict__ dW, float* __restrict__ ws,
+                                                             int accumulate) {
+  __shared__ __attribute__((aligned(16))) float xg[NW_ROWS * 27 * 4];
+  __shared__ __attribute__((aligned(16))) float dyS[NW_ROWS * 64];
+  __shared__ int idxS[NW_ROWS * 27];
+  __shared__ int maskS[NW_ROWS];
+  const int t = threadIdx.x, co = t & 63, g = t >> 6;
+  float acc[7][CIN];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc[i][c] = 0.f;
+  const int rbeg = blockIdx.x * rows_per_split, rend = min(n_out, rbeg + rows_per_split);
+  const bool vec = ((ldy & 3) == 0) && ((((uintptr_t)dY) & 15) == 0);
+  for (int row0 = rbeg; row0 < rend; row0 += NW_ROWS) {
+    for (int e = t; e < NW_ROWS * 16; e += 256) {             // the dY tile: 16 float4 per row
+      const int r = e >> 4, c4 = (e & 15) * 4, j = row0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < rend) {
+        const float* p = dY + (size_t)j * ldy + c4;
+        if (vec) v = *(const float4*)p;
+        else v = make_float4(p[0], p[1], p[2], p[3]);
+      }
+      *(float4*)&dyS[r * 64 + c4] = v;
+    }
+    narrow_stage<CIN>(X, ldx, nbr, row0, rend, n_in, xg, idxS, maskS);
+    const int nr = min(NW_ROWS, rend - row0);
+    for (int r = 0; r < nr; ++r) {
+      const int m = NW_UNIFORM(maskS[r]) >> g;
+      if (!(m & 0x1111111)) continue;
+      const float dv = dyS[r * 64 + co];
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+        if (m & (1 << (4 * i))) {                                // tap g + 4 i (bit 27 and up of a mask are never set)
+          const float4 x4 = *(const float4*)&xg[(r * 27 + g + 4 * i) * 4];
+          acc[i][0] = fmaf(x4.x, dv, acc[i][0]);
+          if (CIN > 1) acc[i][1] = fmaf(x4.y, dv, acc[i][1]);
+          if (CIN > 2) acc[i][2] = fmaf(x4.z, dv, acc[i][2]);
+          if (CIN > 3) acc[i][3] = fmaf(x4.w, dv, acc[i][3]);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int k = g + 4 * i;
+    if (k < 27)
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+        wgrad_emit(dW, ws, blockIdx.x, (size_t)27 * CIN * 64, ((size_t)k * CIN + c) * 64 + co, acc[i][c], accumulate);
+  }
+}
 static WgradPlan wgrad_plan_f32(int n_out, int K, int Cin, int Cout, bool have_ws) {
+  if (ES_OPT_NARROW && K == 27 && Cin == 3 && Cout == 64) {      // (the launcher falls back to one slice of the tiled kernel without a map)
+    int splits = cap_splits(es_cdiv(n_out, NW_ROWS) < 256 ? es_cdiv(n_out, NW_ROWS) : 256, (long long)K * Cin * Cout, have_ws);
+    int rows_per_split = es_cdiv(es_cdiv(n_out, splits), NW_ROWS) * NW_ROWS;
+    return WgradPlan{4, es_cdiv(n_out, rows_per_split), rows_per_split};
+  }
   int base = K * es_cdiv(Cin, WM) * es_cdiv(Cout, WN);
   int splits = es_cdiv(2048, base);
   int max_splits = es_cdiv(n_out, 128);
@@ -452,6 +610,12 @@ extern "C" int es_spconv_wgrad(const float* X, int ldx, const float* dY, int ldy
   WgradPlan p = wgrad_plan_f32(n_out, K, Cin, Cout, ws != nullptr);
   const size_t nw = (size_t)K * Cin * Cout;
   if (p.splits > 1 && ws_floats < (size_t)p.splits * nw) return -5;
+  if (p.kind == 4 && nbr != nullptr) {
+    hipLaunchKernelGGL(k_spconv_narrow_wgrad<3>, dim3(p.splits), dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out, n_in,
+                       p.rows_per_split, dW, p.splits > 1 ? ws : nullptr, accumulate);
+    ES_CHECK_LAUNCH();
+    return wgrad_reduce(ws, p.splits, nw, dW, accumulate, (hipStream_t)stream);
+  }
   dim3 grid(K * es_cdiv(Cin, WM), es_cdiv(Cout, WN), p.splits);
   hipLaunchKernelGGL(k_spconv_wgrad, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, dY, ldy, nbr, n_out, n_in, K,
                      Cin, Cout, p.rows_per_split, dW, p.splits > 1 ? ws : nullptr, accumulate);
@@ -475,6 +639,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // activation-storage flags of the image backbone (round 3): bit 0: the Y rows are bf16, bit 1: the ep_res rows are bf16
 #define ES_IO_Y16 1
 #define ES_IO_R16 2
+#define ES_IO_WSHARE 0x10000    // tap-split launches: workgroup order in which the row tiles of one (column tile, tap slice) share an XCD
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 v) {
   return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
                      __uint_as_float(v.y & 0xffff0000u));
@@ -751,8 +916,20 @@ __global__ __launch_bounds__(256, 3) void k_spconv_bf16_fast(const void* __restr
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   // (An XCD-aware row-tile order -- contiguous eighths of the tiles per XCD -- was measured: no gain, the halo rows
   // already hit in MALL; plain order kept.)
-  const int bz = blockIdx.z;
-  const int row0 = blockIdx.x * BM, n0 = blockIdx.y * BNT;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (io & ES_IO_WSHARE) {
+    // tap-split launches are the small-row / wide-channel layers: a (column tile, tap slice) pair reads a weight slice of hundreds of
+    // KB that EVERY row tile of the pair re-reads, and in launch order (x fastest, workgroup L on XCD L % 8) those row tiles sit on
+    // different XCDs -- each private L2 fetches the slice again.  Here XCD c walks pairs c, c + 8, ... and inside a pair all row
+    // tiles, so the slice is fetched into one L2 once (pairs past the last full group of eight keep the launch order).
+    const int gx = gridDim.x, gy = gridDim.y, L = bx + gx * (by + gy * bz);
+    const int full = ((gy * (int)gridDim.z) >> 3) << 3;
+    if (L < full * gx) {
+      const int j = L >> 3, pair = (j / gx) * 8 + (L & 7);
+      bx = j % gx; by = pair % gy; bz = pair / gy;
+    }
+  }
+  const int row0 = bx * BM, n0 = by * BNT;
 
   __shared__ int tapFlag[32];
   if (t < 32) tapFlag[t] = 0;
@@ -1607,7 +1784,7 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
                                 int y_half = 0, int r_half = 0) {
   if (n_out <= 0 || Cout <= 0) return 0;
   if (K > MAXK) return -2;
-  const int io = (y_half ? ES_IO_Y16 : 0) | ((r_half && ep_res) ? ES_IO_R16 : 0) | (y_half & 0xff00);   // (bits 8-15: dev ablation switches of k_rowgemm2_bf16, tools/bench_rowgemm.py)
+  int io = (y_half ? ES_IO_Y16 : 0) | ((r_half && ep_res) ? ES_IO_R16 : 0) | (y_half & 0xff00);   // (bits 8-15: dev ablation switches of k_rowgemm2_bf16, tools/bench_rowgemm.py)
   if (y_half && (accumulate || (ldy % 4) || (Cout % 4) || (((uintptr_t)Y) & 7))) return -7;   // bf16 rows: 8-byte stores
   if ((io & ES_IO_R16) && ((ep_ldr % 4) || (((uintptr_t)ep_res) & 7))) return -7;
   hipStream_t st = (hipStream_t)stream;
@@ -1673,6 +1850,7 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
       ep_res = ws + ES_SPLIT_TICKETS;
       ep_act = 7;
       g128.z = g64.z = split;
+      if (ES_OPT_WSHARE && !ES_OPT_SPLIT_FOLD) io |= ES_IO_WSHARE;
     }                                      // (without a workspace the launch keeps one workgroup per tile: no f32 atomics)
   }
   if (fast && ES_OPT_DMA && x_is_bf16 && Cin >= ES_OPT_DMA_MIN_CIN) {

@@ -157,6 +157,12 @@ def test_sparse_conv_forward_on_the_emulated_matrix_cores(emu, dma):
                 emu('es_spconv_fwd_bf16_ws', P(xh), 1, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y3), cout, 0, P(ws), nf, 0)
                 assert np.abs(y3 - want).max() / scale < 2e-6
                 assert not ws[:1024].view(np.int32).any()        # the tile tickets are left at zero
+                # the weight-sharing workgroup order of a split launch (option 20) is a permutation of the same tiles: same bits
+                emu('es_set_option', 20, 1)
+                y4 = np.full((n_out, cout), np.nan, np.float32)
+                emu('es_spconv_fwd_bf16_ws', P(xh), 1, cin, P(wt), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y4), cout, 0, P(ws), nf, 0)
+                emu('es_set_option', 20, 0)
+                assert np.array_equal(y4, y3)
     finally:
         emu.lib.es_emu_set_dma_mode(0)
         emu('es_set_option', 10, 2)
@@ -425,6 +431,55 @@ def test_convolution_entry_points_on_ragged_and_degenerate_shapes(emu):
             dw = np.full((K, cin, cout), np.nan, np.float32)
             emu(fn, P(x), cin, P(dy), cout, P(nbr), n_out, n_in, K, cin, cout, P(dw), 0, 0, 0, 0)
             assert np.abs(dw - wantw).max() <= 1e-5 * max(np.abs(wantw).max(), 1e-3), (fn, case)
+
+
+def test_narrow_input_convolution_kernels(emu):
+    """MinkResNet.conv1's shape (K = 27, 3 -> 64 channels, exact f32): the lane-per-output-channel forward / weight-gradient kernels
+    (option 21, default on) against f64 and against the tiled kernels they replace -- ragged last tile, rows with no neighbour, a
+    tap nobody uses, bias, accumulate, the row-sliced workspace form and the single-slice form, strided dY rows"""
+    rng = np.random.default_rng(31)
+    for n_out, n_in, fill in ((1, 5, 1.0), (130, 77, 0.2), (64, 300, 0.0), (517, 400, 0.35)):
+        K, cin, cout = 27, 3, 64
+        nbr = _map(rng, n_out, n_in, K, fill)
+        nbr[:, 11] = -1
+        if n_out > 3:
+            nbr[3] = -1
+        x = rng.standard_normal((n_in, cin)).astype(np.float32)
+        w = (rng.standard_normal((K, cin, cout)) / 9).astype(np.float32)
+        bias = rng.standard_normal(cout).astype(np.float32)
+        want = _conv_ref(x, w, nbr, bias)
+        tol = 1e-5 * max(np.abs(want).max(), 1e-3)
+        got = {}
+        for on in (1, 0):
+            emu('es_set_option', 21, on)
+            emu.launches()
+            y = np.full((n_out, cout + 8), np.nan, np.float32)
+            emu('es_spconv_fwd', P(x), cin, P(w), P(nbr), n_out, n_in, K, cin, cout, P(bias), P(y), cout + 8, 0, 0, 0)
+            assert any('k_spconv_narrow_fwd' in k for k in emu.launches()) == bool(on)
+            assert np.abs(y[:, :cout] - want).max() <= tol and np.isnan(y[:, cout:]).all(), (n_out, on)
+            got[on] = y[:, :cout].copy()
+            y2 = np.ascontiguousarray(y[:, :cout]) * 0 + 1
+            emu('es_spconv_fwd', P(x), cin, P(w), P(nbr), n_out, n_in, K, cin, cout, 0, P(y2), cout, 0, 1, 0)       # accumulate, no bias
+            assert np.abs(y2 - 1 - (want - bias)).max() <= tol
+        assert np.abs(got[1] - got[0]).max() <= tol
+        dyb = rng.standard_normal((n_out, cout + 4)).astype(np.float32)
+        dy = dyb[:, :cout]
+        wantw = np.zeros((K, cin, cout))
+        for k in range(K):
+            rows = np.flatnonzero(nbr[:, k] >= 0)
+            wantw[k] = x[nbr[rows, k]].astype(np.float64).T @ dy[rows].astype(np.float64)
+        tolw = 1e-5 * max(np.abs(wantw).max(), 1e-3)
+        for on in (1, 0):
+            emu('es_set_option', 21, on)
+            nf = int(emu.fns['es_spconv_wgrad_workspace_floats'](0, 0, 0, cin, 0, 0, cout + 4, n_out, n_in, K, cin, cout))
+            ws = np.full(max(nf, 1), np.nan, np.float32)
+            for use_ws in (1, 0):
+                emu.launches()
+                dw = np.full((K, cin, cout), 2.0, np.float32)
+                emu('es_spconv_wgrad', P(x), cin, P(dy), cout + 4, P(nbr), n_out, n_in, K, cin, cout, P(dw), 1, P(ws) if use_ws else 0, nf if use_ws else 0, 0)
+                assert any('k_spconv_narrow_wgrad' in k for k in emu.launches()) == bool(on)
+                assert np.abs(dw - 2 - wantw).max() <= tolw, (n_out, on, use_ws)
+    emu('es_set_option', 21, 1)
 
 
 def test_segmented_norm_and_attention_on_odd_shapes(emu):
