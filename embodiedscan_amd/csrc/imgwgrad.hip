@@ -178,6 +178,7 @@ __global__ void k_img_wgrad_reduce(const float* __restrict__ ws, int parts, int 
 }
 
 static int ES_OPT_IMG_WGRAD = 1;
+static int ES_OPT_ROWS_WGRAD_320 = 1;                        // ... and for 320 output columns as one tile (key 44)
 static int ES_OPT_ROWS_WGRAD_MIN_ROWS = 500000;              // 1x1 streaming kernel: rows from which it is taken whatever the width (key 43)
 static int ES_OPT_IMG_WGRAD_WGS32 = 400, ES_OPT_IMG_WGRAD_WGS64 = 160;      // workgroups a launch aims for (partial tensors: 36 / 147 KB each)
 extern "C" int es_img_wgrad_set_option(int key, int value) {
@@ -185,6 +186,7 @@ extern "C" int es_img_wgrad_set_option(int key, int value) {
   if (key == 41) { ES_OPT_IMG_WGRAD_WGS32 = value; return 0; }
   if (key == 42) { ES_OPT_IMG_WGRAD_WGS64 = value; return 0; }
   if (key == 43) { ES_OPT_ROWS_WGRAD_MIN_ROWS = value; return 0; }
+  if (key == 44) { ES_OPT_ROWS_WGRAD_320 = value; return 0; }
   return -1;
 }
 
@@ -296,11 +298,14 @@ static bool rows_wgrad_plan(int n, int Cin, int Cout, int& ci, int& co, int& sli
   if (!ES_OPT_IMG_WGRAD || n < 4096) return false;
   // A/B against the ring kernel (profiles/r6h_imgwgrad_ab.txt): that one already streams these launches at 2 - 3 TB/s; this kernel wins from
   // 256 input channels (38 -> 27 us) or half a million rows (144 -> 98 us, 160 -> 129 us) and loses a few us below
-  if (!(Cin >= 256 || n >= ES_OPT_ROWS_WGRAD_MIN_ROWS)) return false;
+  // ... and 320 output columns (fcaf3d_head.py: a level's class / box / centerness outputs as one GEMM): ONE (128 x 320) tile per slice, both
+  // operands read once (the 64-column tiles of the ring kernel read the input rows five times: 369 us on 352 k rows)
+  const bool whole = ES_OPT_ROWS_WGRAD_320 && Cout == 320 && Cin % 128 == 0;
+  if (!(Cin >= 256 || n >= ES_OPT_ROWS_WGRAD_MIN_ROWS || whole)) return false;
   ci = Cin % 128 == 0 ? 128 : Cin % 64 == 0 ? 64 : Cin == 32 ? 32 : 0;
-  co = Cout % 128 == 0 ? 128 : Cout % 64 == 0 ? 64 : Cout == 32 ? 32 : 0;
+  co = whole ? 320 : Cout % 128 == 0 ? 128 : Cout % 64 == 0 ? 64 : Cout == 32 ? 32 : 0;
   if (!ci || !co || (ci == 32 && co == 32) || Cin > 512 || Cout > 512) return false;
-  const long long tiles = (long long)(Cin / ci) * (Cout / co);
+  const long long tiles = (long long)(Cin / ci) * (Cout / co) * (whole ? 2 : 1);      // (one workgroup per CU: half the slices)
   // slices: enough workgroups to stream at full bandwidth, few enough that the partial tensors stay a fraction of the operand bytes
   const long long in_bytes = (long long)n * (Cin * 2 + Cout * 4), dw_bytes = (long long)Cin * Cout * 4;
   long long s = in_bytes / (4 * dw_bytes);
@@ -331,7 +336,8 @@ extern "C" int es_rows_wgrad1_bf16(const void* Xh, int ldx, const float* dY, int
   const int to_ws = slices > 1;
   dim3 grid(slices, Cin / ci, Cout / co);
 #define RW_LAUNCH(CI_, CO_) hipLaunchKernelGGL((k_rows_wgrad1<CI_, CO_>), grid, dim3(256), 0, st, X, ldx, dY, ldy, n, Cin, Cout, rows, out, to_ws, accumulate)
-  if (ci == 128 && co == 128) RW_LAUNCH(128, 128);
+  if (ci == 128 && co == 320) RW_LAUNCH(128, 320);
+  else if (ci == 128 && co == 128) RW_LAUNCH(128, 128);
   else if (ci == 128 && co == 64) RW_LAUNCH(128, 64);
   else if (ci == 128 && co == 32) RW_LAUNCH(128, 32);
   else if (ci == 64 && co == 128) RW_LAUNCH(64, 128);

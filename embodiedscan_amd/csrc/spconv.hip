@@ -45,6 +45,8 @@ static int ES_OPT_SPLIT_FOLD = 0;           // tap-split launches: partial tiles
                                            // L2 write-backs inside a streaming kernel cost far more than the 70 reduce launches they replace:
                                            // mv-3ddet step 30.9 ms against 25.9 (with a seq_cst fence, i.e. + buffer_inv: 32.6).  Kept as a tested option.
 static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
+static int ES_OPT_NARROW_SLICES = 768;      // ... row slices (workgroups) of their weight gradient (key 22): three per CU
+static int ES_OPT_RG320 = 1;               // row GEMM with 320 output columns as one column tile (key 23)
 static int ES_OPT_NARROW = 1;              // 3-channel K = 27 convolutions (MinkResNet.conv1) on the lane-per-output-channel kernels (key 21)
 static int ES_OPT_WSHARE = 0;              // tap-split launches in the weight-sharing workgroup order (key 20)
 static int ES_OPT_RG128_MIN_WGS = 0;       // ... and only for launches with at least this many 128-column workgroups (key 19; round 6 A/B: no measurable change, off)
@@ -74,6 +76,8 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 19) { ES_OPT_RG128_MIN_WGS = value; return 0; }
   if (key == 20) { ES_OPT_WSHARE = value; return 0; }
   if (key == 21) { ES_OPT_NARROW = value; return 0; }
+  if (key == 22) { ES_OPT_NARROW_SLICES = value; return 0; }
+  if (key == 23) { ES_OPT_RG320 = value; return 0; }
   return -2;
 }
 
@@ -264,21 +268,35 @@ template <int CIN>
 __device__ __forceinline__ void narrow_stage(const float* __restrict__ X, int ldx, const int* __restrict__ nbr, int row0,
                                              int n_out, int n_in, float* xg, int* idxS, int* maskS) {
   const int t = threadIdx.x;
-  for (int e = t; e < NW_ROWS * 27; e += 256) {
-    const int r = e / 27, j = row0 + r;
-    int v = -1;
-    if (j < n_out) v = nbr[(size_t)row0 * 27 + e];
-    if (v >= n_in) v = -1;
-    idxS[e] = v;
-    float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (v >= 0) {
-      const float* p = X + (size_t)v * ldx;
-      x4.x = p[0];
-      if (CIN > 1) x4.y = p[1];
-      if (CIN > 2) x4.z = p[2];
-      if (CIN > 3) x4.w = p[3];
+  // two rounds of INDEPENDENT loads (all map entries of this thread, then all input rows): two memory latencies per tile, not 2 x 7
+  constexpr int NI = (NW_ROWS * 27 + 255) / 256;
+  int v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = t + i * 256;
+    v[i] = -1;
+    if (e < NW_ROWS * 27 && row0 + e / 27 < n_out) v[i] = nbr[(size_t)row0 * 27 + e];
+    if (v[i] >= n_in) v[i] = -1;
+  }
+  float xv[NI][CIN];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const float* p = X + (size_t)(v[i] >= 0 ? v[i] : 0) * ldx;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) xv[i][c] = p[c];
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = t + i * 256;
+    if (e < NW_ROWS * 27) {
+      idxS[e] = v[i];
+      const bool ok = v[i] >= 0;
+      float4 x4 = make_float4(ok ? xv[i][0] : 0.f, 0.f, 0.f, 0.f);
+      if (CIN > 1) x4.y = ok ? xv[i][1] : 0.f;
+      if (CIN > 2) x4.z = ok ? xv[i][2] : 0.f;
+      if (CIN > 3) x4.w = ok ? xv[i][3] : 0.f;
+      *(float4*)&xg[e * 4] = x4;
     }
-    *(float4*)&xg[e * 4] = x4;
   }
   __syncthreads();
   if (t < NW_ROWS) {
@@ -528,7 +546,7 @@ __global__ __launch_bounds__(256) void k_spconv_narrow_wgrad(const float* __rest
 }
 static WgradPlan wgrad_plan_f32(int n_out, int K, int Cin, int Cout, bool have_ws) {
   if (ES_OPT_NARROW && K == 27 && Cin == 3 && Cout == 64) {      // (the launcher falls back to one slice of the tiled kernel without a map)
-    int splits = cap_splits(es_cdiv(n_out, NW_ROWS) < 256 ? es_cdiv(n_out, NW_ROWS) : 256, (long long)K * Cin * Cout, have_ws);
+    int splits = cap_splits(es_cdiv(n_out, NW_ROWS) < ES_OPT_NARROW_SLICES ? es_cdiv(n_out, NW_ROWS) : ES_OPT_NARROW_SLICES, (long long)K * Cin * Cout, have_ws);
     int rows_per_split = es_cdiv(es_cdiv(n_out, splits), NW_ROWS) * NW_ROWS;
     return WgradPlan{4, es_cdiv(n_out, rows_per_split), rows_per_split};
   }
@@ -1545,7 +1563,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 // (its own weight slice and output column block); data gradient: the taps are extra steps of the k loop (tap t reads the
 // input columns t * a_tap .. and the weight slice t * w_tap ..).  MT = false compiles to the kernel described above.
 struct RowGemmTaps { int z_w, z_y_bytes, taps, a_tap, w_tap; };
-template <int NT, bool XH, bool MT = false>
+// PRE = false (NT = 320: the head's 128 -> 320 output GEMM as ONE column tile, the input rows read once instead of five times): no
+// second epilogue operand, so its 16 bytes x 2 NP prefetch registers per row are not allocated.
+template <int NT, bool XH, bool MT = false, bool PRE = true>
 __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ Xv, int ldx,
                                                        const unsigned short* __restrict__ W, int n_out, int n_in, int Cin,
                                                        int Cout, const float* __restrict__ bias, float* __restrict__ Y,
@@ -1560,7 +1580,7 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
   }
   const float* X = (const float*)Xv;
   const unsigned short* Xh = (const unsigned short*)Xv;
-  constexpr int NF = NT / 16, NP = NT / 32;
+  constexpr int NF = NT / 16, NP = NT / 32, NBP = (NT + 63) / 64, NPF = PRE ? NP : 1;
   __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * NT * HLD];       // [2][NT][HLD]
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
   const int row0 = blockIdx.x * BM + wv * 32, n0 = blockIdx.y * NT;
@@ -1573,7 +1593,7 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
     for (int b = 0; b < NF; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int ns = (Cin + HBK - 1) / HBK;
   float4 a00, a01, a10, a11;
-  uint4 bg0, bg1;
+  uint4 bg[NBP];
   const int rowA0 = row0 + li, rowA1 = row0 + 16 + li;
   const float* pa0 = X + (size_t)min(rowA0, n_rows - 1) * ldx + kq * 8;
   const float* pa1 = X + (size_t)min(rowA1, n_rows - 1) * ldx + kq * 8;
@@ -1582,15 +1602,14 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
   const int abl = io >> 8;                                // dev ablation: 1 no stores, 2 no input-row loads, 4 no residual loads
   const bool va0 = rowA0 < n_rows && !(abl & 2), va1 = rowA1 < n_rows && !(abl & 2);
   const int bc0 = t >> 2, bq = t & 3;
-  const unsigned short* pb0 = W + (size_t)(n0 + (bc0 < NT ? bc0 : 0)) * Cin + bq * 8;
-  const unsigned short* pb1 = W + (size_t)(n0 + (NT > 64 ? 64 : 0) + bc0) * Cin + bq * 8;
+  const unsigned short* pb0 = W + (size_t)(n0 + (bc0 < NT ? bc0 : 0)) * Cin + bq * 8;       // + 64 j rows for pass j
 #define RG2_LOAD(s_)                                                                   \
   do {                                                                                 \
     const int tap_ = MT ? (s_) / ns : 0, ss_ = (s_) - tap_ * ns;                        \
     const int ao_ = ss_ * HBK + (MT ? tap_ * tp.a_tap : 0), bo_ = ss_ * HBK + (MT ? tap_ * tp.w_tap : 0); \
     const bool ka_ = ss_ * HBK + kq * 8 < Cin, kb_ = ss_ * HBK + bq * 8 < Cin;         \
     a00 = a01 = a10 = a11 = make_float4(0.f, 0.f, 0.f, 0.f);                           \
-    bg0 = bg1 = make_uint4(0u, 0u, 0u, 0u);                                            \
+    _Pragma("unroll") for (int j_ = 0; j_ < NBP; ++j_) bg[j_] = make_uint4(0u, 0u, 0u, 0u); \
     if (XH) {                                                                          \
       if (va0 && ka_) a00 = *(const float4*)(ph0 + ao_);                                    \
       if (va1 && ka_) a10 = *(const float4*)(ph1 + ao_);                                    \
@@ -1604,13 +1623,15 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
         a10 = q1_[0]; a11 = q1_[1];                                                    \
       }                                                                                \
     }                                                                                  \
-    if (kb_ && bc0 < NT) bg0 = *(const uint4*)(pb0 + bo_);                                  \
-    if (NT > 64 && kb_) bg1 = *(const uint4*)(pb1 + bo_);                                   \
+    if (kb_ && bc0 < NT) bg[0] = *(const uint4*)(pb0 + bo_);                                \
+    _Pragma("unroll") for (int j_ = 1; j_ < NBP; ++j_)                                 \
+      if (kb_) bg[j_] = *(const uint4*)(pb0 + (size_t)64 * j_ * Cin + bo_);            \
   } while (0)
 #define RG2_STORE_B(buf_)                                                              \
   do {                                                                                 \
-    if (bc0 < NT) *(uint4*)&Bs[((buf_) * NT + bc0) * HLD + bq * 8] = bg0;              \
-    if (NT > 64) *(uint4*)&Bs[((buf_) * NT + 64 + bc0) * HLD + bq * 8] = bg1;          \
+    if (bc0 < NT) *(uint4*)&Bs[((buf_) * NT + bc0) * HLD + bq * 8] = bg[0];            \
+    _Pragma("unroll") for (int j_ = 1; j_ < NBP; ++j_)                                 \
+      *(uint4*)&Bs[((buf_) * NT + 64 * j_ + bc0) * HLD + bq * 8] = bg[j_];             \
   } while (0)
   // this lane's output: row (mf * 16 + li), channels n0 + 32 p + 8 kq + {0 .. 7}
   const int rowE0 = row0 + li, rowE1 = row0 + 16 + li;
@@ -1619,14 +1640,14 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
   const bool r16 = (io & ES_IO_R16) != 0;
   const float* pre = ep_res ? ep_res : (accumulate ? Y : nullptr);
   const int pre_ld = ep_res ? ep_ldr : ldy;
-  float4 pf[2][NP][2];
+  float4 pf[2][NPF][2];
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-    for (int p2 = 0; p2 < NP; ++p2) {
+    for (int p2 = 0; p2 < NPF; ++p2) {
       const int row = mf ? rowE1 : rowE0, col = colE + 32 * p2;
       pf[mf][p2][0] = pf[mf][p2][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pre && row < n_out && !((io >> 8) & 4)) {
+      if (PRE && pre && row < n_out && !((io >> 8) & 4)) {
         if (ep_res && r16) {                              // 8 bf16 = 16 bytes, kept as raw bits in [0]
           pf[mf][p2][0] = *(const float4*)((const unsigned short*)ep_res + (size_t)row * pre_ld + col);
         } else {
@@ -1677,7 +1698,7 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
       float v[8], q[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = acc[mf][2 * p2][r]; v[4 + r] = acc[mf][2 * p2 + 1][r]; }
-      const float4 h0 = pf[mf][p2][0], h1 = pf[mf][p2][1];
+      const float4 h0 = pf[mf][PRE ? p2 : 0][0], h1 = pf[mf][PRE ? p2 : 0][1];
       if (ep_res && r16) {
         const uint32_t u[4] = {__float_as_uint(h0.x), __float_as_uint(h0.y), __float_as_uint(h0.z), __float_as_uint(h0.w)};
 #pragma unroll
@@ -1803,7 +1824,10 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
     // column (round 6 A/B with the threshold at 256: grounding 53.35 vs 53.03, mv-3ddet 23.62 vs 23.56, occupancy 34.69 vs 34.76: noise; default 0 = off)
     const bool wide = Cout % 128 == 0 && Cin >= ES_OPT_RG128_MIN_CIN &&
                       (long long)es_cdiv(n_out, BM) * (Cout / 128) >= ES_OPT_RG128_MIN_WGS;
-    const int nt = wide ? 128 : (Cout % 64 == 0) ? 64 : (Cout % 32 == 0) ? 32 : 16;
+    // Cout = 320 (fcaf3d_head.py: the level's class / box / centerness outputs as one GEMM), no second epilogue operand: ONE 320-column tile
+    // (profiles/r6j_rows_ab.txt: 264 -> 224 us on 352 k rows, 52 -> 40 on 60 k, 11.5 -> 19 on 7.5 k: one workgroup per CU needs rows)
+    const bool whole = ES_OPT_RG320 && Cout == 320 && n_out >= 16384 && !ep_res && !accumulate && !y_half && ES_OPT_ROWGEMM2 && (ldy % 4 == 0) && ((((uintptr_t)Y) & 15) == 0);
+    const int nt = whole ? 320 : wide ? 128 : (Cout % 64 == 0) ? 64 : (Cout % 32 == 0) ? 32 : 16;
     dim3 g(es_cdiv(n_out, BM), Cout / nt);
 #define RG_LAUNCH(NT_)                                                                                              \
     do {                                                                                                            \
@@ -1826,7 +1850,14 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
     // second-generation kernel: 16-byte epilogue accesses need 8-channel alignment of every row matrix it touches
     const bool g2 = ES_OPT_ROWGEMM2 && nt >= 32 && (ldy % (y_half ? 8 : 4) == 0) && ((((uintptr_t)Y) & 15) == 0) &&
                     (!ep_res || ((ep_ldr % ((io & ES_IO_R16) ? 8 : 4) == 0) && ((((uintptr_t)ep_res) & 15) == 0)));
-    if (g2 && nt == 128) RG2_LAUNCH(128);
+    if (whole) {
+      if (x_is_bf16)
+        hipLaunchKernelGGL((k_rowgemm2_bf16<320, true, false, false>), g, dim3(256), 0, st, Xv, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy,
+                           0, ep_scale, ep_shift, (const float*)nullptr, 0, ep_act, io, RowGemmTaps{0, 0, 1, 0, 0});
+      else
+        hipLaunchKernelGGL((k_rowgemm2_bf16<320, false, false, false>), g, dim3(256), 0, st, Xv, ldx, Wh, n_out, n_in, Cin, Cout, bias, Y, ldy,
+                           0, ep_scale, ep_shift, (const float*)nullptr, 0, ep_act, io, RowGemmTaps{0, 0, 1, 0, 0});
+    } else if (g2 && nt == 128) RG2_LAUNCH(128);
     else if (g2 && nt == 64) RG2_LAUNCH(64);
     else if (g2) RG2_LAUNCH(32);
     else if (nt == 128) RG_LAUNCH(128);

@@ -3,6 +3,7 @@ kernels.  Same registry name, constructor arguments and forward(inputs, data_sam
 
 extract_feat is the mv-3ddet feature path (2-D / 3-D backbones + projection fusion, inherited) followed by MinkNeck;
 pre_decoder / forward_decoder / the head run on padded channels-last token matrices.  Text: see embodiedscan_amd/text.py."""
+import os
 import torch
 from ... import engine as E
 from ... import hip
@@ -12,6 +13,8 @@ from ...registry import MODELS
 from ...text import HashTokenizer, build_text_encoder, create_positive_map
 from ..layers.ground_transformer.decoder import SparseFeatureFusionTransformerDecoder, _Lin
 from .sparse_featfusion_single_stage import SparseFeatureFusionSingleStage3DDetector
+
+TEXT_ASYNC = [os.environ.get('ES_TEXT_ASYNC', '1') != '0']     # round 6: the frozen text encoder on its own stream, queued before the backbones
 
 
 @MODELS.register_module()
@@ -112,9 +115,10 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         return self
 
     # ------------------------------------------------------------------ text
-    def encode_text(self, batch_data_samples):
-        """:475-498: tokenise, positive maps, frozen RoBERTa, text_feat_map.  Returns (text Var (B*T, E), mask (B,T) bool
-        on the device, tlen (B,) int32 on the device, T) and attaches positive_maps / text_token_mask to the samples."""
+    def start_text(self, batch_data_samples):
+        """:475-481, first half of encode_text: tokenise, positive maps, frozen RoBERTa.  The encoder depends on the prompts only, so it is
+        queued on its OWN stream before the backbones (round 6: its ~ 300 small launches used to sit between the neck and the decoder
+        on the main stream, 4.6 ms of a 52.6 ms step); finish_text() joins.  ES_TEXT_ASYNC=0: on the calling stream, as before."""
         texts = [ds.text for ds in batch_data_samples]
         tok = self.tokenizer.batch_encode_plus(texts, padding='longest', return_tensors='pt')
         if all(getattr(ds, 'tokens_positive', None) is not None for ds in batch_data_samples):
@@ -122,19 +126,48 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         else:
             tps = [[[0, 1]] for _ in batch_data_samples]
         pmaps = [create_positive_map(tok, tp, i, self.max_num_entities) for i, tp in enumerate(tps)]
-        tok = tok.to(self.device)
-        with torch.no_grad():
-            hs = self.text_encoder(input_ids=tok.input_ids, attention_mask=tok.attention_mask).last_hidden_state
-        B, T = tok.input_ids.shape
-        mask = tok.attention_mask.bool()
+        side = TEXT_ASYNC[0] and self.device.type == 'cuda'
+        ev = None
+        if side:
+            if getattr(self, '_text_stream', None) is None:
+                self._text_stream = torch.cuda.Stream(device=self.device)
+            ctx = torch.cuda.stream(self._text_stream)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            tok = tok.to(self.device)
+            with torch.no_grad():
+                hs = self.text_encoder(input_ids=tok.input_ids, attention_mask=tok.attention_mask).last_hidden_state
+                B, T = tok.input_ids.shape
+                hs32 = hs.reshape(B * T, self.text_dim).float().contiguous()
+                tlen = tok.attention_mask.sum(1).to(torch.int32).contiguous()
+                mask = tok.attention_mask.bool()
+            if side:
+                ev = torch.cuda.Event()
+                ev.record(self._text_stream)
+        return dict(tok=tok, pmaps=pmaps, hs=hs, hs32=hs32, tlen=tlen, mask=mask, ev=ev, B=B, T=T)
+
+    def finish_text(self, job, batch_data_samples):
+        """:482-498, second half: the calling stream waits for the encoder, then text_feat_map (trainable, recorded on the tape HERE)"""
+        if job['ev'] is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(job['ev'])
+            for t in (job['hs'], job['hs32'], job['tlen'], job['mask'], job['tok'].input_ids, job['tok'].attention_mask):
+                t.record_stream(cur)             # allocated on the text stream, read on this one
+        mask, B, T = job['mask'], job['B'], job['T']
         for i, ds in enumerate(batch_data_samples):
-            pm = pmaps[i].bool().float()
+            pm = job['pmaps'][i].bool().float()
             ds.gt_instances_3d.positive_maps = pm
             ds.gt_instances_3d.text_token_mask = mask[i].unsqueeze(0).repeat(len(pm), 1)
-        text = self.text_feat_map(E.Var(hs.reshape(B * T, self.text_dim).float().contiguous(), rg=False), need_dx=False)
-        tlen = tok.attention_mask.sum(1).to(torch.int32).contiguous()
-        self.last_text = dict(hidden=hs, mask=mask, input_ids=tok.input_ids)
-        return text, mask, tlen, T
+        text = self.text_feat_map(E.Var(job['hs32'], rg=False), need_dx=False)
+        self.last_text = dict(hidden=job['hs'], mask=mask, input_ids=job['tok'].input_ids)
+        return text, mask, job['tlen'], T
+
+    def encode_text(self, batch_data_samples):
+        """:475-498: tokenise, positive maps, frozen RoBERTa, text_feat_map.  Returns (text Var (B*T, E), mask (B,T) bool
+        on the device, tlen (B,) int32 on the device, T) and attaches positive_maps / text_token_mask to the samples."""
+        return self.finish_text(self.start_text(batch_data_samples), batch_data_samples)
 
     # ------------------------------------------------------------------ features
     def extract_feat(self, batch_inputs_dict, batch_data_samples):
@@ -180,9 +213,10 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
     # ------------------------------------------------------------------ reference protocol
     def loss(self, batch_inputs_dict, batch_data_samples, **kwargs):
         self._bind()
+        job = self.start_text(batch_data_samples)
         self.extract_feat(batch_inputs_dict, batch_data_samples)
         E.mark('A19 MinkNeck (+ pruning, token padding)')
-        text, mask, tlen, T = self.encode_text(batch_data_samples)
+        text, mask, tlen, T = self.finish_text(job, batch_data_samples)
         E.mark('A19 frozen text encoder + text_feat_map')
         hidden, boxes = self.forward_transformer(text, tlen, T, batch_data_samples)
         E.mark('A19 query selection + 6-layer decoder')
@@ -197,8 +231,9 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         E.TAPE.enabled = False
         try:
             self._bind()
+            job = self.start_text(batch_data_samples)
             self.extract_feat(batch_inputs_dict, batch_data_samples)
-            text, mask, tlen, T = self.encode_text(batch_data_samples)
+            text, mask, tlen, T = self.finish_text(job, batch_data_samples)
             hidden, boxes = self.forward_transformer(text, tlen, T, batch_data_samples)
             results = self.bbox_head.predict(hidden, boxes, text, mask, batch_data_samples, tlen=tlen)
         finally:

@@ -86,8 +86,8 @@ def test_rows_weight_gradient_of_1x1_layers(emu, lazy):
     emu('es_img_wgrad_set_option', 43, 0)                 # (every width from 4 096 rows: the shipped rule takes < 256 channels only from 500 000)
     try:
         cases = [(4500, 32, 128, 0, 0), (4200, 128, 32, 8, 1), (4100, 64, 256, 0, 0), (4300, 256, 64, 0, 1), (4096, 64, 64, 16, 0),
-                 (4400, 32, 64, 0, 0), (4200, 128, 128, 0, 0), (4150, 192, 32, 0, 0)]
-        for n, cin, cout, ext, acc in (cases if not lazy else cases[:3]):
+                 (4400, 32, 64, 0, 0), (4200, 128, 128, 0, 0), (4150, 192, 32, 0, 0), (4130, 128, 320, 8, 1)]     # (last: one 128 x 320 tile)
+        for n, cin, cout, ext, acc in (cases if not lazy else cases[:3] + cases[-1:]):
             nf = emu.fns['es_rows_wgrad1_workspace_floats'](n, cin, cout)
             assert nf > 0 and nf % (cin * cout) == 0, (n, cin, cout, nf)
             x = rng.standard_normal((n, cin + ext)).astype(np.float32)
@@ -105,6 +105,10 @@ def test_rows_weight_gradient_of_1x1_layers(emu, lazy):
         assert wsf(288000, 32, 128) > 0 and wsf(18000, 128, 512) > 0
         emu('es_img_wgrad_set_option', 43, 500000)
         assert wsf(288000, 32, 128) == 0 and wsf(864000, 32, 128) > 0 and wsf(72000, 256, 64) > 0
+        assert wsf(60224, 128, 320) > 0 and wsf(60224, 64, 320) == 0
+        emu('es_img_wgrad_set_option', 44, 0)
+        assert wsf(60224, 128, 320) == 0
+        emu('es_img_wgrad_set_option', 44, 1)
     finally:
         emu.lib.es_emu_set_dma_mode(0)
         emu('es_img_wgrad_set_option', 43, 500000)

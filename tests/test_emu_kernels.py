@@ -190,6 +190,32 @@ def test_row_gemm_with_fused_epilogue(emu):
     emu('es_set_option', 13, 1)
 
 
+def test_row_gemm_whole_width_tile(emu):
+    """the head's 128 -> 320 output GEMM (K = 1, identity map, bias, no second epilogue operand) as ONE 320-column tile (option 23):
+    f32 and bf16 input rows, ragged last row tile; same bits as the 64-column tiles it replaces"""
+    rng = np.random.default_rng(9)
+    n, cin, cout = 16384 + 44, 128, 320          # (taken from 16 384 rows)
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    wt, wn = np.zeros((1, cout, cin), np.uint16), np.zeros((1, cin, cout), np.uint16)
+    emu('es_cast_weight_bf16', P(w), 1, cin, cout, P(wn), P(wt), 0)
+    want = bf16_round(x).astype(np.float64) @ bf16_round(w)[0].astype(np.float64) + bias
+    xh = bf16_bits(x)
+    got = {}
+    for on in (1, 0):
+        emu('es_set_option', 23, on)
+        for half, rows in ((0, x), (1, xh)):
+            y = np.full((n, cout), np.nan, np.float32)
+            emu.launches()
+            emu('es_spconv_fwd_bf16', P(rows), half, cin, P(wt), 0, n, n, 1, cin, cout, P(bias), P(y), cout, 0, 0)
+            assert any('k_rowgemm2_bf16<320' in k for k in emu.launches()) == bool(on)
+            assert np.abs(y - want).max() / np.abs(want).max() < 2e-6, (on, half)
+            got[on, half] = y
+    emu('es_set_option', 23, 1)
+    assert np.array_equal(got[1, 0], got[0, 0]) and np.array_equal(got[1, 1], got[0, 1]) and np.array_equal(got[1, 0], got[1, 1])
+
+
 def test_weight_gradient_tiles(emu):
     """dW[k] = X[nbr[:, k]]^T dY through the bf16 weight-gradient kernels (64 x 64 tile, 128 x 128 tile, and the LDS-DMA +
     transposed-read tile whose lane mapping was probed on the GPU) -- row slices through the workspace included"""

@@ -106,7 +106,7 @@ def test_engine_takes_the_image_kernel_for_the_backbone_conv2():
 
 
 @pytest.mark.parametrize('case', [(288000, 32, 128), (288000, 128, 32), (72000, 64, 256), (72000, 256, 64), (18000, 128, 512), (18000, 512, 128),
-                                  (1152000, 64, 32), (5000, 64, 64)])
+                                  (1152000, 64, 32), (5000, 64, 64), (352224, 128, 320), (7528, 128, 320)])
 def test_rows_wgrad_of_1x1_layers_vs_map_kernel(case):
     """es_rows_wgrad1_bf16 against the ring / gather kernel on the same operands (identity map), run-to-run bit-identical"""
     from embodiedscan_amd.engine import _wgrad as WG

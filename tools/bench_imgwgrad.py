@@ -47,7 +47,7 @@ raw('es_img_wgrad_set_option')(42, 160)
 print('--- 1x1 layers on contiguous rows: map kernel vs streaming kernel')
 raw('es_img_wgrad_set_option')(43, 0)
 for n, cin, cout in ((288000, 32, 128), (288000, 128, 32), (72000, 64, 256), (72000, 256, 64), (18000, 128, 512), (18000, 512, 128), (1152000, 64, 32),
-                     (864000, 32, 128), (864000, 128, 32), (216000, 64, 256), (216000, 256, 64)):
+                     (864000, 32, 128), (864000, 128, 32), (216000, 64, 256), (216000, 256, 64), (352224, 128, 320), (60224, 128, 320), (7528, 128, 320)):
     xh = torch.randn(n, cin, device=dev).to(torch.bfloat16)
     gy = torch.randn(n, cout, device=dev)
     d1, d2 = torch.zeros(1, cin, cout, device=dev), torch.zeros(cin, cout, device=dev)
@@ -57,3 +57,20 @@ for n, cin, cout in ((288000, 32, 128), (288000, 128, 32), (72000, 64, 256), (72
     t2 = timeit(lambda: call('es_rows_wgrad1_bf16', P(xh), cin, P(gy), cout, n, cin, cout, P(d2), 0, P(ws), nf, st))
     mb = n * (cin * 2 + cout * 4) / 1e6
     print(f'{n} x {cin}->{cout}: {mb:.0f} MB | map kernel {t1:6.1f} us ({mb / t1 / 1e3 * 1e3:.2f} TB/s) | rows kernel {t2:6.1f} us ({mb / t2:.2f} TB/s), {nf // (cin * cout)} slices')
+
+print('--- the head\'s 128 -> 320 forward GEMM (K = 1): 64-column tiles vs one 320-column tile (option 23)')
+for n in (352224, 60224, 7528):
+    cin, cout = 128, 320
+    x = torch.randn(n, cin, device=dev)
+    w = torch.randn(1, cin, cout, device=dev) * 0.05
+    bias = torch.randn(cout, device=dev)
+    wn, wt = torch.empty((1, cin, cout), dtype=torch.bfloat16, device=dev), torch.empty((1, cout, cin), dtype=torch.bfloat16, device=dev)
+    call('es_cast_weight_bf16', P(w), 1, cin, cout, P(wn), P(wt), st)
+    ys, ts = [], []
+    for on in (0, 1):
+        raw('es_set_option')(23, on)
+        y = torch.empty(n, cout, device=dev)
+        ts.append(timeit(lambda: call('es_spconv_fwd_bf16', P(x), 0, cin, P(wt), 0, n, n, 1, cin, cout, P(bias), P(y), cout, 0, st)))
+        ys.append(y)
+    mb = n * (cin * 4 + cout * 4) / 1e6
+    print(f'{n} x {cin}->{cout}: {mb:.0f} MB | 64-column tiles {ts[0]:6.1f} us ({mb / ts[0]:.2f} TB/s) | one tile {ts[1]:6.1f} us ({mb / ts[1]:.2f} TB/s) | bit-identical {bool(torch.equal(ys[0], ys[1]))}')
