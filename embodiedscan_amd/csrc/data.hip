@@ -178,6 +178,127 @@ extern "C" int es_stem_conv_fwd(const float* x, const float* w, const float* sca
   return 0;
 }
 
+// ------------------------------------------------------------------ stem + max pool in one launch (round 6)
+// ResNet stem as above followed by MaxPool2d(3, stride 2, padding 1) (mmdet ResNet.forward: conv1 - norm1 - relu - maxpool), forward only
+// (frozen_stages >= 1), bf16 rows out.  The pair used to be two launches with 393 MB of f32 stem rows written and read back through a
+// 9-wide map (446 + 291 us for 80 views of 480 x 640).  Here a workgroup owns 7 x 8 POOLED pixels: its 15 x 17 stem pixels (one per
+// thread, 255 of 256; the one-pixel overlap between tiles is recomputed: x 1.14) from a 35 x 39 x 3 input patch in LDS, the stem values
+// through LDS into the 3 x 3 maxima.  The arithmetic per stem value is the old kernel's, term for term (f32 FMAs in (ky, kx, c_in) order)
+// -- the bf16 rows are bit-identical to the pair's -- but the weights are read with wave-uniform addresses (scalar loads, no LDS traffic)
+// and two output channels share one v_pk_fma_f32.
+#define SP_PY 7
+#define SP_SY (2 * SP_PY + 1)
+#define SP_IY (2 * SP_SY + 5)
+typedef float es_f2 __attribute__((ext_vector_type(2)));
+// PX = pooled pixels per tile row: 8 (15 x 17 stem pixels, one per thread; the default) or 16 (15 x 33 = 495, two per thread: the scalar-loaded
+// weight pair of a v_pk_fma_f32 serves both, and the tile overlap falls from x 1.14 to x 1.10 -- measured slower, kept as option 60)
+template <int CO, int PX>
+__global__ __launch_bounds__(256) void k_stem_pool(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift, int H, int W,
+                                                   int Ho, int Wo, int Hp, int Wp, unsigned short* __restrict__ y) {
+  constexpr int SX = 2 * PX + 1, IX = 2 * SX + 5, NS = SP_SY * SX, NPT = (NS + 255) / 256;
+  __shared__ float patch[SP_IY * IX * 3];
+  __shared__ __attribute__((aligned(16))) float stemS[NS * CO];
+  const int t = threadIdx.x;
+  const int im = blockIdx.z, py0 = blockIdx.y * SP_PY, px0 = blockIdx.x * PX;
+  const int hs0 = 2 * py0 - 1, ws0 = 2 * px0 - 1;          // first stem pixel of the tile (pool padding 1)
+  const int hi0 = 2 * hs0 - 3, wi0 = 2 * ws0 - 3;          // first input pixel (stem padding 3)
+  const float* xi = x + (size_t)im * H * W * 3;
+  for (int e = t; e < SP_IY * IX * 3; e += 256) {
+    const int ph = e / (IX * 3), r = e - ph * (IX * 3), pw = r / 3, c = r - pw * 3;
+    const int hi = hi0 + ph, wi = wi0 + pw;
+    patch[e] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? xi[((size_t)hi * W + wi) * 3 + c] : 0.f;
+  }
+  __syncthreads();
+  {
+    int po[NPT];                                            // patch offset of this thread's stem pixels (pixels past the tile: the first one's)
+    bool in_tile[NPT], ok[NPT];
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+      const int sp = t + q * 256;
+      in_tile[q] = sp < NS;
+      const int spc = in_tile[q] ? sp : t;
+      const int sy = spc / SX, sx = spc - sy * SX;
+      const int hs = hs0 + sy, ws_ = ws0 + sx;
+      ok[q] = in_tile[q] && hs >= 0 && hs < Ho && ws_ >= 0 && ws_ < Wo;
+      po[q] = (sy * 2 * IX + sx * 2) * 3;
+    }
+    es_f2 acc[NPT][CO / 2];
+#pragma unroll
+    for (int q = 0; q < NPT; ++q)
+#pragma unroll
+      for (int j = 0; j < CO / 2; ++j) acc[q][j] = (es_f2){0.f, 0.f};
+    for (int ky = 0; ky < 7; ++ky) {
+      const float* wr = w + ky * 7 * 3 * CO;
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          const float* wp = wr + (kx * 3 + ci) * CO;
+          es_f2 vv[NPT];
+#pragma unroll
+          for (int q = 0; q < NPT; ++q) {
+            const float v = patch[po[q] + ky * IX * 3 + kx * 3 + ci];
+            vv[q] = (es_f2){v, v};
+          }
+#pragma unroll
+          for (int j = 0; j < CO / 2; ++j) {
+            const es_f2 ww = (es_f2){wp[2 * j], wp[2 * j + 1]};
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) acc[q][j] = __builtin_elementwise_fma(vv[q], ww, acc[q][j]);
+          }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPT; ++q)
+      if (in_tile[q]) {
+        float* so = &stemS[(t + q * 256) * CO];
+#pragma unroll
+        for (int j = 0; j < CO / 2; ++j) {                   // outside the stem grid: the pool's padding
+          so[2 * j] = ok[q] ? fmaxf(acc[q][j].x * scale[2 * j] + shift[2 * j], 0.f) : -INFINITY;
+          so[2 * j + 1] = ok[q] ? fmaxf(acc[q][j].y * scale[2 * j + 1] + shift[2 * j + 1], 0.f) : -INFINITY;
+        }
+      }
+  }
+  __syncthreads();
+  for (int e = t; e < SP_PY * PX * CO; e += 256) {
+    const int p = e / CO, c = e - p * CO;
+    const int py = p / PX, px = p - py * PX;
+    if (py0 + py >= Hp || px0 + px >= Wp) continue;
+    float m = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, stemS[((2 * py + dy) * SX + 2 * px + dx) * CO + c]);
+    uint32_t u = __float_as_uint(m == -INFINITY ? 0.f : m);
+    u += 0x7fffu + ((u >> 16) & 1u);                       // RNE to bf16 (finite values)
+    y[(((size_t)im * Hp + py0 + py) * Wp + px0 + px) * CO + c] = (unsigned short)(u >> 16);
+  }
+}
+static int ES_OPT_STEM_PX = 8;                 // (profiles/r6l_stem_pool_ab.txt: 16 -- two stem pixels per thread, 169 VGPRs, 61 KB LDS -- 207 us against 161 on 20 views)
+extern "C" int es_stem_pool_set_option(int key, int value) {
+  if (key == 60) { ES_OPT_STEM_PX = value; return 0; }     // pooled pixels per tile row (8 / 16): A/B switch
+  return -1;
+}
+extern "C" int es_stem_pool_fwd(const float* x, const float* w, const float* scale, const float* shift, int n_img, int H, int W,
+                                int Cout, void* y_bf16, void* stream) {
+  if (n_img <= 0) return 0;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+  if (Hp <= 0 || Wp <= 0 || n_img > 65535) return -4;
+  const int px = (ES_OPT_STEM_PX == 16 && Cout == 16) ? 16 : 8;
+  dim3 grid(es_cdiv(Wp, px), es_cdiv(Hp, SP_PY), n_img);
+#define SP_LAUNCH(CO_, PX_) hipLaunchKernelGGL((k_stem_pool<CO_, PX_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, H, W, Ho, Wo, Hp, Wp, (unsigned short*)y_bf16)
+  if (Cout == 16 && px == 16) SP_LAUNCH(16, 16);
+  else if (Cout == 16) SP_LAUNCH(16, 8);
+  else if (Cout == 32) SP_LAUNCH(32, 8);
+#undef SP_LAUNCH
+  else
+    return -6;
+  ES_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------ N4: PointSample on the device (counter-based draws)
 // datasets/transforms/points.py:155-213 draws `np.random.choice(range(n), k, replace=False)` per depth frame and once more over
 // the aggregated cloud: a uniform k-subset in uniform random order.  On the host that is a Fisher-Yates over all ~3e5 valid pixels

@@ -5,11 +5,14 @@ Stand-in for the `backbone=dict(type='mmdet.ResNet', depth=50, base_channels=16,
 norm_eval=True, ...)` entry of configs/detection/mv-det3d_8xb4_embodiedscan-3d-284class-9dof.py:24-34,
 called at embodiedscan/models/detectors/sparse_featfusion_single_stage.py:130-136.
 """
+import os
 import torch
 from ... import engine as E
 from ... import hip
 from ...hip import P, call
 from ...registry import MODELS
+
+STEM_POOL = [os.environ.get('ES_STEM_POOL', '1') != '0']      # round 6: frozen stem + max pool as one launch (A/B switch)
 
 
 def _stream():
@@ -116,7 +119,13 @@ class ResNet:
         # ---- stem: direct 7x7 s2 conv + frozen BN + ReLU (one fused kernel), then 3x3 s2 max pool
         w1 = self.arena.p[self.prefix + 'conv1.weight']
         xin = x.reshape(n_img * H * W, 3)
-        if self.base in (16, 32) and self.frozen_stages >= 0:
+        a16 = bool(self.act16 and E.ACT16[0] and E.PRECISION[0] == 'bf16' and self.frozen_stages >= 0)
+        if self.base in (16, 32) and self.frozen_stages >= 0 and a16 and STEM_POOL[0]:
+            # round 6: stem + max pool in one launch, bf16 rows out (bit-identical to the pair below)
+            yp = torch.empty((pool[2], self.base), dtype=torch.bfloat16, device=dev)
+            call('es_stem_pool_fwd', P(xin), P(w1), P(self.fold['bn1'][0]), P(self.fold['bn1'][1]), n_img, H, W, self.base, P(yp), s)
+            cur = None
+        elif self.base in (16, 32) and self.frozen_stages >= 0:
             y = torch.empty((stem[2], self.base), dtype=torch.float32, device=dev)
             call('es_stem_conv_fwd', P(xin), P(w1), P(self.fold['bn1'][0]), P(self.fold['bn1'][1]), n_img, H, W,
                  self.base, P(y), s)
@@ -128,8 +137,10 @@ class ResNet:
             call('es_spconv_fwd', P(xin), 3, w1.data_ptr() + 4 * 27 * 3 * self.base, P(nbr_b), stem[2], xin.shape[0], 22,
                  3, self.base, 0, P(y), self.base, 0, 1, s)
             cur = E.affine_act(E.Var(y, rg=False), *self.fold['bn1'], act=1)
-        a16 = bool(self.act16 and E.ACT16[0] and E.PRECISION[0] == 'bf16' and self.frozen_stages >= 0)
-        if a16:                                 # frozen stem: forward-only pooling straight into bf16 rows
+        if cur is None:
+            cur = E.Var(yp, rg=False)
+            cur.dh = yp
+        elif a16:                               # frozen stem: forward-only pooling straight into bf16 rows
             yp = torch.empty((pool[2], self.base), dtype=torch.bfloat16, device=dev)
             call('es_maxpool_fwd_h', P(cur.d), self.base, P(pool[0]), pool[2], pool[0].shape[1], self.base, P(yp), s)
             cur = E.Var(yp, rg=False)

@@ -10,10 +10,11 @@ from ... import hip
 from ...hip import P, call
 from ...params import ParamArena, grounder_specs
 from ...registry import MODELS
-from ...text import HashTokenizer, build_text_encoder, create_positive_map
+from ...text import HashTokenizer, TextGraph, build_text_encoder, create_positive_map
 from ..layers.ground_transformer.decoder import SparseFeatureFusionTransformerDecoder, _Lin
 from .sparse_featfusion_single_stage import SparseFeatureFusionSingleStage3DDetector
 
+TEXT_GRAPH = [os.environ.get('ES_TEXT_GRAPH', '1') != '0']     # ... as a captured graph per token shape (text.TextGraph)
 TEXT_ASYNC = [os.environ.get('ES_TEXT_ASYNC', '1') != '0']     # round 6: the frozen text encoder on its own stream, queued before the backbones
 
 
@@ -138,8 +139,10 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         with ctx:
             tok = tok.to(self.device)
             with torch.no_grad():
-                hs = self.text_encoder(input_ids=tok.input_ids, attention_mask=tok.attention_mask).last_hidden_state
                 B, T = tok.input_ids.shape
+                hs = self._encode_graph(tok, B, T) if (side and TEXT_GRAPH[0]) else None
+                if hs is None:
+                    hs = self.text_encoder(input_ids=tok.input_ids, attention_mask=tok.attention_mask).last_hidden_state
                 hs32 = hs.reshape(B * T, self.text_dim).float().contiguous()
                 tlen = tok.attention_mask.sum(1).to(torch.int32).contiguous()
                 mask = tok.attention_mask.bool()
@@ -147,6 +150,24 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
                 ev = torch.cuda.Event()
                 ev.record(self._text_stream)
         return dict(tok=tok, pmaps=pmaps, hs=hs, hs32=hs32, tlen=tlen, mask=mask, ev=ev, B=B, T=T)
+
+    def _encode_graph(self, tok, B, T):
+        """the frozen encoder as a graph replay per (B, T) token shape (text.TextGraph); None: this shape runs eagerly (capture failed once,
+        or more than 16 shapes are alive).  Called with the text stream current."""
+        graphs = self.__dict__.setdefault('_text_graphs', {})
+        g = graphs.get((B, T))
+        if g is None and len(graphs) < 16:
+            try:
+                g = TextGraph(self.text_encoder, B, T, self.device, self._text_stream)
+            except Exception as exc:            # (a capture the libraries underneath do not allow: keep the eager path, say so once)
+                import warnings
+                warnings.warn(f'text encoder graph capture failed for shape {(B, T)}: {exc!r}; running eagerly')
+                torch.cuda.synchronize(self.device)
+                g = False
+            graphs[(B, T)] = g
+        if not g:
+            return None
+        return g.run(tok.input_ids, tok.attention_mask).clone()
 
     def finish_text(self, job, batch_data_samples):
         """:482-498, second half: the calling stream waits for the encoder, then text_feat_map (trainable, recorded on the tape HERE)"""

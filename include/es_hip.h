@@ -331,6 +331,12 @@ int es_depth_to_points(const float* depth, int H, int W, const int* sel_view, co
  * w is [49][3][Cout] (tap = ky*7+kx).  y: (n_img, Ho, Wo, Cout), Ho = (H-1)/2+1. */
 int es_stem_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, int n_img, int H, int W,
                      int Cout, float* y, void* stream);
+/* ... followed by MaxPool2d(3, stride 2, padding 1) in the same launch (mmdet ResNet.forward: conv1 - norm1 - relu - maxpool;
+ * configs/detection/mv-det3d_8xb4_embodiedscan-3d-284class-9dof.py:24-34, frozen_stages = 1: forward only): bf16 rows
+ * (n_img, Hp, Wp, Cout), Hp = (Ho-1)/2+1, bit-identical to es_stem_conv_fwd + es_maxpool_fwd_h on the 3x3 s2 p1 image map. */
+int es_stem_pool_fwd(const float* x, const float* w, const float* scale, const float* shift, int n_img, int H, int W,
+                     int Cout, void* y_bf16, void* stream);
+int es_stem_pool_set_option(int key, int value);   /* 60: pooled pixels per tile row (8 / 16), A/B switch of the kernel above */
 /* u8 (n_img,3,H,W) -> f32 channels-last (n_img,Hp,Wp,3): optional channel flip (bgr_to_rgb), (x-mean)/std, bottom/right
  * padding to (Hp,Wp) with pad_value.  data_preprocessor.py:249-264,286-305; data_preprocessors/utils.py:9-63 */
 int es_preprocess_img(const unsigned char* img, int n_img, int H, int W, int Hp, int Wp, int flip,

@@ -109,3 +109,27 @@ def test_image_convolution_support_rule(emu):
     assert sup(80, 120, 120, 32, 2, 0) == 1 and sup(80, 60, 60, 64, 2, 0) == 0        # (64 channels, stride 2: the map kernel is faster)
     assert sup(80, 60, 60, 32, 1, 1) == 1 and sup(80, 120, 120, 32, 2, 1) == 0        # no strided data gradient
     assert sup(80, 15, 15, 128, 1, 0) == 0 and sup(80, 120, 160, 32, 1, 0) == 0 and sup(80, 240, 240, 16, 2, 0) == 0
+
+
+def test_stem_and_max_pool_in_one_launch(emu):
+    """es_stem_pool_fwd (7x7 s2 p3 conv + frozen BN + ReLU + MaxPool2d(3, 2, 1), bf16 rows) against the two launches it replaces
+    (es_stem_conv_fwd, es_maxpool_fwd_h on the 3x3 s2 p1 image map): bit-identical, on image sizes that are no multiple of any tile"""
+    rng = np.random.default_rng(12)
+    for n_img, H, W, C in ((2, 37, 50, 16), (1, 64, 30, 32), (3, 9, 11, 16)):
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        x = rng.standard_normal((n_img, H, W, 3)).astype(np.float32)
+        w = (rng.standard_normal((49, 3, C)) / 12).astype(np.float32)
+        scale, shift = (rng.random(C) + 0.5).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+        y = np.zeros((n_img * Ho * Wo, C), np.float32)
+        emu('es_stem_conv_fwd', P(x), P(w), P(scale), P(shift), n_img, H, W, C, P(y), 0)
+        nbr = np.zeros((n_img * Hp * Wp, 9), np.int32)
+        emu('es_image_map', n_img, Ho, Wo, Hp, Wp, 3, 3, 2, 1, P(nbr), 0)
+        want = np.zeros((n_img * Hp * Wp, C), np.uint16)
+        emu('es_maxpool_fwd_h', P(y), C, P(nbr), n_img * Hp * Wp, 9, C, P(want), 0)
+        for px in (16, 8):                                    # two stem pixels per thread / one
+            emu('es_stem_pool_set_option', 60, px)
+            got = np.full((n_img * Hp * Wp, C), 0xffff, np.uint16)
+            emu('es_stem_pool_fwd', P(x), P(w), P(scale), P(shift), n_img, H, W, C, P(got), 0)
+            assert np.array_equal(got, want), (n_img, H, W, C, px, int((got != want).sum()))
+        emu('es_stem_pool_set_option', 60, 8)

@@ -71,3 +71,48 @@ def test_gated_data_gradient_vs_map_kernel(case):
     err = float((d1 - d2).abs().max() / d1.abs().max())
     print(f'{case}: gated data gradient vs map kernel {err:.2e} (tol 3e-6); zero rows agree: {bool(((d1 == 0) == (d2 == 0)).all())}')
     assert err < 3e-6 and bool(((d1 == 0) == (d2 == 0)).all())
+
+
+@pytest.mark.parametrize('case', [(20, 480, 640, 16), (3, 97, 131, 16), (2, 64, 64, 32)])
+def test_stem_and_max_pool_in_one_launch(case):
+    """es_stem_pool_fwd against es_stem_conv_fwd + es_maxpool_fwd_h (the oracle-pinned pair of tests/test_gpu_resnet2d.py): same bits"""
+    from embodiedscan_amd.hip import P, call
+    n_img, H, W, C = case
+    dev = torch.device('cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n_img, H, W, 3, generator=g).to(dev)
+    w = (torch.randn(49, 3, C, generator=g) / 12).to(dev)
+    scale, shift = (0.5 + torch.rand(C, generator=g)).to(dev), torch.randn(C, generator=g).to(dev)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    y = torch.empty((n_img * Ho * Wo, C), device=dev)
+    nbr = torch.empty((n_img * Hp * Wp, 9), dtype=torch.int32, device=dev)
+    call('es_image_map', n_img, Ho, Wo, Hp, Wp, 3, 3, 2, 1, P(nbr), st)
+    want = torch.empty((n_img * Hp * Wp, C), dtype=torch.bfloat16, device=dev)
+    got = torch.full((n_img * Hp * Wp, C), float('nan'), dtype=torch.bfloat16, device=dev)
+
+    def pair():
+        call('es_stem_conv_fwd', P(x), P(w), P(scale), P(shift), n_img, H, W, C, P(y), st)
+        call('es_maxpool_fwd_h', P(y), C, P(nbr), n_img * Hp * Wp, 9, C, P(want), st)
+
+    def fused():
+        call('es_stem_pool_fwd', P(x), P(w), P(scale), P(shift), n_img, H, W, C, P(got), st)
+    from embodiedscan_amd.hip import raw
+    got8 = torch.full_like(got, float('nan'))
+
+    def fused8():                                # (option 60 = 16: two stem pixels per thread)
+        raw('es_stem_pool_set_option')(60, 16)
+        call('es_stem_pool_fwd', P(x), P(w), P(scale), P(shift), n_img, H, W, C, P(got8), st)
+        raw('es_stem_pool_set_option')(60, 8)
+    ts = []
+    for fn in (pair, fused, fused8):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 5 * 1e3)
+    print(f'{case}: stem + pool as two launches {ts[0]:.1f} us, as one {ts[1]:.1f} us (two stem pixels per thread: {ts[2]:.1f} us)')
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)) and torch.equal(got8.view(torch.int16), want.view(torch.int16))
