@@ -46,6 +46,9 @@ static int ES_OPT_SPLIT_FOLD = 0;           // tap-split launches: partial tiles
                                            // mv-3ddet step 30.9 ms against 25.9 (with a seq_cst fence, i.e. + buffer_inv: 32.6).  Kept as a tested option.
 static int ES_OPT_RG128_MIN_CIN = 0;       // row GEMM (K = 1): 128-column tiles only for layers with at least this many input channels
 static int ES_OPT_NARROW_SLICES = 768;      // ... row slices (workgroups) of their weight gradient (key 22): three per CU
+static int ES_OPT_LIN_SMALL = 256;         // K = 1 launches with fewer 128-row workgroups than this run the 64 x 64 whole-stage kernel (key 24; 0: off)
+static int ES_OPT_EXPAND = 65536;          // C -> 4 C bf16 expansion layers from this many rows on k_expand_bf16 (key 25; 0: off)
+static int ES_OPT_EXPAND_WGS = 1024;       // ... its persistent workgroups (key 26)
 static int ES_OPT_RG320 = 1;               // row GEMM with 320 output columns as one column tile (key 23)
 static int ES_OPT_NARROW = 1;              // 3-channel K = 27 convolutions (MinkResNet.conv1) on the lane-per-output-channel kernels (key 21)
 static int ES_OPT_WSHARE = 0;              // tap-split launches in the weight-sharing workgroup order (key 20)
@@ -78,6 +81,9 @@ extern "C" int es_set_option(int key, int value) {
   if (key == 21) { ES_OPT_NARROW = value; return 0; }
   if (key == 22) { ES_OPT_NARROW_SLICES = value; return 0; }
   if (key == 23) { ES_OPT_RG320 = value; return 0; }
+  if (key == 24) { ES_OPT_LIN_SMALL = value; return 0; }
+  if (key == 25) { ES_OPT_EXPAND = value; return 0; }
+  if (key == 26) { ES_OPT_EXPAND_WGS = value; return 0; }
   return -2;
 }
 
@@ -1753,6 +1759,176 @@ __global__ __launch_bounds__(256) void k_rowgemm2_bf16(const void* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ expansion convolutions of the image backbone (round 6)
+// Bottleneck.conv3 / downsample (1x1, C -> 4 C with C = 16 / 32 / 64, frozen BN, (+ residual) (+ ReLU), bf16 rows in and out) on 10^5 .. 10^6 pixel rows
+// are OUTPUT streams: 32 .. 128 input bytes and 128 .. 512 output (+ as many residual) bytes per row.  On k_rowgemm2_bf16 a 128-row workgroup pays
+// three dependent latencies (operands -> LDS -> barrier; epilogue constants; stores) for 36 KB of traffic: 1.4 - 1.6 TB/s (340 us for 16 -> 64 on
+// 3.5 M rows; profiles/r6m_slowest_launches_grounding.txt).  Here nothing goes through LDS: a wave keeps its 64 output channels' weight fragments and
+// BN constants in registers for the whole launch and walks 16-row tiles -- input fragment and residual of the NEXT tile in flight under the MFMAs,
+// epilogue and 16-byte stores of the current one.  Waves of a workgroup split the output channels (C = 32: two groups, 64: four).  Same MFMA sequence
+// and epilogue arithmetic as k_rowgemm2_bf16.
+template <int CIN>
+__global__ __launch_bounds__(256) void k_expand_bf16(const unsigned short* __restrict__ X, int ldx, const unsigned short* __restrict__ W, int n,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const unsigned short* __restrict__ R, int ldr, int act, unsigned short* __restrict__ Y,
+                                                     int ldy) {
+  constexpr int COUT = 4 * CIN, WS = COUT / 64, RT = 4 / WS;      // channel groups per workgroup, row tiles per workgroup and round
+  constexpr int KS = CIN <= 32 ? 1 : CIN / 32;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int cw0 = (wv % WS) * 64;                                // this wave's first output channel
+  const int wrow = (li >> 2) * 8 + (li & 3);
+  bf16x8_t b[4][KS];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 32 + kq * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (k < CIN) v = *(const uint4*)(W + (size_t)(cw0 + 32 * (nf >> 1) + 4 * (nf & 1) + wrow) * CIN + k);
+      b[nf][ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  float sc[2][8], sh[2][8];
+#pragma unroll
+  for (int p2 = 0; p2 < 2; ++p2) {
+    const int col = cw0 + 32 * p2 + kq * 8;
+    const float4 s0 = *(const float4*)(scale + col), s1 = *(const float4*)(scale + col + 4);
+    const float4 h0 = *(const float4*)(shift + col), h1 = *(const float4*)(shift + col + 4);
+    sc[p2][0] = s0.x; sc[p2][1] = s0.y; sc[p2][2] = s0.z; sc[p2][3] = s0.w; sc[p2][4] = s1.x; sc[p2][5] = s1.y; sc[p2][6] = s1.z; sc[p2][7] = s1.w;
+    sh[p2][0] = h0.x; sh[p2][1] = h0.y; sh[p2][2] = h0.z; sh[p2][3] = h0.w; sh[p2][4] = h1.x; sh[p2][5] = h1.y; sh[p2][6] = h1.z; sh[p2][7] = h1.w;
+  }
+  const int tiles = (n + 15) >> 4;
+  const int stride = gridDim.x * RT;
+  uint4 an[KS], rn[2];
+  auto load = [&](int tile) {
+    const int row = tile * 16 + li;
+    const bool ok = tile < tiles && row < n;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 32 + kq * 8;
+      an[ks] = (ok && k < CIN) ? *(const uint4*)(X + (size_t)row * ldx + k) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2)
+      rn[p2] = (ok && R) ? *(const uint4*)(R + (size_t)row * ldr + cw0 + 32 * p2 + kq * 8) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  int tile = blockIdx.x * RT + wv / WS;
+  load(tile);
+  for (; tile < tiles; tile += stride) {
+    uint4 ac[KS], rc[2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ac[ks] = an[ks];
+    rc[0] = rn[0]; rc[1] = rn[1];
+    load(tile + stride);
+    f32x4 acc[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t a = __builtin_bit_cast(bf16x8_t, ac[ks]);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nf][ks], a, acc[nf], 0, 0, 0);
+    }
+    const int row = tile * 16 + li;
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+      float o[8];
+      const uint32_t u[4] = {rc[p2].x, rc[p2].y, rc[p2].z, rc[p2].w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = (e < 4 ? acc[2 * p2][e] : acc[2 * p2 + 1][e - 4]) + 0.f;
+        x = x * sc[p2][e] + sh[p2][e];
+        if (R) x += (e & 1) ? __uint_as_float(u[e >> 1] & 0xffff0000u) : __uint_as_float(u[e >> 1] << 16);
+        if (act) x = fmaxf(x, 0.f);
+        o[e] = x;
+      }
+      if (row < n)
+        *(uint4*)(Y + (size_t)row * ldy + cw0 + 32 * p2 + kq * 8) =
+            make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------ small-row linear layers (round 6)
+// The grounding decoder (ground_transformer/decoder.py:91-179) runs ~ 190 K = 1 GEMMs per step on 3 072 query rows (256 -> 256, 256 <-> 2 048)
+// and a few on 396 text rows: 48 workgroups of the 128-row kernel above, each walking its reduction in 32-channel steps with ONE step of
+// prefetch -- 8 .. 64 dependent memory latencies per launch (18.6 us for 256 -> 256, 72 us for 2 048 -> 256; profiles/r6m_slowest_launches_grounding.txt).
+// Here a workgroup owns 64 rows x 64 output channels and moves a WHOLE 256-channel stage per memory latency: 24 independent 16-byte loads per
+// thread (input rows f32, weights bf16) -> bf16 tiles in LDS (row pitch 528 B: the 16 rows of a fragment read sit on 16 distinct bank groups) ->
+// 8 x (1 + 4) fragment reads and 32 MFMAs per wave; the next stage's loads are in flight under them.  Operands swapped like k_rowgemm2_bf16 (a
+// lane ends up with 4 consecutive channels of one row: 16-byte stores), same accumulation order -> same bits as that kernel.
+#define LS_KS 256
+#define LS_LD (LS_KS + 8)
+__global__ __launch_bounds__(256) void k_lin_small(const float* __restrict__ X, int ldx, const unsigned short* __restrict__ W, int n, int Cin,
+                                                   int Cout, const float* __restrict__ bias, float* __restrict__ Y, int ldy, int accumulate) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[64 * LS_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[64 * LS_LD];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int lr = t >> 2, lk = (t & 3) * 64;                   // this thread's tile row (input row / output channel) and its 64 reduction indices
+  const bool rv = row0 + lr < n;
+  const float* pa = X + (size_t)(rv ? row0 + lr : 0) * ldx + lk;
+  const unsigned short* pb = W + (size_t)(n0 + lr) * Cin + lk;
+  float4 ra[16];
+  uint4 rb[8];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ra[i] = (rv && k0 + lk + 4 * i < Cin) ? *(const float4*)(pa + k0 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rb[i] = (k0 + lk + 8 * i < Cin) ? *(const uint4*)(pb + k0 + 8 * i) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      *(uint4*)&As[lr * LS_LD + lk + 8 * i] = make_uint4(pack_bf16(ra[2 * i].x, ra[2 * i].y), pack_bf16(ra[2 * i].z, ra[2 * i].w),
+                                                          pack_bf16(ra[2 * i + 1].x, ra[2 * i + 1].y), pack_bf16(ra[2 * i + 1].z, ra[2 * i + 1].w));
+      *(uint4*)&Bs[lr * LS_LD + lk + 8 * i] = rb[i];
+    }
+  };
+  f32x4 acc[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // weight row this lane reads for fragment nf as the FIRST operand: fragment pair p = nf >> 1 takes channels 32 p + 8 q + {0..3} (even nf) /
+  // {4..7} (odd nf), so that a lane owns 8 consecutive channels per pair (k_rowgemm2_bf16's permutation)
+  const int wrow = (li >> 2) * 8 + (li & 3);
+  load(0);
+  for (int k0 = 0; k0 < Cin; k0 += LS_KS) {
+    store();
+    __syncthreads();
+    if (k0 + LS_KS < Cin) load(k0 + LS_KS);
+    const int ks_n = min(LS_KS, Cin - k0 + 31 & ~31) / 32;
+    for (int ks = 0; ks < ks_n; ++ks) {
+      const bf16x8_t a = *(const bf16x8_t*)&As[(wv * 16 + li) * LS_LD + ks * 32 + kq * 8];
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const bf16x8_t b = *(const bf16x8_t*)&Bs[(32 * (nf >> 1) + 4 * (nf & 1) + wrow) * LS_LD + ks * 32 + kq * 8];
+        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc[nf], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int row = row0 + wv * 16 + li;
+  if (row < n) {
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+      const int col = n0 + 32 * p2 + kq * 8;
+      float o[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { o[r] = acc[2 * p2][r]; o[4 + r] = acc[2 * p2 + 1][r]; }
+      if (bias) {
+        const float4 b0 = *(const float4*)(bias + col), b1 = *(const float4*)(bias + col + 4);
+        o[0] += b0.x; o[1] += b0.y; o[2] += b0.z; o[3] += b0.w; o[4] += b1.x; o[5] += b1.y; o[6] += b1.z; o[7] += b1.w;
+      }
+      float4* py = (float4*)(Y + (size_t)row * ldy + col);
+      if (accumulate) {
+        const float4 y0 = py[0], y1 = py[1];
+        o[0] += y0.x; o[1] += y0.y; o[2] += y0.z; o[3] += y0.w; o[4] += y1.x; o[5] += y1.y; o[6] += y1.z; o[7] += y1.w;
+      }
+      py[0] = make_float4(o[0], o[1], o[2], o[3]);
+      py[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
 // 1 if (shape, alignment) is served by the fast kernels -- the host uses it to decide whether a bf16 shadow of X pays
 extern "C" int es_spconv_bf16_is_fast(int n_in, int ldx, int K, int Cin, int Cout) {
   return (Cin % HBK == 0) && (ldx % 8 == 0) && (Cout % 64 == 0) && ((long long)n_in * ldx < (1ll << 31)) &&
@@ -1824,6 +2000,30 @@ static int spconv_fwd_bf16_impl(const void* Xv, int x_is_bf16, int ldx, const vo
     // column (round 6 A/B with the threshold at 256: grounding 53.35 vs 53.03, mv-3ddet 23.62 vs 23.56, occupancy 34.69 vs 34.76: noise; default 0 = off)
     const bool wide = Cout % 128 == 0 && Cin >= ES_OPT_RG128_MIN_CIN &&
                       (long long)es_cdiv(n_out, BM) * (Cout / 128) >= ES_OPT_RG128_MIN_WGS;
+    // the image backbone's C -> 4 C expansion layers on bf16 rows: register-resident weights, no LDS (k_expand_bf16)
+    if (ES_OPT_EXPAND && x_is_bf16 && y_half && !(y_half & 0xff00) && ep_scale && ep_shift && !bias && !accumulate && (ep_act == 0 || ep_act == 1) &&
+        (!ep_res || r_half) && Cout == 4 * Cin && (Cin == 16 || Cin == 32 || Cin == 64) && n_out >= ES_OPT_EXPAND && n_in >= n_out &&
+        (ldx % 8 == 0) && (ldy % 8 == 0) && (!ep_res || (ep_ldr % 8 == 0 && ((((uintptr_t)ep_res) & 15) == 0))) && ((((uintptr_t)Y) & 15) == 0) &&
+        (((((uintptr_t)ep_scale) | ((uintptr_t)ep_shift)) & 15) == 0) && (long long)n_out * (ldy > ldx ? ldy : ldx) < (1ll << 31)) {
+      const int rt = 4 / (Cout / 64), tiles = es_cdiv(n_out, 16), want = es_cdiv(tiles, rt);
+      dim3 ge(want < ES_OPT_EXPAND_WGS ? want : ES_OPT_EXPAND_WGS);
+#define EX_LAUNCH(C_) hipLaunchKernelGGL((k_expand_bf16<C_>), ge, dim3(256), 0, st, (const unsigned short*)Xv, ldx, Wh, n_out, ep_scale, ep_shift, \
+                                         (const unsigned short*)ep_res, ep_ldr, ep_act, (unsigned short*)Y, ldy)
+      if (Cin == 16) EX_LAUNCH(16);
+      else if (Cin == 32) EX_LAUNCH(32);
+      else EX_LAUNCH(64);
+#undef EX_LAUNCH
+      ES_CHECK_LAUNCH();
+      return 0;
+    }
+    // few rows (the grounding decoder's linears): 64 x 64 tiles moving a 256-channel stage per memory latency
+    if (ES_OPT_LIN_SMALL && !x_is_bf16 && !y_half && !ep_scale && !ep_res && !ep_act && (Cin % 8 == 0) && (Cout % 64 == 0) && Cin >= 64 &&
+        (long long)es_cdiv(n_out, BM) * es_cdiv(Cout, 128) < ES_OPT_LIN_SMALL && n_in >= n_out && (ldy % 4 == 0) && ((((uintptr_t)Y) & 15) == 0) &&
+        (!bias || ((((uintptr_t)bias) & 15) == 0))) {
+      hipLaunchKernelGGL(k_lin_small, dim3(es_cdiv(n_out, 64), Cout / 64), dim3(256), 0, st, X, ldx, Wh, n_out, Cin, Cout, bias, Y, ldy, accumulate);
+      ES_CHECK_LAUNCH();
+      return 0;
+    }
     // Cout = 320 (fcaf3d_head.py: the level's class / box / centerness outputs as one GEMM), no second epilogue operand: ONE 320-column tile
     // (profiles/r6j_rows_ab.txt: 264 -> 224 us on 352 k rows, 52 -> 40 on 60 k, 11.5 -> 19 on 7.5 k: one workgroup per CU needs rows)
     const bool whole = ES_OPT_RG320 && Cout == 320 && n_out >= 16384 && !ep_res && !accumulate && !y_half && ES_OPT_ROWGEMM2 && (ldy % 4 == 0) && ((((uintptr_t)Y) & 15) == 0);
@@ -2575,9 +2775,72 @@ __global__ __launch_bounds__(512) void k_spconv_wgrad_bf16_huge(const unsigned s
 }
 
 // which tile and how many row slices a bf16 weight-gradient launch uses (shared by the launch and the workspace query)
+// weight gradient of the same layers: dW[ci][co] = sum over rows X[row][ci] dY[row][co], f32 rows rounded to bf16 while staged.  A workgroup owns a
+// (64 x 64) tile of dW and a slice of 256 rows: one round of independent loads (a row's 64 + 64 channels per thread), TRANSPOSED 2-byte LDS stores
+// ([channel][row], pitch 528 B) so that both operands are read as 16-byte row-contiguous fragments, 32 MFMAs per wave, partial tile to the slice's
+// workspace block (added in slice order by the reduction launch every weight-gradient launch ends with).
+__global__ __launch_bounds__(256) void k_lin_wgrad_small(const float* __restrict__ X, int ldx, const float* __restrict__ dY, int ldy, int n,
+                                                         int Cin, int Cout, int rows_per_split, float* __restrict__ dW,
+                                                         float* __restrict__ ws, int accumulate) {
+  __shared__ __attribute__((aligned(16))) unsigned short Xt[64 * LS_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short Yt[64 * LS_LD];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, kq = lane >> 4;
+  const int c0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int rbeg = blockIdx.z * rows_per_split, rend = min(n, rbeg + rows_per_split);
+  f32x4 acc[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r0 = rbeg; r0 < rend; r0 += LS_KS) {
+    const int row = r0 + t;
+    float4 rx[16], ry[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      rx[i] = row < rend ? *(const float4*)(X + (size_t)row * ldx + c0 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ry[i] = row < rend ? *(const float4*)(dY + (size_t)row * ldy + n0 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t x01 = pack_bf16(rx[i].x, rx[i].y), x23 = pack_bf16(rx[i].z, rx[i].w);
+      const uint32_t y01 = pack_bf16(ry[i].x, ry[i].y), y23 = pack_bf16(ry[i].z, ry[i].w);
+      Xt[(4 * i + 0) * LS_LD + t] = (unsigned short)(x01 & 0xffffu);
+      Xt[(4 * i + 1) * LS_LD + t] = (unsigned short)(x01 >> 16);
+      Xt[(4 * i + 2) * LS_LD + t] = (unsigned short)(x23 & 0xffffu);
+      Xt[(4 * i + 3) * LS_LD + t] = (unsigned short)(x23 >> 16);
+      Yt[(4 * i + 0) * LS_LD + t] = (unsigned short)(y01 & 0xffffu);
+      Yt[(4 * i + 1) * LS_LD + t] = (unsigned short)(y01 >> 16);
+      Yt[(4 * i + 2) * LS_LD + t] = (unsigned short)(y23 & 0xffffu);
+      Yt[(4 * i + 3) * LS_LD + t] = (unsigned short)(y23 >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < LS_KS / 32; ++ks) {
+      const bf16x8_t a = *(const bf16x8_t*)&Xt[(wv * 16 + li) * LS_LD + ks * 32 + kq * 8];
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const bf16x8_t b = *(const bf16x8_t*)&Yt[(nf * 16 + li) * LS_LD + ks * 32 + kq * 8];
+        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nf], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      wgrad_emit(dW, ws, blockIdx.z, (size_t)Cin * Cout, (size_t)(c0 + wv * 16 + kq * 4 + r) * Cout + n0 + nf * 16 + li, acc[nf][r], accumulate);
+}
+static bool lin_wgrad_small_ok(int XH, int YH, const void* X, int ldx, const void* dY, int ldy, int n_out, int n_in, int K, int Cin, int Cout) {
+  return ES_OPT_LIN_SMALL && K == 1 && !XH && !YH && n_out == n_in && n_out <= 8192 && (Cin % 64 == 0) && (Cout % 64 == 0) &&
+         (long long)Cin * Cout <= 256ll * 256ll && (ldx % 4 == 0) && (ldy % 4 == 0) && ((((uintptr_t)X) | ((uintptr_t)dY)) & 15) == 0;
+}
 static WgradPlan wgrad_plan_bf16(int XH, int YH, const void* X, int ldx, const void* dY, int ldy, int n_out, int n_in, int K,
                                  int Cin, int Cout, bool have_ws) {
   const long long nw = (long long)K * Cin * Cout;
+  if (lin_wgrad_small_ok(XH, YH, X, ldx, dY, ldy, n_out, n_in, K, Cin, Cout)) {     // few rows, narrow layers (identity map: the launcher checks)
+    const int splits = cap_splits(es_cdiv(n_out, LS_KS), nw, have_ws);
+    const int rows_per_split = es_cdiv(es_cdiv(n_out, splits), LS_KS) * LS_KS;
+    return WgradPlan{5, es_cdiv(n_out, rows_per_split), rows_per_split};
+  }
   // 16-byte row segments: 4 floats or 8 bf16 per load
   const int ax = XH ? 8 : 4, ay = YH ? 8 : 4;
   bool big = (Cin % 128 == 0) && (Cout % 128 == 0) && (ldx % ax == 0) && (ldy % ay == 0) &&
@@ -2626,7 +2889,10 @@ static int wgrad_bf16_launch(const void* X, int ldx, const void* dY, int ldy, co
   float* wsk = p.splits > 1 ? ws : nullptr;
   const int gz = es_cdiv(p.splits, 8) * 8;                // XCD-aware slice order: slices >= p.splits exit
   hipStream_t st = (hipStream_t)stream;
-  if (p.kind == 3) {
+  if (p.kind == 5 && nbr == nullptr) {
+    hipLaunchKernelGGL(k_lin_wgrad_small, dim3(Cin / 64, Cout / 64, p.splits), dim3(256), 0, st, (const float*)X, ldx, (const float*)dY, ldy,
+                       n_out, Cin, Cout, p.rows_per_split, dW, wsk, accumulate);
+  } else if (p.kind == 3) {
     dim3 grid(K * (Cin / 256), Cout / 256, gz);
     hipLaunchKernelGGL(k_spconv_wgrad_bf16_huge, grid, dim3(512), 0, st, (const unsigned short*)X, ldx,
                        (const unsigned short*)dY, ldy, nbr, n_out, n_in, K, Cin, Cout, p.rows_per_split, p.splits, dW, wsk, accumulate);

@@ -60,7 +60,7 @@ if os.environ.get('ES_ROWGEMM') is not None:           # A/B switch of the K = 1
 # tuning sweeps without a rebuild (tools/gpu_sweep.sh): weight-gradient slice targets, workspace cap, forward tap-split threshold
 for _key, _env in ((4, 'ES_WG_BIG_TARGET'), (5, 'ES_WG_BIG_ROWS'), (6, 'ES_WG_SMALL_TARGET'), (7, 'ES_WG_CAP_MB'), (8, 'ES_FWD_SPLIT_WGS'),
                   (10, 'ES_DMA'), (11, 'ES_DMA_MIN_CIN'), (12, 'ES_RG128_MIN_CIN'), (14, 'ES_WGRAD_TR'), (15, 'ES_NORM_CB_ROWS'),
-                  (16, 'ES_SPLIT_FOLD'), (19, 'ES_RG128_MIN_WGS'), (20, 'ES_WSHARE'), (21, 'ES_NARROW'), (23, 'ES_RG320')):
+                  (16, 'ES_SPLIT_FOLD'), (19, 'ES_RG128_MIN_WGS'), (20, 'ES_WSHARE'), (21, 'ES_NARROW'), (23, 'ES_RG320'), (24, 'ES_LIN_SMALL'), (25, 'ES_EXPAND'), (26, 'ES_EXPAND_WGS')):
     if os.environ.get(_env) is not None:
         _fn['es_set_option'](_key, int(os.environ[_env]))
 

@@ -216,6 +216,90 @@ def test_row_gemm_whole_width_tile(emu):
     assert np.array_equal(got[1, 0], got[0, 0]) and np.array_equal(got[1, 1], got[0, 1]) and np.array_equal(got[1, 0], got[1, 1])
 
 
+def test_small_row_linear_kernel(emu):
+    """K = 1 launches with few rows (the grounding decoder's linears) on the 64 x 64 whole-stage kernel (option 24): one and several
+    256-channel stages, a last stage of 8 channels, ragged rows, bias, accumulation, strided input rows -- against f64 on the rounded
+    operands and bit for bit against the 128-row kernel it replaces"""
+    rng = np.random.default_rng(10)
+    for n, cin, cout, ext, acc in ((300, 256, 256, 0, 0), (70, 64, 128, 4, 1), (130, 520, 64, 0, 0), (64, 2048, 256, 0, 1), (1, 256, 64, 0, 0)):
+        xb = rng.standard_normal((n, cin + ext)).astype(np.float32)
+        x = xb[:, :cin]
+        w = (rng.standard_normal((1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        bias = rng.standard_normal(cout).astype(np.float32)
+        wt, wn = np.zeros((1, cout, cin), np.uint16), np.zeros((1, cin, cout), np.uint16)
+        emu('es_cast_weight_bf16', P(w), 1, cin, cout, P(wn), P(wt), 0)
+        y0 = rng.standard_normal((n, cout)).astype(np.float32)
+        want = bf16_round(x).astype(np.float64) @ bf16_round(w)[0].astype(np.float64) + bias + (y0 if acc else 0)
+        got = {}
+        for on in (256, 0):
+            emu('es_set_option', 24, on)
+            y = y0.copy() if acc else np.full((n, cout), np.nan, np.float32)
+            emu.launches()
+            emu('es_spconv_fwd_bf16', P(xb), 0, cin + ext, P(wt), 0, n, n, 1, cin, cout, P(bias), P(y), cout, acc, 0)
+            assert any('k_lin_small' in k for k in emu.launches()) == bool(on)
+            assert np.abs(y - want).max() / np.abs(want).max() < 2e-6, (n, cin, cout, on)
+            got[on] = y
+        emu('es_set_option', 24, 256)
+        assert np.array_equal(got[256], got[0]), (n, cin, cout)
+
+
+def test_small_row_linear_weight_gradient(emu):
+    """dW = X^T dY of the few-row linear layers (es_spconv_wgrad_bf16, K = 1, identity map, f32 rows, <= 256 x 256 weights) on the 64 x 64 tile
+    kernel: ragged last slice, several slices through the workspace and the single-slice form, strided rows, accumulation; the same shape
+    with a map keeps the gather kernels"""
+    rng = np.random.default_rng(13)
+    for n, cin, cout, ext, acc in ((300, 256, 256, 0, 0), (700, 64, 128, 4, 1), (256, 128, 64, 0, 0), (5, 64, 64, 0, 1)):
+        xb = rng.standard_normal((n, cin + ext)).astype(np.float32)
+        gb = rng.standard_normal((n, cout + ext)).astype(np.float32)
+        x, gy = xb[:, :cin], gb[:, :cout]
+        want = bf16_round(x).astype(np.float64).T @ bf16_round(gy).astype(np.float64)
+        dw0 = rng.standard_normal((1, cin, cout)).astype(np.float32)
+        nf = int(emu.fns['es_spconv_wgrad_workspace_floats'](1, P(xb), 0, cin + ext, P(gb), 0, cout + ext, n, n, 1, cin, cout))
+        assert nf == (-(-n // 256)) * cin * cout * (n > 256), (n, nf)
+        ws = np.full(max(nf, 1), np.nan, np.float32)
+        for use_ws in (1, 0):
+            dw = dw0.copy()
+            emu.launches()
+            emu('es_spconv_wgrad_bf16', P(xb), cin + ext, P(gb), cout + ext, 0, n, n, 1, cin, cout, P(dw), acc, P(ws) if use_ws else 0, nf if use_ws else 0, 0)
+            assert any('k_lin_wgrad_small' in k for k in emu.launches())
+            err = np.abs(dw[0] - (want + (dw0[0] if acc else 0))).max() / np.abs(want).max()
+            assert err < 2e-6, (n, cin, cout, use_ws, err)
+        ident = np.arange(n, dtype=np.int32)[:, None].copy()
+        dw = dw0.copy()
+        emu.launches()
+        emu('es_spconv_wgrad_bf16', P(xb), cin + ext, P(gb), cout + ext, P(ident), n, n, 1, cin, cout, P(dw), acc, P(ws), nf, 0)
+        assert not any('k_lin_wgrad_small' in k for k in emu.launches())
+        assert np.abs(dw[0] - (want + (dw0[0] if acc else 0))).max() / np.abs(want).max() < 2e-6
+
+
+def test_expansion_convolution_stream_kernel(emu):
+    """the image backbone's 1x1 C -> 4 C layers on bf16 rows (frozen BN (+ bf16 residual) (+ ReLU)) on the register-resident kernel (option 25)
+    against the row GEMM it replaces: 16 / 32 / 64 input channels, ragged last tile, more tiles than persistent waves, strided rows"""
+    rng = np.random.default_rng(21)
+    for n, cin, with_res, act, ext, wgs in ((333, 16, 1, 1, 0, 1024), (1000, 32, 0, 0, 8, 3), (517, 64, 1, 1, 0, 5), (16, 64, 1, 0, 0, 1024)):
+        cout = 4 * cin
+        x = bf16_bits(rng.standard_normal((n, cin + ext)).astype(np.float32))
+        res = bf16_bits(rng.standard_normal((n, cout + ext)).astype(np.float32))
+        w = (rng.standard_normal((1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        wt, wn = np.zeros((1, cout, cin), np.uint16), np.zeros((1, cin, cout), np.uint16)
+        emu('es_cast_weight_bf16', P(w), 1, cin, cout, P(wn), P(wt), 0)
+        scale, shift = (rng.random(cout) + 0.5).astype(np.float32), rng.standard_normal(cout).astype(np.float32)
+        got = {}
+        for on in (1, 0):
+            emu('es_set_option', 25, on)
+            emu('es_set_option', 26, wgs)
+            y = np.full((n, cout + ext), 0x7fc0, np.uint16)
+            emu.launches()
+            emu('es_spconv_fwd_bf16_io', P(x), 1, cin + ext, P(wt), 0, n, n, 1, cin, cout, P(scale), P(shift), P(res) if with_res else 0, 1, cout + ext,
+                act, P(y), 1, cout + ext, 0)
+            assert any('k_expand_bf16' in k for k in emu.launches()) == bool(on)
+            got[on] = y
+        emu('es_set_option', 25, 65536)
+        emu('es_set_option', 26, 1024)
+        assert np.array_equal(got[1], got[0]), (n, cin, int((got[1] != got[0]).sum()))
+        assert (got[1][:, cout:] == 0x7fc0).all()
+
+
 def test_weight_gradient_tiles(emu):
     """dW[k] = X[nbr[:, k]]^T dY through the bf16 weight-gradient kernels (64 x 64 tile, 128 x 128 tile, and the LDS-DMA +
     transposed-read tile whose lane mapping was probed on the GPU) -- row slices through the workspace included"""
