@@ -172,6 +172,8 @@ extern "C" int es_stem_conv_fwd(const float* x, const float* w, const float* sca
     hipLaunchKernelGGL(k_stem_conv<16>, grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, H, W, Ho, Wo, y);
   else if (Cout == 32)
     hipLaunchKernelGGL(k_stem_conv<32>, grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, H, W, Ho, Wo, y);
+  else if (Cout == 64)
+    hipLaunchKernelGGL(k_stem_conv<64>, grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, H, W, Ho, Wo, y);
   else
     return -6;
   ES_CHECK_LAUNCH();
@@ -292,6 +294,7 @@ extern "C" int es_stem_pool_fwd(const float* x, const float* w, const float* sca
   if (Cout == 16 && px == 16) SP_LAUNCH(16, 16);
   else if (Cout == 16) SP_LAUNCH(16, 8);
   else if (Cout == 32) SP_LAUNCH(32, 8);
+  else if (Cout == 64) SP_LAUNCH(64, 8);            // (the occupancy detector's full-width ResNet-50: 81 KB of LDS, one workgroup per CU)
 #undef SP_LAUNCH
   else
     return -6;

@@ -96,9 +96,11 @@ class ResNet:
         """x: (n_img, H, W, 3) f32 channels-last.  Returns [(Var (n_img*h*w, C), h, w)] for the out_indices."""
         n_img, H, W, _ = x.shape
         dev = x.device
-        key = (n_img, H, W)
+        a16 = bool(self.act16 and E.ACT16[0] and E.PRECISION[0] == 'bf16' and self.frozen_stages >= 0)
+        fused = self.base in (16, 32, 64) and self.frozen_stages >= 0 and a16 and STEM_POOL[0]     # stem + max pool in one launch
+        direct = (self.base in (16, 32) and self.frozen_stages >= 0) or fused
+        key = (n_img, H, W, direct)
         if key not in self.grids:
-            direct = self.base in (16, 32) and self.frozen_stages >= 0
             if direct:                          # fused stem kernel: no 49-tap image map needed
                 Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
                 stem, nbr_a, nbr_b = (None, None, n_img * Ho * Wo, Ho, Wo), None, None
@@ -119,8 +121,7 @@ class ResNet:
         # ---- stem: direct 7x7 s2 conv + frozen BN + ReLU (one fused kernel), then 3x3 s2 max pool
         w1 = self.arena.p[self.prefix + 'conv1.weight']
         xin = x.reshape(n_img * H * W, 3)
-        a16 = bool(self.act16 and E.ACT16[0] and E.PRECISION[0] == 'bf16' and self.frozen_stages >= 0)
-        if self.base in (16, 32) and self.frozen_stages >= 0 and a16 and STEM_POOL[0]:
+        if fused:
             # round 6: stem + max pool in one launch, bf16 rows out (bit-identical to the pair below)
             yp = torch.empty((pool[2], self.base), dtype=torch.bfloat16, device=dev)
             call('es_stem_pool_fwd', P(xin), P(w1), P(self.fold['bn1'][0]), P(self.fold['bn1'][1]), n_img, H, W, self.base, P(yp), s)

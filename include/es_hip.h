@@ -327,7 +327,7 @@ int es_norm_from_partials(const double* partial, int n_partials, float scale, fl
 /* ---- A1-A3, A18 data side ---------------------------------------------------------------------------- */
 int es_depth_to_points(const float* depth, int H, int W, const int* sel_view, const int* sel_pix, int n,
                        const float* mats /* (V,32) */, const float* aug /* 15 */, float* out, void* stream);
-/* mmdet.ResNet stem: conv 7x7 s2 p3 (3 -> Cout in {16,32}) + frozen BN + ReLU, channels-last, forward only.
+/* mmdet.ResNet stem: conv 7x7 s2 p3 (3 -> Cout in {16,32,64}) + frozen BN + ReLU, channels-last, forward only.
  * w is [49][3][Cout] (tap = ky*7+kx).  y: (n_img, Ho, Wo, Cout), Ho = (H-1)/2+1. */
 int es_stem_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, int n_img, int H, int W,
                      int Cout, float* y, void* stream);

@@ -115,7 +115,7 @@ def test_stem_and_max_pool_in_one_launch(emu):
     """es_stem_pool_fwd (7x7 s2 p3 conv + frozen BN + ReLU + MaxPool2d(3, 2, 1), bf16 rows) against the two launches it replaces
     (es_stem_conv_fwd, es_maxpool_fwd_h on the 3x3 s2 p1 image map): bit-identical, on image sizes that are no multiple of any tile"""
     rng = np.random.default_rng(12)
-    for n_img, H, W, C in ((2, 37, 50, 16), (1, 64, 30, 32), (3, 9, 11, 16)):
+    for n_img, H, W, C in ((2, 37, 50, 16), (1, 64, 30, 32), (3, 9, 11, 16), (1, 33, 41, 64)):
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
         x = rng.standard_normal((n_img, H, W, 3)).astype(np.float32)

@@ -73,7 +73,7 @@ def test_gated_data_gradient_vs_map_kernel(case):
     assert err < 3e-6 and bool(((d1 == 0) == (d2 == 0)).all())
 
 
-@pytest.mark.parametrize('case', [(20, 480, 640, 16), (3, 97, 131, 16), (2, 64, 64, 32)])
+@pytest.mark.parametrize('case', [(20, 480, 640, 16), (3, 97, 131, 16), (2, 64, 64, 32), (10, 480, 640, 64)])
 def test_stem_and_max_pool_in_one_launch(case):
     """es_stem_pool_fwd against es_stem_conv_fwd + es_maxpool_fwd_h (the oracle-pinned pair of tests/test_gpu_resnet2d.py): same bits"""
     from embodiedscan_amd.hip import P, call
