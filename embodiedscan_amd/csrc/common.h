@@ -138,6 +138,13 @@ __device__ inline unsigned int es_coh_load_u(const unsigned int* p) { return __h
 __device__ inline float es_coh_sum(const float* p, int count, size_t stride) {
   float t = 0.f;
   int b = 0;
+  for (; b + 32 <= count; b += 32) {          // (round 6: 32 in flight where the list is long enough -- same order of additions)
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = es_coh_load(p + (size_t)(b + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) t += v[u];
+  }
   for (; b + 16 <= count; b += 16) {
     float v[16];
 #pragma unroll
@@ -147,6 +154,19 @@ __device__ inline float es_coh_sum(const float* p, int count, size_t stride) {
   }
   for (; b < count; ++b) t += es_coh_load(p + (size_t)b * stride);
   return t;
+}
+// two lists at once (LayerNorm backward: dw and db partials of the same workgroups): 2 x 16 loads in flight, each sum in index order
+__device__ inline void es_coh_sum2(const float* pa, const float* pb, int count, size_t stride, float& ta, float& tb) {
+  ta = tb = 0.f;
+  int b = 0;
+  for (; b + 16 <= count; b += 16) {
+    float va[16], vb[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { va[u] = es_coh_load(pa + (size_t)(b + u) * stride); vb[u] = es_coh_load(pb + (size_t)(b + u) * stride); }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { ta += va[u]; tb += vb[u]; }
+  }
+  for (; b < count; ++b) { ta += es_coh_load(pa + (size_t)b * stride); tb += es_coh_load(pb + (size_t)b * stride); }
 }
 __device__ inline bool es_last_block_light(unsigned int* ticket, unsigned int nblocks) {
   __shared__ unsigned int es_s_last3;

@@ -192,13 +192,13 @@ extern "C" int es_stem_conv_fwd(const float* x, const float* w, const float* sca
 #define SP_SY (2 * SP_PY + 1)
 #define SP_IY (2 * SP_SY + 5)
 typedef float es_f2 __attribute__((ext_vector_type(2)));
-// PX = pooled pixels per tile row: 8 (15 x 17 stem pixels, one per thread; the default) or 16 (15 x 33 = 495, two per thread: the scalar-loaded
-// weight pair of a v_pk_fma_f32 serves both, and the tile overlap falls from x 1.14 to x 1.10 -- measured slower, kept as option 60)
+// PX = pooled pixels per tile row: 8 (15 x 17 stem pixels, one per thread).  PX = 16 (15 x 33 = 495 stem pixels, two per thread sharing the
+// scalar-loaded weight pairs, overlap x 1.10) was measured: 207 us against 161 on 20 views (169 VGPRs, 61 KB LDS, SGPR spills) -- not instantiated.
 template <int CO, int PX>
 __global__ __launch_bounds__(256) void k_stem_pool(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ shift, int H, int W,
                                                    int Ho, int Wo, int Hp, int Wp, unsigned short* __restrict__ y) {
-  constexpr int SX = 2 * PX + 1, IX = 2 * SX + 5, NS = SP_SY * SX, NPT = (NS + 255) / 256;
+  constexpr int SX = 2 * PX + 1, IX = 2 * SX + 5, NS = SP_SY * SX, NPT = (NS + 255) / 256, CI_UNROLL = CO <= 16 ? 3 : 1;
   __shared__ float patch[SP_IY * IX * 3];
   __shared__ __attribute__((aligned(16))) float stemS[NS * CO];
   const int t = threadIdx.x;
@@ -232,10 +232,10 @@ __global__ __launch_bounds__(256) void k_stem_pool(const float* __restrict__ x, 
       for (int j = 0; j < CO / 2; ++j) acc[q][j] = (es_f2){0.f, 0.f};
     for (int ky = 0; ky < 7; ++ky) {
       const float* wr = w + ky * 7 * 3 * CO;
-#pragma unroll
-      for (int kx = 0; kx < 7; ++kx)
-#pragma unroll
-        for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll 1
+      for (int kx = 0; kx < 7; ++kx)             // (rolled: a whole ky row of weights in flight wants 336 SGPRs and spilled 48 of them)
+#pragma unroll CI_UNROLL
+        for (int ci = 0; ci < 3; ++ci) {         // (32 / 64 output channels: one input channel's weights at a time fill the SGPR file)
           const float* wp = wr + (kx * 3 + ci) * CO;
           es_f2 vv[NPT];
 #pragma unroll
@@ -277,22 +277,16 @@ __global__ __launch_bounds__(256) void k_stem_pool(const float* __restrict__ x, 
     y[(((size_t)im * Hp + py0 + py) * Wp + px0 + px) * CO + c] = (unsigned short)(u >> 16);
   }
 }
-static int ES_OPT_STEM_PX = 8;                 // (profiles/r6l_stem_pool_ab.txt: 16 -- two stem pixels per thread, 169 VGPRs, 61 KB LDS -- 207 us against 161 on 20 views)
-extern "C" int es_stem_pool_set_option(int key, int value) {
-  if (key == 60) { ES_OPT_STEM_PX = value; return 0; }     // pooled pixels per tile row (8 / 16): A/B switch
-  return -1;
-}
 extern "C" int es_stem_pool_fwd(const float* x, const float* w, const float* scale, const float* shift, int n_img, int H, int W,
                                 int Cout, void* y_bf16, void* stream) {
   if (n_img <= 0) return 0;
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
   if (Hp <= 0 || Wp <= 0 || n_img > 65535) return -4;
-  const int px = (ES_OPT_STEM_PX == 16 && Cout == 16) ? 16 : 8;
+  const int px = 8;
   dim3 grid(es_cdiv(Wp, px), es_cdiv(Hp, SP_PY), n_img);
 #define SP_LAUNCH(CO_, PX_) hipLaunchKernelGGL((k_stem_pool<CO_, PX_>), grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, H, W, Ho, Wo, Hp, Wp, (unsigned short*)y_bf16)
-  if (Cout == 16 && px == 16) SP_LAUNCH(16, 16);
-  else if (Cout == 16) SP_LAUNCH(16, 8);
+  if (Cout == 16) SP_LAUNCH(16, 8);
   else if (Cout == 32) SP_LAUNCH(32, 8);
   else if (Cout == 64) SP_LAUNCH(64, 8);            // (the occupancy detector's full-width ResNet-50: 81 KB of LDS, one workgroup per CU)
 #undef SP_LAUNCH

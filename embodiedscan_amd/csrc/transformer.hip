@@ -418,32 +418,51 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
     wc[q] = c < C ? w[c] : 0.f;
   }
   int r_end = min(n, (int)(blockIdx.x + 1) * rows_per_block);
-  for (int i = blockIdx.x * rows_per_block + wv; i < r_end; i += 4) {
-    float mu = mean[i], rs = rstd[i];
-    float g[8], xh[8], s1 = 0.f, s2 = 0.f;
+  // two rows of this wave per iteration (i and i + 4): their loads are independent, so one memory latency serves both (round 6: a wave walked
+  // its 8 rows one dependent latency at a time -- 32 us per launch on the decoder's 3 072 x 256 matrices); sums accumulate in the old row order
+  for (int i0 = blockIdx.x * rows_per_block + wv; i0 < r_end; i0 += 8) {
+    float d[2][8], zz[2][8], mu[2], rs[2];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      int c = lane + q * 64;
-      g[q] = xh[q] = 0.f;
-      if (c < C) {
-        float d = dy[(size_t)i * C + c];
-        xh[q] = (z[(size_t)i * C + c] - mu) * rs;
-        g[q] = d * wc[q];
-        s1 += g[q];
-        s2 += g[q] * xh[q];
-        aw[q] += d * xh[q];
-        ab[q] += d;
+    for (int h = 0; h < 2; ++h) {
+      const int i = i0 + 4 * h;
+      const bool ok = i < r_end;
+      mu[h] = ok ? mean[i] : 0.f;
+      rs[h] = ok ? rstd[i] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = lane + q * 64;
+        d[h][q] = zz[h][q] = 0.f;
+        if (ok && c < C) { d[h][q] = dy[(size_t)i * C + c]; zz[h][q] = z[(size_t)i * C + c]; }
       }
     }
-    s1 = es_wave_sum(s1) / (float)C;
-    s2 = es_wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      int c = lane + q * 64;
-      if (c < C) {
-        float v = rs * (g[q] - s1 - xh[q] * s2);
-        float* p = dz + (size_t)i * C + c;
-        *p = accumulate ? *p + v : v;
+    for (int h = 0; h < 2; ++h) {
+      const int i = i0 + 4 * h;
+      if (i >= r_end) break;
+      float g[8], xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = lane + q * 64;
+        g[q] = xh[q] = 0.f;
+        if (c < C) {
+          xh[q] = (zz[h][q] - mu[h]) * rs[h];
+          g[q] = d[h][q] * wc[q];
+          s1 += g[q];
+          s2 += g[q] * xh[q];
+          aw[q] += d[h][q] * xh[q];
+          ab[q] += d[h][q];
+        }
+      }
+      s1 = es_wave_sum(s1) / (float)C;
+      s2 = es_wave_sum(s2) / (float)C;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = lane + q * 64;
+        if (c < C) {
+          const float v = rs[h] * (g[q] - s1 - xh[q] * s2);
+          float* p = dz + (size_t)i * C + c;
+          *p = accumulate ? *p + v : v;
+        }
       }
     }
   }
@@ -461,8 +480,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, co
   }
   if (!es_last_block_sel((unsigned int*)ws, gridDim.x, safe)) return;
   for (int c = threadIdx.x; c < C; c += 256) {
-    const float a = es_coh_sum(part + c, (int)gridDim.x, (size_t)2 * C);
-    const float bsum = es_coh_sum(part + C + c, (int)gridDim.x, (size_t)2 * C);
+    float a, bsum;
+    es_coh_sum2(part + c, part + C + c, (int)gridDim.x, (size_t)2 * C, a, bsum);
     if (dw) dw[c] += a;
     if (db) db[c] += bsum;
   }

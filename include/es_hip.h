@@ -336,7 +336,6 @@ int es_stem_conv_fwd(const float* x, const float* w, const float* scale, const f
  * (n_img, Hp, Wp, Cout), Hp = (Ho-1)/2+1, bit-identical to es_stem_conv_fwd + es_maxpool_fwd_h on the 3x3 s2 p1 image map. */
 int es_stem_pool_fwd(const float* x, const float* w, const float* scale, const float* shift, int n_img, int H, int W,
                      int Cout, void* y_bf16, void* stream);
-int es_stem_pool_set_option(int key, int value);   /* 60: pooled pixels per tile row (8 / 16), A/B switch of the kernel above */
 /* u8 (n_img,3,H,W) -> f32 channels-last (n_img,Hp,Wp,3): optional channel flip (bgr_to_rgb), (x-mean)/std, bottom/right
  * padding to (Hp,Wp) with pad_value.  data_preprocessor.py:249-264,286-305; data_preprocessors/utils.py:9-63 */
 int es_preprocess_img(const unsigned char* img, int n_img, int H, int W, int Hp, int Wp, int flip,

@@ -127,9 +127,6 @@ def test_stem_and_max_pool_in_one_launch(emu):
         emu('es_image_map', n_img, Ho, Wo, Hp, Wp, 3, 3, 2, 1, P(nbr), 0)
         want = np.zeros((n_img * Hp * Wp, C), np.uint16)
         emu('es_maxpool_fwd_h', P(y), C, P(nbr), n_img * Hp * Wp, 9, C, P(want), 0)
-        for px in (16, 8):                                    # two stem pixels per thread / one
-            emu('es_stem_pool_set_option', 60, px)
-            got = np.full((n_img * Hp * Wp, C), 0xffff, np.uint16)
-            emu('es_stem_pool_fwd', P(x), P(w), P(scale), P(shift), n_img, H, W, C, P(got), 0)
-            assert np.array_equal(got, want), (n_img, H, W, C, px, int((got != want).sum()))
-        emu('es_stem_pool_set_option', 60, 8)
+        got = np.full((n_img * Hp * Wp, C), 0xffff, np.uint16)
+        emu('es_stem_pool_fwd', P(x), P(w), P(scale), P(shift), n_img, H, W, C, P(got), 0)
+        assert np.array_equal(got, want), (n_img, H, W, C, int((got != want).sum()))
