@@ -536,7 +536,7 @@ def main():
         roof = dict(bound='hbm', achieved=base['comp_GBps'], peak=K_PEAK_HBM, unit='GB/s',
                     frac=round(base['comp_GBps'] / K_PEAK_HBM, 4))
     roofline = dict(roof, traffic=traffic, **traffic_extra,
-                    kernel='convolution engine: k_spconv_bf16* / k_rowgemm_bf16 (fwd/dgrad) + k_spconv_wgrad_bf16*' if args.precision == 'bf16'
+                    kernel='convolution engine: k_spconv_* (gather / halo / narrow) / k_rowgemm2 / k_lin_small / k_expand / k_img_conv3 (fwd, dgrad) + k_spconv_wgrad_bf16* / k_img_wgrad9 / k_rows_wgrad1' if args.precision == 'bf16'
                     else 'convolution engine: k_spconv / k_spconv_wgrad (exact-f32 MFMA)',
                     launches_per_step=base['launches'], kernel_ms_per_step=base['ms'],
                     frac_of_binding_roof=base['frac_binding'],

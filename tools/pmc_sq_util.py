@@ -18,7 +18,7 @@ def table(path):
 
 
 def main(path, *patterns):
-    pats = patterns or ('k_spconv', 'k_rowgemm', 'k_attn', 'k_wgrad')
+    pats = patterns or ('k_spconv', 'k_rowgemm', 'k_attn', 'k_wgrad', 'k_img_conv3', 'k_img_wgrad9', 'k_rows_wgrad1', 'k_lin_', 'k_expand_bf16', 'k_dconv')
     clock, simds = 2.0e9, 256 * 4
     t = table(path)
     print(f'# MFMA utilisation from {path} (assumed effective clock {clock / 1e9:.1f} GHz, 256 CUs x 4 SIMDs)')

@@ -12,8 +12,12 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILY = {
     # the convolution engine: every kernel behind the es_spconv_* entry points (+ their split reductions)
-    'mv3ddet': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits', 'k_dconv', 'k_halo_plan'),     # round 6: + the halo kernel (k_spconv_halo) and its plan
-    'occupancy': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits', 'k_dconv'),     # round 5: + the dense-volume engine
+    # round 6: + the halo kernel (k_spconv_halo) and its plan, the image-grid kernels (k_img_conv3, k_img_wgrad9 + reduce, k_rows_wgrad1), the few-row
+    # linear kernels and the expansion stream kernel -- every kernel bench.py's ENGINE entry points can launch
+    'mv3ddet': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits', 'k_dconv', 'k_halo_plan', 'k_img_conv3', 'k_img_wgrad', 'k_rows_wgrad1',
+                'k_lin_small', 'k_lin_wgrad_small', 'k_expand_bf16'),
+    'occupancy': ('k_spconv', 'k_rowgemm', 'k_wgrad_reduce', 'k_sum_splits', 'k_dconv', 'k_img_conv3', 'k_img_wgrad', 'k_rows_wgrad1', 'k_lin_small',
+                  'k_lin_wgrad_small', 'k_expand_bf16'),     # round 5: + the dense-volume engine
     'grounding': ('k_attn_',),
 }
 SCATTER = ('k_voxel_keys', 'k_insert_min', 'k_unique', 'k_morton', 'k_rs_', 'k_apply_sorted', 'k_stride_keys', 'k_kernel_map',
