@@ -387,6 +387,19 @@ def _img_wgrad(sw, dW, xh, ldx, gy, ldy, img, C, need):
     call('es_img_wgrad9_bf16', P(xh), ldx, P(gy), ldy, img[0], img[1], img[2], C, img[3], dW, _first_write(dW), P(ws), ws.numel(), sw)
 
 
+def wgrad_stream_obj():
+    """the torch Stream that carries the weight-gradient launches of the current compute stream (created on first use) -- idle during
+    the forward pass, so small independent forward-time work (the grounder's frozen text encoder) can ride on it instead of opening
+    one more stream: a process has four hardware queues, and a fifth, sixth ... stream ends up sharing one with a stream it was meant to
+    overlap (bench.py copy_stream: ~ 10 - 18 % per step when that happens)"""
+    h = _stream()
+    ws = _WGRAD_STREAMS.get(h)
+    if ws is None:
+        st = torch.cuda.Stream()
+        ws = _WGRAD_STREAMS[h] = dict(s=st, h=st.cuda_stream, fork=torch.cuda.Event(), join=torch.cuda.Event(), used=False)
+    return ws['s']
+
+
 def join_wgrad_streams(final=True):
     """make the current stream wait for every queued weight-gradient launch (before the gradients are reduced or
     consumed by the optimiser)"""

@@ -131,7 +131,10 @@ class SparseFeatureFusion3DGrounder(SparseFeatureFusionSingleStage3DDetector):
         ev = None
         if side:
             if getattr(self, '_text_stream', None) is None:
-                self._text_stream = torch.cuda.Stream(device=self.device)
+                # the weight-gradient stream of the compute stream (idle during the forward pass) unless told otherwise: a stream of its
+                # own is a fifth .. seventh stream on four hardware queues (ES_TEXT_STREAM=own: A/B)
+                own = os.environ.get('ES_TEXT_STREAM', 'wgrad') == 'own' or not E.WGRAD_ASYNC[0]
+                self._text_stream = torch.cuda.Stream(device=self.device) if own else E.wgrad_stream_obj()
             ctx = torch.cuda.stream(self._text_stream)
         else:
             import contextlib
