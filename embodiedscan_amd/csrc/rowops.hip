@@ -1076,30 +1076,37 @@ static int colsum_rows(int n) { int r = es_cdiv(n > 0 ? n : 1, 256); r = (r + 3)
 // (64 chunks were too few for the head's 4e5-row launches: 64 workgroups, 0.64 ms, profiles/r4_single_stream_kernel_stats.txt)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int ld, int n, int C, float* __restrict__ dst, int accumulate,
                                                 float* __restrict__ ws, int rows_per_block, int safe) {
+  // round 6: gridDim.y (<= 4: one ticket each) workgroups share the 64-column groups of a row chunk instead of one workgroup walking them one
+  // dependent latency after the other (4 groups at 256 columns: 12.6 us per launch on the decoder's 3 072-row matrices, 117 launches per
+  // grounding step), and 16 rows of a stripe are in flight instead of 8; the order of the additions -- and so every bit of the result -- is unchanged
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
   float* part = ws + ES_TICKET_FLOATS + (size_t)blockIdx.x * C;
-  for (int c0 = 0; c0 < C; c0 += 64) {
+  for (int c0 = blockIdx.y * 64; c0 < C; c0 += 64 * gridDim.y) {
     const int c = c0 + tx;
     float s = 0.f;
     if (c < C)
-      for (int r = r0 + ty; r < r1; r += 32) {          // 8 rows of this stripe in flight (a load per iteration was 98 us per launch:
-        float v[8];                                     // 256 serialised L2 round trips in 12 workgroups); same order of additions
+      for (int r = r0 + ty; r < r1; r += 64) {
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (r + 4 * u) < r1 ? g[(size_t)(r + 4 * u) * ld + c] : 0.f;
+        for (int u = 0; u < 16; ++u) v[u] = (r + 4 * u) < r1 ? g[(size_t)(r + 4 * u) * ld + c] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 16; ++u) s += v[u];
       }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < C) es_coh_store(part + c, (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
     __syncthreads();
   }
-  if (!es_last_block_sel((unsigned int*)ws, gridDim.x, safe)) return;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float t = es_coh_sum(ws + ES_TICKET_FLOATS + c, (int)gridDim.x, (size_t)C);
-    dst[c] = accumulate ? dst[c] + t : t;
+  if (!es_last_block_sel((unsigned int*)ws + blockIdx.y, gridDim.x, safe)) return;
+  const int ngroups = (C + 63) / 64, mine = (ngroups - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+  for (int idx = threadIdx.x; idx < mine * 64; idx += 256) {
+    const int c = ((int)blockIdx.y + (idx >> 6) * (int)gridDim.y) * 64 + (idx & 63);
+    if (c < C) {
+      float t = es_coh_sum(ws + ES_TICKET_FLOATS + c, (int)gridDim.x, (size_t)C);
+      dst[c] = accumulate ? dst[c] + t : t;
+    }
   }
 }
 extern "C" size_t es_colsum_workspace_floats(int n, int C) { return (size_t)ES_TICKET_FLOATS + (size_t)es_cdiv(n > 0 ? n : 1, colsum_rows(n)) * C; }
@@ -1109,7 +1116,8 @@ extern "C" int es_colsum(const float* g, int ld, int n, int C, float* dst, int a
   if (n <= 0) { if (!accumulate) ES_TRY(hipMemsetAsync(dst, 0, (size_t)C * 4, (hipStream_t)stream)); return 0; }
   if (!workspace || workspace_floats < es_colsum_workspace_floats(n, C)) return -5;
   const int rpb = colsum_rows(n);
-  hipLaunchKernelGGL(k_colsum, dim3(es_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, g, ld, n, C, dst, accumulate, workspace, rpb, ES_OPT_ELECT_SAFE);
+  const int ng = es_cdiv(C, 64);
+  hipLaunchKernelGGL(k_colsum, dim3(es_cdiv(n, rpb), ng < 4 ? ng : 4), dim3(256), 0, (hipStream_t)stream, g, ld, n, C, dst, accumulate, workspace, rpb, ES_OPT_ELECT_SAFE);
   ES_CHECK_LAUNCH();
   return 0;
 }

@@ -421,7 +421,7 @@ def test_radix_sort_and_topk_and_column_sums(emu):
         emu('es_topk_mask_ws', P(v), P(off), len(seg_sizes), k, P(m2), P(ws), nw, 0)
         assert np.array_equal(m1, want), (seg_sizes, k)
         assert np.array_equal(m2, want), (seg_sizes, k)
-    for n, C in ((1, 8), (700, 64), (20000, 24), (100000, 4)):
+    for n, C in ((1, 8), (700, 64), (20000, 24), (100000, 4), (3072, 256), (300, 320), (130, 2048)):      # (1 .. 32 column groups over <= 4 workgroup columns)
         g = rng.standard_normal((n, C + 4)).astype(np.float32)[:, :C]   # strided rows
         ld = g.strides[0] // 4
         nf = int(emu.fns['es_colsum_workspace_floats'](n, C))
