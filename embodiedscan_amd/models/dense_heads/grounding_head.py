@@ -5,6 +5,7 @@ Per decoder layer the loss is five launches for the WHOLE batch: contrastive log
 Hungarian, no D2H / scipy), labels + focal loss with its gradient, corner-Chamfer loss on the matched pairs with its
 gradient -- the reference loops over samples with a host round trip each."""
 import math
+import os
 import torch
 from ... import engine as E
 from ... import hip
@@ -12,6 +13,8 @@ from ...hip import P, call, farr
 from ...parallel import reduce_mean
 from ...registry import MODELS, TASK_UTILS
 from ..layers.ground_transformer.decoder import _Lin
+
+MATCH_BATCH = [os.environ.get('ES_MATCH_BATCH', '1') != '0']     # round 6: the decoder layers' assignments in one launch (A/B switch)
 
 
 @MODELS.register_module()
@@ -150,6 +153,9 @@ class GroundingHead:
         if tlen is None:
             tlen = text_token_mask.sum(1).to(torch.int32).to(dev)
         gt_boxes, pos_map, gt_off, Gs = self.pack_gt(gis, T, dev)
+        gt_off_host = [0]
+        for g_ in Gs:
+            gt_off_host.append(gt_off_host[-1] + g_)
         Gmax = max(Gs) if Gs else 0
         assert Gmax <= Q, 'more target boxes than queries'
         n_pos = sum(Gs)
@@ -168,10 +174,25 @@ class GroundingHead:
         s = hip.stream()
         losses, self.last = {}, []
         L = len(hidden_states)
+        logits_l = [self.cls_branch(hidden_states[l], text_feats, B, Q, T, tlen)[0] for l in range(L)]
+        q2g_all = None
+        if MATCH_BATCH[0] and L > 1:
+            # round 6: the assignments of the L decoder layers are independent -- ONE cost + assignment launch over L * B "samples" (the targets
+            # tiled L times) instead of L dependent pairs on the main stream (0.2 ms each: a few hundred f64 box-IoU threads, far from filling
+            # the chip); same kernels, same per-(layer, sample) arithmetic
+            sumG = int(gt_off_host[-1])
+            all_logits = torch.cat([lg.d for lg in logits_l]).view(L * B, Q, T)
+            all_boxes = torch.cat([bx.d for bx in all_layers_pred_bboxes]).view(L * B, Q, 9)
+            off_L = torch.tensor([l * sumG + o for l in range(L) for o in gt_off_host[:-1]] + [L * sumG], dtype=torch.int32).to(dev, non_blocking=True)
+            q2g_all = self.assigner.match(all_logits, all_boxes, gt_boxes.repeat(L, 1), pos_map.repeat(L, 1), off_L, Gmax, tlen.repeat(L), s)
+            self.assigner.last_cost = self.assigner.last_cost.view(L, B, max(Gmax, 1), Q)[-1]
         for l in range(L):
-            logits, _ = self.cls_branch(hidden_states[l], text_feats, B, Q, T, tlen)
+            logits = logits_l[l]
             boxes = all_layers_pred_bboxes[l]
-            q2g = self.assigner.match(logits.d.view(B, Q, T), boxes.d.view(B, Q, 9), gt_boxes, pos_map, gt_off, Gmax, tlen, s)
+            if q2g_all is not None:
+                q2g = q2g_all[l * B:(l + 1) * B]
+            else:
+                q2g = self.assigner.match(logits.d.view(B, Q, T), boxes.d.view(B, Q, 9), gt_boxes, pos_map, gt_off, Gmax, tlen, s)
             if getattr(self, 'force_assign', None) is not None:      # test hook (teacher forcing): the oracle's assignment of layer l
                 free, q2g = q2g, self.force_assign[l].to(device=dev, dtype=torch.int32).reshape(B, Q).contiguous()
             lsum = torch.zeros(1, dtype=torch.float64, device=dev)

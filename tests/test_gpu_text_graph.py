@@ -38,7 +38,6 @@ def test_detector_text_paths_agree():
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dev = torch.device('cuda:0')
-    E.PRECISION[0] = 'bf16'
     cfg = load_config(os.path.join(root, 'configs', 'mv_grounding.py'))
     det = build_detector(cfg, device=dev, seed=0).to(dev)
     det._bind()
