@@ -186,6 +186,11 @@ class GroundingHead:
             off_L = torch.tensor([l * sumG + o for l in range(L) for o in gt_off_host[:-1]] + [L * sumG], dtype=torch.int32).to(dev, non_blocking=True)
             q2g_all = self.assigner.match(all_logits, all_boxes, gt_boxes.repeat(L, 1), pos_map.repeat(L, 1), off_L, Gmax, tlen.repeat(L), s)
             self.assigner.last_cost = self.assigner.last_cost.view(L, B, max(Gmax, 1), Q)[-1]
+        # one zero-filled accumulator pair / gradient buffer for all layers, the loss scalars derived once behind the loop (round 6: the loop
+        # used to issue ~ 8 one-element torch launches per layer)
+        lsum_all = torch.zeros(L, dtype=torch.float64, device=dev)
+        lbox_all = torch.zeros(L, dtype=torch.float64, device=dev)         # (f64 accumulators: order-independent, see csrc/losses.hip)
+        bgrad_all = torch.zeros((L,) + tuple(all_layers_pred_bboxes[0].d.shape), dtype=torch.float32, device=dev)
         for l in range(L):
             logits = logits_l[l]
             boxes = all_layers_pred_bboxes[l]
@@ -195,21 +200,21 @@ class GroundingHead:
                 q2g = self.assigner.match(logits.d.view(B, Q, T), boxes.d.view(B, Q, 9), gt_boxes, pos_map, gt_off, Gmax, tlen, s)
             if getattr(self, 'force_assign', None) is not None:      # test hook (teacher forcing): the oracle's assignment of layer l
                 free, q2g = q2g, self.force_assign[l].to(device=dev, dtype=torch.int32).reshape(B, Q).contiguous()
-            lsum = torch.zeros(1, dtype=torch.float64, device=dev)
             logits.g = torch.empty_like(logits.d)
             call('es_ground_focal', P(logits.d), T, B, Q, P(q2g), P(pos_map), P(gt_off), P(tlen), T, self.focal_alpha,
-                 self.focal_gamma, P(avg), self.loss_cls_weight, P(logits.g), P(lsum), s)
-            lbox = torch.zeros(1, dtype=torch.float64, device=dev)         # (f64 accumulator: order-independent, see csrc/losses.hip)
-            boxes.g = torch.zeros_like(boxes.d)
+                 self.focal_gamma, P(avg), self.loss_cls_weight, P(logits.g), lsum_all.data_ptr() + 8 * l, s)
+            boxes.g = bgrad_all[l]
             if n_pos:
-                call('es_box_cd_pairs', P(boxes.d), P(q2g), B, Q, P(gt_boxes), P(gt_off), n_pos, 1.0, gwa, P(boxes.g), P(lbox), s)
-            loss_cls = (lsum.float() / (avg + eps) * self.loss_cls_weight)[0]
-            name = '' if l == L - 1 else f'd{l}.'
-            losses[name + 'loss_cls'] = loss_cls
-            losses[name + 'loss_bbox'] = lbox.float()[0]
+                call('es_box_cd_pairs', P(boxes.d), P(q2g), B, Q, P(gt_boxes), P(gt_off), n_pos, 1.0, gwa, P(boxes.g), lbox_all.data_ptr() + 8 * l, s)
             self.last.append(dict(logits=logits, boxes=boxes, q2g=q2g))
             if getattr(self, 'force_assign', None) is not None:
                 self.last[-1]['q2g_free'] = free
+        loss_cls_all = lsum_all.float() / (avg + eps) * self.loss_cls_weight
+        loss_box_all = lbox_all.float()
+        for l in range(L):
+            name = '' if l == L - 1 else f'd{l}.'
+            losses[name + 'loss_cls'] = loss_cls_all[l]
+            losses[name + 'loss_bbox'] = loss_box_all[l]
         out = dict(loss_cls=losses['loss_cls'], loss_bbox=losses['loss_bbox'])
         out.update({k: v for k, v in losses.items() if k.startswith('d')})
         return out
