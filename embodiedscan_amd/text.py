@@ -80,7 +80,8 @@ class TextGraph:
                 encoder(input_ids=self.ids, attention_mask=self.mask)
         stream.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, stream=stream):
+        # (thread-local capture errors: a loader / feeder thread pinning memory while the capture runs must not invalidate it)
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode='thread_local'):
             self.out = encoder(input_ids=self.ids, attention_mask=self.mask).last_hidden_state
 
     def run(self, ids, mask):
