@@ -127,7 +127,14 @@ int es_gen_transpose_dgrad_bf16(const float* dY, const void* Wn_bf16, int n, int
  * rows; key 16 = fold the tap-split reduction into the launch (default 0, see es_spconv_fwd_bf16_ws);
  * key 18 = last-workgroup elections of the deterministic in-launch reductions (es_colsum, es_layernorm_bwd, es_contrastive_bwd,
  * es_topk_mask_ws): 0 (default) coherent (sc1) stores + drained ticket, no cache maintenance; 1 adds an agent-scope release
- * fence in every workgroup and an acquire fence in the winner (csrc/common.h es_last_block_sel; tests/test_gpu_elect.py) */
+ * fence in every workgroup and an acquire fence in the winner (csrc/common.h es_last_block_sel; tests/test_gpu_elect.py);
+ * round 6: key 9 = rows per norm-statistics chunk; 19 = fewest 128-column workgroups for the 128-column row-GEMM tile (0);
+ * 20 = tap-split launches in a weight-sharing workgroup order (0: measured, no gain); 21 = K = 27, 3 -> 64 channel
+ * convolutions (MinkResNet.conv1, es_spconv_fwd / es_spconv_wgrad) on the lane-per-output-channel kernels (1), 22 = their
+ * weight-gradient row slices (768); 23 = 320 output columns of a K = 1 launch as one column tile (1, from 16 384 rows);
+ * 24 = K = 1 launches with fewer 128-row workgroups than this on the 64 x 64 whole-stage kernels (256; 0: off; same bits);
+ * 25 = C -> 4 C bf16 expansion layers from this many rows on the register-resident stream kernel (65 536; 0: off; same bits),
+ * 26 = its persistent workgroups (1 024) */
 int es_set_option(int key, int value);
 /* Y = act((X*W) * scale[c] + shift[c] (+ res)): conv2d + frozen BatchNorm2d (+ residual) (+ ReLU) of mmdet.ResNet in one
  * launch (any shape; the tap-split of under-filled launches is not applied to fused calls).  act: 0 none, 1 ReLU,
