@@ -31,6 +31,13 @@ for kind in occupancy grounding; do
   C2="python $B --no-cpu-baseline --only $kind --steps 3 --warmup 1 --other-steps 3"
   (cd /tmp && ES_TWO_STREAMS=0 ES_WGRAD_ASYNC=0 timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks_$kind -o p -- $C2 > /tmp/prof_ks_$kind.log 2>&1); echo "rc $?"
   python tools/rocpd_stats.py "$(db ks_$kind)" $OUT/${T}_single_stream_kernel_stats_$kind.txt > /dev/null
+  # HBM-side bytes of the configuration's roofline family (separate counter passes, kernel trace only)
+  (cd /tmp && timeout 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d /tmp/prof_pf_$kind -o p -- $C2 > /tmp/prof_pf_$kind.log 2>&1); echo "rc $?"
+  python tools/rocpd_pmc.py "$(db pf_$kind)" $OUT/${T}_pmc_fetch_$kind.txt > /dev/null
+  (cd /tmp && timeout 250 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum -d /tmp/prof_pw_$kind -o p -- $C2 > /tmp/prof_pw_$kind.log 2>&1); echo "rc $?"
+  python tools/rocpd_pmc.py "$(db pw_$kind)" $OUT/${T}_pmc_write_$kind.txt > /dev/null
+  python tools/pmc_traffic.py --tag $T --config $kind --fetch $OUT/${T}_pmc_fetch_$kind.txt --write $OUT/${T}_pmc_write_$kind.txt --command "$C2" > $OUT/${T}_pmc_traffic_stdout_$kind.txt 2>&1
+  cp profiles/${T}_pmc_traffic_$kind.json $OUT/ 2>/dev/null
 done
 timeout 300 python tools/bench_halo.py > $OUT/${T}_halo_ab.txt 2>&1
 timeout 300 python tools/bench_imgwgrad.py > $OUT/${T}_imgwgrad_ab.txt 2>&1

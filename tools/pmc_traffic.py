@@ -38,12 +38,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--tag', default='r3')
     ap.add_argument('--config', default='mv3ddet', choices=sorted(FAMILY))
-    ap.add_argument('--steps', type=int, required=True, help='train steps the profiled command executed (timed + warm-up + extra)')
+    ap.add_argument('--steps', type=int, default=0, help='train steps the profiled command executed (timed + warm-up + extra); 0: the number of optimiser launches (k_adamw*) in the table')
     ap.add_argument('--fetch', required=True)
     ap.add_argument('--write', required=True)
     ap.add_argument('--command', default='python bench.py --no-cpu-baseline --no-other-configs --steps 4 --warmup 2')
     a = ap.parse_args()
     f, w = table(a.fetch), table(a.write)
+    if a.steps <= 0:
+        a.steps = max(1, int(sum(v['calls'] for k, v in f.items() if k.startswith('k_adamw'))))
     pick = lambda fam: [k for k in f if any(p in k for p in fam)]
     fam = pick(FAMILY[a.config])
     fetch = sum(f[k]['FETCH_SIZE'] for k in fam) * 1024 * 2
